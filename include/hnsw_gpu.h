@@ -1,0 +1,140 @@
+/*
+ * hnsw_gpu.h — additive C API of the MI355X (gfx950) HNSW hot path.
+ *
+ * The reference boundary (hnsw_abi.h == embedding.h:17-56) hands the library ONE
+ * query per call and lets it reach the index only through per-element storage
+ * callbacks.  One query can never fill an MI355X (≈131 dependent hops), so beside
+ * the four drop-in symbols this header adds a batch API over an HBM-resident
+ * mirror of the index.  Plain C, opaque handle, int error codes, no exceptions
+ * and no framework types cross this line.
+ *
+ * Each entry point names the reference interface it stands in for.
+ */
+#ifndef PG_EMBEDDING_AMD_HNSW_GPU_H
+#define PG_EMBEDDING_AMD_HNSW_GPU_H
+
+#include "hnsw_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct hnsw_gpu_index hnsw_gpu_index;   /* opaque: the device mirror of one index */
+
+enum {
+	HNSW_GPU_OK            =  0,
+	HNSW_GPU_ERR_HIP       = -1,   /* a HIP runtime call failed (see hnsw_gpu_last_error) */
+	HNSW_GPU_ERR_ARG       = -2,   /* bad argument / unsupported configuration           */
+	HNSW_GPU_ERR_NOMEM     = -3,
+	HNSW_GPU_ERR_INTERNAL  = -4,   /* a device-side invariant tripped                    */
+	HNSW_GPU_ERR_NODEVICE  = -5    /* no gfx950 device visible: the library never falls  */
+	                               /* back to a CPU path                                 */
+};
+
+/* Text of the last failure on the calling thread ("" if none). */
+const char *hnsw_gpu_last_error(void);
+
+/* Number of visible HIP devices (0 when there is none). */
+int hnsw_gpu_device_count(void);
+
+/* ---------------------------------------------------------------- index mirror */
+
+/* Build the device mirror from `n` element images laid out as the host stores
+ * them (embedding.c:222-228: [u32 count][u32 link*maxM][f32*dim][u64 label],
+ * meta->size_data_per_element bytes apart).  Stands in for the per-element
+ * hnsw_begin_read walk (embedding.c:704-757).  Elements are re-laid-out in HBM as
+ * three arrays (links / 16-byte-aligned zero-padded rows / labels). */
+int hnsw_gpu_index_create_from_flat(const HnswMetadata *meta, const void *elements, size_t n,
+									int device, hnsw_gpu_index **out);
+
+/* An empty mirror with room for `capacity` elements (used by the device builder). */
+int hnsw_gpu_index_create_empty(const HnswMetadata *meta, size_t capacity, int device,
+								hnsw_gpu_index **out);
+
+/* Append `n` un-linked rows.  vectors: n*dim floats; labels: n values or NULL
+ * (label = element number).  The *_dev form takes device pointers and enqueues on
+ * `stream` (a hipStream_t, may be NULL).  Equivalent of the "store zero-linked
+ * element" half of hnsw_add_point (embedding.c:619-621,670). */
+int hnsw_gpu_index_append(hnsw_gpu_index *ix, const coord_t *vectors, const label_t *labels, size_t n);
+int hnsw_gpu_index_append_dev(hnsw_gpu_index *ix, const coord_t *d_vectors, const label_t *d_labels,
+							  size_t n, void *stream);
+
+/* Write the mirror back as host element images (inverse of create_from_flat), so a
+ * CPU host can search the identical bytes.  `elements` holds count*size_data_per_element. */
+int hnsw_gpu_index_export_flat(hnsw_gpu_index *ix, void *elements);
+
+/* Set / clear the vacuum flag of one element's label (embedding.c:920-926). */
+int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int deleted);
+
+size_t hnsw_gpu_index_count(const hnsw_gpu_index *ix);
+int    hnsw_gpu_index_device(const hnsw_gpu_index *ix);
+void   hnsw_gpu_index_destroy(hnsw_gpu_index *ix);
+
+/* ---------------------------------------------------------------------- search */
+
+/* nq independent hnsw_search() calls (hnswalg.cpp:256-277 = searchKnn(k = ef),
+ * hnswalg.cpp:234-252, over searchBaseLayer, hnswalg.cpp:42-114) in one launch.
+ *   queries : nq*dim floats
+ *   labels  : nq*ef, row q = the reference's result array for query q: ascending
+ *             by (distance, label), vacuumed labels removed; unused tail = ~0
+ *   dists   : nq*ef distances in the same order (may be NULL; the reference does
+ *             not return them, embedding.c:345-351 wishes it did); tail = +inf
+ *   counts  : nq result counts (<= ef)
+ * Host-pointer form: copies in, runs, copies out, synchronises. */
+int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries, size_t nq, size_t ef,
+						  label_t *labels, dist_t *dists, uint32_t *counts);
+
+/* Device-pointer form: everything resident in HBM, enqueued on `stream`
+ * (hipStream_t or NULL), no synchronisation.
+ *   d_stats : NULL or nq*2 u32 = {distance evaluations E_q, hops H_q} per query
+ *             (the counts of hnswalg.cpp:59,96 and :76 — SURVEY.md §8d). */
+int hnsw_gpu_search_batch_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t ef,
+							  label_t *d_labels, dist_t *d_dists, uint32_t *d_counts,
+							  uint32_t *d_stats, void *stream);
+
+/* searchBaseLayer() alone (hnswalg.cpp:42-114): element numbers + distances
+ * ascending by (distance, idx), no label lookup / vacuum filter.  Device pointers. */
+int hnsw_gpu_search_base_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t ef,
+							 idx_t *d_idx, dist_t *d_dists, uint32_t *d_counts,
+							 uint32_t *d_stats, void *stream);
+
+/* Milliseconds the most recent search kernel of this index spent on the device,
+ * from HIP events recorded on its stream around the launch (waits for it). */
+int hnsw_gpu_last_search_ms(hnsw_gpu_index *ix, float *ms);
+
+/* Resident query slots (waves) the last search launch used — occupancy figure. */
+int hnsw_gpu_last_search_slots(hnsw_gpu_index *ix, uint32_t *slots);
+
+/* ------------------------------------------------------------------- distances */
+
+/* out[i] = hnsw_dist_func(func, q, rows + i*dim, dim)  (distfunc.c:171-174) for
+ * i < nrows, one launch.  Host pointers. */
+int hnsw_gpu_dist_batch(dist_func_t func, const coord_t *q, const coord_t *rows, size_t nrows,
+						size_t dim, dist_t *out);
+
+/* Device form: rows are row_stride floats apart (row_stride % 4 == 0, rows 16-byte
+ * aligned, padding zero); q holds dim floats. */
+int hnsw_gpu_dist_batch_dev(dist_func_t func, const coord_t *d_q, const coord_t *d_rows,
+							size_t nrows, size_t dim, size_t row_stride, dist_t *d_out, void *stream);
+
+/* Exact k nearest rows of the mirror by exhaustive scoring with the same distance
+ * code (ground truth for recall; ties broken by lower idx).  Device pointers;
+ * d_idx: nq*k. */
+int hnsw_gpu_bruteforce_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t k,
+							idx_t *d_idx, dist_t *d_dists, void *stream);
+
+/* ----------------------------------------------------------------- multi-shard */
+
+/* Merge `nlists` per-shard result lists per query (each ef entries: ascending by
+ * (dist, label), tail padded with dist=+inf / label=~0) into the ef best overall.
+ * Stands in for nothing in the single-process reference; it is the one exchange
+ * step of a row-sharded index.  Layout: d_in_*[list][query][ef]. */
+int hnsw_gpu_merge_topk_dev(int device, const label_t *d_in_labels, const dist_t *d_in_dists,
+							size_t nlists, size_t nq, size_t ef,
+							label_t *d_out_labels, dist_t *d_out_dists, uint32_t *d_out_counts,
+							void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PG_EMBEDDING_AMD_HNSW_GPU_H */

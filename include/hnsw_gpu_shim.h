@@ -1,0 +1,31 @@
+/*
+ * hnsw_gpu_shim.h — the few additive calls of libembedding_gpu.so, the library that
+ * exports the reference's own four symbols (hnsw_abi.h) on top of libhnsw_gpu.so.
+ *
+ * They exist because HnswMetadata (embedding.h:28-42) identifies no relation and is
+ * re-created for every scan (embedding.c:254): without them the drop-in hnsw_search()
+ * must re-mirror the index on every call.  INTEGRATION.md shows where the Postgres
+ * glue would call them.
+ */
+#ifndef PG_EMBEDDING_AMD_HNSW_GPU_SHIM_H
+#define PG_EMBEDDING_AMD_HNSW_GPU_SHIM_H
+
+#include "hnsw_gpu.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Walk the host index through hnsw_begin_read/hnsw_end_read (embedding.c:704-767)
+ * and build its device mirror.  The caller owns *out (hnsw_gpu_index_destroy). */
+int hnsw_gpu_shim_snapshot(HnswMetadata *meta, hnsw_gpu_index **out);
+
+/* From now on hnsw_search(meta, ...) uses `ix` instead of re-mirroring.  The host
+ * promises the index does not change while attached (or re-attaches a fresh mirror). */
+int hnsw_gpu_shim_attach(HnswMetadata *meta, hnsw_gpu_index *ix);
+int hnsw_gpu_shim_detach(HnswMetadata *meta);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

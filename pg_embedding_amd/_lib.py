@@ -1,0 +1,109 @@
+"""ctypes loader for the in-tree gfx950 libraries.  Fails loudly: there is no CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+_f32p = C.POINTER(C.c_float)
+_u32p = C.POINTER(C.c_uint32)
+_u64p = C.POINTER(C.c_uint64)
+
+
+class HnswMetadata(C.Structure):
+    """ctypes image of HnswMetadata (embedding.h:28-42 == include/hnsw_abi.h)."""
+    _fields_ = [(n, C.c_size_t) for n in (
+        "dim", "data_size", "offset_data", "offset_label", "size_data_per_element",
+        "elems_per_page", "M", "maxM", "efConstruction", "efSearch")] + [
+        ("enterpoint_node", C.c_uint32), ("dist_func", C.c_int)]
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+_gpu = None
+_shim = None
+
+
+def _preload_torch_runtime() -> None:
+    # PyTorch-ROCm ships its own libamdhip64.so.7; whichever copy is loaded first wins
+    # for the whole process.  When torch is going to be used (device tensors, streams,
+    # torch.distributed) it must be the one that is loaded first.
+    if os.environ.get("PGEMB_NO_TORCH_PRELOAD") == "1":
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
+def gpu_lib():
+    """libhnsw_gpu.so with argtypes set (include/hnsw_gpu.h)."""
+    global _gpu
+    if _gpu is not None:
+        return _gpu
+    if not os.path.exists(_build.GPU_LIB):
+        raise LibraryMissing(
+            f"{_build.GPU_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  pg_embedding_amd has no CPU fallback.")
+    _preload_torch_runtime()
+    L = C.CDLL(_build.GPU_LIB, mode=C.RTLD_GLOBAL)
+    vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
+    MP = C.POINTER(HnswMetadata)
+    L.hnsw_gpu_last_error.restype = C.c_char_p
+    L.hnsw_gpu_device_count.restype = i32
+    L.hnsw_gpu_index_create_from_flat.argtypes = [MP, vp, sz, i32, C.POINTER(vp)]
+    L.hnsw_gpu_index_create_empty.argtypes = [MP, sz, i32, C.POINTER(vp)]
+    L.hnsw_gpu_index_append.argtypes = [vp, vp, vp, sz]
+    L.hnsw_gpu_index_append_dev.argtypes = [vp, vp, vp, sz, vp]
+    L.hnsw_gpu_index_export_flat.argtypes = [vp, vp]
+    L.hnsw_gpu_index_set_deleted.argtypes = [vp, C.c_uint32, i32]
+    L.hnsw_gpu_index_count.restype = sz
+    L.hnsw_gpu_index_count.argtypes = [vp]
+    L.hnsw_gpu_index_device.argtypes = [vp]
+    L.hnsw_gpu_index_destroy.restype = None
+    L.hnsw_gpu_index_destroy.argtypes = [vp]
+    L.hnsw_gpu_search_batch.argtypes = [vp, vp, sz, sz, vp, vp, vp]
+    L.hnsw_gpu_search_batch_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp]
+    L.hnsw_gpu_search_base_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp]
+    L.hnsw_gpu_last_search_ms.argtypes = [vp, _f32p]
+    L.hnsw_gpu_last_search_slots.argtypes = [vp, _u32p]
+    L.hnsw_gpu_dist_batch.argtypes = [i32, vp, vp, sz, sz, vp]
+    L.hnsw_gpu_dist_batch_dev.argtypes = [i32, vp, vp, sz, sz, sz, vp, vp]
+    L.hnsw_gpu_bruteforce_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp]
+    L.hnsw_gpu_merge_topk_dev.argtypes = [i32, vp, vp, sz, sz, sz, vp, vp, vp, vp]
+    _gpu = L
+    return L
+
+
+def shim_lib():
+    """libembedding_gpu.so: the reference's four symbols.  Its host callbacks must already
+    be resolvable in the global scope when a search through it is made."""
+    global _shim
+    if _shim is not None:
+        return _shim
+    gpu_lib()
+    if not os.path.exists(_build.SHIM_LIB):
+        raise LibraryMissing(f"{_build.SHIM_LIB} is missing: run __graft_entry__.build()")
+    L = C.CDLL(_build.SHIM_LIB, mode=C.RTLD_GLOBAL | os.RTLD_LAZY)
+    MP = C.POINTER(HnswMetadata)
+    L.hnsw_dist_func.restype = C.c_float
+    L.hnsw_dist_func.argtypes = [C.c_int, _f32p, _f32p, C.c_size_t]
+    L.hnsw_init_dist_func.restype = None
+    L.hnsw_search.restype = C.c_bool
+    L.hnsw_search.argtypes = [MP, _f32p, C.POINTER(C.c_size_t), C.POINTER(_u64p)]
+    L.hnsw_bind_point.restype = C.c_bool
+    L.hnsw_bind_point.argtypes = [MP, _f32p, C.c_uint32]
+    L.hnsw_gpu_shim_snapshot.argtypes = [MP, C.POINTER(C.c_void_p)]
+    L.hnsw_gpu_shim_attach.argtypes = [MP, C.c_void_p]
+    L.hnsw_gpu_shim_detach.argtypes = [MP]
+    _shim = L
+    return L
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = gpu_lib().hnsw_gpu_last_error()
+        raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,73 @@
+"""Compile the gfx950 libraries in-tree (pg_embedding_amd/lib/*.so).
+
+    libhnsw_gpu.so       HIP kernels + additive C API   (include/hnsw_gpu.h)
+    libembedding_gpu.so  the reference's four symbols   (include/hnsw_abi.h) on top of it
+
+hipcc cross-compiles for gfx950 without a GPU.  The .so files are git-ignored but travel
+to the GPU box with the tree.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(PKG)
+CSRC = os.path.join(PKG, "csrc")
+LIBDIR = os.path.join(PKG, "lib")
+INC = os.path.join(ROOT, "include")
+
+GPU_LIB = os.path.join(LIBDIR, "libhnsw_gpu.so")
+SHIM_LIB = os.path.join(LIBDIR, "libembedding_gpu.so")
+
+HIPCC_FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # the canonical summation order (oracle/hnsw_port.c) relies on explicit FMAs only
+    "-ffp-contract=off",
+]
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found (need ROCm with gfx950 support)")
+
+
+def _newer(target: str, sources) -> bool:
+    if not os.path.exists(target):
+        return False
+    t = os.path.getmtime(target)
+    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _run(cmd) -> None:
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+
+
+def build(force: bool = False, verbose: bool = False) -> None:
+    os.makedirs(LIBDIR, exist_ok=True)
+    hdrs = [os.path.join(INC, h) for h in ("hnsw_abi.h", "hnsw_gpu.h", "hnsw_gpu_shim.h")]
+    gpu_src = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + hdrs
+    if force or not _newer(GPU_LIB, gpu_src):
+        cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INC, "-I", CSRC,
+                                          os.path.join(CSRC, "hnsw_gpu.hip"), "-o", GPU_LIB]
+        if verbose:
+            print(" ".join(cmd))
+        _run(cmd)
+    shim_src = [os.path.join(CSRC, "embedding_shim.cpp")] + hdrs
+    if force or not _newer(SHIM_LIB, shim_src + [GPU_LIB]):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", INC,
+               os.path.join(CSRC, "embedding_shim.cpp"), "-o", SHIM_LIB,
+               "-L", LIBDIR, "-lhnsw_gpu", "-Wl,-rpath,$ORIGIN", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        _run(cmd)
+
+
+if __name__ == "__main__":
+    build(force=True, verbose=True)
+    print("built", GPU_LIB, SHIM_LIB)

@@ -1,0 +1,186 @@
+// device_dist.h — gfx950 distance primitives for the HNSW hot path.
+//
+// Replaces the per-pair loops of distfunc.c (l2 :28-65/:67-118/:121-130, cosine
+// :133-145, manhattan :147-155) with a wave64 formulation:
+//
+//   * a wavefront is split into four 16-lane groups; each group scores ONE row, so
+//     one `global_load_dwordx4` wave-instruction moves 4 rows x 256 contiguous bytes
+//     (1 KiB, fully coalesced per row segment);
+//   * lane `sub` of a group owns the float4 chunks sub, sub+16, sub+32, ... of the
+//     row and of the LDS-staged query -> element e accumulates into partial sum
+//     number e % 64, with ONE fused multiply-add per element;
+//   * the 4 components are folded as (x+y)+(z+w) and the 16 lanes by an xor
+//     butterfly 1,2,4,8 done with DPP row operations (no LDS traffic);
+//   * epilogues exactly as the reference writes them (sqrtf / double-precision
+//     1 - dot/sqrt(na*nb) / none).
+//
+// This fixes the summation ORDER.  oracle/hnsw_port.c restates the same order on the
+// CPU, so oracle and device agree bit-for-bit; versus the reference's -Ofast build
+// (whose order is compiler-chosen) the difference is round-off only.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pgemb {
+
+enum : int { F_L2 = 0, F_COSINE = 1, F_MANHATTAN = 2 };   // embedding.h:22-26
+
+// Compiler-level ordering point for cross-lane LDS hand-offs inside ONE wavefront
+// (LDS operations of a wave execute in order; this only stops the compiler from
+// moving memory operations across the hand-off).
+__device__ __forceinline__ void wave_sync()
+{
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v)
+{
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+
+// Sum over the 16 lanes of a DPP row; every lane of the row ends with the total.
+// Order: xor 1, xor 2 (quad_perm), then row_half_mirror and row_mirror, which after
+// the quads / octets are uniform deliver exactly the xor-4 / xor-8 partner's value.
+__device__ __forceinline__ float row16_sum(float t)
+{
+	t = t + dpp_move<0xB1>(t);    // quad_perm [1,0,3,2]  == lane ^ 1
+	t = t + dpp_move<0x4E>(t);    // quad_perm [2,3,0,1]  == lane ^ 2
+	t = t + dpp_move<0x141>(t);   // row_half_mirror      == value of lane ^ 4
+	t = t + dpp_move<0x140>(t);   // row_mirror           == value of lane ^ 8
+	return t;
+}
+
+__device__ __forceinline__ float fold4(const float4 &a)
+{
+	return (a.x + a.y) + (a.z + a.w);
+}
+
+// Per-row running state: L2 / Manhattan use `a`; cosine uses a = dot, b = |x|^2.
+struct RowAcc
+{
+	float4 a, b;
+};
+
+__device__ __forceinline__ void acc_zero(RowAcc &s)
+{
+	s.a = make_float4(0.f, 0.f, 0.f, 0.f);
+	s.b = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+template <int FUNC>
+__device__ __forceinline__ void acc_step(RowAcc &s, const float4 &q, const float4 &x)
+{
+	if (FUNC == F_L2)
+	{
+		float d0 = q.x - x.x, d1 = q.y - x.y, d2 = q.z - x.z, d3 = q.w - x.w;
+		s.a.x = __builtin_fmaf(d0, d0, s.a.x);
+		s.a.y = __builtin_fmaf(d1, d1, s.a.y);
+		s.a.z = __builtin_fmaf(d2, d2, s.a.z);
+		s.a.w = __builtin_fmaf(d3, d3, s.a.w);
+	}
+	else if (FUNC == F_COSINE)
+	{
+		s.a.x = __builtin_fmaf(q.x, x.x, s.a.x);
+		s.a.y = __builtin_fmaf(q.y, x.y, s.a.y);
+		s.a.z = __builtin_fmaf(q.z, x.z, s.a.z);
+		s.a.w = __builtin_fmaf(q.w, x.w, s.a.w);
+		s.b.x = __builtin_fmaf(x.x, x.x, s.b.x);
+		s.b.y = __builtin_fmaf(x.y, x.y, s.b.y);
+		s.b.z = __builtin_fmaf(x.z, x.z, s.b.z);
+		s.b.w = __builtin_fmaf(x.w, x.w, s.b.w);
+	}
+	else
+	{
+		s.a.x = s.a.x + __builtin_fabsf(q.x - x.x);
+		s.a.y = s.a.y + __builtin_fabsf(q.y - x.y);
+		s.a.z = s.a.z + __builtin_fabsf(q.z - x.z);
+		s.a.w = s.a.w + __builtin_fabsf(q.w - x.w);
+	}
+}
+
+// Group-wide finish.  `qnorm` = |q|^2 in the same canonical order (cosine only).
+// Must be executed by all 64 lanes (DPP reads neighbours).
+template <int FUNC>
+__device__ __forceinline__ float acc_finish(const RowAcc &s, float qnorm)
+{
+	if (FUNC == F_L2)
+		return __builtin_sqrtf(row16_sum(fold4(s.a)));             // distfunc.c:64,117,129
+	if (FUNC == F_COSINE)
+	{
+		float dot = row16_sum(fold4(s.a));
+		float nb = row16_sum(fold4(s.b));
+		float prod = qnorm * nb;                                    // float product, distfunc.c:144
+		double r = 1.0 - (double) dot / __builtin_sqrt((double) prod);
+		return (float) r;
+	}
+	return row16_sum(fold4(s.a));                                   // distfunc.c:154
+}
+
+// |q|^2 of the LDS-staged query, canonical order; all lanes return the same value.
+__device__ __forceinline__ float query_norm(const float4 *q4, uint32_t nchunks, uint32_t kiters, int lane)
+{
+	const uint32_t sub = lane & 15;
+	float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+	for (uint32_t k = 0; k < kiters; k++)
+	{
+		uint32_t c = k * 16 + sub;
+		float4 q = (c < nchunks) ? q4[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+		a.x = __builtin_fmaf(q.x, q.x, a.x);
+		a.y = __builtin_fmaf(q.y, q.y, a.y);
+		a.z = __builtin_fmaf(q.z, q.z, a.z);
+		a.w = __builtin_fmaf(q.w, q.w, a.w);
+	}
+	return row16_sum(fold4(a));
+}
+
+// Score `nrows` rows against the LDS-staged query.
+//   row r lives at vec + rowid(r) * stride (floats; stride % 4 == 0, zero padded)
+//   q4     : query in LDS as float4 chunks, zero padded to kiters2*32 chunks
+//   out[r] : distance, written by the first lane of the owning group
+// Eight rows per pass (two per 16-lane group) and two chunk-steps per iteration keep
+// 4 x 16-byte loads per lane (4 KiB per wave) in flight before the first use.
+template <int FUNC, typename RowId>
+__device__ __forceinline__ void score_rows(const float *__restrict__ vec, size_t stride,
+										   const float4 *q4, uint32_t nchunks, uint32_t kiters,
+										   float qnorm, RowId rowid, uint32_t nrows,
+										   float *out, int lane)
+{
+	const uint32_t g = lane >> 4, sub = lane & 15;
+	const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+	for (uint32_t base = 0; base < nrows; base += 8)
+	{
+		const uint32_t r0 = base + g, r1 = base + 4 + g;
+		const bool v0 = r0 < nrows, v1 = r1 < nrows;
+		const float4 *p0 = reinterpret_cast<const float4 *>(vec + (size_t) (v0 ? rowid(r0) : 0) * stride) + sub;
+		const float4 *p1 = reinterpret_cast<const float4 *>(vec + (size_t) (v1 ? rowid(r1) : 0) * stride) + sub;
+		RowAcc s0, s1;
+		acc_zero(s0);
+		acc_zero(s1);
+		for (uint32_t k = 0; k < kiters; k += 2)
+		{
+			const uint32_t c0 = k * 16 + sub, c1 = c0 + 16;
+			const bool in0 = c0 < nchunks, in1 = c1 < nchunks;
+			float4 x00 = zero4, x01 = zero4, x10 = zero4, x11 = zero4;
+			if (v0 && in0) x00 = p0[k * 16];
+			if (v1 && in0) x10 = p1[k * 16];
+			if (v0 && in1) x01 = p0[k * 16 + 16];
+			if (v1 && in1) x11 = p1[k * 16 + 16];
+			const float4 qa = q4[c0], qb = q4[c1];     // LDS image is zero padded
+			acc_step<FUNC>(s0, qa, x00);
+			acc_step<FUNC>(s1, qa, x10);
+			acc_step<FUNC>(s0, qb, x01);
+			acc_step<FUNC>(s1, qb, x11);
+		}
+		const float d0 = acc_finish<FUNC>(s0, qnorm);
+		const float d1 = acc_finish<FUNC>(s1, qnorm);
+		if (sub == 0)
+		{
+			if (v0) out[r0] = d0;
+			if (v1) out[r1] = d1;
+		}
+	}
+}
+
+}  // namespace pgemb

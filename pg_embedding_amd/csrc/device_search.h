@@ -1,0 +1,336 @@
+// device_search.h — fused traverse + score kernel: searchBaseLayer (hnswalg.cpp:42-114),
+// searchKnn (hnswalg.cpp:234-252) and the result ordering of hnsw_search
+// (hnswalg.cpp:256-277) for a batch of independent queries.
+//
+// Mapping.  ONE WAVEFRONT = ONE QUERY AT A TIME.  A launch is a fixed set of resident
+// waves ("slots"); each slot pulls query numbers from an atomic ticket until the batch
+// is exhausted, so long and short traversals balance.  Per slot, in LDS:
+//     query (zero padded float4 image) | results[ef+1] | candidates[2ef+1] | hop scratch
+// and in HBM: an exact visited bitmap (N bits) plus a log of the set bits for O(visited)
+// clearing.  Throughput comes from thousands of slots each keeping 4-8 KiB of row
+// reads in flight; a single query is latency-bound by construction (≈ef dependent hops).
+//
+// Heaps.  The reference keeps two std::priority_queue<pair<float,idx>>:
+//   topResults  : max-heap on ( dist, idx)   -> worst on top, evicted when size > ef
+//   candidateSet: max-heap on (-dist, idx)   -> best on top, popped to expand
+// Only the extremes of those strict total orders are observable, so the device keeps
+// two SORTED arrays of 64-bit keys instead:
+//   results  : key = ord(dist)<<32 |  idx   ascending; last  = topResults.top()
+//   candidates: key = ord(dist)<<32 | ~idx   ascending; first = candidateSet.top()
+// (ord() maps float order onto unsigned order).  A candidate whose distance exceeds the
+// current bound can never be expanded (the bound only shrinks once results are full,
+// hnswalg.cpp:70,107), so the candidate array may drop its LARGEST key when it is full:
+// live candidates number < 2*ef (<= ef still in results + <= ef-1 evicted at exactly the
+// bound), hence with capacity 2*ef the largest of 2*ef+1 keys is always dead.  This makes
+// the bounded arrays exact, not approximate.
+//
+// Visited set.  hnswalg.cpp:45-50,82-93 uses a growable bitmap; here one bitmap per
+// slot.  Marking uses a returning atomic OR, which is the test and the set of :91-93 in
+// one memory round trip and is safe when two neighbours share a word.  Link lists are
+// de-duplicated at upload (first occurrence kept), which is behaviour-preserving because
+// a repeated id is always already visited when reached again in pass 2 (:89-93).
+#pragma once
+#include "device_dist.h"
+
+namespace pgemb {
+
+constexpr uint32_t LINK_NONE = 0xFFFFFFFFu;
+
+struct SearchArgs
+{
+	// index mirror
+	const float    *vec;        // rows, `stride` floats apart, zero padded
+	const uint32_t *links;      // lstride ids per element, LINK_NONE padded
+	const uint64_t *labels;
+	uint32_t n, dim, stride, nchunks, kiters, maxM, lstride, entry;
+	// batch
+	const float *queries;       // nq * dim floats
+	uint32_t nq, ef, ccap;      // ccap = 2*ef candidate capacity
+	// outputs
+	uint64_t *out_labels;       // mode 0: nq*ef
+	uint32_t *out_idx;          // mode 1: nq*ef
+	float    *out_dists;        // nq*ef or null
+	uint32_t *out_counts;       // nq
+	uint32_t *out_stats;        // nq*2 {evals, hops} or null
+	// per-slot workspace
+	uint32_t *vis;              // slots * vis_words, all zero between queries
+	uint32_t *vlog;             // slots * logcap
+	uint64_t  vis_words;
+	uint32_t  logcap;
+	uint32_t *ticket;           // zeroed before every launch
+	uint32_t *err;              // device-side invariant failures
+	// LDS carve (bytes, per wave)
+	uint32_t qpad_floats, off_res, off_cand, off_newid, off_newdist, wave_bytes;
+	int mode;                   // 0 = hnsw_search semantics, 1 = searchBaseLayer only
+};
+
+__device__ __forceinline__ uint32_t ord_f32(float f)
+{
+	uint32_t u = __float_as_uint(f);
+	return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float unord_f32(uint32_t o)
+{
+	return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+__device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
+{
+	return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
+}
+
+// Insert `key` into ascending A[0..sz); A has cap+1 slots.  If the array was full the
+// largest key falls off.  Wave-cooperative, wave-uniform arguments.  Returns new size.
+__device__ __forceinline__ uint32_t sorted_insert(uint64_t *A, uint32_t sz, uint64_t key, uint32_t cap, int lane)
+{
+	uint32_t p = 0;
+	for (uint32_t b = 0; b < sz; b += 64)
+	{
+		uint32_t i = b + lane;
+		bool lt = (i < sz) && (A[i] < key);
+		p += (uint32_t) __builtin_popcountll(__ballot(lt));
+	}
+	if (p < sz)
+	{
+		// move A[p..sz) up by one, highest 64-chunk first so nothing is overwritten early
+		for (int b = (int) (sz & ~63u); b >= (int) (p & ~63u); b -= 64)
+		{
+			uint32_t i = (uint32_t) b + lane;
+			bool mv = (i > p) && (i <= sz);
+			uint64_t tmp = 0;
+			if (mv) tmp = A[i - 1];
+			wave_sync();
+			if (mv) A[i] = tmp;
+			wave_sync();
+		}
+	}
+	if (lane == 0) A[p] = key;
+	wave_sync();
+	sz += 1;
+	return sz > cap ? cap : sz;
+}
+
+// Drop A[0] from ascending A[0..sz).
+__device__ __forceinline__ void remove_first(uint64_t *A, uint32_t sz, int lane)
+{
+	for (uint32_t b = 0; b + 1 < sz; b += 64)
+	{
+		uint32_t i = b + lane;
+		bool mv = (i + 1 < sz);
+		uint64_t tmp = 0;
+		if (mv) tmp = A[i + 1];
+		wave_sync();
+		if (mv) A[i] = tmp;
+		wave_sync();
+	}
+}
+
+template <int FUNC>
+__global__ __launch_bounds__(256) void hnsw_search_kernel(const SearchArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = threadIdx.x & 63;
+	const uint32_t wib = threadIdx.x >> 6;
+	unsigned char *my = smem + (size_t) wib * a.wave_bytes;
+	float        *qf      = reinterpret_cast<float *>(my);
+	const float4 *q4      = reinterpret_cast<const float4 *>(my);
+	uint64_t     *res     = reinterpret_cast<uint64_t *>(my + a.off_res);
+	uint64_t     *cand    = reinterpret_cast<uint64_t *>(my + a.off_cand);
+	uint32_t     *newid   = reinterpret_cast<uint32_t *>(my + a.off_newid);
+	float        *newdist = reinterpret_cast<float *>(my + a.off_newdist);
+
+	const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wib;
+	uint32_t *vis  = a.vis + (size_t) slot * a.vis_words;
+	uint32_t *vlog = a.vlog + (size_t) slot * a.logcap;
+	const uint32_t ef = a.ef;
+
+	for (;;)
+	{
+		uint32_t qi = 0;
+		if (lane == 0) qi = atomicAdd(a.ticket, 1u);
+		qi = __builtin_amdgcn_readfirstlane(qi);
+		if (qi >= a.nq) break;
+
+		// ---- stage the query in LDS (zero padded) ---------------------------------
+		const float *qsrc = a.queries + (size_t) qi * a.dim;
+		for (uint32_t e = lane; e < a.qpad_floats; e += 64)
+			qf[e] = (e < a.dim) ? qsrc[e] : 0.f;
+		wave_sync();
+		float qnorm = 0.f;
+		if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
+
+		uint32_t rsize = 0, csize = 0, logn = 0, evals = 0, hops = 0;
+
+		if (a.n > 0)      // empty index: hnsw_begin_read(entry) fails, hnswalg.cpp:56-57
+		{
+			// ---- entry point, hnswalg.cpp:55-65 -----------------------------------
+			const uint32_t ep = a.entry;
+			{
+				auto one = [ep](uint32_t) { return ep; };
+				score_rows<FUNC>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, one, 1u, newdist, lane);
+			}
+			wave_sync();
+			float lowerBound = newdist[0];
+			evals = 1;
+			if (lane == 0)
+			{
+				const uint32_t o = ord_f32(lowerBound);
+				res[0]  = ((uint64_t) o << 32) | ep;
+				cand[0] = ((uint64_t) o << 32) | (uint32_t) ~ep;
+				vis[ep >> 5] = 1u << (ep & 31);       // slot bitmap is all-zero here
+				vlog[0] = ep;
+			}
+			rsize = csize = logn = 1;
+			wave_sync();
+
+			// ---- main loop, hnswalg.cpp:67-112 ------------------------------------
+			while (csize > 0)
+			{
+				const uint64_t ck = cand[0];
+				if (unord_f32((uint32_t) (ck >> 32)) > lowerBound)     // :70-71
+					break;
+				const uint32_t cur = ~(uint32_t) ck;
+				remove_first(cand, csize, lane);                        // :73
+				csize--;
+				hops++;
+
+				for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)           // link list, :76-77
+				{
+					const uint32_t j = j0 + lane;
+					uint32_t t = LINK_NONE;
+					if (j < a.lstride) t = a.links[(size_t) cur * a.lstride + j];
+					bool isnew = false;
+					if (t != LINK_NONE)                                  // :91-93 test-and-set
+					{
+						const uint32_t bit = 1u << (t & 31);
+						const uint32_t old = atomicOr(&vis[t >> 5], bit);
+						isnew = !(old & bit);
+					}
+					const uint64_t mask = __ballot(isnew);
+					const uint32_t nnew = (uint32_t) __builtin_popcountll(mask);
+					if (nnew == 0) continue;
+					const uint32_t rank = lane_rank(mask);               // keeps link order j
+					if (isnew)
+					{
+						newid[rank] = t;
+						const uint32_t lp = logn + rank;
+						if (lp < a.logcap) vlog[lp] = t;
+					}
+					logn += nnew;
+					wave_sync();
+
+					{                                                    // :95-97, batched
+						const uint32_t *ids = newid;
+						auto by_id = [ids](uint32_t r) { return ids[r]; };
+						score_rows<FUNC>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, by_id, nnew, newdist, lane);
+					}
+					evals += nnew;
+					wave_sync();
+
+					for (uint32_t r = 0; r < nnew; r++)                  // :99-108, in link order
+					{
+						const float d = newdist[r];
+						if (rsize < ef || lowerBound > d)
+						{
+							const uint32_t t2 = newid[r];
+							const uint64_t hi = (uint64_t) ord_f32(d) << 32;
+							csize = sorted_insert(cand, csize, hi | (uint32_t) ~t2, a.ccap, lane);   // :100
+							rsize = sorted_insert(res, rsize, hi | t2, ef, lane);                   // :102-105
+							lowerBound = unord_f32((uint32_t) (res[rsize - 1] >> 32));               // :107
+						}
+					}
+				}
+			}
+		}
+
+		// ---- emit ---------------------------------------------------------------------
+		const size_t obase = (size_t) qi * ef;
+		uint32_t nout = 0;
+		if (a.mode == 1)
+		{
+			for (uint32_t b = 0; b < ef; b += 64)
+			{
+				const uint32_t i = b + lane;
+				if (i < ef)
+				{
+					const bool ok = i < rsize;
+					const uint64_t k = ok ? res[i] : 0;
+					a.out_idx[obase + i] = ok ? (uint32_t) k : LINK_NONE;
+					if (a.out_dists) a.out_dists[obase + i] = ok ? unord_f32((uint32_t) (k >> 32)) : __builtin_inff();
+				}
+			}
+			nout = rsize;
+		}
+		else
+		{
+			// searchKnn, hnswalg.cpp:241-249: label lookup, vacuum filter, order by (dist, label)
+			uint64_t *lab = cand;                       // candidate array is dead now
+			bool tie = false;
+			for (uint32_t b = 0; b < rsize; b += 64)
+			{
+				const uint32_t i = b + lane;
+				if (i < rsize)
+				{
+					lab[i] = a.labels[(uint32_t) res[i]];
+					if (i + 1 < rsize && (uint32_t) (res[i] >> 32) == (uint32_t) (res[i + 1] >> 32)) tie = true;
+				}
+			}
+			wave_sync();
+			const bool any_tie = __ballot(tie) != 0;
+			for (uint32_t b = 0; b < rsize; b += 64)
+			{
+				const uint32_t i = b + lane;
+				const bool in = i < rsize;
+				const uint64_t li = in ? lab[i] : 0;
+				const uint32_t di = in ? (uint32_t) (res[i] >> 32) : 0;
+				const bool keep = in && !((li >> 48) & 1);           // hnsw_is_deleted, embedding.c:948-953
+				const uint64_t kmask = __ballot(keep);
+				uint32_t rank;
+				if (!any_tie)
+					rank = nout + lane_rank(kmask);                  // already in (dist, idx) = (dist, label) order
+				else
+				{
+					rank = 0;
+					for (uint32_t jx = 0; jx < rsize; jx++)          // rank by (dist, label), hnswalg.cpp:236,246
+					{
+						const uint64_t lj = lab[jx];
+						const uint32_t dj = (uint32_t) (res[jx] >> 32);
+						const bool kj = !((lj >> 48) & 1);
+						rank += (kj && (dj < di || (dj == di && lj < li))) ? 1u : 0u;
+					}
+				}
+				if (keep)
+				{
+					a.out_labels[obase + rank] = li;
+					if (a.out_dists) a.out_dists[obase + rank] = unord_f32(di);
+				}
+				nout += (uint32_t) __builtin_popcountll(kmask);
+			}
+			for (uint32_t i = nout + lane; i < ef; i += 64)          // pad the tail
+			{
+				a.out_labels[obase + i] = ~0ull;
+				if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
+			}
+		}
+		if (lane == 0)
+		{
+			a.out_counts[qi] = nout;
+			if (a.out_stats) { a.out_stats[2 * (size_t) qi] = evals; a.out_stats[2 * (size_t) qi + 1] = hops; }
+		}
+
+		// ---- restore the all-zero bitmap for the next query of this slot --------------
+		wave_sync();
+		if (logn <= a.logcap)
+		{
+			for (uint32_t i = lane; i < logn; i += 64) vis[vlog[i] >> 5] = 0u;
+		}
+		else
+		{
+			for (uint64_t w = lane; w < a.vis_words; w += 64) vis[w] = 0u;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_s_waitcnt(0);   // drain: the next query's atomics must see the zeros
+		wave_sync();
+	}
+}
+
+}  // namespace pgemb

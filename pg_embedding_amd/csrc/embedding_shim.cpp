@@ -1,0 +1,226 @@
+// embedding_shim.cpp — libembedding_gpu.so: the four symbols embedding.c links against
+// (embedding.h:46-47,55-56), implemented on the MI355X library (libhnsw_gpu.so).
+//
+//   hnsw_search          hnswalg.cpp:256-277  -> one-query launch of the fused search kernel
+//   hnsw_dist_func       distfunc.c:171-174   -> one-row launch of the distance kernel
+//   hnsw_init_dist_func  distfunc.c:159-169   -> device selection / runtime warm-up
+//   hnsw_bind_point      hnswalg.cpp:279-291  -> NOT in this round's scope;
+//                                                returns false, as the reference does on failure
+//
+// It imports the host's storage callbacks (embedding.h:44,48-53) exactly like hnswalg.cpp does.
+// There is no CPU implementation behind any of these: without a gfx950 device every call fails
+// (false / NaN) and says why on stderr.
+//
+// Where does the index come from?  HnswMetadata carries no relation identity and Postgres
+// rebuilds it for every scan (embedding.c:254), so by default each hnsw_search() call walks the
+// host's elements through hnsw_begin_read/hnsw_end_read (one pin at a time: the host allows at
+// most 4, embedding.c:40,714-715) into a fresh device mirror: always correct, O(N) per call.
+// A host that knows its index is unchanged attaches a mirror once (hnsw_gpu_shim_attach) and
+// every later search through the drop-in symbol is a single kernel launch — see INTEGRATION.md.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+#include "hnsw_gpu.h"
+#include "hnsw_gpu_shim.h"
+
+namespace {
+
+std::mutex g_mu;
+int g_device = -1;                 // chosen by hnsw_init_dist_func
+
+struct Attachment { HnswMetadata *meta; hnsw_gpu_index *ix; };
+const int MAX_ATTACH = 64;
+Attachment g_attached[MAX_ATTACH];
+int g_nattached = 0;
+
+int pick_device()
+{
+	if (g_device >= 0) return g_device;
+	const char *env = getenv("PG_EMBEDDING_GPU_DEVICE");
+	int dev = env ? atoi(env) : 0;
+	int n = hnsw_gpu_device_count();
+	if (n <= 0) return -1;
+	if (dev < 0 || dev >= n) dev = 0;
+	g_device = dev;
+	return dev;
+}
+
+hnsw_gpu_index *find_attached(HnswMetadata *meta)
+{
+	for (int i = 0; i < g_nattached; i++)
+		if (g_attached[i].meta == meta) return g_attached[i].ix;
+	return nullptr;
+}
+
+// Staging buffer for the callback walk.  Static and reused so that a host callback which
+// leaves by longjmp (elog(ERROR), embedding.c:715) cannot leak it.
+thread_local char  *t_stage = nullptr;
+thread_local size_t t_stage_bytes = 0;
+
+bool stage_reserve(size_t bytes)
+{
+	if (bytes <= t_stage_bytes) return true;
+	size_t nb = t_stage_bytes ? t_stage_bytes : (1u << 20);
+	while (nb < bytes) nb *= 2;
+	char *p = (char *) realloc(t_stage, nb);
+	if (!p) return false;
+	memset(p + t_stage_bytes, 0, nb - t_stage_bytes);
+	t_stage = p;
+	t_stage_bytes = nb;
+	return true;
+}
+
+}  // namespace
+
+// Copy every element of the host index into one contiguous image by the same accessor the
+// reference search uses (hnsw_begin_read, embedding.c:704-757).  Element numbers may have
+// holes at the tail of a page (idx = blk*elems_per_page + off-1 with un-aligned
+// elems_per_page, embedding.c:229,693 / SURVEY.md §0.8): a miss inside a page skips to the
+// next page; a miss at a page start ends the walk.  Holes become zero-linked, vacuum-flagged
+// placeholders that nothing links to.
+extern "C" int hnsw_gpu_shim_snapshot(HnswMetadata *meta, hnsw_gpu_index **out)
+{
+	if (!meta || !out) return HNSW_GPU_ERR_ARG;
+	int dev = pick_device();
+	if (dev < 0)
+	{
+		fprintf(stderr, "pg_embedding_amd: no HIP device visible; the GPU hot path has no CPU fallback\n");
+		return HNSW_GPU_ERR_NODEVICE;
+	}
+	const size_t esz = meta->size_data_per_element;
+	const size_t epp = meta->elems_per_page ? meta->elems_per_page : 1;
+	size_t n = 0;
+	for (size_t idx = 0; idx < 0xFFFFFFFEull;)
+	{
+		idx_t *links = nullptr;
+		if (hnsw_begin_read(meta, (idx_t) idx, &links, nullptr, nullptr))
+		{
+			if (!stage_reserve((idx + 1) * esz)) { hnsw_end_read(meta); return HNSW_GPU_ERR_NOMEM; }
+			if (idx > n)        // holes skipped since the last real element
+			{
+				for (size_t h = n; h < idx; h++)
+				{
+					char *p = t_stage + h * esz;
+					memset(p, 0, esz);
+					const label_t dead = (label_t) 1 << HNSW_LABEL_DELETED_BIT;
+					memcpy(p + meta->offset_label, &dead, sizeof(dead));
+				}
+			}
+			memcpy(t_stage + idx * esz, links, esz);     // the element image is contiguous
+			hnsw_end_read(meta);
+			n = idx + 1;
+			idx++;
+		}
+		else
+		{
+			if (idx % epp == 0) break;                    // page does not exist: end of index
+			idx = (idx / epp + 1) * epp;                  // tail hole: continue on the next page
+		}
+	}
+	return hnsw_gpu_index_create_from_flat(meta, t_stage, n, dev, out);
+}
+
+extern "C" int hnsw_gpu_shim_attach(HnswMetadata *meta, hnsw_gpu_index *ix)
+{
+	if (!meta || !ix) return HNSW_GPU_ERR_ARG;
+	std::lock_guard<std::mutex> lk(g_mu);
+	for (int i = 0; i < g_nattached; i++)
+		if (g_attached[i].meta == meta) { g_attached[i].ix = ix; return HNSW_GPU_OK; }
+	if (g_nattached == MAX_ATTACH) return HNSW_GPU_ERR_NOMEM;
+	g_attached[g_nattached].meta = meta;
+	g_attached[g_nattached].ix = ix;
+	g_nattached++;
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_shim_detach(HnswMetadata *meta)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	for (int i = 0; i < g_nattached; i++)
+		if (g_attached[i].meta == meta)
+		{
+			g_attached[i] = g_attached[g_nattached - 1];
+			g_nattached--;
+			return HNSW_GPU_OK;
+		}
+	return HNSW_GPU_ERR_ARG;
+}
+
+// ---------------------------------------------------------------------------------------
+// the drop-in symbols
+// ---------------------------------------------------------------------------------------
+
+extern "C" void hnsw_init_dist_func(void)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	(void) pick_device();
+}
+
+extern "C" dist_t hnsw_dist_func(dist_func_t dist, coord_t const *ax, coord_t const *bx, size_t dim)
+{
+	dist_t out = NAN;
+	if (pick_device() < 0 || hnsw_gpu_dist_batch(dist, ax, bx, 1, dim, &out) != HNSW_GPU_OK)
+	{
+		fprintf(stderr, "pg_embedding_amd: hnsw_dist_func failed: %s\n", hnsw_gpu_last_error());
+		return NAN;
+	}
+	return out;
+}
+
+extern "C" bool hnsw_search(HnswMetadata *meta, const coord_t *point, size_t *n_results, label_t **results)
+{
+	if (!meta || !point || !n_results || !results) return false;
+	const size_t ef = meta->efSearch;
+	hnsw_gpu_index *ix = nullptr;
+	bool own = false;
+	{
+		std::lock_guard<std::mutex> lk(g_mu);
+		ix = find_attached(meta);
+	}
+	if (!ix)
+	{
+		if (hnsw_gpu_shim_snapshot(meta, &ix) != HNSW_GPU_OK)
+		{
+			fprintf(stderr, "pg_embedding_amd: hnsw_search: cannot mirror the index: %s\n", hnsw_gpu_last_error());
+			return false;
+		}
+		own = true;
+	}
+	bool ok = false;
+	label_t *buf = nullptr;
+	if (ef == 0)
+	{
+		// searchKnn trims to k = 0 results (hnswalg.cpp:238-240)
+		buf = (label_t *) malloc(1);
+		*n_results = 0;
+		ok = buf != nullptr;
+	}
+	else
+	{
+		buf = (label_t *) malloc(ef * sizeof(label_t));   // caller frees (embedding.c:327)
+		uint32_t cnt = 0;
+		if (buf && hnsw_gpu_search_batch(ix, point, 1, ef, buf, nullptr, &cnt) == HNSW_GPU_OK)
+		{
+			*n_results = cnt;
+			ok = true;
+		}
+		else
+			fprintf(stderr, "pg_embedding_amd: hnsw_search failed: %s\n", hnsw_gpu_last_error());
+	}
+	if (own) hnsw_gpu_index_destroy(ix);
+	if (!ok) { free(buf); return false; }
+	*results = buf;
+	return true;
+}
+
+extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t idx)
+{
+	(void) meta; (void) point; (void) idx;
+	fprintf(stderr, "pg_embedding_amd: hnsw_bind_point is not provided by the GPU library in this round "
+					"(insert path = SURVEY.md §8(f) rank 1)\n");
+	return false;
+}

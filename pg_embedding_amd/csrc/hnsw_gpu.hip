@@ -1,0 +1,810 @@
+// hnsw_gpu.hip — C-ABI implementation (include/hnsw_gpu.h) of the MI355X HNSW hot path.
+// gfx950 only; plain HIP runtime, no framework types in any signature.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "hnsw_gpu.h"
+#include "device_dist.h"
+#include "device_search.h"
+
+using namespace pgemb;
+
+// ------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(g_err, sizeof(g_err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+#define HIPCHK(expr)                                                                          \
+	do {                                                                                      \
+		hipError_t e_ = (expr);                                                               \
+		if (e_ != hipSuccess)                                                                 \
+			return fail(HNSW_GPU_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+						__FILE__, __LINE__);                                                  \
+	} while (0)
+
+extern "C" const char *hnsw_gpu_last_error(void) { return g_err; }
+
+extern "C" int hnsw_gpu_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+static inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+// ------------------------------------------------------------------------------------
+// the device mirror
+// ------------------------------------------------------------------------------------
+struct hnsw_gpu_index
+{
+	HnswMetadata meta;
+	int      device = 0;
+	int      num_cu = 0;
+	size_t   n = 0, cap = 0;
+	uint32_t stride = 0;      // floats per row (dim rounded up to 4)
+	uint32_t lstride = 0;     // link slots per element (maxM rounded up to 16)
+	float    *vec = nullptr;
+	uint32_t *links = nullptr;
+	uint64_t *labels = nullptr;
+	// search workspace (grow-only)
+	uint32_t *vis = nullptr;  size_t vis_slots = 0, vis_words = 0;
+	uint32_t *vlog = nullptr; uint32_t logcap = 0;
+	uint32_t *ticket = nullptr;       // [0] ticket, [1] err
+	hipEvent_t ev0 = nullptr, ev1 = nullptr;
+	bool     timed = false;
+	uint32_t last_slots = 0;
+	// scratch for the host-pointer entry points
+	void *scratch = nullptr; size_t scratch_bytes = 0;
+};
+
+static int ensure_scratch(hnsw_gpu_index *ix, size_t bytes)
+{
+	if (bytes <= ix->scratch_bytes) return HNSW_GPU_OK;
+	if (ix->scratch) (void) hipFree(ix->scratch);
+	ix->scratch = nullptr; ix->scratch_bytes = 0;
+	HIPCHK(hipMalloc(&ix->scratch, bytes));
+	ix->scratch_bytes = bytes;
+	return HNSW_GPU_OK;
+}
+
+static int check_meta(const HnswMetadata *m)
+{
+	if (!m) return fail(HNSW_GPU_ERR_ARG, "meta is NULL");
+	if (m->dim == 0 || m->dim > (1u << 20)) return fail(HNSW_GPU_ERR_ARG, "unsupported dim %zu", m->dim);
+	if (m->maxM == 0 || m->maxM > 4096) return fail(HNSW_GPU_ERR_ARG, "unsupported maxM %zu", m->maxM);
+	if ((int) m->dist_func < 0 || (int) m->dist_func > 2) return fail(HNSW_GPU_ERR_ARG, "bad dist_func %d", (int) m->dist_func);
+	// element image offsets must be the ones of embedding.c:225-228
+	if (m->offset_data != (m->maxM + 1) * sizeof(idx_t) || m->offset_label != m->offset_data + m->dim * sizeof(coord_t) ||
+		m->size_data_per_element != m->offset_label + sizeof(label_t))
+		return fail(HNSW_GPU_ERR_ARG, "meta offsets do not describe [count|links|vector|label]");
+	return HNSW_GPU_OK;
+}
+
+static int alloc_index(const HnswMetadata *meta, size_t capacity, int device, hnsw_gpu_index **out)
+{
+	int rc = check_meta(meta);
+	if (rc) return rc;
+	int ndev = hnsw_gpu_device_count();
+	if (ndev <= 0) return fail(HNSW_GPU_ERR_NODEVICE, "no HIP device visible (this library has no CPU path)");
+	if (device < 0 || device >= ndev) return fail(HNSW_GPU_ERR_ARG, "device %d out of range (%d visible)", device, ndev);
+	if (capacity >= 0xFFFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "capacity exceeds idx_t range");
+	HIPCHK(hipSetDevice(device));
+	hnsw_gpu_index *ix = new (std::nothrow) hnsw_gpu_index();
+	if (!ix) return fail(HNSW_GPU_ERR_NOMEM, "out of host memory");
+	ix->meta = *meta;
+	ix->device = device;
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess) ix->num_cu = prop.multiProcessorCount;
+	if (ix->num_cu <= 0) ix->num_cu = 256;
+	ix->cap = capacity ? capacity : 1;
+	ix->stride = (uint32_t) round_up(meta->dim, 4);
+	ix->lstride = (uint32_t) round_up(meta->maxM, 16);
+	hipError_t e;
+	if ((e = hipMalloc(&ix->vec, ix->cap * ix->stride * sizeof(float))) != hipSuccess ||
+		(e = hipMalloc(&ix->links, ix->cap * ix->lstride * sizeof(uint32_t))) != hipSuccess ||
+		(e = hipMalloc(&ix->labels, ix->cap * sizeof(uint64_t))) != hipSuccess ||
+		(e = hipMalloc(&ix->ticket, 64)) != hipSuccess ||
+		(e = hipEventCreate(&ix->ev0)) != hipSuccess || (e = hipEventCreate(&ix->ev1)) != hipSuccess)
+	{
+		hnsw_gpu_index_destroy(ix);
+		return fail(e == hipErrorOutOfMemory ? HNSW_GPU_ERR_NOMEM : HNSW_GPU_ERR_HIP, "index allocation failed: %s",
+					hipGetErrorString(e));
+	}
+	(void) hipMemset(ix->ticket, 0, 64);
+	*out = ix;
+	return HNSW_GPU_OK;
+}
+
+extern "C" void hnsw_gpu_index_destroy(hnsw_gpu_index *ix)
+{
+	if (!ix) return;
+	(void) hipSetDevice(ix->device);
+	if (ix->vec) (void) hipFree(ix->vec);
+	if (ix->links) (void) hipFree(ix->links);
+	if (ix->labels) (void) hipFree(ix->labels);
+	if (ix->vis) (void) hipFree(ix->vis);
+	if (ix->vlog) (void) hipFree(ix->vlog);
+	if (ix->ticket) (void) hipFree(ix->ticket);
+	if (ix->scratch) (void) hipFree(ix->scratch);
+	if (ix->ev0) (void) hipEventDestroy(ix->ev0);
+	if (ix->ev1) (void) hipEventDestroy(ix->ev1);
+	delete ix;
+}
+
+extern "C" size_t hnsw_gpu_index_count(const hnsw_gpu_index *ix) { return ix ? ix->n : 0; }
+extern "C" int    hnsw_gpu_index_device(const hnsw_gpu_index *ix) { return ix ? ix->device : -1; }
+
+// ------------------------------------------------------------------------------------
+// element image <-> mirror
+// ------------------------------------------------------------------------------------
+
+// One wavefront per element: [count|links|vector|label] -> links row / padded vector row / label.
+// Everything in the image is 4-byte aligned only (embedding.c:226), so it is read as u32 words.
+__global__ __launch_bounds__(256) void import_elements_kernel(const uint32_t *__restrict__ raw, size_t elem_words,
+															  uint32_t first, uint32_t count, uint32_t n_total,
+															  uint32_t dim, uint32_t stride, uint32_t maxM, uint32_t lstride,
+															  float *vec, uint32_t *links, uint64_t *labels, uint32_t *bad)
+{
+	const int lane = threadIdx.x & 63;
+	const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	if (w >= count) return;
+	const uint32_t *src = raw + (size_t) w * elem_words;
+	const size_t e = (size_t) first + w;
+	uint32_t cnt = src[0];
+	if (cnt > maxM) { if (lane == 0) atomicAdd(bad, 1u); cnt = maxM; }
+	for (uint32_t j = lane; j < lstride; j += 64)
+	{
+		uint32_t t = LINK_NONE;
+		if (j < cnt)
+		{
+			t = src[1 + j];
+			if (t >= n_total) { atomicAdd(bad, 1u); t = LINK_NONE; }
+			for (uint32_t k = 0; k < j && t != LINK_NONE; k++)      // keep the first occurrence only
+				if (src[1 + k] == t) t = LINK_NONE;
+		}
+		links[e * lstride + j] = t;
+	}
+	const uint32_t *v = src + (maxM + 1);
+	for (uint32_t c = lane; c < stride; c += 64)
+		vec[e * stride + c] = (c < dim) ? __uint_as_float(v[c]) : 0.f;
+	if (lane == 0)
+	{
+		const uint32_t *l = v + dim;
+		labels[e] = (uint64_t) l[0] | ((uint64_t) l[1] << 32);
+	}
+}
+
+__global__ __launch_bounds__(256) void export_elements_kernel(uint32_t *__restrict__ raw, size_t elem_words,
+															  uint32_t first, uint32_t count,
+															  uint32_t dim, uint32_t stride, uint32_t maxM, uint32_t lstride,
+															  const float *vec, const uint32_t *links, const uint64_t *labels)
+{
+	const int lane = threadIdx.x & 63;
+	const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	if (w >= count) return;
+	uint32_t *dst = raw + (size_t) w * elem_words;
+	const size_t e = (size_t) first + w;
+	// links are stored compacted (no holes) with their count in front
+	uint32_t cnt = 0;
+	for (uint32_t j0 = 0; j0 < maxM; j0 += 64)
+	{
+		const uint32_t j = j0 + lane;
+		uint32_t t = (j < lstride && j < maxM) ? links[e * lstride + j] : LINK_NONE;
+		const uint64_t m = __ballot(t != LINK_NONE);
+		if (t != LINK_NONE) dst[1 + cnt + lane_rank(m)] = t;
+		cnt += (uint32_t) __builtin_popcountll(m);
+	}
+	for (uint32_t j = cnt + lane; j < maxM; j += 64) dst[1 + j] = 0u;
+	if (lane == 0) dst[0] = cnt;
+	uint32_t *v = dst + (maxM + 1);
+	for (uint32_t c = lane; c < dim; c += 64) v[c] = __float_as_uint(vec[e * stride + c]);
+	if (lane == 0)
+	{
+		const uint64_t l = labels[e];
+		v[dim] = (uint32_t) l;
+		v[dim + 1] = (uint32_t) (l >> 32);
+	}
+}
+
+// rows given as dim-strided floats (host order) -> padded rows, links cleared, labels set.
+__global__ __launch_bounds__(256) void append_rows_kernel(const float *__restrict__ src, const uint64_t *__restrict__ src_labels,
+														  uint32_t first, uint32_t count, uint32_t dim, uint32_t stride,
+														  uint32_t lstride, float *vec, uint32_t *links, uint64_t *labels)
+{
+	const int lane = threadIdx.x & 63;
+	const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	if (w >= count) return;
+	const size_t e = (size_t) first + w;
+	for (uint32_t c = lane; c < stride; c += 64)
+		vec[e * stride + c] = (c < dim) ? src[(size_t) w * dim + c] : 0.f;
+	for (uint32_t j = lane; j < lstride; j += 64) links[e * lstride + j] = LINK_NONE;
+	if (lane == 0) labels[e] = src_labels ? src_labels[w] : (uint64_t) e;
+}
+
+static const size_t STAGE_BYTES = (size_t) 256 << 20;   // host<->device staging granule
+
+extern "C" int hnsw_gpu_index_create_from_flat(const HnswMetadata *meta, const void *elements, size_t n,
+											   int device, hnsw_gpu_index **out)
+{
+	if (!out) return fail(HNSW_GPU_ERR_ARG, "out is NULL");
+	if (n && !elements) return fail(HNSW_GPU_ERR_ARG, "elements is NULL");
+	hnsw_gpu_index *ix = nullptr;
+	int rc = alloc_index(meta, n, device, &ix);
+	if (rc) return rc;
+	const size_t esz = meta->size_data_per_element;
+	const size_t per = std::max<size_t>(1, STAGE_BYTES / esz);
+	uint32_t *stage = nullptr;
+	uint32_t *bad = ix->ticket + 8;
+	hipError_t e = hipMalloc(&stage, std::min(per, std::max<size_t>(n, 1)) * esz);
+	if (e != hipSuccess) { hnsw_gpu_index_destroy(ix); return fail(HNSW_GPU_ERR_NOMEM, "staging allocation failed"); }
+	for (size_t first = 0; first < n && e == hipSuccess; first += per)
+	{
+		const size_t cnt = std::min(per, n - first);
+		e = hipMemcpy(stage, (const char *) elements + first * esz, cnt * esz, hipMemcpyHostToDevice);
+		if (e != hipSuccess) break;
+		const uint32_t blocks = (uint32_t) ((cnt + 3) / 4);
+		hipLaunchKernelGGL(import_elements_kernel, dim3(blocks), dim3(256), 0, 0, stage, esz / 4, (uint32_t) first,
+						   (uint32_t) cnt, (uint32_t) n, (uint32_t) meta->dim, ix->stride, (uint32_t) meta->maxM,
+						   ix->lstride, ix->vec, ix->links, ix->labels, bad);
+		e = hipDeviceSynchronize();
+	}
+	uint32_t nbad = 0;
+	if (e == hipSuccess) e = hipMemcpy(&nbad, bad, 4, hipMemcpyDeviceToHost);
+	(void) hipFree(stage);
+	if (e != hipSuccess)
+	{
+		hnsw_gpu_index_destroy(ix);
+		return fail(HNSW_GPU_ERR_HIP, "index upload failed: %s", hipGetErrorString(e));
+	}
+	if (nbad)
+	{
+		hnsw_gpu_index_destroy(ix);
+		return fail(HNSW_GPU_ERR_ARG, "element image is corrupt: %u bad link counts / link targets", nbad);
+	}
+	ix->n = n;
+	*out = ix;
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_index_create_empty(const HnswMetadata *meta, size_t capacity, int device, hnsw_gpu_index **out)
+{
+	if (!out) return fail(HNSW_GPU_ERR_ARG, "out is NULL");
+	return alloc_index(meta, capacity, device, out);
+}
+
+extern "C" int hnsw_gpu_index_append_dev(hnsw_gpu_index *ix, const coord_t *d_vectors, const label_t *d_labels,
+										 size_t n, void *stream)
+{
+	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
+	if (n == 0) return HNSW_GPU_OK;
+	if (!d_vectors) return fail(HNSW_GPU_ERR_ARG, "vectors is NULL");
+	if (ix->n + n > ix->cap) return fail(HNSW_GPU_ERR_ARG, "append exceeds capacity (%zu + %zu > %zu)", ix->n, n, ix->cap);
+	HIPCHK(hipSetDevice(ix->device));
+	const uint32_t blocks = (uint32_t) ((n + 3) / 4);
+	hipLaunchKernelGGL(append_rows_kernel, dim3(blocks), dim3(256), 0, (hipStream_t) stream, d_vectors, d_labels,
+					   (uint32_t) ix->n, (uint32_t) n, (uint32_t) ix->meta.dim, ix->stride, ix->lstride, ix->vec,
+					   ix->links, ix->labels);
+	HIPCHK(hipGetLastError());
+	ix->n += n;
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_index_append(hnsw_gpu_index *ix, const coord_t *vectors, const label_t *labels, size_t n)
+{
+	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
+	if (n == 0) return HNSW_GPU_OK;
+	if (!vectors) return fail(HNSW_GPU_ERR_ARG, "vectors is NULL");
+	if (ix->n + n > ix->cap) return fail(HNSW_GPU_ERR_ARG, "append exceeds capacity (%zu + %zu > %zu)", ix->n, n, ix->cap);
+	HIPCHK(hipSetDevice(ix->device));
+	const size_t dim = ix->meta.dim;
+	const size_t per = std::max<size_t>(1, STAGE_BYTES / (dim * 4 + 8));
+	int rc = ensure_scratch(ix, std::min(per, n) * (dim * 4 + 8));
+	if (rc) return rc;
+	for (size_t first = 0; first < n; first += per)
+	{
+		const size_t cnt = std::min(per, n - first);
+		float *dv = (float *) ix->scratch;
+		uint64_t *dl = (uint64_t *) ((char *) ix->scratch + round_up(cnt * dim * 4, 8));
+		HIPCHK(hipMemcpy(dv, vectors + first * dim, cnt * dim * 4, hipMemcpyHostToDevice));
+		if (labels) HIPCHK(hipMemcpy(dl, labels + first, cnt * 8, hipMemcpyHostToDevice));
+		rc = hnsw_gpu_index_append_dev(ix, dv, labels ? dl : nullptr, cnt, nullptr);
+		if (rc) return rc;
+		HIPCHK(hipDeviceSynchronize());
+	}
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_index_export_flat(hnsw_gpu_index *ix, void *elements)
+{
+	if (!ix || !elements) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	HIPCHK(hipSetDevice(ix->device));
+	const size_t esz = ix->meta.size_data_per_element;
+	const size_t per = std::max<size_t>(1, STAGE_BYTES / esz);
+	uint32_t *stage = nullptr;
+	HIPCHK(hipMalloc(&stage, std::min(per, std::max<size_t>(ix->n, 1)) * esz));
+	hipError_t e = hipSuccess;
+	for (size_t first = 0; first < ix->n && e == hipSuccess; first += per)
+	{
+		const size_t cnt = std::min(per, ix->n - first);
+		const uint32_t blocks = (uint32_t) ((cnt + 3) / 4);
+		hipLaunchKernelGGL(export_elements_kernel, dim3(blocks), dim3(256), 0, 0, stage, esz / 4, (uint32_t) first,
+						   (uint32_t) cnt, (uint32_t) ix->meta.dim, ix->stride, (uint32_t) ix->meta.maxM, ix->lstride,
+						   ix->vec, ix->links, ix->labels);
+		e = hipMemcpy((char *) elements + first * esz, stage, cnt * esz, hipMemcpyDeviceToHost);
+	}
+	(void) hipFree(stage);
+	if (e != hipSuccess) return fail(HNSW_GPU_ERR_HIP, "index download failed: %s", hipGetErrorString(e));
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int deleted)
+{
+	if (!ix || idx >= ix->n) return fail(HNSW_GPU_ERR_ARG, "bad element %u", (unsigned) idx);
+	HIPCHK(hipSetDevice(ix->device));
+	uint64_t l;
+	HIPCHK(hipMemcpy(&l, ix->labels + idx, 8, hipMemcpyDeviceToHost));
+	if (deleted) l |= (uint64_t) 1 << HNSW_LABEL_DELETED_BIT; else l &= ~((uint64_t) 1 << HNSW_LABEL_DELETED_BIT);
+	HIPCHK(hipMemcpy(ix->labels + idx, &l, 8, hipMemcpyHostToDevice));
+	return HNSW_GPU_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// search
+// ------------------------------------------------------------------------------------
+typedef void (*search_kernel_t)(const SearchArgs);
+
+static search_kernel_t pick_search_kernel(int func)
+{
+	switch (func)
+	{
+		case F_L2:     return hnsw_search_kernel<F_L2>;
+		case F_COSINE: return hnsw_search_kernel<F_COSINE>;
+		default:       return hnsw_search_kernel<F_MANHATTAN>;
+	}
+}
+
+static const size_t LDS_PER_CU = 160 * 1024;
+static const size_t VIS_BUDGET_BYTES = (size_t) 24 << 30;     // cap on bitmap workspace
+
+static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t nq, size_t ef, int mode,
+						 uint64_t *d_labels, uint32_t *d_idx, float *d_dists, uint32_t *d_counts,
+						 uint32_t *d_stats, hipStream_t stream)
+{
+	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
+	if (nq == 0) return HNSW_GPU_OK;
+	if (!d_queries || !d_counts || (mode == 0 && !d_labels) || (mode == 1 && !d_idx))
+		return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
+	if (ef == 0 || ef > 65536) return fail(HNSW_GPU_ERR_ARG, "ef %zu out of range [1, 65536]", ef);
+	if (nq >= 0xFFFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "too many queries");
+	HIPCHK(hipSetDevice(ix->device));
+
+	SearchArgs a;
+	memset(&a, 0, sizeof(a));
+	a.vec = ix->vec; a.links = ix->links; a.labels = ix->labels;
+	a.n = (uint32_t) ix->n; a.dim = (uint32_t) ix->meta.dim; a.stride = ix->stride;
+	a.nchunks = ix->stride / 4; a.kiters = (a.nchunks + 15) / 16;
+	a.maxM = (uint32_t) ix->meta.maxM; a.lstride = ix->lstride; a.entry = ix->meta.enterpoint_node;
+	a.queries = d_queries; a.nq = (uint32_t) nq; a.ef = (uint32_t) ef; a.ccap = (uint32_t) (2 * ef);
+	a.out_labels = d_labels; a.out_idx = d_idx; a.out_dists = d_dists; a.out_counts = d_counts; a.out_stats = d_stats;
+	a.mode = mode;
+	if (a.n > 0 && a.entry >= a.n) return fail(HNSW_GPU_ERR_ARG, "enterpoint_node %u >= count %u", a.entry, a.n);
+
+	// LDS carve per wave
+	const uint32_t kit2 = (uint32_t) round_up(a.kiters, 2);
+	a.qpad_floats = kit2 * 64;
+	size_t off = (size_t) a.qpad_floats * 4;
+	a.off_res = (uint32_t) off;     off += round_up((ef + 1) * 8, 16);
+	a.off_cand = (uint32_t) off;    off += round_up((2 * ef + 1) * 8, 16);
+	a.off_newid = (uint32_t) off;   off += 64 * 4;
+	a.off_newdist = (uint32_t) off; off += 64 * 4;
+	a.wave_bytes = (uint32_t) round_up(off, 16);
+	if (a.wave_bytes > LDS_PER_CU)
+		return fail(HNSW_GPU_ERR_ARG, "ef=%zu dim=%zu needs %u bytes of LDS per query (> %zu)", ef, ix->meta.dim,
+					a.wave_bytes, LDS_PER_CU);
+	uint32_t wpb = 4;
+	while (wpb > 1 && (size_t) wpb * a.wave_bytes > 64 * 1024) wpb >>= 1;
+	const size_t lds = (size_t) wpb * a.wave_bytes;
+	search_kernel_t kern = pick_search_kernel((int) ix->meta.dist_func);
+	if (lds > 48 * 1024)
+		HIPCHK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+	int per_cu = 0;
+	HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, (int) (wpb * 64), lds));
+	if (per_cu < 1) per_cu = 1;
+	const char *env = getenv("HNSW_GPU_BLOCKS_PER_CU");
+	if (env && atoi(env) > 0) per_cu = std::min(per_cu, atoi(env));
+	size_t blocks = std::min<size_t>((nq + wpb - 1) / wpb, (size_t) per_cu * ix->num_cu);
+
+	// workspace: one bitmap + log per resident wave
+	const size_t words = std::max<size_t>(1, (ix->n + 31) / 32);
+	const size_t max_slots = std::max<size_t>(wpb, VIS_BUDGET_BYTES / (words * 4));
+	if (blocks * wpb > max_slots) blocks = std::max<size_t>(1, max_slots / wpb);
+	const size_t slots = blocks * wpb;
+	const uint32_t logcap = 8192;
+	if (slots > ix->vis_slots || words != ix->vis_words)
+	{
+		if (ix->vis) (void) hipFree(ix->vis);
+		if (ix->vlog) (void) hipFree(ix->vlog);
+		ix->vis = nullptr; ix->vlog = nullptr; ix->vis_slots = 0;
+		HIPCHK(hipMalloc(&ix->vis, slots * words * 4));
+		HIPCHK(hipMalloc(&ix->vlog, slots * (size_t) logcap * 4));
+		HIPCHK(hipMemsetAsync(ix->vis, 0, slots * words * 4, stream));
+		ix->vis_slots = slots; ix->vis_words = words; ix->logcap = logcap;
+	}
+	a.vis = ix->vis; a.vis_words = words; a.vlog = ix->vlog; a.logcap = ix->logcap;
+	a.ticket = ix->ticket; a.err = ix->ticket + 1;
+	HIPCHK(hipMemsetAsync(ix->ticket, 0, 8, stream));
+
+	HIPCHK(hipEventRecord(ix->ev0, stream));
+	hipLaunchKernelGGL(kern, dim3((uint32_t) blocks), dim3(wpb * 64), lds, stream, a);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipEventRecord(ix->ev1, stream));
+	ix->timed = true;
+	ix->last_slots = (uint32_t) slots;
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_search_batch_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t ef,
+										 label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
+										 void *stream)
+{
+	return launch_search(ix, d_queries, nq, ef, 0, d_labels, nullptr, d_dists, d_counts, d_stats, (hipStream_t) stream);
+}
+
+extern "C" int hnsw_gpu_search_base_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t ef,
+										idx_t *d_idx, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
+										void *stream)
+{
+	return launch_search(ix, d_queries, nq, ef, 1, nullptr, d_idx, d_dists, d_counts, d_stats, (hipStream_t) stream);
+}
+
+extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries, size_t nq, size_t ef,
+									 label_t *labels, dist_t *dists, uint32_t *counts)
+{
+	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
+	if (nq == 0) return HNSW_GPU_OK;
+	if (!queries || !labels || !counts) return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
+	if (ef == 0 || ef > 65536) return fail(HNSW_GPU_ERR_ARG, "ef %zu out of range [1, 65536]", ef);
+	HIPCHK(hipSetDevice(ix->device));
+	const size_t dim = ix->meta.dim;
+	const size_t qb = round_up(nq * dim * 4, 256), lb = round_up(nq * ef * 8, 256), db = round_up(nq * ef * 4, 256),
+				 cb = round_up(nq * 4, 256);
+	int rc = ensure_scratch(ix, qb + lb + db + cb);
+	if (rc) return rc;
+	char *p = (char *) ix->scratch;
+	float *dq = (float *) p; uint64_t *dl = (uint64_t *) (p + qb); float *dd = (float *) (p + qb + lb);
+	uint32_t *dc = (uint32_t *) (p + qb + lb + db);
+	HIPCHK(hipMemcpy(dq, queries, nq * dim * 4, hipMemcpyHostToDevice));
+	rc = launch_search(ix, dq, nq, ef, 0, dl, nullptr, dd, dc, nullptr, nullptr);
+	if (rc) return rc;
+	HIPCHK(hipMemcpy(labels, dl, nq * ef * 8, hipMemcpyDeviceToHost));
+	if (dists) HIPCHK(hipMemcpy(dists, dd, nq * ef * 4, hipMemcpyDeviceToHost));
+	HIPCHK(hipMemcpy(counts, dc, nq * 4, hipMemcpyDeviceToHost));
+	uint32_t err = 0;
+	HIPCHK(hipMemcpy(&err, ix->ticket + 1, 4, hipMemcpyDeviceToHost));
+	if (err) return fail(HNSW_GPU_ERR_INTERNAL, "device-side invariant failed (%u)", err);
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_last_search_ms(hnsw_gpu_index *ix, float *ms)
+{
+	if (!ix || !ms) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	if (!ix->timed) return fail(HNSW_GPU_ERR_ARG, "no search has been launched on this index");
+	HIPCHK(hipSetDevice(ix->device));
+	HIPCHK(hipEventSynchronize(ix->ev1));
+	HIPCHK(hipEventElapsedTime(ms, ix->ev0, ix->ev1));
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_last_search_slots(hnsw_gpu_index *ix, uint32_t *slots)
+{
+	if (!ix || !slots) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	*slots = ix->last_slots;
+	return HNSW_GPU_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// batched distances (hnsw_dist_func over many rows)
+// ------------------------------------------------------------------------------------
+template <int FUNC>
+__global__ __launch_bounds__(256) void dist_batch_kernel(const float *__restrict__ q, const float *__restrict__ rows,
+														 uint32_t nrows, uint32_t dim, uint32_t stride, uint32_t nchunks,
+														 uint32_t kiters, uint32_t qpad_floats, float *__restrict__ out)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	float *qf = reinterpret_cast<float *>(smem);
+	const float4 *q4 = reinterpret_cast<const float4 *>(smem);
+	for (uint32_t e = threadIdx.x; e < qpad_floats; e += blockDim.x) qf[e] = (e < dim) ? q[e] : 0.f;
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
+	float qnorm = 0.f;
+	if (FUNC == F_COSINE) qnorm = query_norm(q4, nchunks, kiters, lane);
+	for (uint32_t base = wave * 8; base < nrows; base += nwaves * 8)
+	{
+		const uint32_t cnt = min(8u, nrows - base);
+		auto direct = [base](uint32_t r) { return base + r; };
+		score_rows<FUNC>(rows, stride, q4, nchunks, kiters, qnorm, direct, cnt, out + base, lane);
+	}
+}
+
+extern "C" int hnsw_gpu_dist_batch_dev(dist_func_t func, const coord_t *d_q, const coord_t *d_rows, size_t nrows,
+									   size_t dim, size_t row_stride, dist_t *d_out, void *stream)
+{
+	if (nrows == 0) return HNSW_GPU_OK;
+	if (!d_q || !d_rows || !d_out) return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
+	if ((int) func < 0 || (int) func > 2) return fail(HNSW_GPU_ERR_ARG, "bad dist_func %d", (int) func);
+	if (dim == 0 || row_stride < dim || (row_stride & 3) || (((uintptr_t) d_rows) & 15))
+		return fail(HNSW_GPU_ERR_ARG, "rows must be 16-byte aligned with stride %% 4 == 0 and stride >= dim");
+	if (nrows >= 0xFFFFFFF0ull) return fail(HNSW_GPU_ERR_ARG, "too many rows");
+	const uint32_t nchunks = (uint32_t) (row_stride / 4), kiters = (nchunks + 15) / 16;
+	const uint32_t qpad = (uint32_t) round_up(kiters, 2) * 64;
+	const size_t lds = (size_t) qpad * 4;
+	if (lds > 64 * 1024) return fail(HNSW_GPU_ERR_ARG, "dim %zu too large", dim);
+	const uint32_t blocks = (uint32_t) std::min<size_t>((nrows + 31) / 32, 256 * 8);
+	hipStream_t s = (hipStream_t) stream;
+	switch ((int) func)
+	{
+		case F_L2:
+			hipLaunchKernelGGL(dist_batch_kernel<F_L2>, dim3(blocks), dim3(256), lds, s, d_q, d_rows, (uint32_t) nrows,
+							   (uint32_t) dim, (uint32_t) row_stride, nchunks, kiters, qpad, d_out);
+			break;
+		case F_COSINE:
+			hipLaunchKernelGGL(dist_batch_kernel<F_COSINE>, dim3(blocks), dim3(256), lds, s, d_q, d_rows, (uint32_t) nrows,
+							   (uint32_t) dim, (uint32_t) row_stride, nchunks, kiters, qpad, d_out);
+			break;
+		default:
+			hipLaunchKernelGGL(dist_batch_kernel<F_MANHATTAN>, dim3(blocks), dim3(256), lds, s, d_q, d_rows, (uint32_t) nrows,
+							   (uint32_t) dim, (uint32_t) row_stride, nchunks, kiters, qpad, d_out);
+			break;
+	}
+	HIPCHK(hipGetLastError());
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_dist_batch(dist_func_t func, const coord_t *q, const coord_t *rows, size_t nrows, size_t dim,
+								   dist_t *out)
+{
+	if (nrows == 0) return HNSW_GPU_OK;
+	if (!q || !rows || !out) return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
+	if (dim == 0) return fail(HNSW_GPU_ERR_ARG, "dim is 0");
+	if (hnsw_gpu_device_count() <= 0) return fail(HNSW_GPU_ERR_NODEVICE, "no HIP device visible (this library has no CPU path)");
+	const size_t stride = round_up(dim, 4);
+	float *dq = nullptr, *dr = nullptr, *dout = nullptr;
+	hipError_t e = hipSuccess;
+	int rc = HNSW_GPU_OK;
+	if ((e = hipMalloc(&dq, dim * 4)) != hipSuccess || (e = hipMalloc(&dr, nrows * stride * 4)) != hipSuccess ||
+		(e = hipMalloc(&dout, nrows * 4)) != hipSuccess)
+		rc = fail(HNSW_GPU_ERR_NOMEM, "device allocation failed: %s", hipGetErrorString(e));
+	if (!rc && stride != dim && (e = hipMemset(dr, 0, nrows * stride * 4)) != hipSuccess) rc = fail(HNSW_GPU_ERR_HIP, "memset failed");
+	if (!rc && ((e = hipMemcpy(dq, q, dim * 4, hipMemcpyHostToDevice)) != hipSuccess ||
+				(e = hipMemcpy2D(dr, stride * 4, rows, dim * 4, dim * 4, nrows, hipMemcpyHostToDevice)) != hipSuccess))
+		rc = fail(HNSW_GPU_ERR_HIP, "upload failed: %s", hipGetErrorString(e));
+	if (!rc) rc = hnsw_gpu_dist_batch_dev(func, dq, dr, nrows, dim, stride, dout, nullptr);
+	if (!rc && (e = hipMemcpy(out, dout, nrows * 4, hipMemcpyDeviceToHost)) != hipSuccess)
+		rc = fail(HNSW_GPU_ERR_HIP, "download failed: %s", hipGetErrorString(e));
+	if (dq) (void) hipFree(dq);
+	if (dr) (void) hipFree(dr);
+	if (dout) (void) hipFree(dout);
+	return rc;
+}
+
+// ------------------------------------------------------------------------------------
+// exhaustive k-NN with the same distance code (recall ground truth)
+// ------------------------------------------------------------------------------------
+// grid = (splits, nq); each wave scans a contiguous slice of the rows for one query and keeps a
+// sorted top-k of (ord(dist)<<32 | idx) keys in LDS; partial lists are merged by topk_merge_kernel.
+template <int FUNC>
+__global__ __launch_bounds__(256) void bruteforce_kernel(const float *__restrict__ vec, uint32_t n, uint32_t dim,
+														 uint32_t stride, uint32_t nchunks, uint32_t kiters,
+														 uint32_t qpad_floats, const float *__restrict__ queries,
+														 uint32_t k, uint64_t *__restrict__ part /* [nq][splits*4][k] */)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const uint32_t qi = blockIdx.y;
+	float *qf = reinterpret_cast<float *>(smem);
+	const float4 *q4 = reinterpret_cast<const float4 *>(smem);
+	for (uint32_t e = threadIdx.x; e < qpad_floats; e += blockDim.x) qf[e] = (e < dim) ? queries[(size_t) qi * dim + e] : 0.f;
+	__syncthreads();
+	const int lane = threadIdx.x & 63;
+	const uint32_t wib = threadIdx.x >> 6;
+	uint64_t *top = reinterpret_cast<uint64_t *>(smem + (size_t) qpad_floats * 4) + (size_t) wib * (k + 1);
+	float *dist8 = reinterpret_cast<float *>(smem + (size_t) qpad_floats * 4 + (size_t) 4 * (k + 1) * 8) + wib * 8;
+	const uint32_t nw = gridDim.x * 4, w = blockIdx.x * 4 + wib;
+	const uint32_t lo = (uint32_t) ((uint64_t) n * w / nw), hi = (uint32_t) ((uint64_t) n * (w + 1) / nw);
+	float qnorm = 0.f;
+	if (FUNC == F_COSINE) qnorm = query_norm(q4, nchunks, kiters, lane);
+	uint32_t tsize = 0;
+	uint64_t worst = ~0ull;
+	for (uint32_t base = lo; base < hi; base += 8)
+	{
+		const uint32_t cnt = min(8u, hi - base);
+		auto direct = [base](uint32_t r) { return base + r; };
+		score_rows<FUNC>(vec, stride, q4, nchunks, kiters, qnorm, direct, cnt, dist8, lane);
+		wave_sync();
+		for (uint32_t r = 0; r < cnt; r++)
+		{
+			const uint64_t key = ((uint64_t) ord_f32(dist8[r]) << 32) | (base + r);
+			if (tsize < k || key < worst)
+			{
+				tsize = sorted_insert(top, tsize, key, k, lane);
+				worst = top[tsize - 1];
+			}
+		}
+		wave_sync();
+	}
+	uint64_t *dst = part + ((size_t) qi * nw + w) * k;
+	for (uint32_t i = lane; i < k; i += 64) dst[i] = (i < tsize) ? top[i] : ~0ull;
+}
+
+// One wave per query: merge `nlists` ascending key lists of length k into the k smallest.
+__global__ __launch_bounds__(64) void key_merge_kernel(const uint64_t *__restrict__ part, uint32_t nlists, uint32_t k,
+													   uint32_t *__restrict__ out_idx, float *__restrict__ out_dist)
+{
+	const uint32_t qi = blockIdx.x;
+	const int lane = threadIdx.x;
+	const uint64_t *src = part + (size_t) qi * nlists * k;
+	const uint32_t total = nlists * k;
+	for (uint32_t x = lane; x < total; x += 64)
+	{
+		const uint32_t l = x / k;
+		const uint64_t key = src[x];
+		if (key == ~0ull) continue;
+		uint32_t rank = x - l * k;
+		for (uint32_t m = 0; m < nlists && rank < k; m++)
+		{
+			if (m == l) continue;
+			const uint64_t *o = src + (size_t) m * k;
+			uint32_t lo = 0, hi = k;                       // number of keys in list m below `key` (keys are unique)
+			while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (o[mid] < key) lo = mid + 1; else hi = mid; }
+			rank += lo;
+		}
+		if (rank < k)
+		{
+			out_idx[(size_t) qi * k + rank] = (uint32_t) key;
+			if (out_dist) out_dist[(size_t) qi * k + rank] = unord_f32((uint32_t) (key >> 32));
+		}
+	}
+}
+
+__global__ void fill_u32_kernel(uint32_t *p, size_t n, uint32_t v)
+{
+	size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < n) p[i] = v;
+}
+
+extern "C" int hnsw_gpu_bruteforce_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t k, idx_t *d_idx,
+									   dist_t *d_dists, void *stream)
+{
+	if (!ix || !d_queries || !d_idx) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	if (nq == 0) return HNSW_GPU_OK;
+	if (k == 0 || k > 1024) return fail(HNSW_GPU_ERR_ARG, "k %zu out of range [1, 1024]", k);
+	if (nq > 65535) return fail(HNSW_GPU_ERR_ARG, "at most 65535 queries per call");
+	HIPCHK(hipSetDevice(ix->device));
+	hipStream_t s = (hipStream_t) stream;
+	const uint32_t nchunks = ix->stride / 4, kiters = (nchunks + 15) / 16;
+	const uint32_t qpad = (uint32_t) round_up(kiters, 2) * 64;
+	uint32_t splits = (uint32_t) std::max<size_t>(1, std::min<size_t>(64, (size_t) (4 * ix->num_cu) / nq));
+	splits = (uint32_t) std::min<size_t>(splits, std::max<size_t>(1, ix->n / 64));
+	const uint32_t nlists = splits * 4;
+	const size_t lds = (size_t) qpad * 4 + (size_t) 4 * (k + 1) * 8 + 4 * 8 * 4;
+	if (lds > 64 * 1024) return fail(HNSW_GPU_ERR_ARG, "k/dim too large for brute force");
+	int rc = ensure_scratch(ix, nq * nlists * k * 8);
+	if (rc) return rc;
+	uint64_t *part = (uint64_t *) ix->scratch;
+	const size_t tot = nq * k;
+	hipLaunchKernelGGL(fill_u32_kernel, dim3((uint32_t) ((tot + 255) / 256)), dim3(256), 0, s, d_idx, tot, LINK_NONE);
+	if (d_dists)
+		hipLaunchKernelGGL(fill_u32_kernel, dim3((uint32_t) ((tot + 255) / 256)), dim3(256), 0, s, (uint32_t *) d_dists, tot,
+						   0x7F800000u);
+	dim3 grid(splits, (uint32_t) nq);
+#define BF_LAUNCH(F)                                                                                                   \
+	hipLaunchKernelGGL(bruteforce_kernel<F>, grid, dim3(256), lds, s, ix->vec, (uint32_t) ix->n, (uint32_t) ix->meta.dim, \
+					   ix->stride, nchunks, kiters, qpad, d_queries, (uint32_t) k, part)
+	switch ((int) ix->meta.dist_func)
+	{
+		case F_L2: BF_LAUNCH(F_L2); break;
+		case F_COSINE: BF_LAUNCH(F_COSINE); break;
+		default: BF_LAUNCH(F_MANHATTAN); break;
+	}
+#undef BF_LAUNCH
+	hipLaunchKernelGGL(key_merge_kernel, dim3((uint32_t) nq), dim3(64), 0, s, part, nlists, (uint32_t) k, d_idx, d_dists);
+	HIPCHK(hipGetLastError());
+	return HNSW_GPU_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// multi-shard merge: nlists x (dist,label) lists per query -> ef best by (dist, label)
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ bool dl_less(uint32_t da, uint64_t la, uint32_t db, uint64_t lb)
+{
+	return da < db || (da == db && la < lb);
+}
+
+__global__ __launch_bounds__(64) void topk_merge_kernel(const uint64_t *__restrict__ in_labels, const float *__restrict__ in_dists,
+														uint32_t nlists, uint32_t nq, uint32_t ef,
+														uint64_t *__restrict__ out_labels, float *__restrict__ out_dists,
+														uint32_t *__restrict__ out_counts)
+{
+	const uint32_t qi = blockIdx.x;
+	const int lane = threadIdx.x;
+	const uint32_t total = nlists * ef;
+	uint32_t kept = 0;
+	for (uint32_t x0 = 0; x0 < total; x0 += 64)
+	{
+		const uint32_t x = x0 + lane;
+		bool emit = false;
+		if (x < total)
+		{
+			const uint32_t l = x / ef, i = x - l * ef;
+			const size_t at = ((size_t) l * nq + qi) * ef + i;
+			const uint64_t lab = in_labels[at];
+			const uint32_t d = ord_f32(in_dists[at]);
+			if (lab != ~0ull)
+			{
+				uint32_t rank = i;
+				for (uint32_t m = 0; m < nlists && rank < ef; m++)
+				{
+					if (m == l) continue;
+					const size_t ob = ((size_t) m * nq + qi) * ef;
+					uint32_t lo = 0, hi = ef;
+					while (lo < hi)
+					{
+						const uint32_t mid = (lo + hi) >> 1;
+						const uint64_t ol = in_labels[ob + mid];
+						const uint32_t od = ord_f32(in_dists[ob + mid]);
+						// equal keys (cannot happen for disjoint shards) go to the lower list number
+						const bool below = (ol != ~0ull) && (dl_less(od, ol, d, lab) || (od == d && ol == lab && m < l));
+						if (below) lo = mid + 1; else hi = mid;
+					}
+					rank += lo;
+				}
+				if (rank < ef)
+				{
+					out_labels[(size_t) qi * ef + rank] = lab;
+					if (out_dists) out_dists[(size_t) qi * ef + rank] = unord_f32(d);
+					emit = true;
+				}
+			}
+		}
+		kept += (uint32_t) __builtin_popcountll(__ballot(emit));
+	}
+	for (uint32_t i = kept + lane; i < ef; i += 64)
+	{
+		out_labels[(size_t) qi * ef + i] = ~0ull;
+		if (out_dists) out_dists[(size_t) qi * ef + i] = __builtin_inff();
+	}
+	if (lane == 0) out_counts[qi] = kept;
+}
+
+extern "C" int hnsw_gpu_merge_topk_dev(int device, const label_t *d_in_labels, const dist_t *d_in_dists, size_t nlists,
+									   size_t nq, size_t ef, label_t *d_out_labels, dist_t *d_out_dists,
+									   uint32_t *d_out_counts, void *stream)
+{
+	if (nq == 0) return HNSW_GPU_OK;
+	if (!d_in_labels || !d_in_dists || !d_out_labels || !d_out_counts) return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
+	if (nlists == 0 || ef == 0) return fail(HNSW_GPU_ERR_ARG, "nlists and ef must be positive");
+	if (nlists * ef >= 0xFFFFFFFFull || nq >= 0x7FFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "merge too large");
+	HIPCHK(hipSetDevice(device));
+	hipLaunchKernelGGL(topk_merge_kernel, dim3((uint32_t) nq), dim3(64), 0, (hipStream_t) stream, d_in_labels, d_in_dists,
+					   (uint32_t) nlists, (uint32_t) nq, (uint32_t) ef, d_out_labels, d_out_dists, d_out_counts);
+	HIPCHK(hipGetLastError());
+	return HNSW_GPU_OK;
+}

@@ -1,0 +1,248 @@
+"""Host-side face of the device mirror (include/hnsw_gpu.h) — thin ctypes plumbing.
+
+Names follow the reference's domain: an *index* of *elements* (links | vector | label),
+searched with a beam of ``efSearch``; see embedding.c:214-244 for the metadata derivation
+mirrored by :func:`make_meta`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from ._lib import HnswMetadata, check, gpu_lib
+
+DIST_L2, DIST_COSINE, DIST_MANHATTAN = 0, 1, 2        # embedding.h:22-26
+# opclass -> metric, embedding--0.3.6.sql:57-70
+OPCLASS = {"ann_l2_ops": DIST_L2, "ann_cos_ops": DIST_COSINE, "ann_manhattan_ops": DIST_MANHATTAN}
+DEFAULT_M, DEFAULT_EF_CONSTRUCTION, DEFAULT_EF_SEARCH = 100, 16, 64   # embedding.c:111-113
+LABEL_DELETED = np.uint64(1) << np.uint64(48)          # embedding.c:44,948-953
+NO_LABEL = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def make_meta(dims: int, m: int = DEFAULT_M, efconstruction: int = DEFAULT_EF_CONSTRUCTION,
+              efsearch: int = DEFAULT_EF_SEARCH, dist_func: int = DIST_L2) -> HnswMetadata:
+    """The reloptions -> HnswMetadata derivation of hnsw_get_index (embedding.c:214-244)."""
+    if dims <= 0:
+        raise ValueError("HNSW index requires 'dims' to be specified")      # embedding.c:219-221
+    mt = HnswMetadata()
+    mt.dim = dims
+    mt.M = m
+    mt.maxM = 2 * m
+    mt.data_size = dims * 4
+    mt.offset_data = (mt.maxM + 1) * 4
+    mt.offset_label = mt.offset_data + mt.data_size
+    mt.size_data_per_element = mt.offset_label + 8
+    mt.elems_per_page = (8192 - 24 - 4) // (mt.size_data_per_element + 4)
+    if mt.elems_per_page == 0:
+        raise ValueError("Element doesn't fit in Postgres page")            # embedding.c:230-231
+    mt.efConstruction = efconstruction
+    mt.efSearch = efsearch
+    mt.dist_func = dist_func
+    mt.enterpoint_node = 0
+    return mt
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def _dptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+class GpuIndex:
+    """An HBM-resident mirror of one HNSW index on one MI355X."""
+
+    def __init__(self, handle: int, meta: HnswMetadata, device: int):
+        self._h = C.c_void_p(handle)
+        self.meta = meta
+        self.device = device
+        self.L = gpu_lib()
+
+    # ------------------------------------------------------------------ lifetime
+    @classmethod
+    def from_flat(cls, meta: HnswMetadata, elements: np.ndarray, n: int, device: int = 0) -> "GpuIndex":
+        """Mirror `n` host element images ([count|links|vector|label], embedding.c:222-228)."""
+        L = gpu_lib()
+        elements = np.ascontiguousarray(elements, dtype=np.uint8)
+        if elements.size != n * meta.size_data_per_element:
+            raise ValueError("element image has the wrong size")
+        h = C.c_void_p()
+        check(L.hnsw_gpu_index_create_from_flat(C.byref(meta), elements.ctypes.data, n, device, C.byref(h)),
+              "hnsw_gpu_index_create_from_flat")
+        return cls(h.value, meta, device)
+
+    @classmethod
+    def empty(cls, meta: HnswMetadata, capacity: int, device: int = 0) -> "GpuIndex":
+        L = gpu_lib()
+        h = C.c_void_p()
+        check(L.hnsw_gpu_index_create_empty(C.byref(meta), capacity, device, C.byref(h)),
+              "hnsw_gpu_index_create_empty")
+        return cls(h.value, meta, device)
+
+    def close(self) -> None:
+        if self._h:
+            self.L.hnsw_gpu_index_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def handle(self) -> int:
+        return self._h.value
+
+    @property
+    def count(self) -> int:
+        return int(self.L.hnsw_gpu_index_count(self._h))
+
+    # ------------------------------------------------------------------- content
+    def append(self, vectors: np.ndarray, labels: Optional[np.ndarray] = None) -> None:
+        vectors = np.ascontiguousarray(vectors, dtype=np.float32).reshape(-1, self.meta.dim)
+        lp = None
+        if labels is not None:
+            labels = np.ascontiguousarray(labels, dtype=np.uint64)
+            lp = labels.ctypes.data
+        check(self.L.hnsw_gpu_index_append(self._h, vectors.ctypes.data, lp, vectors.shape[0]),
+              "hnsw_gpu_index_append")
+
+    def append_torch(self, vectors, labels=None) -> None:
+        torch = _torch()
+        assert vectors.is_cuda and vectors.dtype == torch.float32 and vectors.is_contiguous()
+        s = torch.cuda.current_stream(vectors.device).cuda_stream
+        check(self.L.hnsw_gpu_index_append_dev(self._h, vectors.data_ptr(), _dptr(labels),
+                                               vectors.shape[0], s), "hnsw_gpu_index_append_dev")
+
+    def export_flat(self) -> np.ndarray:
+        out = np.empty(self.count * self.meta.size_data_per_element, np.uint8)
+        check(self.L.hnsw_gpu_index_export_flat(self._h, out.ctypes.data), "hnsw_gpu_index_export_flat")
+        return out
+
+    def set_deleted(self, idx: int, deleted: bool = True) -> None:
+        check(self.L.hnsw_gpu_index_set_deleted(self._h, idx, int(deleted)), "hnsw_gpu_index_set_deleted")
+
+    # -------------------------------------------------------------------- search
+    def search(self, queries: np.ndarray, ef: Optional[int] = None):
+        """Batch of hnsw_search() calls with host buffers.
+        Returns (labels[nq, ef] u64, dists[nq, ef] f32, counts[nq] u32)."""
+        ef = int(ef or self.meta.efSearch)
+        queries = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, self.meta.dim)
+        nq = queries.shape[0]
+        labels = np.empty((nq, ef), np.uint64)
+        dists = np.empty((nq, ef), np.float32)
+        counts = np.empty(nq, np.uint32)
+        check(self.L.hnsw_gpu_search_batch(self._h, queries.ctypes.data, nq, ef, labels.ctypes.data,
+                                           dists.ctypes.data, counts.ctypes.data), "hnsw_gpu_search_batch")
+        return labels, dists, counts
+
+    def search_torch(self, queries, ef: Optional[int] = None, out=None, stats: bool = False, base: bool = False):
+        """Same with everything resident in HBM (torch tensors only carry the pointers).
+        `out` may be a dict from a previous call to reuse its buffers.  With base=True runs
+        searchBaseLayer only and returns element numbers under 'idx'."""
+        torch = _torch()
+        ef = int(ef or self.meta.efSearch)
+        assert queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()
+        nq = queries.shape[0]
+        dev = queries.device
+        if out is None:
+            out = {}
+            if base:
+                out["idx"] = torch.empty((nq, ef), dtype=torch.int32, device=dev)
+            else:
+                out["labels"] = torch.empty((nq, ef), dtype=torch.int64, device=dev)
+            out["dists"] = torch.empty((nq, ef), dtype=torch.float32, device=dev)
+            out["counts"] = torch.empty(nq, dtype=torch.int32, device=dev)
+            out["stats"] = torch.zeros((nq, 2), dtype=torch.int32, device=dev) if stats else None
+        s = torch.cuda.current_stream(dev).cuda_stream
+        if base:
+            check(self.L.hnsw_gpu_search_base_dev(self._h, queries.data_ptr(), nq, ef, out["idx"].data_ptr(),
+                                                  out["dists"].data_ptr(), out["counts"].data_ptr(),
+                                                  _dptr(out.get("stats")), s), "hnsw_gpu_search_base_dev")
+        else:
+            check(self.L.hnsw_gpu_search_batch_dev(self._h, queries.data_ptr(), nq, ef, out["labels"].data_ptr(),
+                                                   out["dists"].data_ptr(), out["counts"].data_ptr(),
+                                                   _dptr(out.get("stats")), s), "hnsw_gpu_search_batch_dev")
+        return out
+
+    def last_search_ms(self) -> float:
+        ms = C.c_float(0)
+        check(self.L.hnsw_gpu_last_search_ms(self._h, C.byref(ms)), "hnsw_gpu_last_search_ms")
+        return float(ms.value)
+
+    def last_search_slots(self) -> int:
+        v = C.c_uint32(0)
+        check(self.L.hnsw_gpu_last_search_slots(self._h, C.byref(v)), "hnsw_gpu_last_search_slots")
+        return int(v.value)
+
+    def bruteforce_torch(self, queries, k: int):
+        """Exact k nearest elements (idx, dists) by exhaustive scoring — recall ground truth."""
+        torch = _torch()
+        assert queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()
+        nq = queries.shape[0]
+        idx = torch.empty((nq, k), dtype=torch.int32, device=queries.device)
+        dst = torch.empty((nq, k), dtype=torch.float32, device=queries.device)
+        s = torch.cuda.current_stream(queries.device).cuda_stream
+        for q0 in range(0, nq, 32768):
+            q1 = min(nq, q0 + 32768)
+            check(self.L.hnsw_gpu_bruteforce_dev(self._h, queries[q0:q1].data_ptr(), q1 - q0, k,
+                                                 idx[q0:q1].data_ptr(), dst[q0:q1].data_ptr(), s),
+                  "hnsw_gpu_bruteforce_dev")
+        return idx, dst
+
+
+# ---------------------------------------------------------------------- distances
+def dist_batch(func: int, q: np.ndarray, rows: np.ndarray) -> np.ndarray:
+    """out[i] = hnsw_dist_func(func, q, rows[i]) on the device (distfunc.c:171-174)."""
+    L = gpu_lib()
+    q = np.ascontiguousarray(q, dtype=np.float32).ravel()
+    rows = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, q.size)
+    out = np.empty(rows.shape[0], np.float32)
+    check(L.hnsw_gpu_dist_batch(func, q.ctypes.data, rows.ctypes.data, rows.shape[0], q.size, out.ctypes.data),
+          "hnsw_gpu_dist_batch")
+    return out
+
+
+def _scalar(func: int, a, b) -> float:
+    a = np.ascontiguousarray(a, dtype=np.float32).ravel()
+    b = np.ascontiguousarray(b, dtype=np.float32).ravel()
+    if a.size != b.size:                      # calc_distance, embedding.c:1030-1035
+        raise ValueError(f"Different array dimensions {a.size} and {b.size}")
+    return float(dist_batch(func, a, b[None, :])[0])
+
+
+def l2_distance(a, b) -> float:
+    """SQL l2_distance(real[], real[]) / operator <-> (embedding--0.3.6.sql:20-21,31-35)."""
+    return _scalar(DIST_L2, a, b)
+
+
+def cosine_distance(a, b) -> float:
+    """SQL cosine_distance / operator <=> (embedding--0.3.6.sql:23-24,36-40)."""
+    return _scalar(DIST_COSINE, a, b)
+
+
+def manhattan_distance(a, b) -> float:
+    """SQL manhattan_distance / operator <~> (embedding--0.3.6.sql:26-27,41-44)."""
+    return _scalar(DIST_MANHATTAN, a, b)
+
+
+def merge_topk_torch(labels, dists, ef: int):
+    """Merge per-shard result lists [nlists, nq, ef] into the ef best per query (device)."""
+    torch = _torch()
+    L = gpu_lib()
+    assert labels.is_cuda and labels.dtype == torch.int64 and labels.is_contiguous()
+    assert dists.is_cuda and dists.dtype == torch.float32 and dists.is_contiguous()
+    nlists, nq = labels.shape[0], labels.shape[1]
+    dev = labels.device
+    ol = torch.empty((nq, ef), dtype=torch.int64, device=dev)
+    od = torch.empty((nq, ef), dtype=torch.float32, device=dev)
+    oc = torch.empty(nq, dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    check(L.hnsw_gpu_merge_topk_dev(dev.index or 0, labels.data_ptr(), dists.data_ptr(), nlists, nq, ef,
+                                    ol.data_ptr(), od.data_ptr(), oc.data_ptr(), s), "hnsw_gpu_merge_topk_dev")
+    return ol, od, oc

@@ -1,0 +1,27 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Make sure the oracle (gcc) and the product libraries (hipcc, cross-compiles) exist."""
+    import oracle
+    oracle.build_oracle()
+    from pg_embedding_amd import build as b
+    b.build()
+
+
+@pytest.fixture(scope="session")
+def gpu_count():
+    from pg_embedding_amd._lib import gpu_lib
+    return gpu_lib().hnsw_gpu_device_count()

@@ -1,0 +1,245 @@
+"""Fused search kernel vs the oracle on identical graph bytes: bit-exact ids, distances,
+evaluation and hop counts; and vs the reference binary: ids equal except at near-ties."""
+import numpy as np
+import pytest
+
+import oracle
+import pg_embedding_amd as pg
+from pg_embedding_amd.datasets import gmm, sift_like
+from util import REL_TOL, bits, build_port, mirror, near_tie_mask
+
+pytestmark = pytest.mark.gpu
+
+FUNCS = [pg.DIST_L2, pg.DIST_COSINE, pg.DIST_MANHATTAN]
+
+
+def assert_same_as_oracle(ix, port, Q, ef):
+    labels, dists, counts = ix.search(Q, ef)
+    want = port.search_many(Q, ef)
+    assert (counts == want["counts"]).all()
+    for q in range(Q.shape[0]):
+        c = counts[q]
+        assert (labels[q, :c] == want["labels"][q, :c]).all(), f"query {q}: ids differ"
+        assert (bits(dists[q, :c]) == bits(want["dists"][q, :c])).all(), f"query {q}: dists differ"
+        assert (labels[q, c:] == pg.NO_LABEL).all() and np.isinf(dists[q, c:]).all()
+    return labels, dists, counts
+
+
+@pytest.mark.parametrize("func", FUNCS)
+@pytest.mark.parametrize("dim,m,n", [(128, 8, 4000), (768, 16, 3000), (100, 4, 2000), (1536, 16, 1200)])
+def test_search_bit_exact_vs_oracle(func, dim, m, n):
+    port, X = build_port(n, dim, m, 48, func, seed=dim + func)
+    Q = gmm(200, dim, k=50, seed=dim + func, stream=1)
+    ix = mirror(port, func)
+    for ef in (1, 10, 64, 128):
+        assert_same_as_oracle(ix, port, Q, ef)
+    ix.close()
+
+
+def test_stats_match_oracle_counters():
+    """E_q / H_q reported by the kernel == coords / link reads of the oracle."""
+    import torch
+    port, X = build_port(5000, 128, 8, 64, pg.DIST_L2, seed=11)
+    Q = gmm(300, 128, k=50, seed=11, stream=1)
+    ix = mirror(port, pg.DIST_L2)
+    out = ix.search_torch(torch.from_numpy(Q).cuda(), 128, stats=True)
+    torch.cuda.synchronize()
+    want = port.search_many(Q, 128)
+    st = out["stats"].cpu().numpy().astype(np.uint32)
+    assert (st[:, 0] == want["evals"]).all()
+    assert (st[:, 1] == want["hops"]).all()
+    assert (out["labels"].cpu().numpy().view(np.uint64) == want["labels"]).all()
+    assert ix.last_search_ms() > 0
+    base = ix.search_torch(torch.from_numpy(Q).cuda(), 64, base=True)
+    torch.cuda.synchronize()
+    for q in range(0, 300, 17):
+        idx, d, _, _ = port.search_base(Q[q], 64)
+        c = int(base["counts"][q])
+        assert c == idx.size
+        assert (base["idx"][q, :c].cpu().numpy().view(np.uint32) == idx).all()
+    ix.close()
+
+
+@pytest.mark.parametrize("func", FUNCS)
+def test_search_vs_reference_binary(func):
+    """Same graph bytes, reference CPU search vs device: ids identical wherever the
+    reference's own neighbouring distances are not within 1e-5 (north-star contract)."""
+    if not oracle.have_ref():
+        pytest.skip("oracle/_ref not built")
+    dim, m, n = 256, 12, 4000
+    X = gmm(n, dim, k=60, seed=5 + func)
+    ref = oracle.RefIndex(dim, m, 64, 100, func)
+    ref.add(X)
+    Q = gmm(200, dim, k=60, seed=5 + func, stream=2)
+    want = ref.search_many(Q, 100)
+    ix = mirror(ref, func)
+    labels, dists, counts = ix.search(Q, 100)
+    assert (counts == want["counts"]).all()
+    exact = 0
+    for q in range(Q.shape[0]):
+        c = counts[q]
+        if (labels[q, :c] == want["labels"][q, :c]).all():
+            exact += 1
+            continue
+        bad = labels[q, :c] != want["labels"][q, :c]
+        assert (near_tie_mask(dists[q, :c], REL_TOL * 4)[bad]).all(), f"query {q}: mismatch away from a near-tie"
+    assert exact >= 0.95 * Q.shape[0]
+    ix.close()
+
+
+def test_toy_golden_orderings():
+    """knn.out:16-19,39-42,56-59 restated at the C boundary (labels = insertion order)."""
+    rows = np.array([[0, 1, 2], [1, 2, 3], [1, 1, 1], [1, 2, 4]], np.float32)
+    q = np.array([[3, 3, 3]], np.float32)
+    expect = {pg.DIST_L2: [1, 3, 2, 0], pg.DIST_COSINE: [2, 1, 3, 0], pg.DIST_MANHATTAN: [1, 3, 0, 2]}
+    for func, order in expect.items():
+        port = oracle.PortIndex(3, 3, 5, 5, func)
+        port.add(rows)
+        ix = mirror(port, func)
+        labels, dists, counts = ix.search(q, 5)
+        assert counts[0] == 4 and labels[0, :4].tolist() == order
+        ix.close()
+
+
+def test_empty_index_returns_no_rows():
+    """gh-2.out:5-8 / hnswalg.cpp:56-57."""
+    meta = pg.make_meta(3, 3, 5, 5, pg.DIST_L2)
+    ix = pg.GpuIndex.from_flat(meta, np.zeros(0, np.uint8), 0)
+    labels, dists, counts = ix.search(np.zeros((4, 3), np.float32), 5)
+    assert (counts == 0).all() and (labels == pg.NO_LABEL).all()
+    ix.close()
+
+
+def test_single_element_and_ef_larger_than_index():
+    port, X = build_port(37, 16, 4, 16, pg.DIST_L2, k=5, seed=2)
+    ix = mirror(port, pg.DIST_L2)
+    Q = gmm(20, 16, k=5, seed=2, stream=3)
+    labels, dists, counts = assert_same_as_oracle(ix, port, Q, 128)
+    assert (counts == 37).all()
+    ix.close()
+    one = oracle.PortIndex(16, 4, 16, 8, pg.DIST_L2)
+    one.add(X[:1], np.array([77], np.uint64))
+    ix = mirror(one, pg.DIST_L2)
+    labels, dists, counts = ix.search(Q, 8)
+    assert (counts == 1).all() and (labels[:, 0] == 77).all()
+    ix.close()
+
+
+def test_deleted_labels_are_filtered_after_search():
+    """knn.out:93-122: vacuumed rows are traversed but not returned (hnswalg.cpp:245)."""
+    port, X = build_port(1500, 64, 6, 32, pg.DIST_L2, seed=9)
+    rng = np.random.default_rng(9)
+    dead = rng.choice(1500, 400, replace=False)
+    for i in dead:
+        port.set_deleted(int(i))
+    ix = mirror(port, pg.DIST_L2)
+    Q = gmm(100, 64, k=50, seed=9, stream=1)
+    labels, dists, counts = assert_same_as_oracle(ix, port, Q, 64)
+    assert (counts < 64).any()
+    live = labels[labels != pg.NO_LABEL]
+    assert not ((live >> np.uint64(48)) & np.uint64(1)).any()
+    # flag set after the mirror was built
+    ix.set_deleted(int(labels[0, 0]) & 0xFFFFFFFF)
+    port.set_deleted(int(labels[0, 0]) & 0xFFFFFFFF)
+    assert_same_as_oracle(ix, port, Q, 64)
+    ix.close()
+
+
+@pytest.mark.parametrize("func", [pg.DIST_L2, pg.DIST_MANHATTAN])
+def test_exact_ties_follow_the_pair_order(func):
+    """Integer data and duplicated rows: distances tie exactly, so results are decided by the
+    (dist, idx) / (dist, label) pair comparisons of the reference heaps (hnswalg.cpp:52-53,236)."""
+    X = sift_like(2500, 32, k=20, seed=4)
+    X[1000:1400] = X[200:600]                    # exact duplicates
+    port = oracle.PortIndex(32, 6, 40, 64, func)
+    labels_in = np.arange(2500, dtype=np.uint64)[::-1].copy()    # label order != idx order
+    port.add(X, labels_in)
+    ix = mirror(port, func)
+    Q = np.concatenate([X[200:260], sift_like(60, 32, k=20, seed=4, stream=1)])
+    labels, dists, counts = assert_same_as_oracle(ix, port, Q, 100)
+    d = dists[:, :100]
+    assert (np.diff(d, axis=1) == 0).any(), "test data produced no ties"
+    if oracle.have_ref():
+        ref = oracle.RefIndex(32, 6, 40, 64, func)
+        ref.load_raw(port.raw(), 2500)
+        want = ref.search_many(Q, 100)
+        assert (labels == want["labels"]).all()      # integer data: bit-exact vs the reference too
+    ix.close()
+
+
+@pytest.mark.parametrize("ef", [200, 512, 1500])
+def test_large_ef(ef):
+    """efSearch doubling path of the scan (embedding.c:334) reaches large beams."""
+    port, X = build_port(3000, 48, 8, 32, pg.DIST_L2, seed=13)
+    ix = mirror(port, pg.DIST_L2)
+    Q = gmm(40, 48, k=50, seed=13, stream=1)
+    assert_same_as_oracle(ix, port, Q, ef)
+    ix.close()
+
+
+def test_default_m_100_link_lists_longer_than_a_wave():
+    """DEFAULT_M = 100 -> maxM = 200 links per element (embedding.c:113,224)."""
+    port, X = build_port(1200, 24, 100, 16, pg.DIST_COSINE, seed=21)
+    ix = mirror(port, pg.DIST_COSINE)
+    Q = gmm(50, 24, k=50, seed=21, stream=1)
+    assert_same_as_oracle(ix, port, Q, 64)
+    ix.close()
+
+
+def test_export_roundtrip_is_identity():
+    port, X = build_port(2000, 40, 5, 32, pg.DIST_L2, seed=17)
+    ix = mirror(port, pg.DIST_L2)
+    meta = ix.meta
+    got = ix.export_flat().reshape(2000, -1)
+    want = port.raw().reshape(2000, -1).copy()
+    # slots past `count` are dead bytes in a host image (a pruned list keeps its old tail,
+    # hnswalg.cpp:214-219); the mirror writes zeros there
+    lw = want[:, :meta.offset_data].copy().view(np.uint32)
+    for e in range(2000):
+        lw[e, 1 + lw[e, 0]:] = 0
+    want[:, :meta.offset_data] = lw.view(np.uint8)
+    assert (got == want).all()
+    again = pg.GpuIndex.from_flat(meta, got.ravel(), 2000)
+    assert (again.export_flat().reshape(2000, -1) == got).all()
+    again.close()
+    ix.close()
+
+
+def test_append_then_export_matches_zero_linked_elements():
+    meta = pg.make_meta(10, 4, 8, 8, pg.DIST_L2)
+    ix = pg.GpuIndex.empty(meta, 100)
+    X = gmm(60, 10, k=5, seed=1)
+    lab = np.arange(100, 160, dtype=np.uint64)
+    ix.append(X[:25], lab[:25])
+    ix.append(X[25:], lab[25:])
+    raw = ix.export_flat().reshape(60, -1)
+    esz = meta.size_data_per_element
+    assert raw.shape[1] == esz
+    assert (raw[:, :meta.offset_data] == 0).all()
+    assert (raw[:, meta.offset_data:meta.offset_label].copy().view(np.float32) == X).all()
+    assert (raw[:, meta.offset_label:].copy().view(np.uint64).ravel() == lab).all()
+    ix.close()
+
+
+def test_corrupt_image_is_rejected():
+    port, X = build_port(50, 8, 3, 8, pg.DIST_L2, k=3, seed=1)
+    raw = port.raw().reshape(50, -1).copy()
+    raw[7, 4:8] = np.frombuffer(np.uint32(9999).tobytes(), np.uint8)     # link to a missing element
+    meta = pg.make_meta(8, 3, 8, 8, pg.DIST_L2)
+    with pytest.raises(RuntimeError, match="corrupt"):
+        pg.GpuIndex.from_flat(meta, raw.ravel(), 50)
+
+
+def test_many_queries_reuse_slots():
+    """More queries than resident waves: every slot runs several queries, so the visited
+    bitmap must come back clean each time."""
+    port, X = build_port(6000, 64, 8, 48, pg.DIST_L2, seed=23)
+    ix = mirror(port, pg.DIST_L2)
+    Q = gmm(30000, 64, k=50, seed=23, stream=1)
+    labels, dists, counts = ix.search(Q, 32)
+    sel = np.random.default_rng(0).choice(30000, 400, replace=False)
+    want = port.search_many(Q[sel], 32)
+    assert (labels[sel] == want["labels"]).all()
+    labels2, _, _ = ix.search(Q, 32)                # second launch on the same workspace
+    assert (labels2 == labels).all()
+    ix.close()
