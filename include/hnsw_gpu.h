@@ -59,6 +59,17 @@ int hnsw_gpu_index_append(hnsw_gpu_index *ix, const coord_t *vectors, const labe
 int hnsw_gpu_index_append_dev(hnsw_gpu_index *ix, const coord_t *d_vectors, const label_t *d_labels,
 							  size_t n, void *stream);
 
+/* Link the stored, still un-linked elements [first, first+count) into the graph; every
+ * element below `first` must already be linked (or first == 0).  This is hnsw_bind_point
+ * (hnswalg.cpp:279-291 = bindPoint :225-232 + mutuallyConnectNewElement :155-223 +
+ * getNeighborsByHeuristic :117-153) for many elements.  Elements are processed in batches of
+ * min(max_batch, linked/ratio): members of one batch search the graph as it was before the
+ * batch.  max_batch = 1 reproduces the reference's serial inserts exactly (graph bytes equal
+ * the oracle's); larger batches give a different, equally valid graph much faster.
+ * 0 selects the defaults (max_batch 4096, ratio 8).  Enqueued on `stream`, not synchronised. */
+int hnsw_gpu_index_link(hnsw_gpu_index *ix, size_t first, size_t count, size_t max_batch, size_t ratio,
+						void *stream);
+
 /* Write the mirror back as host element images (inverse of create_from_flat), so a
  * CPU host can search the identical bytes.  `elements` holds count*size_data_per_element. */
 int hnsw_gpu_index_export_flat(hnsw_gpu_index *ix, void *elements);

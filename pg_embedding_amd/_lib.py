@@ -59,6 +59,7 @@ def gpu_lib():
     L.hnsw_gpu_index_append.argtypes = [vp, vp, vp, sz]
     L.hnsw_gpu_index_append_dev.argtypes = [vp, vp, vp, sz, vp]
     L.hnsw_gpu_index_export_flat.argtypes = [vp, vp]
+    L.hnsw_gpu_index_link.argtypes = [vp, sz, sz, sz, sz, vp]
     L.hnsw_gpu_index_set_deleted.argtypes = [vp, C.c_uint32, i32]
     L.hnsw_gpu_index_count.restype = sz
     L.hnsw_gpu_index_count.argtypes = [vp]

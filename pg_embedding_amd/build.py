@@ -54,7 +54,8 @@ def build(force: bool = False, verbose: bool = False) -> None:
     gpu_src = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + hdrs
     if force or not _newer(GPU_LIB, gpu_src):
         cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INC, "-I", CSRC,
-                                          os.path.join(CSRC, "hnsw_gpu.hip"), "-o", GPU_LIB]
+                                          os.path.join(CSRC, "hnsw_gpu.hip"),
+                                          os.path.join(CSRC, "sort_pairs.hip"), "-o", GPU_LIB]
         if verbose:
             print(" ".join(cmd))
         _run(cmd)

@@ -44,7 +44,8 @@ struct SearchArgs
 	const uint64_t *labels;
 	uint32_t n, dim, stride, nchunks, kiters, maxM, lstride, entry;
 	// batch
-	const float *queries;       // nq * dim floats
+	const float *queries;       // query i at queries + i * q_stride (dim floats used)
+	uint32_t q_stride;
 	uint32_t nq, ef, ccap;      // ccap = 2*ef candidate capacity
 	// outputs
 	uint64_t *out_labels;       // mode 0: nq*ef
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(const SearchArgs a)
 		if (qi >= a.nq) break;
 
 		// ---- stage the query in LDS (zero padded) ---------------------------------
-		const float *qsrc = a.queries + (size_t) qi * a.dim;
+		const float *qsrc = a.queries + (size_t) qi * a.q_stride;
 		for (uint32_t e = lane; e < a.qpad_floats; e += 64)
 			qf[e] = (e < a.dim) ? qsrc[e] : 0.f;
 		wave_sync();

@@ -13,6 +13,7 @@
 #include "hnsw_gpu.h"
 #include "device_dist.h"
 #include "device_search.h"
+#include "device_build.h"
 
 using namespace pgemb;
 
@@ -72,6 +73,8 @@ struct hnsw_gpu_index
 	uint32_t last_slots = 0;
 	// scratch for the host-pointer entry points
 	void *scratch = nullptr; size_t scratch_bytes = 0;
+	// builder scratch (hnsw_gpu_index_link)
+	void *bld = nullptr; size_t bld_batch = 0; size_t bld_tmp_bytes = 0;
 };
 
 static int ensure_scratch(hnsw_gpu_index *ix, size_t bytes)
@@ -143,6 +146,7 @@ extern "C" void hnsw_gpu_index_destroy(hnsw_gpu_index *ix)
 	if (ix->vlog) (void) hipFree(ix->vlog);
 	if (ix->ticket) (void) hipFree(ix->ticket);
 	if (ix->scratch) (void) hipFree(ix->scratch);
+	if (ix->bld) (void) hipFree(ix->bld);
 	if (ix->ev0) (void) hipEventDestroy(ix->ev0);
 	if (ix->ev1) (void) hipEventDestroy(ix->ev1);
 	delete ix;
@@ -383,7 +387,7 @@ static search_kernel_t pick_search_kernel(int func)
 static const size_t LDS_PER_CU = 160 * 1024;
 static const size_t VIS_BUDGET_BYTES = (size_t) 24 << 30;     // cap on bitmap workspace
 
-static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t nq, size_t ef, int mode,
+static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t q_stride, size_t nq, size_t ef, int mode,
 						 uint64_t *d_labels, uint32_t *d_idx, float *d_dists, uint32_t *d_counts,
 						 uint32_t *d_stats, hipStream_t stream)
 {
@@ -401,7 +405,7 @@ static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t nq, 
 	a.n = (uint32_t) ix->n; a.dim = (uint32_t) ix->meta.dim; a.stride = ix->stride;
 	a.nchunks = ix->stride / 4; a.kiters = (a.nchunks + 15) / 16;
 	a.maxM = (uint32_t) ix->meta.maxM; a.lstride = ix->lstride; a.entry = ix->meta.enterpoint_node;
-	a.queries = d_queries; a.nq = (uint32_t) nq; a.ef = (uint32_t) ef; a.ccap = (uint32_t) (2 * ef);
+	a.queries = d_queries; a.q_stride = (uint32_t) q_stride; a.nq = (uint32_t) nq; a.ef = (uint32_t) ef; a.ccap = (uint32_t) (2 * ef);
 	a.out_labels = d_labels; a.out_idx = d_idx; a.out_dists = d_dists; a.out_counts = d_counts; a.out_stats = d_stats;
 	a.mode = mode;
 	if (a.n > 0 && a.entry >= a.n) return fail(HNSW_GPU_ERR_ARG, "enterpoint_node %u >= count %u", a.entry, a.n);
@@ -432,7 +436,7 @@ static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t nq, 
 	size_t blocks = std::min<size_t>((nq + wpb - 1) / wpb, (size_t) per_cu * ix->num_cu);
 
 	// workspace: one bitmap + log per resident wave
-	const size_t words = std::max<size_t>(1, (ix->n + 31) / 32);
+	const size_t words = std::max<size_t>(1, (ix->cap + 31) / 32);   // by capacity: stable while the index grows
 	const size_t max_slots = std::max<size_t>(wpb, VIS_BUDGET_BYTES / (words * 4));
 	if (blocks * wpb > max_slots) blocks = std::max<size_t>(1, max_slots / wpb);
 	const size_t slots = blocks * wpb;
@@ -464,14 +468,14 @@ extern "C" int hnsw_gpu_search_batch_dev(hnsw_gpu_index *ix, const coord_t *d_qu
 										 label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
 										 void *stream)
 {
-	return launch_search(ix, d_queries, nq, ef, 0, d_labels, nullptr, d_dists, d_counts, d_stats, (hipStream_t) stream);
+	return launch_search(ix, d_queries, ix ? ix->meta.dim : 0, nq, ef, 0, d_labels, nullptr, d_dists, d_counts, d_stats, (hipStream_t) stream);
 }
 
 extern "C" int hnsw_gpu_search_base_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t ef,
 										idx_t *d_idx, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
 										void *stream)
 {
-	return launch_search(ix, d_queries, nq, ef, 1, nullptr, d_idx, d_dists, d_counts, d_stats, (hipStream_t) stream);
+	return launch_search(ix, d_queries, ix ? ix->meta.dim : 0, nq, ef, 1, nullptr, d_idx, d_dists, d_counts, d_stats, (hipStream_t) stream);
 }
 
 extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries, size_t nq, size_t ef,
@@ -491,7 +495,7 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 	float *dq = (float *) p; uint64_t *dl = (uint64_t *) (p + qb); float *dd = (float *) (p + qb + lb);
 	uint32_t *dc = (uint32_t *) (p + qb + lb + db);
 	HIPCHK(hipMemcpy(dq, queries, nq * dim * 4, hipMemcpyHostToDevice));
-	rc = launch_search(ix, dq, nq, ef, 0, dl, nullptr, dd, dc, nullptr, nullptr);
+	rc = launch_search(ix, dq, dim, nq, ef, 0, dl, nullptr, dd, dc, nullptr, nullptr);
 	if (rc) return rc;
 	HIPCHK(hipMemcpy(labels, dl, nq * ef * 8, hipMemcpyDeviceToHost));
 	if (dists) HIPCHK(hipMemcpy(dists, dd, nq * ef * 4, hipMemcpyDeviceToHost));
@@ -806,5 +810,111 @@ extern "C" int hnsw_gpu_merge_topk_dev(int device, const label_t *d_in_labels, c
 	hipLaunchKernelGGL(topk_merge_kernel, dim3((uint32_t) nq), dim3(64), 0, (hipStream_t) stream, d_in_labels, d_in_dists,
 					   (uint32_t) nlists, (uint32_t) nq, (uint32_t) ef, d_out_labels, d_out_dists, d_out_counts);
 	HIPCHK(hipGetLastError());
+	return HNSW_GPU_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// insert path: link stored elements into the graph (device_build.h)
+// ------------------------------------------------------------------------------------
+extern "C" int pgemb_sort_u64(void *tmp, size_t *tmp_bytes, const uint64_t *in, uint64_t *out, int n, void *stream);
+
+typedef void (*build_kernel_t)(const BuildArgs);
+
+extern "C" int hnsw_gpu_index_link(hnsw_gpu_index *ix, size_t first, size_t count, size_t max_batch, size_t ratio,
+								   void *stream_)
+{
+	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
+	if (first + count > ix->n) return fail(HNSW_GPU_ERR_ARG, "elements [%zu, %zu) are not stored (count %zu)", first, first + count, ix->n);
+	if (count == 0) return HNSW_GPU_OK;
+	if (max_batch == 0) max_batch = 4096;
+	if (ratio == 0) ratio = 8;
+	const size_t efc = ix->meta.efConstruction, M = ix->meta.M, maxM = ix->meta.maxM;
+	if (efc == 0 || M == 0 || M > maxM) return fail(HNSW_GPU_ERR_ARG, "bad efConstruction/M");
+	HIPCHK(hipSetDevice(ix->device));
+	hipStream_t stream = (hipStream_t) stream_;
+
+	// scratch carve
+	max_batch = std::min(max_batch, count);
+	const size_t slots = max_batch * M;
+	if (slots >= 0x7FFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "batch too large");
+	size_t tmp_bytes = 0;
+	if (pgemb_sort_u64(nullptr, &tmp_bytes, nullptr, nullptr, (int) slots, stream) != 0)
+		return fail(HNSW_GPU_ERR_HIP, "radix sort sizing failed");
+	const size_t o_idx = 0;
+	const size_t o_dist = o_idx + round_up(max_batch * efc * 4, 256);
+	const size_t o_cnt = o_dist + round_up(max_batch * efc * 4, 256);
+	const size_t o_pairs = o_cnt + round_up(max_batch * 4, 256);
+	const size_t o_sorted = o_pairs + round_up(slots * 8, 256);
+	const size_t o_seg = o_sorted + round_up(slots * 8, 256);
+	const size_t o_ctr = o_seg + round_up(slots * 4, 256);
+	const size_t o_tmp = o_ctr + 256;
+	const size_t total = o_tmp + round_up(tmp_bytes, 256);
+	if (max_batch > ix->bld_batch || tmp_bytes > ix->bld_tmp_bytes || !ix->bld)
+	{
+		if (ix->bld) (void) hipFree(ix->bld);
+		ix->bld = nullptr; ix->bld_batch = 0;
+		HIPCHK(hipMalloc(&ix->bld, total));
+		ix->bld_batch = max_batch; ix->bld_tmp_bytes = tmp_bytes;
+	}
+	char *B = (char *) ix->bld;
+	uint32_t *cand_idx = (uint32_t *) (B + o_idx);
+	float *cand_dist = (float *) (B + o_dist);
+	uint32_t *cand_cnt = (uint32_t *) (B + o_cnt);
+	uint64_t *pairs = (uint64_t *) (B + o_pairs), *sorted = (uint64_t *) (B + o_sorted);
+	uint32_t *seg = (uint32_t *) (B + o_seg), *ctr = (uint32_t *) (B + o_ctr);
+
+	BuildArgs a;
+	memset(&a, 0, sizeof(a));
+	a.vec = ix->vec; a.links = ix->links;
+	a.dim = (uint32_t) ix->meta.dim; a.stride = ix->stride; a.nchunks = ix->stride / 4; a.kiters = (a.nchunks + 15) / 16;
+	a.qpad_floats = (uint32_t) round_up(a.kiters, 2) * 64;
+	a.maxM = (uint32_t) maxM; a.M = (uint32_t) M; a.lstride = ix->lstride; a.efc = (uint32_t) efc;
+	a.cand_idx = cand_idx; a.cand_dist = cand_dist; a.cand_cnt = cand_cnt;
+	a.pairs = pairs; a.npairs = ctr; a.sorted_pairs = sorted; a.seg_start = seg; a.nseg = ctr + 1; a.ticket = ctr + 2;
+	const uint32_t cap = (uint32_t) round_up(std::max(efc, maxM + 1), 8);
+	a.wave_bytes = (uint32_t) round_up((size_t) a.qpad_floats * 4 + (size_t) cap * (8 * 2 + 4 * 3) + (maxM + 2) * 4, 16);
+	if (a.wave_bytes > LDS_PER_CU) return fail(HNSW_GPU_ERR_ARG, "efConstruction/maxM/dim need too much LDS (%u bytes)", a.wave_bytes);
+	uint32_t wpb = 4;
+	while (wpb > 1 && (size_t) wpb * a.wave_bytes > 64 * 1024) wpb >>= 1;
+	const size_t lds = (size_t) wpb * a.wave_bytes;
+	build_kernel_t ksel, krev;
+	switch ((int) ix->meta.dist_func)
+	{
+		case F_L2:     ksel = select_links_kernel<F_L2>;        krev = reverse_links_kernel<F_L2>; break;
+		case F_COSINE: ksel = select_links_kernel<F_COSINE>;    krev = reverse_links_kernel<F_COSINE>; break;
+		default:       ksel = select_links_kernel<F_MANHATTAN>; krev = reverse_links_kernel<F_MANHATTAN>; break;
+	}
+	if (lds > 48 * 1024)
+	{
+		HIPCHK(hipFuncSetAttribute((const void *) ksel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+		HIPCHK(hipFuncSetAttribute((const void *) krev, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
+	}
+
+	size_t linked = first, end = first + count;
+	if (linked == 0) linked = 1;                    // element 0 is never bound: hnswalg.cpp:228
+	while (linked < end)
+	{
+		const size_t b = std::min({end - linked, max_batch, std::max<size_t>(1, linked / ratio)});
+		const size_t bslots = b * M;
+		HIPCHK(hipMemsetAsync(ctr, 0, 16, stream));
+		HIPCHK(hipMemsetAsync(pairs, 0xFF, bslots * 8, stream));
+		// 1. searchBaseLayer(ef = efConstruction) for every new element (hnswalg.cpp:229)
+		int rc = launch_search(ix, ix->vec + linked * ix->stride, ix->stride, b, efc, 1, nullptr, cand_idx, cand_dist,
+							   cand_cnt, nullptr, stream);
+		if (rc) return rc;
+		// 2. choose links, emit reverse pairs
+		a.first = (uint32_t) linked; a.count = (uint32_t) b; a.pair_slots = (uint32_t) bslots;
+		hipLaunchKernelGGL(ksel, dim3((uint32_t) ((b + wpb - 1) / wpb)), dim3(wpb * 64), lds, stream, a);
+		// 3. reverse edges grouped by target
+		size_t tb = ix->bld_tmp_bytes;
+		if (pgemb_sort_u64(B + o_tmp, &tb, pairs, sorted, (int) bslots, stream) != 0)
+			return fail(HNSW_GPU_ERR_HIP, "radix sort failed");
+		hipLaunchKernelGGL(mark_segments_kernel, dim3((uint32_t) ((bslots + 255) / 256)), dim3(256), 0, stream, sorted,
+						   (uint32_t) bslots, seg, ctr + 1);
+		const uint32_t rblocks = (uint32_t) std::min<size_t>((bslots + wpb - 1) / wpb, (size_t) ix->num_cu * 4);
+		hipLaunchKernelGGL(krev, dim3(rblocks), dim3(wpb * 64), lds, stream, a);
+		HIPCHK(hipGetLastError());
+		linked += b;
+	}
 	return HNSW_GPU_OK;
 }

@@ -119,6 +119,11 @@ class GpuIndex:
         check(self.L.hnsw_gpu_index_append_dev(self._h, vectors.data_ptr(), _dptr(labels),
                                                vectors.shape[0], s), "hnsw_gpu_index_append_dev")
 
+    def link(self, first: int, count: int, max_batch: int = 0, ratio: int = 0, stream: int = 0) -> None:
+        """hnsw_bind_point for the stored elements [first, first+count) (hnswalg.cpp:225-232,
+        155-223, 117-153).  max_batch=1 == the reference's serial inserts, bit for bit."""
+        check(self.L.hnsw_gpu_index_link(self._h, first, count, max_batch, ratio, stream), "hnsw_gpu_index_link")
+
     def export_flat(self) -> np.ndarray:
         out = np.empty(self.count * self.meta.size_data_per_element, np.uint8)
         check(self.L.hnsw_gpu_index_export_flat(self._h, out.ctypes.data), "hnsw_gpu_index_export_flat")

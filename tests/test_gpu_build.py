@@ -1,0 +1,104 @@
+"""Insert path on the device (hnsw_gpu_index_link): serial mode is bit-identical to the
+oracle's graph; batched mode is validated by recall and by CPU/GPU agreement on its bytes."""
+import numpy as np
+import pytest
+
+import oracle
+import pg_embedding_amd as pg
+from pg_embedding_amd.datasets import gmm, recall_at_k
+from util import bits
+
+pytestmark = pytest.mark.gpu
+
+
+def live_image(raw, meta, n):
+    """element images with the dead link slots (past `count`) zeroed"""
+    img = raw.reshape(n, -1).copy()
+    lw = img[:, :meta.offset_data].copy().view(np.uint32)
+    for e in range(n):
+        lw[e, 1 + lw[e, 0]:] = 0
+    img[:, :meta.offset_data] = lw.view(np.uint8)
+    return img
+
+
+@pytest.mark.parametrize("func", [pg.DIST_L2, pg.DIST_COSINE, pg.DIST_MANHATTAN])
+@pytest.mark.parametrize("dim,m,efc,n", [(24, 4, 16, 1200), (128, 8, 40, 900)])
+def test_serial_link_reproduces_the_oracle_graph(func, dim, m, efc, n):
+    X = gmm(n, dim, k=30, seed=3 * dim + func)
+    labels = (np.arange(n, dtype=np.uint64) * 7 + 5)
+    port = oracle.PortIndex(dim, m, efc, 64, func)
+    port.add(X, labels)
+    meta = pg.make_meta(dim, m, efc, 64, func)
+    ix = pg.GpuIndex.empty(meta, n)
+    ix.append(X, labels)
+    ix.link(0, n, max_batch=1)
+    got = ix.export_flat().reshape(n, -1)
+    want = live_image(port.raw(), meta, n)
+    assert (got == want).all(), f"{(got != want).any(axis=1).sum()} elements differ"
+    ix.close()
+
+
+def test_incremental_serial_link_matches_insert_by_insert():
+    """Link in several calls (first > 0), as repeated hnsw_bind_point calls would."""
+    dim, m, efc, n = 32, 6, 24, 800
+    X = gmm(n, dim, k=20, seed=8)
+    port = oracle.PortIndex(dim, m, efc, 64, pg.DIST_L2)
+    port.add(X)
+    meta = pg.make_meta(dim, m, efc, 64, pg.DIST_L2)
+    ix = pg.GpuIndex.empty(meta, n)
+    for a, b in [(0, 1), (1, 300), (300, 301), (301, 800)]:
+        ix.append(X[a:b])
+        ix.link(a, b - a, max_batch=1)
+    assert (ix.export_flat().reshape(n, -1) == live_image(port.raw(), meta, n)).all()
+    ix.close()
+
+
+@pytest.mark.parametrize("func", [pg.DIST_L2, pg.DIST_COSINE])
+def test_batched_link_gives_a_searchable_graph(func):
+    import torch
+    dim, m, efc, n, nq = 96, 12, 64, 30000, 500
+    X = gmm(n, dim, k=200, seed=12)
+    Q = gmm(nq, dim, k=200, seed=12, stream=1)
+    meta = pg.make_meta(dim, m, efc, 64, func)
+    ix = pg.GpuIndex.empty(meta, n)
+    ix.append(X)
+    ix.link(0, n)                                   # default batching
+    raw = ix.export_flat()
+    cnt = raw.reshape(n, -1)[:, :4].copy().view(np.uint32).ravel()
+    assert cnt.max() <= 2 * m and cnt[1:].min() >= 1
+    # every link list is duplicate free and in range
+    lk = raw.reshape(n, -1)[:, 4:meta.offset_data].copy().view(np.uint32)
+    for e in range(0, n, 37):
+        l = lk[e, :cnt[e]]
+        assert l.max(initial=0) < n and len(set(l.tolist())) == l.size and e not in l
+    # recall of the graph vs exhaustive search with the same metric
+    dq = torch.from_numpy(Q).cuda()
+    truth, tdist = ix.bruteforce_torch(dq, 10)
+    labels, dists, counts = ix.search(Q, 128)
+    rec = recall_at_k(labels.astype(np.int64), truth.cpu().numpy(), 10)
+    assert rec >= 0.95, rec
+    # CPU oracle on the exported bytes agrees with the device search bit for bit
+    port = oracle.PortIndex(dim, m, efc, 64, func)
+    port.load_raw(raw, n)
+    want = port.search_many(Q, 128)
+    assert (labels == want["labels"]).all() and (bits(dists) == bits(want["dists"])).all()
+    ix.close()
+
+
+@pytest.mark.parametrize("func", [pg.DIST_L2, pg.DIST_COSINE, pg.DIST_MANHATTAN])
+def test_bruteforce_is_exact(func):
+    import torch
+    n, dim, nq, k = 5000, 40, 64, 10
+    X = gmm(n, dim, k=30, seed=2)
+    Q = gmm(nq, dim, k=30, seed=2, stream=1)
+    meta = pg.make_meta(dim, 4, 8, 8, func)
+    ix = pg.GpuIndex.empty(meta, n)
+    ix.append(X)
+    idx, dst = ix.bruteforce_torch(torch.from_numpy(Q).cuda(), k)
+    idx, dst = idx.cpu().numpy(), dst.cpu().numpy()
+    for q in range(nq):
+        d = oracle.port_dist_many(func, Q[q], X)
+        order = np.lexsort((np.arange(n), d))[:k]          # ties by lower idx
+        assert (idx[q] == order).all()
+        assert (bits(dst[q]) == bits(d[order])).all()
+    ix.close()
