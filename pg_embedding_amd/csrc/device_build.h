@@ -19,6 +19,8 @@
 
 namespace pgemb {
 
+constexpr int BUILD_KB = 4;     // chunk-steps per load batch in the builder kernels (any dim)
+
 struct BuildArgs
 {
 	const float *vec;
@@ -43,7 +45,10 @@ struct BuildArgs
 __device__ __forceinline__ void stage_row(float *qf, const float *row, uint32_t stride, uint32_t qpad_floats, int lane)
 {
 	for (uint32_t e = lane; e < qpad_floats; e += 64)
-		qf[e] = (e < stride) ? row[e] : 0.f;
+	{
+		const float t = row[e < stride ? e : stride - 1];        // unconditional load, then select
+		qf[e] = (e < stride) ? t : 0.f;
+	}
 	wave_sync();
 }
 
@@ -87,7 +92,7 @@ __device__ __forceinline__ uint32_t heuristic_select(const BuildArgs &a, float *
 			if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
 			const uint32_t *ids = sel_id;
 			auto by_id = [ids](uint32_t r) { return ids[r]; };
-			score_rows<FUNC>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, by_id, nsel, tmpd, lane);
+			score_rows<FUNC, BUILD_KB, 1>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, by_id, nsel, tmpd, lane);
 			wave_sync();
 			bool closer = false;
 			for (uint32_t b = 0; b < nsel; b += 64)
@@ -245,7 +250,7 @@ __global__ __launch_bounds__(256) void reverse_links_kernel(const BuildArgs a)
 			{
 				const uint32_t *cc = cur;
 				auto by_id = [cc](uint32_t r) { return cc[r]; };
-				score_rows<FUNC>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, by_id, cnt + 1, cdist, lane);
+				score_rows<FUNC, BUILD_KB, 1>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, by_id, cnt + 1, cdist, lane);
 			}
 			wave_sync();
 			for (uint32_t k = lane; k <= cnt; k += 64)

@@ -137,11 +137,14 @@ __device__ __forceinline__ float query_norm(const float4 *q4, uint32_t nchunks, 
 
 // Score `nrows` rows against the LDS-staged query.
 //   row r lives at vec + rowid(r) * stride (floats; stride % 4 == 0, zero padded)
-//   q4     : query in LDS as float4 chunks, zero padded to kiters2*32 chunks
+//   q4     : query in LDS as float4 chunks, zero padded to a multiple of KB*16 chunks
 //   out[r] : distance, written by the first lane of the owning group
-// Eight rows per pass (two per 16-lane group) and two chunk-steps per iteration keep
-// 4 x 16-byte loads per lane (4 KiB per wave) in flight before the first use.
-template <int FUNC, typename RowId>
+// Shape <KB, RPG>: every 16-lane group owns RPG rows per pass (4*RPG rows per wave-pass) and
+// issues KB chunk-steps of ALL its rows before the first use, i.e. KB*RPG independent
+// 16-byte loads per lane (KB*RPG KiB per wave) are in flight per memory round trip.  The
+// traversal is a chain of dependent round trips, so the shape is picked per dimensionality
+// to cover a whole row per trip when it fits: 768 dims = <12,1>, 128 dims = <2,4>.
+template <int FUNC, int KB, int RPG, typename RowId>
 __device__ __forceinline__ void score_rows(const float *__restrict__ vec, size_t stride,
 										   const float4 *q4, uint32_t nchunks, uint32_t kiters,
 										   float qnorm, RowId rowid, uint32_t nrows,
@@ -149,38 +152,79 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ vec, size_t
 {
 	const uint32_t g = lane >> 4, sub = lane & 15;
 	const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-	for (uint32_t base = 0; base < nrows; base += 8)
+	// Every load below is UNCONDITIONAL: rows past the end re-read the last valid row and
+	// chunks past the end re-read the last valid chunk, and the unwanted values are replaced
+	// by a select afterwards.  (A load under a per-lane `if` makes hipcc branch around it and
+	// wait vmcnt(0) right behind it, which serialises the whole batch.)
+	for (uint32_t base = 0; base < nrows; base += 4 * RPG)
 	{
-		const uint32_t r0 = base + g, r1 = base + 4 + g;
-		const bool v0 = r0 < nrows, v1 = r1 < nrows;
-		const float4 *p0 = reinterpret_cast<const float4 *>(vec + (size_t) (v0 ? rowid(r0) : 0) * stride) + sub;
-		const float4 *p1 = reinterpret_cast<const float4 *>(vec + (size_t) (v1 ? rowid(r1) : 0) * stride) + sub;
-		RowAcc s0, s1;
-		acc_zero(s0);
-		acc_zero(s1);
-		for (uint32_t k = 0; k < kiters; k += 2)
+		const float4 *row4[RPG];
+		bool v[RPG];
+		RowAcc s[RPG];
+#pragma unroll
+		for (int rr = 0; rr < RPG; rr++)
 		{
-			const uint32_t c0 = k * 16 + sub, c1 = c0 + 16;
-			const bool in0 = c0 < nchunks, in1 = c1 < nchunks;
-			float4 x00 = zero4, x01 = zero4, x10 = zero4, x11 = zero4;
-			if (v0 && in0) x00 = p0[k * 16];
-			if (v1 && in0) x10 = p1[k * 16];
-			if (v0 && in1) x01 = p0[k * 16 + 16];
-			if (v1 && in1) x11 = p1[k * 16 + 16];
-			const float4 qa = q4[c0], qb = q4[c1];     // LDS image is zero padded
-			acc_step<FUNC>(s0, qa, x00);
-			acc_step<FUNC>(s1, qa, x10);
-			acc_step<FUNC>(s0, qb, x01);
-			acc_step<FUNC>(s1, qb, x11);
+			const uint32_t r = base + rr * 4 + g;
+			v[rr] = r < nrows;
+			row4[rr] = reinterpret_cast<const float4 *>(vec + (size_t) rowid(v[rr] ? r : nrows - 1) * stride);
+			acc_zero(s[rr]);
 		}
-		const float d0 = acc_finish<FUNC>(s0, qnorm);
-		const float d1 = acc_finish<FUNC>(s1, qnorm);
-		if (sub == 0)
+		for (uint32_t k0 = 0; k0 < kiters; k0 += KB)
 		{
-			if (v0) out[r0] = d0;
-			if (v1) out[r1] = d1;
+			float4 x[RPG][KB];
+			if ((k0 + KB) * 16 <= nchunks)          // wave-uniform: whole batch inside the row
+			{
+#pragma unroll
+				for (int u = 0; u < KB; u++)
+#pragma unroll
+					for (int rr = 0; rr < RPG; rr++) x[rr][u] = row4[rr][(k0 + u) * 16 + sub];
+			}
+			else
+			{
+#pragma unroll
+				for (int u = 0; u < KB; u++)
+				{
+					const uint32_t c = (k0 + u) * 16 + sub;
+					const uint32_t cc = c < nchunks ? c : nchunks - 1;
+#pragma unroll
+					for (int rr = 0; rr < RPG; rr++)
+					{
+						const float4 t = row4[rr][cc];
+						x[rr][u] = c < nchunks ? t : zero4;
+					}
+				}
+			}
+#pragma unroll
+			for (int u = 0; u < KB; u++)
+			{
+				const float4 q = q4[(k0 + u) * 16 + sub];      // LDS image is zero padded
+#pragma unroll
+				for (int rr = 0; rr < RPG; rr++) acc_step<FUNC>(s[rr], q, x[rr][u]);
+			}
+		}
+#pragma unroll
+		for (int rr = 0; rr < RPG; rr++)
+		{
+			const float d = acc_finish<FUNC>(s[rr], qnorm);
+			const uint32_t r = base + rr * 4 + g;
+			if (sub == 0 && v[rr]) out[r] = d;
 		}
 	}
+}
+
+// Load-batch shapes by chunk-steps per row (kiters = ceil(dim/64)).
+struct Shape2x4  { static constexpr int KB = 2,  RPG = 4; };   // dim <= 128
+struct Shape4x2  { static constexpr int KB = 4,  RPG = 2; };   // dim <= 256
+struct Shape8x2  { static constexpr int KB = 8,  RPG = 2; };   // dim <= 512
+struct Shape12x1 { static constexpr int KB = 12, RPG = 1; };   // larger (768 = one batch)
+
+__host__ __device__ inline int shape_index(uint32_t kiters)
+{
+	return kiters <= 2 ? 0 : kiters <= 4 ? 1 : kiters <= 8 ? 2 : 3;
+}
+__host__ __device__ inline uint32_t shape_kb(int idx)
+{
+	return idx == 0 ? 2u : idx == 1 ? 4u : idx == 2 ? 8u : 12u;
 }
 
 }  // namespace pgemb

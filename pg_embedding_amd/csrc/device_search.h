@@ -125,7 +125,7 @@ __device__ __forceinline__ void remove_first(uint64_t *A, uint32_t sz, int lane)
 	}
 }
 
-template <int FUNC>
+template <int FUNC, typename SH>
 __global__ __launch_bounds__(256) void hnsw_search_kernel(const SearchArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -154,7 +154,10 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(const SearchArgs a)
 		// ---- stage the query in LDS (zero padded) ---------------------------------
 		const float *qsrc = a.queries + (size_t) qi * a.q_stride;
 		for (uint32_t e = lane; e < a.qpad_floats; e += 64)
-			qf[e] = (e < a.dim) ? qsrc[e] : 0.f;
+		{
+			const float t = qsrc[e < a.dim ? e : a.dim - 1];     // unconditional load, then select
+			qf[e] = (e < a.dim) ? t : 0.f;
+		}
 		wave_sync();
 		float qnorm = 0.f;
 		if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
@@ -167,7 +170,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(const SearchArgs a)
 			const uint32_t ep = a.entry;
 			{
 				auto one = [ep](uint32_t) { return ep; };
-				score_rows<FUNC>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, one, 1u, newdist, lane);
+				score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, one, 1u, newdist, lane);
 			}
 			wave_sync();
 			float lowerBound = newdist[0];
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(const SearchArgs a)
 					{                                                    // :95-97, batched
 						const uint32_t *ids = newid;
 						auto by_id = [ids](uint32_t r) { return ids[r]; };
-						score_rows<FUNC>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, by_id, nnew, newdist, lane);
+						score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, by_id, nnew, newdist, lane);
 					}
 					evals += nnew;
 					wave_sync();

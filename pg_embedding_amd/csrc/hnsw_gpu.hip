@@ -374,13 +374,25 @@ extern "C" int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int del
 // ------------------------------------------------------------------------------------
 typedef void (*search_kernel_t)(const SearchArgs);
 
-static search_kernel_t pick_search_kernel(int func)
+template <typename SH>
+static search_kernel_t pick_search_kernel_f(int func)
 {
 	switch (func)
 	{
-		case F_L2:     return hnsw_search_kernel<F_L2>;
-		case F_COSINE: return hnsw_search_kernel<F_COSINE>;
-		default:       return hnsw_search_kernel<F_MANHATTAN>;
+		case F_L2:     return hnsw_search_kernel<F_L2, SH>;
+		case F_COSINE: return hnsw_search_kernel<F_COSINE, SH>;
+		default:       return hnsw_search_kernel<F_MANHATTAN, SH>;
+	}
+}
+
+static search_kernel_t pick_search_kernel(int func, uint32_t kiters)
+{
+	switch (shape_index(kiters))
+	{
+		case 0:  return pick_search_kernel_f<Shape2x4>(func);
+		case 1:  return pick_search_kernel_f<Shape4x2>(func);
+		case 2:  return pick_search_kernel_f<Shape8x2>(func);
+		default: return pick_search_kernel_f<Shape12x1>(func);
 	}
 }
 
@@ -411,8 +423,7 @@ static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t q_st
 	if (a.n > 0 && a.entry >= a.n) return fail(HNSW_GPU_ERR_ARG, "enterpoint_node %u >= count %u", a.entry, a.n);
 
 	// LDS carve per wave
-	const uint32_t kit2 = (uint32_t) round_up(a.kiters, 2);
-	a.qpad_floats = kit2 * 64;
+	a.qpad_floats = (uint32_t) round_up(a.kiters, shape_kb(shape_index(a.kiters))) * 64;
 	size_t off = (size_t) a.qpad_floats * 4;
 	a.off_res = (uint32_t) off;     off += round_up((ef + 1) * 8, 16);
 	a.off_cand = (uint32_t) off;    off += round_up((2 * ef + 1) * 8, 16);
@@ -425,7 +436,7 @@ static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t q_st
 	uint32_t wpb = 4;
 	while (wpb > 1 && (size_t) wpb * a.wave_bytes > 64 * 1024) wpb >>= 1;
 	const size_t lds = (size_t) wpb * a.wave_bytes;
-	search_kernel_t kern = pick_search_kernel((int) ix->meta.dist_func);
+	search_kernel_t kern = pick_search_kernel((int) ix->meta.dist_func, a.kiters);
 	if (lds > 48 * 1024)
 		HIPCHK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 	int per_cu = 0;
@@ -545,7 +556,7 @@ __global__ __launch_bounds__(256) void dist_batch_kernel(const float *__restrict
 	{
 		const uint32_t cnt = min(8u, nrows - base);
 		auto direct = [base](uint32_t r) { return base + r; };
-		score_rows<FUNC>(rows, stride, q4, nchunks, kiters, qnorm, direct, cnt, out + base, lane);
+		score_rows<FUNC, 4, 2>(rows, stride, q4, nchunks, kiters, qnorm, direct, cnt, out + base, lane);
 	}
 }
 
@@ -559,7 +570,7 @@ extern "C" int hnsw_gpu_dist_batch_dev(dist_func_t func, const coord_t *d_q, con
 		return fail(HNSW_GPU_ERR_ARG, "rows must be 16-byte aligned with stride %% 4 == 0 and stride >= dim");
 	if (nrows >= 0xFFFFFFF0ull) return fail(HNSW_GPU_ERR_ARG, "too many rows");
 	const uint32_t nchunks = (uint32_t) (row_stride / 4), kiters = (nchunks + 15) / 16;
-	const uint32_t qpad = (uint32_t) round_up(kiters, 2) * 64;
+	const uint32_t qpad = (uint32_t) round_up(kiters, 4) * 64;
 	const size_t lds = (size_t) qpad * 4;
 	if (lds > 64 * 1024) return fail(HNSW_GPU_ERR_ARG, "dim %zu too large", dim);
 	const uint32_t blocks = (uint32_t) std::min<size_t>((nrows + 31) / 32, 256 * 8);
@@ -641,7 +652,7 @@ __global__ __launch_bounds__(256) void bruteforce_kernel(const float *__restrict
 	{
 		const uint32_t cnt = min(8u, hi - base);
 		auto direct = [base](uint32_t r) { return base + r; };
-		score_rows<FUNC>(vec, stride, q4, nchunks, kiters, qnorm, direct, cnt, dist8, lane);
+		score_rows<FUNC, 4, 2>(vec, stride, q4, nchunks, kiters, qnorm, direct, cnt, dist8, lane);
 		wave_sync();
 		for (uint32_t r = 0; r < cnt; r++)
 		{
@@ -704,7 +715,7 @@ extern "C" int hnsw_gpu_bruteforce_dev(hnsw_gpu_index *ix, const coord_t *d_quer
 	HIPCHK(hipSetDevice(ix->device));
 	hipStream_t s = (hipStream_t) stream;
 	const uint32_t nchunks = ix->stride / 4, kiters = (nchunks + 15) / 16;
-	const uint32_t qpad = (uint32_t) round_up(kiters, 2) * 64;
+	const uint32_t qpad = (uint32_t) round_up(kiters, 4) * 64;
 	uint32_t splits = (uint32_t) std::max<size_t>(1, std::min<size_t>(64, (size_t) (4 * ix->num_cu) / nq));
 	splits = (uint32_t) std::min<size_t>(splits, std::max<size_t>(1, ix->n / 64));
 	const uint32_t nlists = splits * 4;
@@ -867,7 +878,7 @@ extern "C" int hnsw_gpu_index_link(hnsw_gpu_index *ix, size_t first, size_t coun
 	memset(&a, 0, sizeof(a));
 	a.vec = ix->vec; a.links = ix->links;
 	a.dim = (uint32_t) ix->meta.dim; a.stride = ix->stride; a.nchunks = ix->stride / 4; a.kiters = (a.nchunks + 15) / 16;
-	a.qpad_floats = (uint32_t) round_up(a.kiters, 2) * 64;
+	a.qpad_floats = (uint32_t) round_up(a.kiters, BUILD_KB) * 64;
 	a.maxM = (uint32_t) maxM; a.M = (uint32_t) M; a.lstride = ix->lstride; a.efc = (uint32_t) efc;
 	a.cand_idx = cand_idx; a.cand_dist = cand_dist; a.cand_cnt = cand_cnt;
 	a.pairs = pairs; a.npairs = ctr; a.sorted_pairs = sorted; a.seg_start = seg; a.nseg = ctr + 1; a.ticket = ctr + 2;
