@@ -194,12 +194,26 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ vec, size_t
 					}
 				}
 			}
+			// Query chunks come from LDS in groups of QG while the row loads are in flight;
+			// the schedule is pinned so that hipcc does not hoist all KB LDS reads above the
+			// arithmetic (that costs 4*KB more live VGPRs and a wave of occupancy).
+			constexpr int QG = KB < 4 ? KB : 4;
+			__builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-			for (int u = 0; u < KB; u++)
+			for (int u0 = 0; u0 < KB; u0 += QG)
 			{
-				const float4 q = q4[(k0 + u) * 16 + sub];      // LDS image is zero padded
+				float4 q[QG];
 #pragma unroll
-				for (int rr = 0; rr < RPG; rr++) acc_step<FUNC>(s[rr], q, x[rr][u]);
+				for (int j = 0; j < QG; j++)
+					if (u0 + j < KB) q[j] = q4[(k0 + u0 + j) * 16 + sub];      // LDS image is zero padded
+#pragma unroll
+				for (int j = 0; j < QG; j++)
+					if (u0 + j < KB)
+					{
+#pragma unroll
+						for (int rr = 0; rr < RPG; rr++) acc_step<FUNC>(s[rr], q[j], x[rr][u0 + j]);
+					}
+				__builtin_amdgcn_sched_barrier(0);
 			}
 		}
 #pragma unroll

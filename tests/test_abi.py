@@ -1,0 +1,137 @@
+"""The drop-in boundary: struct layout, exported symbols, loud failure without a device."""
+import ctypes as C
+import os
+import re
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import pg_embedding_amd as pg
+from pg_embedding_amd import build as B
+from pg_embedding_amd._lib import HnswMetadata, gpu_lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include")
+REF = "/root/reference"
+
+
+def exported(lib):
+    out = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    return {l.split()[-1] for l in out.splitlines() if " T " in l}
+
+
+def undefined(lib):
+    out = subprocess.run(["nm", "-D", "--undefined-only", lib], capture_output=True, text=True, check=True).stdout
+    return {l.split()[-1] for l in out.splitlines()}
+
+
+def declared(header):
+    txt = open(os.path.join(INC, header)).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return set(re.findall(r"\b(hnsw_[a-z0-9_]+)\s*\(", txt))
+
+
+def test_metadata_layout_is_lp64_88_bytes():
+    assert C.sizeof(HnswMetadata) == 88
+    assert HnswMetadata.enterpoint_node.offset == 80 and HnswMetadata.dist_func.offset == 84
+
+
+def test_make_meta_follows_hnsw_get_index():
+    m = pg.make_meta(768, 16, 200, 128, pg.DIST_L2)           # embedding.c:222-229
+    assert (m.maxM, m.offset_data, m.offset_label, m.size_data_per_element) == (32, 132, 132 + 3072, 3212)
+    assert m.elems_per_page == 2
+    assert pg.make_meta(3, 3).elems_per_page == 157
+    assert pg.make_meta(128, 16).size_data_per_element == 652
+    with pytest.raises(ValueError):
+        pg.make_meta(0)
+    with pytest.raises(ValueError):
+        pg.make_meta(4000, 16)                                # does not fit a page, embedding.c:230-231
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(REF, "embedding.h")), reason="reference not mounted")
+def test_header_is_byte_compatible_with_reference_header():
+    """Compile both headers in separate TUs and compare every size/offset/enum value and
+    the type of every shared prototype."""
+    probe = r'''
+    #include <stdio.h>
+    #include <stddef.h>
+    %s
+    #define P(x) printf(#x "=%%zu\n", (size_t)(x))
+    int main(void){
+      P(sizeof(HnswMetadata)); P(offsetof(HnswMetadata,dim)); P(offsetof(HnswMetadata,data_size));
+      P(offsetof(HnswMetadata,offset_data)); P(offsetof(HnswMetadata,offset_label));
+      P(offsetof(HnswMetadata,size_data_per_element)); P(offsetof(HnswMetadata,elems_per_page));
+      P(offsetof(HnswMetadata,M)); P(offsetof(HnswMetadata,maxM)); P(offsetof(HnswMetadata,efConstruction));
+      P(offsetof(HnswMetadata,efSearch)); P(offsetof(HnswMetadata,enterpoint_node)); P(offsetof(HnswMetadata,dist_func));
+      P(sizeof(coord_t)); P(sizeof(dist_t)); P(sizeof(idx_t)); P(sizeof(label_t)); P(sizeof(dist_func_t));
+      P(DIST_L2); P(DIST_COSINE); P(DIST_MANHATTAN);
+      /* prototypes: assigning to typed function pointers fails to compile on any mismatch */
+      bool (*a)(HnswMetadata*, const coord_t*, size_t*, label_t**) = hnsw_search; (void)a;
+      bool (*b)(HnswMetadata*, const coord_t*, idx_t) = hnsw_bind_point; (void)b;
+      dist_t (*c)(dist_func_t, coord_t const*, coord_t const*, size_t) = hnsw_dist_func; (void)c;
+      void (*d)(void) = hnsw_init_dist_func; (void)d;
+      bool (*e)(HnswMetadata*, idx_t, idx_t**, coord_t**, label_t*) = hnsw_begin_read; (void)e;
+      void (*f)(HnswMetadata*) = hnsw_end_read; (void)f;
+      void (*g)(HnswMetadata*, idx_t, idx_t**, coord_t**, label_t*) = hnsw_begin_write; (void)g;
+      void (*h)(HnswMetadata*) = hnsw_end_write; (void)h;
+      void (*i)(HnswMetadata*, idx_t) = hnsw_prefetch; (void)i;
+      bool (*j)(label_t) = hnsw_is_deleted; (void)j;
+      return 0; }
+    '''
+    outs = []
+    with tempfile.TemporaryDirectory() as td:
+        for tag, inc in (("mine", '#include "hnsw_abi.h"'),
+                         ("ref", '#include <stdint.h>\n#include <stdbool.h>\n#include "embedding.h"')):
+            src = os.path.join(td, tag + ".c")
+            open(src, "w").write(probe % inc)
+            exe = os.path.join(td, tag)
+            subprocess.run(["gcc", "-Wall", "-Werror", "-I", INC, "-I", REF, "-c", src, "-o", exe + ".o"], check=True)
+            # link against stubs: only sizes are executed
+            stub = os.path.join(td, tag + "_stub.c")
+            open(stub, "w").write("".join(f"void {s}(void){{}}\n" for s in (
+                "hnsw_search", "hnsw_bind_point", "hnsw_dist_func", "hnsw_init_dist_func", "hnsw_begin_read",
+                "hnsw_end_read", "hnsw_begin_write", "hnsw_end_write", "hnsw_prefetch", "hnsw_is_deleted")))
+            subprocess.run(["gcc", exe + ".o", stub, "-o", exe], check=True)
+            outs.append(subprocess.run([exe], capture_output=True, text=True, check=True).stdout)
+    assert outs[0] == outs[1]
+    assert "sizeof(HnswMetadata)=88" in outs[0]
+
+
+def test_libraries_export_every_declared_symbol():
+    gpu = exported(B.GPU_LIB)
+    shim = exported(B.SHIM_LIB)
+    assert declared("hnsw_gpu.h") - {"hnsw_search", "hnsw_bind_point", "hnsw_dist_func", "hnsw_init_dist_func",
+                                      "hnsw_begin_read", "hnsw_end_read", "hnsw_begin_write", "hnsw_end_write",
+                                      "hnsw_prefetch", "hnsw_is_deleted"} <= gpu
+    assert {"hnsw_search", "hnsw_bind_point", "hnsw_dist_func", "hnsw_init_dist_func"} <= shim   # embedding.h:46-47,55-56
+    assert declared("hnsw_gpu_shim.h") <= shim
+    # the shim imports the host's storage callbacks exactly like hnswalg.cpp does (embedding.h:44,48-53)
+    und = undefined(B.SHIM_LIB)
+    assert {"hnsw_begin_read", "hnsw_end_read"} <= und
+    # and the core library must be host-independent
+    assert not any(s.startswith("hnsw_begin") or s.startswith("hnsw_end") for s in undefined(B.GPU_LIB))
+
+
+def test_no_cpu_fallback_product_never_links_the_oracle():
+    for lib in (B.GPU_LIB, B.SHIM_LIB):
+        und = undefined(lib) | exported(lib)
+        assert not any(s.startswith("port_") or s.startswith("flat_") for s in und)
+    pkg = os.path.join(ROOT, "pg_embedding_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_fails_loudly_without_a_device(gpu_count):
+    if gpu_count > 0:
+        pytest.skip("a GPU is present")
+    meta = pg.make_meta(8, 4)
+    with pytest.raises(RuntimeError, match="no HIP device|HIP"):
+        pg.GpuIndex.from_flat(meta, np.zeros(0, np.uint8), 0)
+    with pytest.raises(RuntimeError):
+        pg.dist_batch(pg.DIST_L2, np.zeros(8, np.float32), np.zeros((2, 8), np.float32))
+    assert gpu_lib().hnsw_gpu_last_error()
