@@ -125,8 +125,9 @@ __device__ __forceinline__ void remove_first(uint64_t *A, uint32_t sz, int lane)
 	}
 }
 
+// Generic form: results / candidates as sorted arrays in LDS, any ef (used when ef > 256).
 template <int FUNC, typename SH>
-__global__ __launch_bounds__(256) void hnsw_search_kernel(const SearchArgs a)
+__global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = threadIdx.x & 63;
@@ -333,6 +334,411 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel(const SearchArgs a)
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_s_waitcnt(0);   // drain: the next query's atomics must see the zeros
+		wave_sync();
+	}
+}
+
+
+// =====================================================================================
+// Register-resident form (ef <= 64*RREG, RREG in {2,4}): the hot configuration.
+//
+//   results    : SORTED ascending in RREG 64-bit registers per lane (index = reg*64 + lane,
+//                unused slots = ~0).  Insert = ballot-count for the position + one DPP
+//                wave_shr:1 shift; the worst element falls off the end.  No LDS, no waits.
+//   candidates : UNSORTED in 2*RREG registers per lane (capacity 128*RREG >= 2*ef, which the
+//                header comment proves sufficient).  Append = one lane write; pop-best = a
+//                per-lane min + a DPP wave-min of the distance word (ties on the distance
+//                resolved by a second min over ~idx).
+//   accept loop: lane r holds (dist, id) of new row r; rows that cannot beat the bound as
+//                it stood at the start of the hop are masked out with one ballot (the bound
+//                only decreases, so they would be rejected at their turn anyway) and the
+//                survivors are visited in link order via v_readlane.
+// =====================================================================================
+
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v)
+{
+	return (uint32_t) __builtin_amdgcn_update_dpp((int) old, (int) v, CTRL, ROW_MASK, 0xF, false);
+}
+
+// min over the wavefront, returned uniformly
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+	v = min(v, dpp_u32<0xB1>(v, v));           // lane ^ 1
+	v = min(v, dpp_u32<0x4E>(v, v));           // lane ^ 2
+	v = min(v, dpp_u32<0x141>(v, v));          // row_half_mirror
+	v = min(v, dpp_u32<0x140>(v, v));          // row_mirror: every lane of a row = row min
+	v = min(v, dpp_u32<0x142, 0xA>(v, v));     // row_bcast15 into rows 1 and 3
+	v = min(v, dpp_u32<0x143, 0xC>(v, v));     // row_bcast31 into rows 2 and 3
+	return (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
+}
+
+__device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t l)
+{
+	const uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) v, (int) l);
+	const uint32_t hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (v >> 32), (int) l);
+	return ((uint64_t) hi << 32) | lo;
+}
+
+// value of lane-1 (lane 0 receives `fill`)
+__device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v, uint64_t fill)
+{
+	const uint32_t lo = dpp_u32<0x138>((uint32_t) fill, (uint32_t) v);              // wave_shr:1
+	const uint32_t hi = dpp_u32<0x138>((uint32_t) (fill >> 32), (uint32_t) (v >> 32));
+	return ((uint64_t) hi << 32) | lo;
+}
+
+template <int R>
+__device__ __forceinline__ void res_insert(uint64_t (&rk)[R], uint64_t key, uint32_t ef, int lane)
+{
+	uint32_t p = 0;
+#pragma unroll
+	for (int k = 0; k < R; k++) p += (uint32_t) __builtin_popcountll(__ballot(rk[k] < key));
+#pragma unroll
+	for (int k = R - 1; k >= 0; k--)
+	{
+		const uint64_t fill = (k > 0) ? readlane_u64(rk[k > 0 ? k - 1 : 0], 63) : 0ull;
+		const uint64_t prev = wave_shr1_u64(rk[k], fill);
+		const uint32_t i = (uint32_t) k * 64 + lane;
+		const uint64_t nv = (i < p) ? rk[k] : ((i == p) ? key : prev);
+		rk[k] = (i >= ef) ? ~0ull : nv;
+	}
+}
+
+// NOTE: every access below touches ALL registers of the array with compile-time indices and
+// picks by select.  Writing `if (k == sel) a[k] = ...` lets the optimiser fold the unrolled
+// chain back into a dynamically indexed a[sel], which forces the array into scratch memory.
+template <int R>
+__device__ __forceinline__ uint64_t res_at(const uint64_t (&rk)[R], uint32_t i)
+{
+	uint64_t out = 0;
+#pragma unroll
+	for (int k = 0; k < R; k++)
+	{
+		const uint64_t t = readlane_u64(rk[k], i & 63);
+		out = ((i >> 6) == (uint32_t) k) ? t : out;
+	}
+	return out;
+}
+
+template <int C>
+__device__ __forceinline__ void cand_set(uint64_t (&ck)[C], uint32_t slot, uint64_t key, int lane)
+{
+	const uint32_t mine = (uint32_t) lane | 0xFFFFFFC0u;      // matches slot only through the per-register test
+#pragma unroll
+	for (int k = 0; k < C; k++)
+	{
+		const bool hit = slot == ((uint32_t) k * 64 + (uint32_t) lane);
+		ck[k] = hit ? key : ck[k];
+	}
+	(void) mine;
+}
+
+// Smallest key of the set; returns its slot through `slot`.  Set must be non-empty.
+template <int C>
+__device__ __forceinline__ uint64_t cand_min(const uint64_t (&ck)[C], uint32_t &slot, int lane)
+{
+	uint64_t m = ck[0];
+	uint32_t mk = 0;
+#pragma unroll
+	for (int k = 1; k < C; k++)
+	{
+		const bool lt = ck[k] < m;
+		m = lt ? ck[k] : m;
+		mk = lt ? (uint32_t) k : mk;
+	}
+	const uint32_t h = (uint32_t) (m >> 32);
+	const uint32_t hmin = wave_min_u32(h);
+	uint64_t eq = __ballot(h == hmin);
+	if (__builtin_popcountll(eq) > 1)                      // equal distances: larger idx first
+	{
+		const uint32_t lo = (h == hmin) ? (uint32_t) m : 0xFFFFFFFFu;
+		const uint32_t lomin = wave_min_u32(lo);
+		eq = __ballot(h == hmin && lo == lomin);
+	}
+	const uint32_t L = (uint32_t) __builtin_ctzll(eq);
+	slot = ((uint32_t) __builtin_amdgcn_readlane((int) mk, (int) L) << 6) | L;
+	return readlane_u64(m, L);
+}
+
+// Largest real key (set full): used only to make room when the candidate set overflows.
+template <int C>
+__device__ __forceinline__ uint64_t cand_max(const uint64_t (&ck)[C], uint32_t &slot, int lane)
+{
+	uint64_t m = ck[0];
+	uint32_t mk = 0;
+#pragma unroll
+	for (int k = 1; k < C; k++)
+	{
+		const bool gt = ck[k] > m;
+		m = gt ? ck[k] : m;
+		mk = gt ? (uint32_t) k : mk;
+	}
+	const uint32_t h = ~(uint32_t) (m >> 32);
+	const uint32_t hmin = wave_min_u32(h);
+	uint64_t eq = __ballot(h == hmin);
+	if (__builtin_popcountll(eq) > 1)
+	{
+		const uint32_t lo = (h == hmin) ? ~(uint32_t) m : 0xFFFFFFFFu;
+		const uint32_t lomin = wave_min_u32(lo);
+		eq = __ballot(h == hmin && lo == lomin);
+	}
+	const uint32_t L = (uint32_t) __builtin_ctzll(eq);
+	slot = ((uint32_t) __builtin_amdgcn_readlane((int) mk, (int) L) << 6) | L;
+	return readlane_u64(m, L);
+}
+
+template <int FUNC, typename SH, int RREG>
+__global__ __launch_bounds__(256) void hnsw_search_kernel_reg(const SearchArgs a)
+{
+	constexpr int CREG = 2 * RREG;
+	constexpr uint32_t CCAP = 64u * CREG;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = threadIdx.x & 63;
+	const uint32_t wib = threadIdx.x >> 6;
+	unsigned char *my = smem + (size_t) wib * a.wave_bytes;
+	float        *qf      = reinterpret_cast<float *>(my);
+	const float4 *q4      = reinterpret_cast<const float4 *>(my);
+	uint64_t     *tie_key = reinterpret_cast<uint64_t *>(my + a.off_res);     // tie path of the emit only
+	uint64_t     *tie_lab = reinterpret_cast<uint64_t *>(my + a.off_cand);
+	uint32_t     *newid   = reinterpret_cast<uint32_t *>(my + a.off_newid);
+	float        *newdist = reinterpret_cast<float *>(my + a.off_newdist);
+
+	const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wib;
+	uint32_t *vis  = a.vis + (size_t) slot * a.vis_words;
+	uint32_t *vlog = a.vlog + (size_t) slot * a.logcap;
+	const uint32_t ef = a.ef;
+
+	for (;;)
+	{
+		uint32_t qi = 0;
+		if (lane == 0) qi = atomicAdd(a.ticket, 1u);
+		qi = __builtin_amdgcn_readfirstlane(qi);
+		if (qi >= a.nq) break;
+
+		const float *qsrc = a.queries + (size_t) qi * a.q_stride;
+		for (uint32_t e = lane; e < a.qpad_floats; e += 64)
+		{
+			const float t = qsrc[e < a.dim ? e : a.dim - 1];
+			qf[e] = (e < a.dim) ? t : 0.f;
+		}
+		wave_sync();
+		float qnorm = 0.f;
+		if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
+
+		uint64_t rk[RREG], ck[CREG];
+#pragma unroll
+		for (int k = 0; k < RREG; k++) rk[k] = ~0ull;
+#pragma unroll
+		for (int k = 0; k < CREG; k++) ck[k] = ~0ull;
+		uint32_t rsize = 0, csize = 0, logn = 0, evals = 0, hops = 0;
+
+		if (a.n > 0)
+		{
+			const uint32_t ep = a.entry;                                   // hnswalg.cpp:55-65
+			{
+				auto one = [ep](uint32_t) { return ep; };
+				score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, one, 1u, newdist, lane);
+			}
+			wave_sync();
+			float lowerBound = newdist[0];
+			evals = 1;
+			{
+				const uint64_t hi = (uint64_t) ord_f32(lowerBound) << 32;
+				res_insert<RREG>(rk, hi | ep, ef, lane);
+				cand_set<CREG>(ck, 0, hi | (uint32_t) ~ep, lane);
+			}
+			if (lane == 0)
+			{
+				vis[ep >> 5] = 1u << (ep & 31);
+				vlog[0] = ep;
+			}
+			rsize = csize = logn = 1;
+
+			while (csize > 0)                                               // hnswalg.cpp:67-112
+			{
+				uint32_t cslot;
+				const uint64_t ckey = cand_min<CREG>(ck, cslot, lane);
+				if (unord_f32((uint32_t) (ckey >> 32)) > lowerBound)        // :70-71
+					break;
+				const uint32_t cur = ~(uint32_t) ckey;
+				{                                                           // :73 pop = move last into the hole
+					const uint32_t last = csize - 1;
+					const uint64_t lastkey = res_at<CREG>(ck, last);
+					cand_set<CREG>(ck, cslot, lastkey, lane);
+					cand_set<CREG>(ck, last, ~0ull, lane);
+					csize = last;
+				}
+				hops++;
+
+				for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)               // :76-77
+				{
+					const uint32_t j = j0 + lane;
+					const uint32_t t = a.links[(size_t) cur * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
+					bool isnew = false;
+					if (j < a.lstride && t != LINK_NONE)                    // :91-93
+					{
+						const uint32_t bit = 1u << (t & 31);
+						const uint32_t old = atomicOr(&vis[t >> 5], bit);
+						isnew = !(old & bit);
+					}
+					const uint64_t mask = __ballot(isnew);
+					const uint32_t nnew = (uint32_t) __builtin_popcountll(mask);
+					if (nnew == 0) continue;
+					const uint32_t rank = lane_rank(mask);
+					if (isnew)
+					{
+						newid[rank] = t;
+						const uint32_t lp = logn + rank;
+						if (lp < a.logcap) vlog[lp] = t;
+					}
+					logn += nnew;
+					wave_sync();
+					{                                                       // :95-97, batched
+						const uint32_t *ids = newid;
+						auto by_id = [ids](uint32_t r) { return ids[r]; };
+						score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, by_id, nnew, newdist, lane);
+					}
+					evals += nnew;
+					wave_sync();
+					const float    d_mine = newdist[lane];                  // lane r <- row r
+					const uint32_t t_mine = newid[lane];
+					uint64_t todo = __ballot((uint32_t) lane < nnew && (rsize < ef || lowerBound > d_mine));
+					while (todo)                                            // :99-108, in link order
+					{
+						const uint32_t r = (uint32_t) __builtin_ctzll(todo);
+						todo &= todo - 1;
+						const float d = __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(d_mine), (int) r));
+						if (rsize < ef || lowerBound > d)
+						{
+							const uint32_t t2 = (uint32_t) __builtin_amdgcn_readlane((int) t_mine, (int) r);
+							const uint64_t hi = (uint64_t) ord_f32(d) << 32;
+							if (csize == CCAP)                              // make room: the largest key is dead
+							{
+								uint32_t ms;
+								const uint64_t mx = cand_max<CREG>(ck, ms, lane);
+								if ((hi | (uint32_t) ~t2) < mx) cand_set<CREG>(ck, ms, hi | (uint32_t) ~t2, lane);
+							}
+							else
+							{
+								cand_set<CREG>(ck, csize, hi | (uint32_t) ~t2, lane);   // :100
+								csize++;
+							}
+							res_insert<RREG>(rk, hi | t2, ef, lane);        // :102-105
+							rsize = rsize < ef ? rsize + 1 : ef;
+							lowerBound = unord_f32((uint32_t) (res_at<RREG>(rk, rsize - 1) >> 32));   // :107
+						}
+					}
+					wave_sync();
+				}
+			}
+		}
+
+		// ---- emit -------------------------------------------------------------------------
+		const size_t obase = (size_t) qi * ef;
+		uint32_t nout = 0;
+		if (a.mode == 1)
+		{
+#pragma unroll
+			for (int k = 0; k < RREG; k++)
+			{
+				const uint32_t i = (uint32_t) k * 64 + lane;
+				if (i < ef)
+				{
+					const bool ok = i < rsize;
+					a.out_idx[obase + i] = ok ? (uint32_t) rk[k] : LINK_NONE;
+					if (a.out_dists) a.out_dists[obase + i] = ok ? unord_f32((uint32_t) (rk[k] >> 32)) : __builtin_inff();
+				}
+			}
+			nout = rsize;
+		}
+		else
+		{
+			// searchKnn, hnswalg.cpp:241-249
+			uint64_t lab[RREG];
+			bool tie = false;
+#pragma unroll
+			for (int k = 0; k < RREG; k++)
+			{
+				const uint32_t i = (uint32_t) k * 64 + lane;
+				lab[k] = a.labels[(i < rsize) ? (uint32_t) rk[k] : 0];
+				const uint64_t fill = (k > 0) ? readlane_u64(rk[k > 0 ? k - 1 : 0], 63) : 0ull;
+				const uint64_t prev = wave_shr1_u64(rk[k], fill);
+				if (i > 0 && i < rsize && (uint32_t) (prev >> 32) == (uint32_t) (rk[k] >> 32)) tie = true;
+			}
+			if (__ballot(tie) == 0)
+			{
+#pragma unroll
+				for (int k = 0; k < RREG; k++)
+				{
+					const uint32_t i = (uint32_t) k * 64 + lane;
+					const bool keep = i < rsize && !((lab[k] >> 48) & 1);
+					const uint64_t kmask = __ballot(keep);
+					if (keep)
+					{
+						const uint32_t rank = nout + lane_rank(kmask);
+						a.out_labels[obase + rank] = lab[k];
+						if (a.out_dists) a.out_dists[obase + rank] = unord_f32((uint32_t) (rk[k] >> 32));
+					}
+					nout += (uint32_t) __builtin_popcountll(kmask);
+				}
+			}
+			else
+			{
+				// equal distances present: order by (dist, label) through LDS (hnswalg.cpp:236,246)
+#pragma unroll
+				for (int k = 0; k < RREG; k++)
+				{
+					const uint32_t i = (uint32_t) k * 64 + lane;
+					if (i < rsize) { tie_key[i] = rk[k]; tie_lab[i] = lab[k]; }
+				}
+				wave_sync();
+#pragma unroll
+				for (int k = 0; k < RREG; k++)
+				{
+					const uint32_t i = (uint32_t) k * 64 + lane;
+					const bool keep = i < rsize && !((lab[k] >> 48) & 1);
+					const uint32_t di = (uint32_t) (rk[k] >> 32);
+					uint32_t rank = 0;
+					for (uint32_t jx = 0; jx < rsize; jx++)
+					{
+						const uint64_t lj = tie_lab[jx];
+						const uint32_t dj = (uint32_t) (tie_key[jx] >> 32);
+						const bool kj = !((lj >> 48) & 1);
+						rank += (kj && (dj < di || (dj == di && lj < lab[k]))) ? 1u : 0u;
+					}
+					if (keep)
+					{
+						a.out_labels[obase + rank] = lab[k];
+						if (a.out_dists) a.out_dists[obase + rank] = unord_f32(di);
+					}
+					nout += (uint32_t) __builtin_popcountll(__ballot(keep));
+				}
+			}
+			for (uint32_t i = nout + lane; i < ef; i += 64)
+			{
+				a.out_labels[obase + i] = ~0ull;
+				if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
+			}
+		}
+		if (lane == 0)
+		{
+			a.out_counts[qi] = nout;
+			if (a.out_stats) { a.out_stats[2 * (size_t) qi] = evals; a.out_stats[2 * (size_t) qi + 1] = hops; }
+		}
+
+		// ---- restore the all-zero bitmap ---------------------------------------------------
+		wave_sync();
+		if (logn <= a.logcap)
+		{
+			for (uint32_t i = lane; i < logn; i += 64) vis[vlog[i] >> 5] = 0u;
+		}
+		else
+		{
+			for (uint64_t w = lane; w < a.vis_words; w += 64) vis[w] = 0u;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_s_waitcnt(0);
 		wave_sync();
 	}
 }

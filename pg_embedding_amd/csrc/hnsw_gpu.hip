@@ -374,25 +374,45 @@ extern "C" int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int del
 // ------------------------------------------------------------------------------------
 typedef void (*search_kernel_t)(const SearchArgs);
 
-template <typename SH>
+// rreg: 0 = LDS form (any ef), 2 / 4 = register form for ef <= 128 / 256
+template <typename SH, int RREG>
 static search_kernel_t pick_search_kernel_f(int func)
 {
+	if (RREG == 0)
+		switch (func)
+		{
+			case F_L2:     return hnsw_search_kernel_lds<F_L2, SH>;
+			case F_COSINE: return hnsw_search_kernel_lds<F_COSINE, SH>;
+			default:       return hnsw_search_kernel_lds<F_MANHATTAN, SH>;
+		}
+	constexpr int R = RREG == 0 ? 2 : RREG;
 	switch (func)
 	{
-		case F_L2:     return hnsw_search_kernel<F_L2, SH>;
-		case F_COSINE: return hnsw_search_kernel<F_COSINE, SH>;
-		default:       return hnsw_search_kernel<F_MANHATTAN, SH>;
+		case F_L2:     return hnsw_search_kernel_reg<F_L2, SH, R>;
+		case F_COSINE: return hnsw_search_kernel_reg<F_COSINE, SH, R>;
+		default:       return hnsw_search_kernel_reg<F_MANHATTAN, SH, R>;
 	}
 }
 
-static search_kernel_t pick_search_kernel(int func, uint32_t kiters)
+template <typename SH>
+static search_kernel_t pick_search_kernel_s(int func, int rreg)
+{
+	switch (rreg)
+	{
+		case 2:  return pick_search_kernel_f<SH, 2>(func);
+		case 4:  return pick_search_kernel_f<SH, 4>(func);
+		default: return pick_search_kernel_f<SH, 0>(func);
+	}
+}
+
+static search_kernel_t pick_search_kernel(int func, uint32_t kiters, int rreg)
 {
 	switch (shape_index(kiters))
 	{
-		case 0:  return pick_search_kernel_f<Shape2x4>(func);
-		case 1:  return pick_search_kernel_f<Shape4x2>(func);
-		case 2:  return pick_search_kernel_f<Shape8x2>(func);
-		default: return pick_search_kernel_f<Shape12x1>(func);
+		case 0:  return pick_search_kernel_s<Shape2x4>(func, rreg);
+		case 1:  return pick_search_kernel_s<Shape4x2>(func, rreg);
+		case 2:  return pick_search_kernel_s<Shape8x2>(func, rreg);
+		default: return pick_search_kernel_s<Shape12x1>(func, rreg);
 	}
 }
 
@@ -424,9 +444,14 @@ static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t q_st
 
 	// LDS carve per wave
 	a.qpad_floats = (uint32_t) round_up(a.kiters, shape_kb(shape_index(a.kiters))) * 64;
+	// register form keeps results/candidates in VGPRs; its LDS "res"/"cand" areas are only the
+	// (dist,label) tie-break scratch of the emit step
+	int rreg = ef <= 128 ? 2 : (ef <= 256 ? 4 : 0);
+	const char *force = getenv("HNSW_GPU_FORCE_LDS_HEAPS");
+	if (force && atoi(force) > 0) rreg = 0;
 	size_t off = (size_t) a.qpad_floats * 4;
-	a.off_res = (uint32_t) off;     off += round_up((ef + 1) * 8, 16);
-	a.off_cand = (uint32_t) off;    off += round_up((2 * ef + 1) * 8, 16);
+	a.off_res = (uint32_t) off;     off += round_up((rreg ? ef : ef + 1) * 8, 16);
+	a.off_cand = (uint32_t) off;    off += round_up((rreg ? ef : 2 * ef + 1) * 8, 16);
 	a.off_newid = (uint32_t) off;   off += 64 * 4;
 	a.off_newdist = (uint32_t) off; off += 64 * 4;
 	a.wave_bytes = (uint32_t) round_up(off, 16);
@@ -436,7 +461,7 @@ static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t q_st
 	uint32_t wpb = 4;
 	while (wpb > 1 && (size_t) wpb * a.wave_bytes > 64 * 1024) wpb >>= 1;
 	const size_t lds = (size_t) wpb * a.wave_bytes;
-	search_kernel_t kern = pick_search_kernel((int) ix->meta.dist_func, a.kiters);
+	search_kernel_t kern = pick_search_kernel((int) ix->meta.dist_func, a.kiters, rreg);
 	if (lds > 48 * 1024)
 		HIPCHK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 	int per_cu = 0;
