@@ -77,6 +77,13 @@ int hnsw_gpu_index_export_flat(hnsw_gpu_index *ix, void *elements);
 /* Set / clear the vacuum flag of one element's label (embedding.c:920-926). */
 int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int deleted);
 
+/* Grow the mirror's capacity (elements and graph are kept). */
+int hnsw_gpu_index_reserve(hnsw_gpu_index *ix, size_t capacity);
+
+/* Link list of one element in the host image form: out[0] = count, out[1..maxM] = links
+ * (embedding.c:222-226).  `out` holds maxM + 1 values. */
+int hnsw_gpu_index_get_links(hnsw_gpu_index *ix, idx_t idx, idx_t *out);
+
 size_t hnsw_gpu_index_count(const hnsw_gpu_index *ix);
 int    hnsw_gpu_index_device(const hnsw_gpu_index *ix);
 void   hnsw_gpu_index_destroy(hnsw_gpu_index *ix);

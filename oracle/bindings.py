@@ -213,6 +213,10 @@ def _bind_flat(L):
     L.flat_elem_size.restype = C.c_size_t
     L.flat_elem_size.argtypes = [C.c_void_p]
     L.flat_set_ef_search.argtypes = [C.c_void_p, C.c_size_t]
+    L.flat_set_page_real.restype = C.c_int
+    L.flat_set_page_real.argtypes = [C.c_void_p, C.c_size_t]
+    L.flat_idx_end.restype = C.c_size_t
+    L.flat_idx_end.argtypes = [C.c_void_p]
     L.flat_set_ef_construction.argtypes = [C.c_void_p, C.c_size_t]
     L.flat_append.restype = C.c_long
     L.flat_append.argtypes = [C.c_void_p, _f32p, C.c_uint64]
@@ -263,6 +267,15 @@ class _FlatIndexBase:
     @property
     def elem_size(self) -> int:
         return int(self.L.flat_elem_size(self.h))
+
+    def set_page_real(self, page_real: int) -> None:
+        """Give element numbers tail-of-page holes; only on an empty index."""
+        if self.L.flat_set_page_real(self.h, page_real) != 0:
+            raise ValueError("flat_set_page_real")
+
+    @property
+    def idx_end(self) -> int:
+        return int(self.L.flat_idx_end(self.h))
 
     @property
     def meta(self):

@@ -38,6 +38,9 @@ typedef struct FlatIndex
 	size_t  n;              /* elements stored                                        */
 	size_t  cap;            /* elements allocated                                     */
 	int     owns_data;
+	size_t  page_real;      /* 0 = dense idx space; else elements that really fit a page:
+							 * idx = blk*elems_per_page + off with off < page_real, i.e. the
+							 * tail-of-page holes of embedding.c:229,693     */
 } FlatIndex;
 
 /* Per-thread instrumentation (E_q = coords reads, H_q = link reads). */
@@ -49,9 +52,23 @@ static __thread int      tl_max_pin_depth;
 
 #define FLAT_MAX_PINS 4    /* HNSW_STACK_SIZE, embedding.c:40 */
 
-static inline char *elem_ptr(FlatIndex *f, idx_t idx)
+/* element number -> storage slot; false when the element does not exist */
+static inline bool idx_to_slot(const FlatIndex *f, idx_t idx, size_t *slot)
 {
-	return f->data + (size_t) idx * f->meta.size_data_per_element;
+	if (!f->page_real) { *slot = idx; return (size_t) idx < f->n; }
+	size_t epp = f->meta.elems_per_page, blk = idx / epp, off = idx % epp;
+	if (off >= f->page_real) return false;
+	*slot = blk * f->page_real + off;
+	return *slot < f->n;
+}
+static inline idx_t slot_to_idx(const FlatIndex *f, size_t slot)
+{
+	if (!f->page_real) return (idx_t) slot;
+	return (idx_t) ((slot / f->page_real) * f->meta.elems_per_page + slot % f->page_real);
+}
+static inline char *slot_ptr(FlatIndex *f, size_t slot)
+{
+	return f->data + slot * f->meta.size_data_per_element;
 }
 
 /* ------------------------------------------------------------------------- */
@@ -63,8 +80,9 @@ bool hnsw_begin_read(HnswMetadata *meta, idx_t idx, idx_t **indexes, coord_t **c
 {
 	FlatIndex *f = (FlatIndex *) meta;
 	char *p;
+	size_t slot;
 
-	if ((size_t) idx >= f->n)
+	if (!idx_to_slot(f, idx, &slot))
 		return false;
 	if (tl_pin_depth >= FLAT_MAX_PINS)
 	{
@@ -75,7 +93,7 @@ bool hnsw_begin_read(HnswMetadata *meta, idx_t idx, idx_t **indexes, coord_t **c
 	tl_pin_depth++;
 	if (tl_pin_depth > tl_max_pin_depth)
 		tl_max_pin_depth = tl_pin_depth;
-	p = elem_ptr(f, idx);
+	p = slot_ptr(f, slot);
 	if (indexes) { *indexes = (idx_t *) p; tl_link_reads++; }
 	if (coords)  { *coords = (coord_t *) (p + meta->offset_data); tl_coords_reads++; }
 	if (label)   { memcpy(label, p + meta->offset_label, sizeof(label_t)); tl_label_reads++; }
@@ -100,14 +118,15 @@ void hnsw_begin_write(HnswMetadata *meta, idx_t idx, idx_t **indexes, coord_t **
 {
 	FlatIndex *f = (FlatIndex *) meta;
 	char *p;
+	size_t slot;
 
-	if ((size_t) idx >= f->n || tl_write_pins != 0)
+	if (!idx_to_slot(f, idx, &slot) || tl_write_pins != 0)
 	{
 		fprintf(stderr, "flat_host: bad hnsw_begin_write(%u)\n", (unsigned) idx);
 		abort();
 	}
 	tl_write_pins = 1;
-	p = elem_ptr(f, idx);
+	p = slot_ptr(f, slot);
 	if (indexes) *indexes = (idx_t *) p;
 	if (coords)  *coords = (coord_t *) (p + meta->offset_data);
 	if (label)   memcpy(label, p + meta->offset_label, sizeof(label_t));
@@ -123,8 +142,9 @@ void hnsw_end_write(HnswMetadata *meta)
 void hnsw_prefetch(HnswMetadata *meta, idx_t idx)
 {
 	FlatIndex *f = (FlatIndex *) meta;
-	if ((size_t) idx < f->n)
-		__builtin_prefetch(elem_ptr(f, idx) + meta->offset_data);
+	size_t slot;
+	if (idx_to_slot(f, idx, &slot))
+		__builtin_prefetch(slot_ptr(f, slot) + meta->offset_data);
 }
 
 /* embedding.c:948-953: flags half-word bit 0 == bit 48 of the u64. */
@@ -176,6 +196,18 @@ void flat_destroy(FlatIndex *f)
 	free(f);
 }
 
+/* Emulate a page that really holds `page_real` < elems_per_page elements (MAXALIGN padding,
+ * embedding.c:229 vs PageAddItem): element numbers get holes at every page tail.  Must be
+ * called on an empty index. */
+int flat_set_page_real(FlatIndex *f, size_t page_real)
+{
+	if (f->n != 0 || page_real == 0 || page_real > f->meta.elems_per_page) return -1;
+	f->page_real = page_real == f->meta.elems_per_page ? 0 : page_real;
+	return 0;
+}
+/* highest element number + 1 */
+size_t flat_idx_end(FlatIndex *f) { return f->n ? (size_t) slot_to_idx(f, f->n - 1) + 1 : 0; }
+
 HnswMetadata *flat_meta(FlatIndex *f)   { return &f->meta; }
 size_t        flat_count(FlatIndex *f)  { return f->n; }
 void         *flat_data(FlatIndex *f)   { return f->data; }
@@ -202,11 +234,11 @@ static int flat_reserve(FlatIndex *f, size_t want)
 long flat_append(FlatIndex *f, const coord_t *vec, label_t label)
 {
 	if (flat_reserve(f, f->n + 1) != 0) return -1;
-	char *p = elem_ptr(f, (idx_t) f->n);
+	char *p = slot_ptr(f, f->n);
 	memset(p, 0, f->meta.offset_data);
 	memcpy(p + f->meta.offset_data, vec, f->meta.data_size);
 	memcpy(p + f->meta.offset_label, &label, sizeof(label));
-	return (long) f->n++;
+	return (long) slot_to_idx(f, f->n++);
 }
 
 /* Insert = append + hnsw_bind_point (embedding.c:606-701 minus paging/WAL). */
@@ -223,7 +255,7 @@ long flat_add_many(FlatIndex *f, const coord_t *vecs, const label_t *labels, siz
 {
 	for (size_t i = 0; i < n; i++)
 	{
-		long r = flat_add(f, vecs + i * f->meta.dim, labels ? labels[i] : (label_t) (f->n));
+		long r = flat_add(f, vecs + i * f->meta.dim, labels ? labels[i] : (label_t) slot_to_idx(f, f->n));
 		if (r < 0) return r;
 	}
 	return (long) f->n;
@@ -243,7 +275,9 @@ int flat_load_raw(FlatIndex *f, const void *bytes, size_t n)
 void flat_set_deleted(FlatIndex *f, idx_t idx, int deleted)
 {
 	label_t l;
-	char *p = elem_ptr(f, idx) + f->meta.offset_label;
+	size_t slot;
+	if (!idx_to_slot(f, idx, &slot)) return;
+	char *p = slot_ptr(f, slot) + f->meta.offset_label;
 	memcpy(&l, p, sizeof(l));
 	if (deleted) l |= ((label_t) 1 << 48); else l &= ~((label_t) 1 << 48);
 	memcpy(p, &l, sizeof(l));

@@ -60,6 +60,8 @@ def gpu_lib():
     L.hnsw_gpu_index_append_dev.argtypes = [vp, vp, vp, sz, vp]
     L.hnsw_gpu_index_export_flat.argtypes = [vp, vp]
     L.hnsw_gpu_index_link.argtypes = [vp, sz, sz, sz, sz, vp]
+    L.hnsw_gpu_index_reserve.argtypes = [vp, sz]
+    L.hnsw_gpu_index_get_links.argtypes = [vp, C.c_uint32, vp]
     L.hnsw_gpu_index_set_deleted.argtypes = [vp, C.c_uint32, i32]
     L.hnsw_gpu_index_count.restype = sz
     L.hnsw_gpu_index_count.argtypes = [vp]
@@ -89,7 +91,7 @@ def shim_lib():
     if not os.path.exists(_build.SHIM_LIB):
         raise LibraryMissing(f"{_build.SHIM_LIB} is missing: run __graft_entry__.build()")
     L = C.CDLL(_build.SHIM_LIB, mode=C.RTLD_GLOBAL | os.RTLD_LAZY)
-    MP = C.POINTER(HnswMetadata)
+    MP = C.c_void_p          # HnswMetadata*: any ctypes image of the struct may be passed
     L.hnsw_dist_func.restype = C.c_float
     L.hnsw_dist_func.argtypes = [C.c_int, _f32p, _f32p, C.c_size_t]
     L.hnsw_init_dist_func.restype = None

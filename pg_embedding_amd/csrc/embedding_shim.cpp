@@ -4,8 +4,8 @@
 //   hnsw_search          hnswalg.cpp:256-277  -> one-query launch of the fused search kernel
 //   hnsw_dist_func       distfunc.c:171-174   -> one-row launch of the distance kernel
 //   hnsw_init_dist_func  distfunc.c:159-169   -> device selection / runtime warm-up
-//   hnsw_bind_point      hnswalg.cpp:279-291  -> NOT in this round's scope;
-//                                                returns false, as the reference does on failure
+//   hnsw_bind_point      hnswalg.cpp:279-291  -> serial device insert + write-back of the changed
+//                                                link lists through hnsw_begin_write
 //
 // It imports the host's storage callbacks (embedding.h:44,48-53) exactly like hnswalg.cpp does.
 // There is no CPU implementation behind any of these: without a gfx950 device every call fails
@@ -217,10 +217,89 @@ extern "C" bool hnsw_search(HnswMetadata *meta, const coord_t *point, size_t *n_
 	return true;
 }
 
+// hnsw_bind_point (hnswalg.cpp:279-291).  The host has already stored element `idx`
+// zero-linked (embedding.c:619-621,670).  The device runs the reference's insert in its serial
+// form (hnsw_gpu_index_link, max_batch = 1: searchBaseLayer(efConstruction) +
+// mutuallyConnectNewElement + getNeighborsByHeuristic, bit-identical link lists), then the
+// changed lists — the new element's and those of the elements it linked to — are written back
+// to the host through hnsw_begin_write/hnsw_end_write (one write pin at a time,
+// embedding.c:780-781).  With an attached mirror that already holds elements [0, idx) only the
+// new element is uploaded; otherwise the index is mirrored first.
 extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t idx)
 {
-	(void) meta; (void) point; (void) idx;
-	fprintf(stderr, "pg_embedding_amd: hnsw_bind_point is not provided by the GPU library in this round "
-					"(insert path = SURVEY.md §8(f) rank 1)\n");
-	return false;
+	if (!meta || !point) return false;
+	if (idx == 0) return true;                           // bindPoint: nothing for the first element, hnswalg.cpp:228
+	hnsw_gpu_index *ix = nullptr;
+	bool own = false;
+	{
+		std::lock_guard<std::mutex> lk(g_mu);
+		ix = find_attached(meta);
+	}
+	const size_t maxM = meta->maxM;
+	if (maxM > 4096) return false;
+	static thread_local idx_t mine[4097], other[4097];
+	bool ok = false;
+	do
+	{
+		if (ix)
+		{
+			size_t have = hnsw_gpu_index_count(ix);
+			if (have < (size_t) idx)                     // element numbers skipped a page-tail hole
+			{                                            // (embedding.c:229,693): dead placeholders
+				const size_t gap = (size_t) idx - have;
+				if (hnsw_gpu_index_reserve(ix, (size_t) idx + 1 + (size_t) idx / 2) != HNSW_GPU_OK) break;
+				coord_t *zeros = (coord_t *) calloc(gap * meta->dim, sizeof(coord_t));
+				label_t *dead = (label_t *) malloc(gap * sizeof(label_t));
+				bool fine = zeros && dead;
+				for (size_t g = 0; fine && g < gap; g++) dead[g] = (label_t) 1 << HNSW_LABEL_DELETED_BIT;
+				fine = fine && hnsw_gpu_index_append(ix, zeros, dead, gap) == HNSW_GPU_OK;
+				free(zeros); free(dead);
+				if (!fine) break;
+				have = (size_t) idx;
+			}
+			if (have == (size_t) idx)                    // mirror is exactly one element behind: add it
+			{
+				label_t label = 0;
+				if (!hnsw_begin_read(meta, idx, nullptr, nullptr, &label)) break;
+				hnsw_end_read(meta);
+				if (hnsw_gpu_index_reserve(ix, (size_t) idx + 1 + (size_t) idx / 2) != HNSW_GPU_OK) break;
+				if (hnsw_gpu_index_append(ix, point, &label, 1) != HNSW_GPU_OK) break;
+			}
+			else if (have != (size_t) idx + 1)
+			{
+				fprintf(stderr, "pg_embedding_amd: hnsw_bind_point(%u): attached mirror holds %zu elements\n",
+						(unsigned) idx, have);
+				break;
+			}
+		}
+		else
+		{
+			if (hnsw_gpu_shim_snapshot(meta, &ix) != HNSW_GPU_OK) break;
+			own = true;
+			if (hnsw_gpu_index_count(ix) != (size_t) idx + 1) break;
+		}
+		if (hnsw_gpu_index_link(ix, idx, 1, 1, 0, nullptr) != HNSW_GPU_OK) break;
+		if (hnsw_gpu_index_get_links(ix, idx, mine) != HNSW_GPU_OK) break;
+		bool failed = false;
+		for (uint32_t j = 0; j < mine[0] && !failed; j++)   // neighbours first, like hnswalg.cpp:183-222 ...
+		{
+			if (hnsw_gpu_index_get_links(ix, mine[1 + j], other) != HNSW_GPU_OK) { failed = true; break; }
+			idx_t *dst = nullptr;
+			hnsw_begin_write(meta, mine[1 + j], &dst, nullptr, nullptr);
+			memcpy(dst, other, (maxM + 1) * sizeof(idx_t));
+			hnsw_end_write(meta);
+		}
+		if (failed) break;
+		{                                                   // ... then the element itself (:169-181)
+			idx_t *dst = nullptr;
+			hnsw_begin_write(meta, idx, &dst, nullptr, nullptr);
+			memcpy(dst, mine, (maxM + 1) * sizeof(idx_t));
+			hnsw_end_write(meta);
+		}
+		ok = true;
+	} while (0);
+	if (!ok)
+		fprintf(stderr, "pg_embedding_amd: hnsw_bind_point(%u) failed: %s\n", (unsigned) idx, hnsw_gpu_last_error());
+	if (own && ix) hnsw_gpu_index_destroy(ix);
+	return ok;
 }

@@ -954,3 +954,52 @@ extern "C" int hnsw_gpu_index_link(hnsw_gpu_index *ix, size_t first, size_t coun
 	}
 	return HNSW_GPU_OK;
 }
+
+// ------------------------------------------------------------------------------------
+// small accessors used by the drop-in insert (embedding_shim.cpp)
+// ------------------------------------------------------------------------------------
+extern "C" int hnsw_gpu_index_reserve(hnsw_gpu_index *ix, size_t capacity)
+{
+	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
+	if (capacity <= ix->cap) return HNSW_GPU_OK;
+	if (capacity >= 0xFFFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "capacity exceeds idx_t range");
+	HIPCHK(hipSetDevice(ix->device));
+	HIPCHK(hipDeviceSynchronize());
+	float *nv = nullptr; uint32_t *nl = nullptr; uint64_t *nb = nullptr;
+	hipError_t e;
+	if ((e = hipMalloc(&nv, capacity * ix->stride * sizeof(float))) != hipSuccess ||
+		(e = hipMalloc(&nl, capacity * ix->lstride * sizeof(uint32_t))) != hipSuccess ||
+		(e = hipMalloc(&nb, capacity * sizeof(uint64_t))) != hipSuccess)
+	{
+		if (nv) (void) hipFree(nv);
+		if (nl) (void) hipFree(nl);
+		if (nb) (void) hipFree(nb);
+		return fail(HNSW_GPU_ERR_NOMEM, "cannot grow the mirror to %zu elements: %s", capacity, hipGetErrorString(e));
+	}
+	HIPCHK(hipMemcpy(nv, ix->vec, ix->n * ix->stride * sizeof(float), hipMemcpyDeviceToDevice));
+	HIPCHK(hipMemcpy(nl, ix->links, ix->n * ix->lstride * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+	HIPCHK(hipMemcpy(nb, ix->labels, ix->n * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+	(void) hipFree(ix->vec); (void) hipFree(ix->links); (void) hipFree(ix->labels);
+	ix->vec = nv; ix->links = nl; ix->labels = nb;
+	ix->cap = capacity;
+	// the visited bitmaps are sized by capacity: drop them, the next search re-creates them
+	if (ix->vis) (void) hipFree(ix->vis);
+	if (ix->vlog) (void) hipFree(ix->vlog);
+	ix->vis = nullptr; ix->vlog = nullptr; ix->vis_slots = 0; ix->vis_words = 0;
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_index_get_links(hnsw_gpu_index *ix, idx_t idx, idx_t *out)
+{
+	if (!ix || !out || idx >= ix->n) return fail(HNSW_GPU_ERR_ARG, "bad element %u", (unsigned) idx);
+	HIPCHK(hipSetDevice(ix->device));
+	const size_t maxM = ix->meta.maxM;
+	uint32_t tmp[4096 + 16];
+	HIPCHK(hipMemcpy(tmp, ix->links + (size_t) idx * ix->lstride, ix->lstride * 4, hipMemcpyDeviceToHost));
+	uint32_t cnt = 0;
+	for (size_t j = 0; j < maxM; j++)
+		if (tmp[j] != LINK_NONE) out[1 + cnt++] = tmp[j];
+	out[0] = cnt;
+	for (size_t j = cnt; j < maxM; j++) out[1 + j] = 0;
+	return HNSW_GPU_OK;
+}
