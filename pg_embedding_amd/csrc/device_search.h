@@ -62,6 +62,9 @@ struct SearchArgs
 	uint32_t *err;              // device-side invariant failures
 	// LDS carve (bytes, per wave)
 	uint32_t qpad_floats, off_res, off_cand, off_newid, off_newdist, wave_bytes;
+	// register form only: exact visited hash set in LDS (power-of-two entries, 0 = off); ids that
+	// arrive after it is hmax full go to the HBM bitmap instead
+	uint32_t off_hash, hcap, hmax;
 	int mode;                   // 0 = hnsw_search semantics, 1 = searchBaseLayer only
 };
 
@@ -488,6 +491,40 @@ __device__ __forceinline__ uint64_t cand_max(const uint64_t (&ck)[C], uint32_t &
 	return readlane_u64(m, L);
 }
 
+
+// ---- exact visited set in LDS: open addressing, linear probing, lock-free insert ------------
+constexpr uint32_t HASH_EMPTY = 0xFFFFFFFFu;     // never a valid element number (LINK_NONE)
+
+__device__ __forceinline__ uint32_t hash_slot(uint32_t id, uint32_t mask)
+{
+	return ((id * 2654435761u) >> 7) & mask;
+}
+
+// true if `id` was not in the table (and is now); per-lane, lanes may collide on a slot
+__device__ __forceinline__ bool hash_test_and_set(uint32_t *tab, uint32_t mask, uint32_t id)
+{
+	uint32_t s = hash_slot(id, mask);
+	for (;;)
+	{
+		const uint32_t old = atomicCAS(&tab[s], HASH_EMPTY, id);
+		if (old == HASH_EMPTY) return true;
+		if (old == id) return false;
+		s = (s + 1) & mask;
+	}
+}
+
+__device__ __forceinline__ bool hash_contains(const uint32_t *tab, uint32_t mask, uint32_t id)
+{
+	uint32_t s = hash_slot(id, mask);
+	for (;;)
+	{
+		const uint32_t v = tab[s];
+		if (v == id) return true;
+		if (v == HASH_EMPTY) return false;
+		s = (s + 1) & mask;
+	}
+}
+
 template <int FUNC, typename SH, int RREG>
 __global__ __launch_bounds__(256) void hnsw_search_kernel_reg(const SearchArgs a)
 {
@@ -500,7 +537,9 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_reg(const SearchArgs a
 	float        *qf      = reinterpret_cast<float *>(my);
 	const float4 *q4      = reinterpret_cast<const float4 *>(my);
 	uint64_t     *tie_key = reinterpret_cast<uint64_t *>(my + a.off_res);     // tie path of the emit only
-	uint64_t     *tie_lab = reinterpret_cast<uint64_t *>(my + a.off_cand);
+	uint64_t     *tie_lab = reinterpret_cast<uint64_t *>(my + a.off_cand);    // (both overlay the hash set)
+	uint32_t     *htab    = reinterpret_cast<uint32_t *>(my + a.off_hash);
+	const uint32_t hmask  = a.hcap - 1;
 	uint32_t     *newid   = reinterpret_cast<uint32_t *>(my + a.off_newid);
 	float        *newdist = reinterpret_cast<float *>(my + a.off_newdist);
 
@@ -532,6 +571,14 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_reg(const SearchArgs a
 #pragma unroll
 		for (int k = 0; k < CREG; k++) ck[k] = ~0ull;
 		uint32_t rsize = 0, csize = 0, logn = 0, evals = 0, hops = 0;
+		uint32_t hcount = 0;
+		bool spill = a.hcap == 0;            // true: visited ids go to the HBM bitmap
+		if (a.hcap)
+		{
+			uint4 *h4 = reinterpret_cast<uint4 *>(htab);
+			for (uint32_t i = lane; i < a.hcap / 4; i += 64) h4[i] = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
+			wave_sync();
+		}
 
 		if (a.n > 0)
 		{
@@ -550,10 +597,13 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_reg(const SearchArgs a
 			}
 			if (lane == 0)
 			{
-				vis[ep >> 5] = 1u << (ep & 31);
-				vlog[0] = ep;
+				if (spill) { vis[ep >> 5] = 1u << (ep & 31); vlog[0] = ep; }
+				else htab[hash_slot(ep, hmask)] = ep;
 			}
-			rsize = csize = logn = 1;
+			rsize = csize = 1;
+			logn = spill ? 1 : 0;
+			hcount = 1;
+			wave_sync();
 
 			while (csize > 0)                                               // hnswalg.cpp:67-112
 			{
@@ -576,11 +626,16 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_reg(const SearchArgs a
 					const uint32_t j = j0 + lane;
 					const uint32_t t = a.links[(size_t) cur * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
 					bool isnew = false;
-					if (j < a.lstride && t != LINK_NONE)                    // :91-93
+					if (j < a.lstride && t != LINK_NONE)                    // :91-93 test-and-set
 					{
-						const uint32_t bit = 1u << (t & 31);
-						const uint32_t old = atomicOr(&vis[t >> 5], bit);
-						isnew = !(old & bit);
+						if (!spill)
+							isnew = hash_test_and_set(htab, hmask, t);
+						else if (!(a.hcap && hash_contains(htab, hmask, t)))
+						{
+							const uint32_t bit = 1u << (t & 31);
+							const uint32_t old = atomicOr(&vis[t >> 5], bit);
+							isnew = !(old & bit);
+						}
 					}
 					const uint64_t mask = __ballot(isnew);
 					const uint32_t nnew = (uint32_t) __builtin_popcountll(mask);
@@ -589,10 +644,18 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_reg(const SearchArgs a
 					if (isnew)
 					{
 						newid[rank] = t;
-						const uint32_t lp = logn + rank;
-						if (lp < a.logcap) vlog[lp] = t;
+						if (spill)                                          // only bitmap bits need undoing
+						{
+							const uint32_t lp = logn + rank;
+							if (lp < a.logcap) vlog[lp] = t;
+						}
 					}
-					logn += nnew;
+					if (spill) logn += nnew;
+					else
+					{
+						hcount += nnew;
+						if (hcount + 64 > a.hmax) spill = true;             // keep probe chains short: later ids -> bitmap
+					}
 					wave_sync();
 					{                                                       // :95-97, batched
 						const uint32_t *ids = newid;

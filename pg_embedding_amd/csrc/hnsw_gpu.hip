@@ -450,8 +450,27 @@ static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t q_st
 	const char *force = getenv("HNSW_GPU_FORCE_LDS_HEAPS");
 	if (force && atoi(force) > 0) rreg = 0;
 	size_t off = (size_t) a.qpad_floats * 4;
-	a.off_res = (uint32_t) off;     off += round_up((rreg ? ef : ef + 1) * 8, 16);
-	a.off_cand = (uint32_t) off;    off += round_up((rreg ? ef : 2 * ef + 1) * 8, 16);
+	if (rreg)
+	{
+		// [query | hash set (overlaid by the emit step's tie scratch) | newid | newdist]
+		const size_t fixed = off + 64 * 8;
+		uint32_t hcap = 4096;                                  // entries; needs >= 2 four-wave blocks per CU
+		const char *henv = getenv("HNSW_GPU_HASH_ENTRIES");
+		if (henv) hcap = (uint32_t) atoi(henv);
+		while (hcap >= 512 && 8 * (fixed + std::max<size_t>(hcap * 4, 2 * ef * 8)) > LDS_PER_CU) hcap >>= 1;
+		if (hcap < 512 || (hcap & (hcap - 1))) hcap = 0;
+		a.hcap = hcap;
+		a.hmax = hcap - hcap / 4;
+		a.off_hash = (uint32_t) off;
+		a.off_res = (uint32_t) off;
+		a.off_cand = (uint32_t) (off + round_up(ef * 8, 16));
+		off += round_up(std::max<size_t>((size_t) hcap * 4, 2 * round_up(ef * 8, 16)), 16);
+	}
+	else
+	{
+		a.off_res = (uint32_t) off;     off += round_up((ef + 1) * 8, 16);
+		a.off_cand = (uint32_t) off;    off += round_up((2 * ef + 1) * 8, 16);
+	}
 	a.off_newid = (uint32_t) off;   off += 64 * 4;
 	a.off_newdist = (uint32_t) off; off += 64 * 4;
 	a.wave_bytes = (uint32_t) round_up(off, 16);

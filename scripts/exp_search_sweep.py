@@ -23,7 +23,19 @@ def run(nq, bpc, reps=3):
         ix.search_torch(Q, ef, out=out); ms.append(ix.last_search_ms())
     ms = min(ms)
     print(f"nq={nq:6d} blocks/CU={bpc or 'max'} slots={ix.last_search_slots():5d} kernel {ms:8.2f} ms  {nq/ms*1e3:10.0f} QPS  {byt/ms/1e6:7.0f} GB/s alg", flush=True)
-for nq in (1, 256, 2560, 5120, 10000, 20000, 40000, 160000):
-    run(nq, 0)
-for bpc in (1, 2, 3, 4, 5):
-    run(40000, bpc)
+mode = sys.argv[6] if len(sys.argv) > 6 else "full"
+if mode == "full":
+    for nq in (1, 256, 2560, 5120, 10000, 20000, 40000, 160000):
+        run(nq, 0)
+    for bpc in (1, 2, 3, 4, 5):
+        run(40000, bpc)
+elif mode == "hash":
+    for h in (0, 1024, 2048, 4096):
+        os.environ["HNSW_GPU_HASH_ENTRIES"] = str(h)
+        print("hash entries", h, flush=True)
+        for nq in (1, 10000, 40000):
+            run(nq, 0, reps=5)
+else:
+    for bpc in (1, 2, 3):
+        for nq in (5000, 10000, 20000):
+            run(nq, bpc, reps=5)
