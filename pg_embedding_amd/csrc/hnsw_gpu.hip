@@ -412,7 +412,9 @@ static search_kernel_t pick_search_kernel(int func, uint32_t kiters, int rreg)
 		case 0:  return pick_search_kernel_s<Shape2x4>(func, rreg);
 		case 1:  return pick_search_kernel_s<Shape4x2>(func, rreg);
 		case 2:  return pick_search_kernel_s<Shape8x2>(func, rreg);
-		default: return pick_search_kernel_s<Shape12x1>(func, rreg);
+		default:
+			if (getenv("HNSW_GPU_SHAPE_12X1")) return pick_search_kernel_s<Shape12x1>(func, rreg);
+			return pick_search_kernel_s<Shape12x2>(func, rreg);
 	}
 }
 

@@ -29,6 +29,13 @@ if mode == "full":
         run(nq, 0)
     for bpc in (1, 2, 3, 4, 5):
         run(40000, bpc)
+elif mode == "shape":
+    for sh in ("12x2", "12x1"):
+        if sh == "12x1": os.environ["HNSW_GPU_SHAPE_12X1"] = "1"
+        else: os.environ.pop("HNSW_GPU_SHAPE_12X1", None)
+        print("shape", sh, flush=True)
+        for nq in (1, 2048, 10000, 40000, 160000):
+            run(nq, 0, reps=5)
 elif mode == "hash":
     for h in (0, 1024, 2048, 4096):
         os.environ["HNSW_GPU_HASH_ENTRIES"] = str(h)
