@@ -119,6 +119,8 @@ int hnsw_gpu_search_base_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_
 /* Milliseconds the most recent search kernel of this index spent on the device,
  * from HIP events recorded on its stream around the launch (waits for it). */
 int hnsw_gpu_last_search_ms(hnsw_gpu_index *ix, float *ms);
+/* Same for the launch `back` launches ago (0 = most recent; the last 64 are kept). */
+int hnsw_gpu_search_ms(hnsw_gpu_index *ix, unsigned back, float *ms);
 
 /* Resident query slots (waves) the last search launch used — occupancy figure. */
 int hnsw_gpu_last_search_slots(hnsw_gpu_index *ix, uint32_t *slots);

@@ -68,8 +68,9 @@ struct hnsw_gpu_index
 	uint32_t *vis = nullptr;  size_t vis_slots = 0, vis_words = 0;
 	uint32_t *vlog = nullptr; uint32_t logcap = 0;
 	uint32_t *ticket = nullptr;       // [0] ticket, [1] err
-	hipEvent_t ev0 = nullptr, ev1 = nullptr;
-	bool     timed = false;
+	static const int EV_RING = 64;           // HIP-event pairs of the most recent search launches
+	hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};
+	uint64_t launches = 0;
 	uint32_t last_slots = 0;
 	// scratch for the host-pointer entry points
 	void *scratch = nullptr; size_t scratch_bytes = 0;
@@ -123,8 +124,18 @@ static int alloc_index(const HnswMetadata *meta, size_t capacity, int device, hn
 	if ((e = hipMalloc(&ix->vec, ix->cap * ix->stride * sizeof(float))) != hipSuccess ||
 		(e = hipMalloc(&ix->links, ix->cap * ix->lstride * sizeof(uint32_t))) != hipSuccess ||
 		(e = hipMalloc(&ix->labels, ix->cap * sizeof(uint64_t))) != hipSuccess ||
-		(e = hipMalloc(&ix->ticket, 64)) != hipSuccess ||
-		(e = hipEventCreate(&ix->ev0)) != hipSuccess || (e = hipEventCreate(&ix->ev1)) != hipSuccess)
+		(e = hipMalloc(&ix->ticket, 64)) != hipSuccess)
+	{
+		hnsw_gpu_index_destroy(ix);
+		return fail(e == hipErrorOutOfMemory ? HNSW_GPU_ERR_NOMEM : HNSW_GPU_ERR_HIP, "index allocation failed: %s",
+					hipGetErrorString(e));
+	}
+	for (int i = 0; i < hnsw_gpu_index::EV_RING && e == hipSuccess; i++)
+	{
+		e = hipEventCreate(&ix->ev0[i]);
+		if (e == hipSuccess) e = hipEventCreate(&ix->ev1[i]);
+	}
+	if (e != hipSuccess)
 	{
 		hnsw_gpu_index_destroy(ix);
 		return fail(e == hipErrorOutOfMemory ? HNSW_GPU_ERR_NOMEM : HNSW_GPU_ERR_HIP, "index allocation failed: %s",
@@ -147,8 +158,11 @@ extern "C" void hnsw_gpu_index_destroy(hnsw_gpu_index *ix)
 	if (ix->ticket) (void) hipFree(ix->ticket);
 	if (ix->scratch) (void) hipFree(ix->scratch);
 	if (ix->bld) (void) hipFree(ix->bld);
-	if (ix->ev0) (void) hipEventDestroy(ix->ev0);
-	if (ix->ev1) (void) hipEventDestroy(ix->ev1);
+	for (int i = 0; i < hnsw_gpu_index::EV_RING; i++)
+	{
+		if (ix->ev0[i]) (void) hipEventDestroy(ix->ev0[i]);
+		if (ix->ev1[i]) (void) hipEventDestroy(ix->ev1[i]);
+	}
 	delete ix;
 }
 
@@ -512,11 +526,12 @@ static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t q_st
 	a.ticket = ix->ticket; a.err = ix->ticket + 1;
 	HIPCHK(hipMemsetAsync(ix->ticket, 0, 8, stream));
 
-	HIPCHK(hipEventRecord(ix->ev0, stream));
+	const int evi = (int) (ix->launches % hnsw_gpu_index::EV_RING);
+	HIPCHK(hipEventRecord(ix->ev0[evi], stream));
 	hipLaunchKernelGGL(kern, dim3((uint32_t) blocks), dim3(wpb * 64), lds, stream, a);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(ix->ev1, stream));
-	ix->timed = true;
+	HIPCHK(hipEventRecord(ix->ev1[evi], stream));
+	ix->launches++;
 	ix->last_slots = (uint32_t) slots;
 	return HNSW_GPU_OK;
 }
@@ -563,15 +578,19 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 	return HNSW_GPU_OK;
 }
 
-extern "C" int hnsw_gpu_last_search_ms(hnsw_gpu_index *ix, float *ms)
+extern "C" int hnsw_gpu_search_ms(hnsw_gpu_index *ix, unsigned back, float *ms)
 {
 	if (!ix || !ms) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
-	if (!ix->timed) return fail(HNSW_GPU_ERR_ARG, "no search has been launched on this index");
+	if (back >= (unsigned) hnsw_gpu_index::EV_RING || (uint64_t) back >= ix->launches)
+		return fail(HNSW_GPU_ERR_ARG, "no record of the search launch %u launches ago", back);
 	HIPCHK(hipSetDevice(ix->device));
-	HIPCHK(hipEventSynchronize(ix->ev1));
-	HIPCHK(hipEventElapsedTime(ms, ix->ev0, ix->ev1));
+	const int evi = (int) ((ix->launches - 1 - back) % hnsw_gpu_index::EV_RING);
+	HIPCHK(hipEventSynchronize(ix->ev1[evi]));
+	HIPCHK(hipEventElapsedTime(ms, ix->ev0[evi], ix->ev1[evi]));
 	return HNSW_GPU_OK;
 }
+
+extern "C" int hnsw_gpu_last_search_ms(hnsw_gpu_index *ix, float *ms) { return hnsw_gpu_search_ms(ix, 0, ms); }
 
 extern "C" int hnsw_gpu_last_search_slots(hnsw_gpu_index *ix, uint32_t *slots)
 {

@@ -175,9 +175,11 @@ class GpuIndex:
                                                    _dptr(out.get("stats")), s), "hnsw_gpu_search_batch_dev")
         return out
 
-    def last_search_ms(self) -> float:
+    def last_search_ms(self, back: int = 0) -> float:
+        """Device time of the search kernel launched `back` launches ago (HIP events recorded on
+        the launch stream around the kernel; the last 64 launches are kept)."""
         ms = C.c_float(0)
-        check(self.L.hnsw_gpu_last_search_ms(self._h, C.byref(ms)), "hnsw_gpu_last_search_ms")
+        check(self.L.hnsw_gpu_search_ms(self._h, back, C.byref(ms)), "hnsw_gpu_search_ms")
         return float(ms.value)
 
     def last_search_slots(self) -> int:

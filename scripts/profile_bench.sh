@@ -19,9 +19,10 @@ for PASS in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \
 done
 {
   echo "# rocprofv3 summary ($TAG): $BENCH"; echo; echo '```'; cat $OUT/bench_line.json; echo '```'; echo
-  echo "## kernel trace (--kernel-trace --stats)"; python $R/scripts/summarize_prof.py $OUT/trace
-  for d in $OUT/pmc_*/; do echo; echo "## PMC $(basename $d)"; python $R/scripts/summarize_prof.py $d hnsw_search; done
+  echo "## kernel trace (--kernel-trace --stats)"; python $R/scripts/summarize_prof.py $OUT/trace --last 3
+  for d in $OUT/pmc_*/; do echo; echo "## PMC $(basename $d)"; python $R/scripts/summarize_prof.py $d --last 3 hnsw_search; done
 } > $OUT/summary.md 2>&1
+python $R/scripts/make_traffic_json.py $OUT > $OUT/traffic.json
 # keep only the small files for merging back
 find $OUT -name "*.csv" -size +4000k -delete
-cat $OUT/summary.md
+cat $OUT/summary.md; cat $OUT/traffic.json
