@@ -35,9 +35,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--n", type=int, default=1_000_000, help="index rows")
+    ap.add_argument("--rows", dest="n", type=int, default=1_000_000, help="index rows")
     ap.add_argument("--dim", type=int, default=768)
-    ap.add_argument("--m", type=int, default=16)
+    ap.add_argument("--hnsw-m", dest="m", type=int, default=16, help="m reloption (maxM = 2m)")
     ap.add_argument("--efc", type=int, default=200, help="efconstruction for the device build")
     ap.add_argument("--ef", type=int, default=128, help="efsearch")
     ap.add_argument("--nq", type=int, default=40_000, help="queries per step per GPU")
@@ -49,11 +49,16 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--recall-queries", type=int, default=1000)
+    ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
+                    help="replicas: index mirrored on every GPU, queries sharded (headline metric). sharded: rows partitioned "
+                         "across GPUs (config C4), every GPU searches every query, RCCL all-gather + merge kernel")
     return ap.parse_args()
 
 
 def main():
     args = parse()
+    if args.mode == "sharded":
+        return main_sharded(args)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -64,8 +69,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ       # launched by torch.distributed.run
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        torch.cuda.set_device(local)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     if args.gpus != world and rank == 0 and world > 1:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
@@ -75,7 +83,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -146,7 +154,7 @@ def main():
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     rec_t = torch.tensor([recall], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(rec_t, op=dist.ReduceOp.MIN)
     elapsed = float(tmax.item())
@@ -202,7 +210,75 @@ def main():
         result["cpu_baseline"] = cpu_baseline(args, ix, Q, labels0, func)
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
+    if use_dist:
+        dist.destroy_process_group()
+
+
+def main_sharded(args):
+    """Row-sharded index (SURVEY.md §8e mode 2, BASELINE config C4): contiguous row ranges, one
+    graph per shard, every rank searches the same query batch on its shard, ONE exchange
+    (all-gather of (dist,label) lists over RCCL) and the device merge kernel."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    import pg_embedding_amd as pg
+    from pg_embedding_amd.datasets import gmm_torch
+    from pg_embedding_amd.sharded import ShardedIndex, shard_range
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", device_id=dev)
+    func = {"l2": pg.DIST_L2, "cosine": pg.DIST_COSINE, "manhattan": pg.DIST_MANHATTAN}[args.metric]
+    lo, hi = shard_range(args.n, world, rank)
+    t0 = time.time()
+    rows = gmm_torch(hi - lo, args.dim, k=args.clusters, sigma=0.3, seed=42, stream=100 + rank, device=dev)
+    meta = pg.make_meta(args.dim, args.m, args.efc, args.ef, func)
+    sh = ShardedIndex.build(rows, lo, meta, device=local, max_batch=args.max_batch, ratio=args.ratio)
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    del rows
+    nq = args.nq
+    Q = gmm_torch(nq, args.dim, k=args.clusters, sigma=0.3, seed=42, stream=1, device=dev)   # same on every rank
+
+    def barrier():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        sh.search(Q, args.ef)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        labels, dists, counts = sh.search(Q, args.ef)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if use_dist:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    elapsed = float(tmax.item())
+    ok = bool((counts == args.ef).all().item()) and bool((dists[:, 1:] >= dists[:, :-1]).all().item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "queries/sec, row-sharded index, per-shard searchKnn + RCCL top-k merge",
+            "value": nq * args.steps / elapsed, "unit": "queries/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"HNSW search, index of {args.n}x{args.dim} rows sharded over {world} GPU(s) "
+                                   f"({hi - lo} rows/shard), {args.metric}, m={args.m}, efsearch={args.ef}, "
+                                   f"{nq} queries/step (every GPU searches all of them)",
+                       "parallelism": f"row-sharded x{world}, all-gather + merge"},
+            "build_seconds": t_build, "merged_results_sorted_and_full": ok}))
+    if use_dist:
         dist.destroy_process_group()
 
 
