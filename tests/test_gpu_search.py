@@ -243,3 +243,48 @@ def test_many_queries_reuse_slots():
     labels2, _, _ = ix.search(Q, 32)                # second launch on the same workspace
     assert (labels2 == labels).all()
     ix.close()
+
+
+@pytest.mark.parametrize("env", [
+    {"HNSW_GPU_HASH_ENTRIES": "512"},        # tiny LDS visited set: most ids spill to the HBM bitmap
+    {"HNSW_GPU_HASH_ENTRIES": "0"},          # bitmap only
+    {"HNSW_GPU_FORCE_LDS_HEAPS": "1"},       # generic kernel (sorted arrays in LDS) at small ef
+    {"HNSW_GPU_SHAPE_12X1": "1"},
+    {},
+])
+def test_every_kernel_variant_is_exact(env, monkeypatch):
+    """The visited set may live in LDS, spill to the bitmap half-way through a query, or be the
+    bitmap alone; the heaps may be in registers or in LDS: all must give the oracle's answer."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    port, X = build_port(20000, 768, 16, 64, pg.DIST_L2, k=100, seed=77)
+    Q = gmm(300, 768, k=100, seed=77, stream=1)
+    ix = mirror(port, pg.DIST_L2)
+    for ef in (100, 256):
+        import torch
+        out = ix.search_torch(torch.from_numpy(Q).cuda(), ef, stats=True)
+        torch.cuda.synchronize()
+        want = port.search_many(Q, ef)
+        assert (out["labels"].cpu().numpy().view(np.uint64) == want["labels"]).all()
+        assert (bits(out["dists"].cpu().numpy()) == bits(want["dists"])).all()
+        st = out["stats"].cpu().numpy().astype(np.uint32)
+        assert (st[:, 0] == want["evals"]).all() and (st[:, 1] == want["hops"]).all()
+    if env.get("HNSW_GPU_HASH_ENTRIES") == "512":
+        assert want["evals"].max() > 512          # the spill path really ran
+    # a second launch on the same slots: bitmap bits set by the spill path were undone
+    labels2, _, _ = ix.search(Q, 100)
+    assert (labels2 == port.search_many(Q, 100)["labels"]).all()
+    ix.close()
+
+
+def test_visited_sets_larger_than_the_lds_table():
+    """Weakly clustered data at ef=256: thousands of evaluations per query (> 3072-entry budget)."""
+    rng = np.random.default_rng(3)
+    X = rng.standard_normal((40000, 24)).astype(np.float32)
+    Q = rng.standard_normal((100, 24)).astype(np.float32)
+    port = oracle.PortIndex(24, 16, 40, 256, pg.DIST_L2)
+    port.add(X)
+    ix = mirror(port, pg.DIST_L2)
+    labels, dists, counts = assert_same_as_oracle(ix, port, Q, 256)
+    assert port.search_many(Q, 256)["evals"].max() > 3100
+    ix.close()
