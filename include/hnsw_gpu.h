@@ -143,6 +143,17 @@ int hnsw_gpu_dist_batch_dev(dist_func_t func, const coord_t *d_q, const coord_t 
 int hnsw_gpu_bruteforce_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t k,
 							idx_t *d_idx, dist_t *d_dists, void *stream);
 
+/* Same result (exact, same distances), but the Q x N scoring runs as a dense f32 contraction on
+ * the matrix cores (v_mfma_f32_32x32x2_f32) used as a filter against a per-query bound; the few
+ * survivors are re-scored with the canonical distance code (device_bf_mfma.h).  This is the
+ * "batched queries as an MFMA GEMM" form of BASELINE config 5; L2 and cosine only (Manhattan
+ * falls back to the scan above).  Synchronises `stream`. */
+int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t k,
+								 idx_t *d_idx, dist_t *d_dists, void *stream);
+/* Device milliseconds of the GEMM/filter kernel of the last call above (MFMA roofline figure:
+ * 2*nq*n*stride flops). */
+float hnsw_gpu_last_bruteforce_gemm_ms(void);
+
 /* ----------------------------------------------------------------- multi-shard */
 
 /* Merge `nlists` per-shard result lists per query (each ef entries: ascending by

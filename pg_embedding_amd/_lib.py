@@ -77,6 +77,8 @@ def gpu_lib():
     L.hnsw_gpu_dist_batch.argtypes = [i32, vp, vp, sz, sz, vp]
     L.hnsw_gpu_dist_batch_dev.argtypes = [i32, vp, vp, sz, sz, sz, vp, vp]
     L.hnsw_gpu_bruteforce_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp]
+    L.hnsw_gpu_bruteforce_mfma_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp]
+    L.hnsw_gpu_last_bruteforce_gemm_ms.restype = C.c_float
     L.hnsw_gpu_merge_topk_dev.argtypes = [i32, vp, vp, sz, sz, sz, vp, vp, vp, vp]
     _gpu = L
     return L

@@ -1,0 +1,250 @@
+// device_bf_mfma.h — exhaustive scoring as a dense contraction on the matrix cores.
+//
+// Graph search scores a private candidate list per query (a batch of GEMVs: HBM-bound, no MFMA
+// claim).  EXHAUSTIVE scoring of a query batch against every row is different: Q x D times D x N
+// is a genuine GEMM (BASELINE config 5, recall ground truth), bound by the f32 MFMA roof
+// (v_mfma_f32_32x32x2_f32, 157 TFLOP/s on MI355X), not by HBM.
+//
+// Exactness is kept by using the GEMM only as a FILTER:
+//   1. a per-query bound tau_q = k-th smallest CANONICAL distance (device_dist.h) over a
+//      sample of rows — an upper bound of the true k-th distance;
+//   2. this kernel computes all Q x N dot products with MFMA (a k-ordered fused-multiply-add
+//      chain: exact f32, but a different summation order than the canonical one), turns them
+//      into approximate distances and appends every row within tau_q (+ a round-off margin)
+//      to the query's candidate list;
+//   3. the few survivors are re-scored with the canonical code and the top-k is taken from
+//      those distances — identical to the all-canonical brute force, ties by lower idx.
+// L2 uses |q|^2 + |x|^2 - 2 q.x, cosine 1 - q.x / sqrt(|q|^2 |x|^2) (distfunc.c:133-145);
+// Manhattan is not a contraction and is not offered here.
+//
+// Tiling: block = 4 waves, 128 queries x 128 rows per block, K in steps of 32 floats staged
+// through LDS k-major (operand reads are then unit-stride across lanes: conflict-free
+// ds_read_b32), each wave owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles (64 accumulator VGPRs).
+// blockIdx is remapped so that all query tiles of one row tile run on the same XCD
+// (block b -> XCD b % 8) and the row tile is fetched from HBM once per XCD L2.
+#pragma once
+#include "device_search.h"
+
+namespace pgemb {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BF_TQ = 128, BF_TR = 128, BF_TK = 32;
+
+struct BfArgs
+{
+	const float *queries;      // [nq_pad][stride] zero padded copy
+	const float *qnorm;        // |q|^2
+	const float *qbound;       // L2: squared bound; cosine: threshold on dot / sqrt(|x|^2)
+	const float *vec;          // [n][stride]
+	const float *xnorm;        // |x|^2
+	uint32_t nq, n, stride, ksteps;
+	int func;
+	uint32_t *cand;            // [nq][cap]
+	uint32_t *cand_cnt;        // [nq]
+	uint32_t cap;
+	uint32_t nqt, nrt;         // tiles
+};
+
+__global__ __launch_bounds__(256) void bf_mfma_filter_kernel(const BfArgs a)
+{
+	__shared__ float As[BF_TK * BF_TQ];      // [k][q]
+	__shared__ float Bs[BF_TK * BF_TR];      // [k][r]
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	// XCD-aware tile order: the nqt query tiles of one row tile share b % 8
+	const uint32_t b = blockIdx.x;
+	const uint32_t xcd = b & 7, rest = b >> 3;
+	const uint32_t qt = rest % a.nqt, rgrp = rest / a.nqt;
+	const uint32_t rt = rgrp * 8 + xcd;
+	if (rt >= a.nrt) return;
+	const uint32_t q0 = qt * BF_TQ, r0 = rt * BF_TR;
+
+	// staging role: thread owns one tile row (query or index row) and half of the K step
+	const uint32_t srow = t & 127, shalf = t >> 7;
+	const uint32_t qrow = min(q0 + srow, a.nq - 1), xrow = min(r0 + srow, a.n - 1);
+	const float4 *qsrc = reinterpret_cast<const float4 *>(a.queries + (size_t) qrow * a.stride);
+	const float4 *xsrc = reinterpret_cast<const float4 *>(a.vec + (size_t) xrow * a.stride);
+	const uint32_t nchunks = a.stride / 4;
+
+	floatx16 acc[2][2];
+#pragma unroll
+	for (int i = 0; i < 2; i++)
+#pragma unroll
+		for (int j = 0; j < 2; j++)
+#pragma unroll
+			for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
+	const uint32_t wm = wave >> 1, wn = wave & 1;          // 2 x 2 waves over the block tile
+	const uint32_t kk = lane >> 5, col = lane & 31;
+
+	for (uint32_t ks = 0; ks < a.ksteps; ks++)
+	{
+		float4 qa[4], xb[4];
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+		{
+			const uint32_t c = ks * 8 + shalf * 4 + j;              // float4 chunk along K
+			const uint32_t cc = c < nchunks ? c : nchunks - 1;       // unconditional loads, then select
+			const float4 tq = qsrc[cc], tx = xsrc[cc];
+			qa[j] = c < nchunks ? tq : make_float4(0.f, 0.f, 0.f, 0.f);
+			xb[j] = c < nchunks ? tx : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+		__syncthreads();                                            // previous step's reads are done
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+		{
+			const uint32_t k = shalf * 16 + j * 4;
+			As[(k + 0) * BF_TQ + srow] = qa[j].x; As[(k + 1) * BF_TQ + srow] = qa[j].y;
+			As[(k + 2) * BF_TQ + srow] = qa[j].z; As[(k + 3) * BF_TQ + srow] = qa[j].w;
+			Bs[(k + 0) * BF_TR + srow] = xb[j].x; Bs[(k + 1) * BF_TR + srow] = xb[j].y;
+			Bs[(k + 2) * BF_TR + srow] = xb[j].z; Bs[(k + 3) * BF_TR + srow] = xb[j].w;
+		}
+		__syncthreads();
+#pragma unroll
+		for (int k2 = 0; k2 < BF_TK; k2 += 2)
+		{
+			const float a0 = As[(k2 + kk) * BF_TQ + wm * 64 + col];
+			const float a1 = As[(k2 + kk) * BF_TQ + wm * 64 + 32 + col];
+			const float b0 = Bs[(k2 + kk) * BF_TR + wn * 64 + col];
+			const float b1 = Bs[(k2 + kk) * BF_TR + wn * 64 + 32 + col];
+			acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+			acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+			acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+			acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+		}
+	}
+
+	// epilogue: C[q][r]; lane holds column r = lane & 31, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+#pragma unroll
+	for (int j = 0; j < 2; j++)
+	{
+		const uint32_t r = r0 + wn * 64 + j * 32 + col;
+		const bool rok = r < a.n;
+		const float xn = a.xnorm[rok ? r : 0];
+		const float xs = (a.func == F_COSINE) ? __builtin_sqrtf(xn) : xn;
+#pragma unroll
+		for (int i = 0; i < 2; i++)
+#pragma unroll
+			for (int e = 0; e < 16; e++)
+			{
+				const uint32_t q = q0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
+				if (!rok || q >= a.nq) continue;
+				const float dot = acc[i][j][e];
+				bool pass;
+				if (a.func == F_COSINE)
+					pass = dot >= a.qbound[q] * xs;                  // 1 - dot/sqrt(nq nx) <= tau (+margin)
+				else
+					pass = a.qnorm[q] + xs - 2.f * dot <= a.qbound[q];   // |q-x|^2 <= tau^2 (+margin)
+				if (pass)
+				{
+					const uint32_t pos = atomicAdd(&a.cand_cnt[q], 1u);
+					if (pos < a.cap) a.cand[(size_t) q * a.cap + pos] = r;
+				}
+			}
+	}
+}
+
+// |row|^2 for every row (plain accumulation; only used by the filter and its margin)
+__global__ void row_norm2_kernel(const float *__restrict__ vec, uint32_t n, uint32_t stride, float *__restrict__ out)
+{
+	const uint32_t w = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+	const int lane = threadIdx.x & 63;
+	if (w >= n) return;
+	const float4 *p = reinterpret_cast<const float4 *>(vec + (size_t) w * stride);
+	float s = 0.f;
+	for (uint32_t c = lane; c < stride / 4; c += 64)
+	{
+		const float4 v = p[c];
+		s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+	}
+	for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+	if (lane == 0) out[w] = s;
+}
+
+// queries [nq][dim] -> zero padded [nq][stride]
+__global__ void pad_queries_kernel(const float *__restrict__ q, uint32_t nq, uint32_t dim, uint32_t stride, float *__restrict__ out)
+{
+	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= (size_t) nq * stride) return;
+	const uint32_t r = (uint32_t) (i / stride), c = (uint32_t) (i % stride);
+	out[i] = c < dim ? q[(size_t) r * dim + c] : 0.f;
+}
+
+// tau_q (canonical k-th distance over the sample) -> the filter's comparison value with margin
+__global__ void make_bounds_kernel(const float *__restrict__ tau, const float *__restrict__ qnorm, uint32_t nq, int func,
+								   float *__restrict__ qbound)
+{
+	const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+	if (q >= nq) return;
+	const float t = tau[q];
+	if (func == F_COSINE)
+	{
+		// pass if dot >= (1 - tau - eps) * sqrt(nq) * sqrt(nx); eps covers both summation orders
+		qbound[q] = (1.f - t - 2e-5f - 1e-5f * __builtin_fabsf(t)) * __builtin_sqrtf(qnorm[q]);
+		if (!(t == t)) qbound[q] = -__builtin_inff();               // NaN bound: keep everything
+	}
+	else
+	{
+		// pass if |q|^2 + |x|^2 - 2 dot <= tau^2 (1 + eps) + eps' (|q|^2 + ...): generous
+		qbound[q] = t * t * (1.f + 1e-4f) + 1e-5f * (qnorm[q] + t * t) + 1e-12f;
+	}
+}
+
+// One wave per query: canonical distances of the surviving rows, top-k by (dist, idx).
+template <int FUNC>
+__global__ __launch_bounds__(256) void bf_rescore_kernel(const float *__restrict__ vec, uint32_t dim, uint32_t stride,
+														 uint32_t nchunks, uint32_t kiters, uint32_t qpad_floats,
+														 const float *__restrict__ queries, uint32_t nq,
+														 const uint32_t *__restrict__ cand, const uint32_t *__restrict__ cand_cnt,
+														 uint32_t cap, uint32_t k, uint32_t *__restrict__ out_idx,
+														 float *__restrict__ out_dist, uint32_t *__restrict__ overflow)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = threadIdx.x & 63;
+	const uint32_t wib = threadIdx.x >> 6;
+	const uint32_t qi = blockIdx.x * 4 + wib;
+	if (qi >= nq) return;
+	const size_t wave_bytes = (size_t) qpad_floats * 4 + (size_t) (k + 1) * 8 + 8 * 4;
+	unsigned char *my = smem + wib * ((wave_bytes + 15) & ~(size_t) 15);
+	float *qf = reinterpret_cast<float *>(my);
+	const float4 *q4 = reinterpret_cast<const float4 *>(my);
+	uint64_t *top = reinterpret_cast<uint64_t *>(my + (size_t) qpad_floats * 4);
+	float *dist8 = reinterpret_cast<float *>(top + (k + 1));
+	for (uint32_t e = lane; e < qpad_floats; e += 64)
+	{
+		const float t = queries[(size_t) qi * dim + (e < dim ? e : dim - 1)];
+		qf[e] = e < dim ? t : 0.f;
+	}
+	wave_sync();
+	float qnorm = 0.f;
+	if (FUNC == F_COSINE) qnorm = query_norm(q4, nchunks, kiters, lane);
+	uint32_t cnt = cand_cnt[qi];
+	if (cnt > cap) { if (lane == 0) atomicAdd(overflow, 1u); cnt = cap; }
+	const uint32_t *ids = cand + (size_t) qi * cap;
+	uint32_t tsize = 0;
+	uint64_t worst = ~0ull;
+	for (uint32_t base = 0; base < cnt; base += 8)
+	{
+		const uint32_t c8 = min(8u, cnt - base);
+		auto by_id = [ids, base](uint32_t r) { return ids[base + r]; };
+		score_rows<FUNC, 4, 2>(vec, stride, q4, nchunks, kiters, qnorm, by_id, c8, dist8, lane);
+		wave_sync();
+		for (uint32_t r = 0; r < c8; r++)
+		{
+			const uint64_t key = ((uint64_t) ord_f32(dist8[r]) << 32) | ids[base + r];
+			if (tsize < k || key < worst)
+			{
+				tsize = sorted_insert(top, tsize, key, k, lane);
+				worst = top[tsize - 1];
+			}
+		}
+		wave_sync();
+	}
+	for (uint32_t i = lane; i < k; i += 64)
+	{
+		const bool ok = i < tsize;
+		out_idx[(size_t) qi * k + i] = ok ? (uint32_t) top[i] : LINK_NONE;
+		if (out_dist) out_dist[(size_t) qi * k + i] = ok ? unord_f32((uint32_t) (top[i] >> 32)) : __builtin_inff();
+	}
+}
+
+}  // namespace pgemb

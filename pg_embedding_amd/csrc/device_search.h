@@ -46,7 +46,7 @@ struct SearchArgs
 	// batch
 	const float *queries;       // query i at queries + i * q_stride (dim floats used)
 	uint32_t q_stride;
-	uint32_t nq, ef, ccap;      // ccap = 2*ef candidate capacity
+	uint32_t nq, ef, ccap;      // ccap = 2*ef candidate capacity (LDS form)
 	// outputs
 	uint64_t *out_labels;       // mode 0: nq*ef
 	uint32_t *out_idx;          // mode 1: nq*ef
@@ -59,7 +59,6 @@ struct SearchArgs
 	uint64_t  vis_words;
 	uint32_t  logcap;
 	uint32_t *ticket;           // zeroed before every launch
-	uint32_t *err;              // device-side invariant failures
 	// LDS carve (bytes, per wave)
 	uint32_t qpad_floats, off_res, off_cand, off_newid, off_newdist, wave_bytes;
 	// register form only: exact visited hash set in LDS (power-of-two entries, 0 = off); ids that
@@ -427,19 +426,17 @@ __device__ __forceinline__ uint64_t res_at(const uint64_t (&rk)[R], uint32_t i)
 template <int C>
 __device__ __forceinline__ void cand_set(uint64_t (&ck)[C], uint32_t slot, uint64_t key, int lane)
 {
-	const uint32_t mine = (uint32_t) lane | 0xFFFFFFC0u;      // matches slot only through the per-register test
 #pragma unroll
 	for (int k = 0; k < C; k++)
 	{
 		const bool hit = slot == ((uint32_t) k * 64 + (uint32_t) lane);
 		ck[k] = hit ? key : ck[k];
 	}
-	(void) mine;
 }
 
 // Smallest key of the set; returns its slot through `slot`.  Set must be non-empty.
 template <int C>
-__device__ __forceinline__ uint64_t cand_min(const uint64_t (&ck)[C], uint32_t &slot, int lane)
+__device__ __forceinline__ uint64_t cand_min(const uint64_t (&ck)[C], uint32_t &slot)
 {
 	uint64_t m = ck[0];
 	uint32_t mk = 0;
@@ -466,7 +463,7 @@ __device__ __forceinline__ uint64_t cand_min(const uint64_t (&ck)[C], uint32_t &
 
 // Largest real key (set full): used only to make room when the candidate set overflows.
 template <int C>
-__device__ __forceinline__ uint64_t cand_max(const uint64_t (&ck)[C], uint32_t &slot, int lane)
+__device__ __forceinline__ uint64_t cand_max(const uint64_t (&ck)[C], uint32_t &slot)
 {
 	uint64_t m = ck[0];
 	uint32_t mk = 0;
@@ -608,7 +605,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_reg(const SearchArgs a
 			while (csize > 0)                                               // hnswalg.cpp:67-112
 			{
 				uint32_t cslot;
-				const uint64_t ckey = cand_min<CREG>(ck, cslot, lane);
+				const uint64_t ckey = cand_min<CREG>(ck, cslot);
 				if (unord_f32((uint32_t) (ckey >> 32)) > lowerBound)        // :70-71
 					break;
 				const uint32_t cur = ~(uint32_t) ckey;
@@ -679,7 +676,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_reg(const SearchArgs a
 							if (csize == CCAP)                              // make room: the largest key is dead
 							{
 								uint32_t ms;
-								const uint64_t mx = cand_max<CREG>(ck, ms, lane);
+								const uint64_t mx = cand_max<CREG>(ck, ms);
 								if ((hi | (uint32_t) ~t2) < mx) cand_set<CREG>(ck, ms, hi | (uint32_t) ~t2, lane);
 							}
 							else

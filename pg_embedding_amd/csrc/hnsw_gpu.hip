@@ -14,6 +14,7 @@
 #include "device_dist.h"
 #include "device_search.h"
 #include "device_build.h"
+#include "device_bf_mfma.h"
 
 using namespace pgemb;
 
@@ -76,6 +77,9 @@ struct hnsw_gpu_index
 	void *scratch = nullptr; size_t scratch_bytes = 0;
 	// builder scratch (hnsw_gpu_index_link)
 	void *bld = nullptr; size_t bld_batch = 0; size_t bld_tmp_bytes = 0;
+	// exhaustive MFMA scorer: |row|^2 cache + scratch
+	float *xnorm = nullptr; size_t xnorm_n = 0, xnorm_cap = 0;
+	void *bf = nullptr; size_t bf_bytes = 0;
 };
 
 static int ensure_scratch(hnsw_gpu_index *ix, size_t bytes)
@@ -158,6 +162,8 @@ extern "C" void hnsw_gpu_index_destroy(hnsw_gpu_index *ix)
 	if (ix->ticket) (void) hipFree(ix->ticket);
 	if (ix->scratch) (void) hipFree(ix->scratch);
 	if (ix->bld) (void) hipFree(ix->bld);
+	if (ix->xnorm) (void) hipFree(ix->xnorm);
+	if (ix->bf) (void) hipFree(ix->bf);
 	for (int i = 0; i < hnsw_gpu_index::EV_RING; i++)
 	{
 		if (ix->ev0[i]) (void) hipEventDestroy(ix->ev0[i]);
@@ -523,7 +529,7 @@ static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t q_st
 		ix->vis_slots = slots; ix->vis_words = words; ix->logcap = logcap;
 	}
 	a.vis = ix->vis; a.vis_words = words; a.vlog = ix->vlog; a.logcap = ix->logcap;
-	a.ticket = ix->ticket; a.err = ix->ticket + 1;
+	a.ticket = ix->ticket;
 	HIPCHK(hipMemsetAsync(ix->ticket, 0, 8, stream));
 
 	const int evi = (int) (ix->launches % hnsw_gpu_index::EV_RING);
@@ -572,9 +578,6 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 	HIPCHK(hipMemcpy(labels, dl, nq * ef * 8, hipMemcpyDeviceToHost));
 	if (dists) HIPCHK(hipMemcpy(dists, dd, nq * ef * 4, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(counts, dc, nq * 4, hipMemcpyDeviceToHost));
-	uint32_t err = 0;
-	HIPCHK(hipMemcpy(&err, ix->ticket + 1, 4, hipMemcpyDeviceToHost));
-	if (err) return fail(HNSW_GPU_ERR_INTERNAL, "device-side invariant failed (%u)", err);
 	return HNSW_GPU_OK;
 }
 
@@ -770,8 +773,8 @@ __global__ void fill_u32_kernel(uint32_t *p, size_t n, uint32_t v)
 	if (i < n) p[i] = v;
 }
 
-extern "C" int hnsw_gpu_bruteforce_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t k, idx_t *d_idx,
-									   dist_t *d_dists, void *stream)
+static int bruteforce_prefix(hnsw_gpu_index *ix, size_t nrows, const coord_t *d_queries, size_t nq, size_t k, idx_t *d_idx,
+							 dist_t *d_dists, void *stream)
 {
 	if (!ix || !d_queries || !d_idx) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
 	if (nq == 0) return HNSW_GPU_OK;
@@ -782,7 +785,7 @@ extern "C" int hnsw_gpu_bruteforce_dev(hnsw_gpu_index *ix, const coord_t *d_quer
 	const uint32_t nchunks = ix->stride / 4, kiters = (nchunks + 15) / 16;
 	const uint32_t qpad = (uint32_t) round_up(kiters, 4) * 64;
 	uint32_t splits = (uint32_t) std::max<size_t>(1, std::min<size_t>(64, (size_t) (4 * ix->num_cu) / nq));
-	splits = (uint32_t) std::min<size_t>(splits, std::max<size_t>(1, ix->n / 64));
+	splits = (uint32_t) std::min<size_t>(splits, std::max<size_t>(1, nrows / 64));
 	const uint32_t nlists = splits * 4;
 	const size_t lds = (size_t) qpad * 4 + (size_t) 4 * (k + 1) * 8 + 4 * 8 * 4;
 	if (lds > 64 * 1024) return fail(HNSW_GPU_ERR_ARG, "k/dim too large for brute force");
@@ -796,7 +799,7 @@ extern "C" int hnsw_gpu_bruteforce_dev(hnsw_gpu_index *ix, const coord_t *d_quer
 						   0x7F800000u);
 	dim3 grid(splits, (uint32_t) nq);
 #define BF_LAUNCH(F)                                                                                                   \
-	hipLaunchKernelGGL(bruteforce_kernel<F>, grid, dim3(256), lds, s, ix->vec, (uint32_t) ix->n, (uint32_t) ix->meta.dim, \
+	hipLaunchKernelGGL(bruteforce_kernel<F>, grid, dim3(256), lds, s, ix->vec, (uint32_t) nrows, (uint32_t) ix->meta.dim, \
 					   ix->stride, nchunks, kiters, qpad, d_queries, (uint32_t) k, part)
 	switch ((int) ix->meta.dist_func)
 	{
@@ -809,6 +812,121 @@ extern "C" int hnsw_gpu_bruteforce_dev(hnsw_gpu_index *ix, const coord_t *d_quer
 	HIPCHK(hipGetLastError());
 	return HNSW_GPU_OK;
 }
+
+extern "C" int hnsw_gpu_bruteforce_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t k, idx_t *d_idx,
+									   dist_t *d_dists, void *stream)
+{
+	if (!ix) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	return bruteforce_prefix(ix, ix->n, d_queries, nq, k, d_idx, d_dists, stream);
+}
+
+// ------------------------------------------------------------------------------------
+// exhaustive k-NN with the dense part on the matrix cores (device_bf_mfma.h)
+// ------------------------------------------------------------------------------------
+static float g_last_bf_gemm_ms = 0.f;
+
+extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t k,
+											idx_t *d_idx, dist_t *d_dists, void *stream_)
+{
+	if (!ix || !d_queries || !d_idx) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	if (nq == 0) return HNSW_GPU_OK;
+	if (k == 0 || k > 1024) return fail(HNSW_GPU_ERR_ARG, "k %zu out of range [1, 1024]", k);
+	if (nq > 65535) return fail(HNSW_GPU_ERR_ARG, "at most 65535 queries per call");
+	const int func = (int) ix->meta.dist_func;
+	if (func == F_MANHATTAN || ix->n < 4096)          // not a contraction / too small to matter
+		return hnsw_gpu_bruteforce_dev(ix, d_queries, nq, k, d_idx, d_dists, stream_);
+	HIPCHK(hipSetDevice(ix->device));
+	hipStream_t s = (hipStream_t) stream_;
+	const uint32_t n = (uint32_t) ix->n, stride = ix->stride, dim = (uint32_t) ix->meta.dim;
+	const uint32_t nchunks = stride / 4, kiters = (nchunks + 15) / 16;
+
+	// |row|^2 cache
+	if (ix->xnorm_cap < ix->n)
+	{
+		if (ix->xnorm) (void) hipFree(ix->xnorm);
+		ix->xnorm = nullptr; ix->xnorm_cap = 0; ix->xnorm_n = 0;
+		HIPCHK(hipMalloc(&ix->xnorm, ix->cap * sizeof(float)));
+		ix->xnorm_cap = ix->cap;
+	}
+	if (ix->xnorm_n != ix->n)
+	{
+		hipLaunchKernelGGL(row_norm2_kernel, dim3((n + 3) / 4), dim3(256), 0, s, ix->vec, n, stride, ix->xnorm);
+		ix->xnorm_n = ix->n;
+	}
+
+	const uint32_t cap = 16384;
+	const size_t sample = std::min<size_t>(ix->n, std::max<size_t>(8192, (size_t) k * ix->n / 2048));
+	// scratch carve
+	const size_t o_q = 0;
+	const size_t o_qn = o_q + round_up(nq * stride * 4, 256);
+	const size_t o_sidx = o_qn + round_up(nq * 4, 256);
+	const size_t o_sdist = o_sidx + round_up(nq * k * 4, 256);
+	const size_t o_bound = o_sdist + round_up(nq * k * 4, 256);
+	const size_t o_cnt = o_bound + round_up(nq * 4, 256);
+	const size_t o_cand = o_cnt + round_up(nq * 4 + 64, 256);
+	const size_t total = o_cand + round_up(nq * (size_t) cap * 4, 256);
+	if (total > ix->bf_bytes)
+	{
+		if (ix->bf) (void) hipFree(ix->bf);
+		ix->bf = nullptr; ix->bf_bytes = 0;
+		HIPCHK(hipMalloc(&ix->bf, total));
+		ix->bf_bytes = total;
+	}
+	char *B = (char *) ix->bf;
+	float *qpad = (float *) (B + o_q), *qn = (float *) (B + o_qn), *sdist = (float *) (B + o_sdist), *bound = (float *) (B + o_bound);
+	uint32_t *sidx = (uint32_t *) (B + o_sidx), *cnt = (uint32_t *) (B + o_cnt), *cand = (uint32_t *) (B + o_cand);
+	uint32_t *overflow = cnt + nq;
+
+	// 1. bound per query from a canonical scan of the sample rows
+	int rc = bruteforce_prefix(ix, sample, d_queries, nq, k, sidx, sdist, s);
+	if (rc) return rc;
+	const size_t qtot = nq * (size_t) stride;
+	hipLaunchKernelGGL(pad_queries_kernel, dim3((uint32_t) ((qtot + 255) / 256)), dim3(256), 0, s, d_queries, (uint32_t) nq, dim, stride, qpad);
+	hipLaunchKernelGGL(row_norm2_kernel, dim3((uint32_t) ((nq + 3) / 4)), dim3(256), 0, s, qpad, (uint32_t) nq, stride, qn);
+	// tau_q = sdist[q*k + k-1]: gather with a strided view
+	{
+		// reuse make_bounds on a compacted tau array: write tau into `bound` first
+		hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(1), 0, s, overflow, (size_t) 1, 0u);
+		HIPCHK(hipMemcpy2DAsync(bound, 4, sdist + (k - 1), k * 4, 4, nq, hipMemcpyDeviceToDevice, s));
+		hipLaunchKernelGGL(make_bounds_kernel, dim3((uint32_t) ((nq + 255) / 256)), dim3(256), 0, s, bound, qn, (uint32_t) nq, func, bound);
+	}
+	HIPCHK(hipMemsetAsync(cnt, 0, nq * 4, s));
+
+	// 2. the dense contraction + filter
+	BfArgs a;
+	memset(&a, 0, sizeof(a));
+	a.queries = qpad; a.qnorm = qn; a.qbound = bound; a.vec = ix->vec; a.xnorm = ix->xnorm;
+	a.nq = (uint32_t) nq; a.n = n; a.stride = stride; a.ksteps = (stride + BF_TK - 1) / BF_TK; a.func = func;
+	a.cand = cand; a.cand_cnt = cnt; a.cap = cap;
+	a.nqt = (uint32_t) ((nq + BF_TQ - 1) / BF_TQ); a.nrt = (n + BF_TR - 1) / BF_TR;
+	const uint32_t rgroups = (a.nrt + 7) / 8;
+	hipEvent_t e0 = ix->ev0[hnsw_gpu_index::EV_RING - 1], e1 = ix->ev1[hnsw_gpu_index::EV_RING - 1];
+	HIPCHK(hipEventRecord(e0, s));
+	hipLaunchKernelGGL(bf_mfma_filter_kernel, dim3(rgroups * a.nqt * 8), dim3(256), 0, s, a);
+	HIPCHK(hipEventRecord(e1, s));
+
+	// 3. canonical re-score of the survivors
+	const uint32_t qpadf = (uint32_t) round_up(kiters, 4) * 64;
+	const size_t wave_bytes = round_up((size_t) qpadf * 4 + (k + 1) * 8 + 32, 16);
+	const size_t lds = wave_bytes * 4;
+	if (lds > 64 * 1024) return fail(HNSW_GPU_ERR_ARG, "k/dim too large for the rescoring step");
+#define RS_LAUNCH(F)                                                                                                      \
+	hipLaunchKernelGGL(bf_rescore_kernel<F>, dim3((uint32_t) ((nq + 3) / 4)), dim3(256), lds, s, ix->vec, dim, stride,      \
+					   nchunks, kiters, qpadf, d_queries, (uint32_t) nq, cand, cnt, cap, (uint32_t) k, d_idx, d_dists, overflow)
+	if (func == F_L2) RS_LAUNCH(F_L2); else RS_LAUNCH(F_COSINE);
+#undef RS_LAUNCH
+	HIPCHK(hipGetLastError());
+	uint32_t ovf = 0;
+	HIPCHK(hipMemcpyAsync(&ovf, overflow, 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipStreamSynchronize(s));
+	(void) hipEventElapsedTime(&g_last_bf_gemm_ms, e0, e1);
+	if (ovf)      // a candidate list overflowed (bound far too loose for some query): canonical scan instead
+		return hnsw_gpu_bruteforce_dev(ix, d_queries, nq, k, d_idx, d_dists, stream_);
+	return HNSW_GPU_OK;
+}
+
+/* device time of the MFMA filter kernel of the most recent hnsw_gpu_bruteforce_mfma_dev call */
+extern "C" float hnsw_gpu_last_bruteforce_gemm_ms(void) { return g_last_bf_gemm_ms; }
 
 // ------------------------------------------------------------------------------------
 // multi-shard merge: nlists x (dist,label) lists per query -> ef best by (dist, label)

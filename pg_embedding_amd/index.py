@@ -187,19 +187,21 @@ class GpuIndex:
         check(self.L.hnsw_gpu_last_search_slots(self._h, C.byref(v)), "hnsw_gpu_last_search_slots")
         return int(v.value)
 
-    def bruteforce_torch(self, queries, k: int):
-        """Exact k nearest elements (idx, dists) by exhaustive scoring — recall ground truth."""
+    def bruteforce_torch(self, queries, k: int, mfma: bool = False):
+        """Exact k nearest elements (idx, dists) by exhaustive scoring — recall ground truth.
+        mfma=True runs the Q x N part as an f32 GEMM on the matrix cores (same result)."""
         torch = _torch()
         assert queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()
         nq = queries.shape[0]
         idx = torch.empty((nq, k), dtype=torch.int32, device=queries.device)
         dst = torch.empty((nq, k), dtype=torch.float32, device=queries.device)
         s = torch.cuda.current_stream(queries.device).cuda_stream
-        for q0 in range(0, nq, 32768):
-            q1 = min(nq, q0 + 32768)
-            check(self.L.hnsw_gpu_bruteforce_dev(self._h, queries[q0:q1].data_ptr(), q1 - q0, k,
-                                                 idx[q0:q1].data_ptr(), dst[q0:q1].data_ptr(), s),
-                  "hnsw_gpu_bruteforce_dev")
+        step = 4096 if mfma else 32768
+        for q0 in range(0, nq, step):
+            q1 = min(nq, q0 + step)
+            fn = self.L.hnsw_gpu_bruteforce_mfma_dev if mfma else self.L.hnsw_gpu_bruteforce_dev
+            check(fn(self._h, queries[q0:q1].data_ptr(), q1 - q0, k,
+                     idx[q0:q1].data_ptr(), dst[q0:q1].data_ptr(), s), "hnsw_gpu_bruteforce")
         return idx, dst
 
 

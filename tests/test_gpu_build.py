@@ -102,3 +102,25 @@ def test_bruteforce_is_exact(func):
         assert (idx[q] == order).all()
         assert (bits(dst[q]) == bits(d[order])).all()
     ix.close()
+
+
+@pytest.mark.parametrize("func", [pg.DIST_L2, pg.DIST_COSINE])
+@pytest.mark.parametrize("n,dim,nq,k", [(50000, 200, 300, 10), (20000, 768, 129, 32), (9000, 30, 64, 5)])
+def test_mfma_exhaustive_scorer_equals_canonical_scan(func, n, dim, nq, k):
+    """The dense MFMA pass is only a filter; the answer must equal the canonical brute force
+    bit for bit (ids, and distances from the canonical code)."""
+    import torch
+    X = gmm(n, dim, k=60, seed=19)
+    X[100:140] = X[300:340]                  # exact duplicates: equal distances, tie by lower idx
+    Q = gmm(nq, dim, k=60, seed=19, stream=1)
+    Q[0] = X[5]                              # zero distance
+    meta = pg.make_meta(min(dim, 1900), 4, 8, 8, func)
+    ix = pg.GpuIndex.empty(meta, n)
+    ix.append(X)
+    dq = torch.from_numpy(Q).cuda()
+    i0, d0 = ix.bruteforce_torch(dq, k)
+    i1, d1 = ix.bruteforce_torch(dq, k, mfma=True)
+    torch.cuda.synchronize()
+    assert (i0 == i1).all()
+    assert (d0.view(torch.int32) == d1.view(torch.int32)).all()
+    ix.close()

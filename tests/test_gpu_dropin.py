@@ -128,3 +128,53 @@ def test_page_tail_holes_in_element_numbers():
     for q in range(10):
         v = rng.integers(0, 9, dim).astype(np.float32)
         assert (h.search(v, efs) == ref.search(v, efs)).all()
+
+
+def test_index_scan_follows_hnsw_gettuple():
+    """embedding.c:284-370 restated over the reference binary (oracle/_ref hnsw_search) vs
+    pg_embedding_amd.scan.IndexScan over the device search: same TIDs in the same order,
+    including the efSearch-doubling re-scan and its de-duplication."""
+    from pg_embedding_amd.scan import IndexScan
+    dim, m, n, efs = 16, 4, 900, 8
+    X = sift_like_rows(n, dim)
+    port = oracle.PortIndex(dim, m, 16, efs, pg.DIST_L2)
+    port.add(X)
+    ix = pg.GpuIndex.from_flat(pg.make_meta(dim, m, 16, efs, pg.DIST_L2), port.raw(), n)
+
+    def reference_scan(q, limit):
+        ef = efs
+        res = list(port.search(q, ef)[0].tolist())
+        no_more = len(res) < ef
+        out, curr = [], 0
+        while len(out) < limit:
+            if curr >= len(res):
+                if no_more:
+                    break
+                ef *= 2
+                r = port.search(q, ef)[0].tolist()
+                if len(r) <= len(res):
+                    break
+                no_more = len(r) < ef
+                seen = set(res)
+                res.extend(x for x in r if x not in seen)
+                if curr >= len(res):
+                    break
+            out.append(res[curr])
+            curr += 1
+        return out
+
+    for qi in range(10):
+        q = X[qi * 13] + 0.25
+        want = reference_scan(q, 100)
+        got = []
+        for lab in IndexScan(ix, q, efs):
+            got.append(lab)
+            if len(got) == 100:
+                break
+        assert got == want and len(got) == 100
+    ix.close()
+
+
+def sift_like_rows(n, dim):
+    from pg_embedding_amd.datasets import sift_like
+    return sift_like(n, dim, k=10, seed=6)
