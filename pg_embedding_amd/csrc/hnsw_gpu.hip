@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "hnsw_gpu.h"
@@ -56,6 +57,10 @@ static inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; 
 // ------------------------------------------------------------------------------------
 struct hnsw_gpu_index
 {
+	// One search / build / scratch user at a time per mirror: the public entry points that touch
+	// the shared workspace take this lock (launches stay asynchronous on the caller's stream, but
+	// two host threads must not interleave their launches on one handle).
+	std::recursive_mutex mu;
 	HnswMetadata meta;
 	int      device = 0;
 	int      num_cu = 0;
@@ -316,6 +321,8 @@ extern "C" int hnsw_gpu_index_create_empty(const HnswMetadata *meta, size_t capa
 extern "C" int hnsw_gpu_index_append_dev(hnsw_gpu_index *ix, const coord_t *d_vectors, const label_t *d_labels,
 										 size_t n, void *stream)
 {
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
 	if (n == 0) return HNSW_GPU_OK;
 	if (!d_vectors) return fail(HNSW_GPU_ERR_ARG, "vectors is NULL");
@@ -332,6 +339,8 @@ extern "C" int hnsw_gpu_index_append_dev(hnsw_gpu_index *ix, const coord_t *d_ve
 
 extern "C" int hnsw_gpu_index_append(hnsw_gpu_index *ix, const coord_t *vectors, const label_t *labels, size_t n)
 {
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
 	if (n == 0) return HNSW_GPU_OK;
 	if (!vectors) return fail(HNSW_GPU_ERR_ARG, "vectors is NULL");
@@ -357,6 +366,8 @@ extern "C" int hnsw_gpu_index_append(hnsw_gpu_index *ix, const coord_t *vectors,
 
 extern "C" int hnsw_gpu_index_export_flat(hnsw_gpu_index *ix, void *elements)
 {
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix || !elements) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
 	HIPCHK(hipSetDevice(ix->device));
 	const size_t esz = ix->meta.size_data_per_element;
@@ -380,6 +391,8 @@ extern "C" int hnsw_gpu_index_export_flat(hnsw_gpu_index *ix, void *elements)
 
 extern "C" int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int deleted)
 {
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix || idx >= ix->n) return fail(HNSW_GPU_ERR_ARG, "bad element %u", (unsigned) idx);
 	HIPCHK(hipSetDevice(ix->device));
 	uint64_t l;
@@ -445,6 +458,8 @@ static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t q_st
 						 uint64_t *d_labels, uint32_t *d_idx, float *d_dists, uint32_t *d_counts,
 						 uint32_t *d_stats, hipStream_t stream)
 {
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
 	if (nq == 0) return HNSW_GPU_OK;
 	if (!d_queries || !d_counts || (mode == 0 && !d_labels) || (mode == 1 && !d_idx))
@@ -559,6 +574,8 @@ extern "C" int hnsw_gpu_search_base_dev(hnsw_gpu_index *ix, const coord_t *d_que
 extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries, size_t nq, size_t ef,
 									 label_t *labels, dist_t *dists, uint32_t *counts)
 {
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
 	if (nq == 0) return HNSW_GPU_OK;
 	if (!queries || !labels || !counts) return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
@@ -776,6 +793,8 @@ __global__ void fill_u32_kernel(uint32_t *p, size_t n, uint32_t v)
 static int bruteforce_prefix(hnsw_gpu_index *ix, size_t nrows, const coord_t *d_queries, size_t nq, size_t k, idx_t *d_idx,
 							 dist_t *d_dists, void *stream)
 {
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix || !d_queries || !d_idx) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
 	if (nq == 0) return HNSW_GPU_OK;
 	if (k == 0 || k > 1024) return fail(HNSW_GPU_ERR_ARG, "k %zu out of range [1, 1024]", k);
@@ -828,6 +847,8 @@ static float g_last_bf_gemm_ms = 0.f;
 extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t k,
 											idx_t *d_idx, dist_t *d_dists, void *stream_)
 {
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix || !d_queries || !d_idx) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
 	if (nq == 0) return HNSW_GPU_OK;
 	if (k == 0 || k > 1024) return fail(HNSW_GPU_ERR_ARG, "k %zu out of range [1, 1024]", k);
@@ -1017,6 +1038,8 @@ typedef void (*build_kernel_t)(const BuildArgs);
 extern "C" int hnsw_gpu_index_link(hnsw_gpu_index *ix, size_t first, size_t count, size_t max_batch, size_t ratio,
 								   void *stream_)
 {
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
 	if (first + count > ix->n) return fail(HNSW_GPU_ERR_ARG, "elements [%zu, %zu) are not stored (count %zu)", first, first + count, ix->n);
 	if (count == 0) return HNSW_GPU_OK;
@@ -1118,6 +1141,8 @@ extern "C" int hnsw_gpu_index_link(hnsw_gpu_index *ix, size_t first, size_t coun
 // ------------------------------------------------------------------------------------
 extern "C" int hnsw_gpu_index_reserve(hnsw_gpu_index *ix, size_t capacity)
 {
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
 	if (capacity <= ix->cap) return HNSW_GPU_OK;
 	if (capacity >= 0xFFFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "capacity exceeds idx_t range");
@@ -1149,6 +1174,8 @@ extern "C" int hnsw_gpu_index_reserve(hnsw_gpu_index *ix, size_t capacity)
 
 extern "C" int hnsw_gpu_index_get_links(hnsw_gpu_index *ix, idx_t idx, idx_t *out)
 {
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix || !out || idx >= ix->n) return fail(HNSW_GPU_ERR_ARG, "bad element %u", (unsigned) idx);
 	HIPCHK(hipSetDevice(ix->device));
 	const size_t maxM = ix->meta.maxM;
