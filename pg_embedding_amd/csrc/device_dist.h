@@ -227,11 +227,11 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ vec, size_t
 }
 
 // Load-batch shapes by chunk-steps per row (kiters = ceil(dim/64)).
-struct Shape2x4  { static constexpr int KB = 2,  RPG = 4; };   // dim <= 128
-struct Shape4x2  { static constexpr int KB = 4,  RPG = 2; };   // dim <= 256
-struct Shape8x2  { static constexpr int KB = 8,  RPG = 2; };   // dim <= 512
-struct Shape12x1 { static constexpr int KB = 12, RPG = 1; };   // larger (768 = one batch)
-struct Shape12x2 { static constexpr int KB = 12, RPG = 2; };   // same, 8 rows per round trip
+struct Shape2x4  { static constexpr int KB = 2,  RPG = 4, MIN_WAVES = 4; };   // dim <= 128
+struct Shape4x2  { static constexpr int KB = 4,  RPG = 2, MIN_WAVES = 4; };   // dim <= 256
+struct Shape8x2  { static constexpr int KB = 8,  RPG = 2, MIN_WAVES = 2; };   // dim <= 512
+struct Shape12x1 { static constexpr int KB = 12, RPG = 1, MIN_WAVES = 2; };   // larger (768 = one batch)
+struct Shape12x2 { static constexpr int KB = 12, RPG = 2, MIN_WAVES = 2; };   // same, 8 rows per round trip
 
 __host__ __device__ inline int shape_index(uint32_t kiters)
 {

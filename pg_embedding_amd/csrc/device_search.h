@@ -390,8 +390,12 @@ __device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v, uint64_t fill)
 	return ((uint64_t) hi << 32) | lo;
 }
 
+// Insert into the sorted result registers.  Only registers at or above the insert position
+// change.  Capacity is 64*R >= ef: elements pushed past index ef-1 are not cleared — they were the
+// maximum when they fell off and the valid maximum only decreases afterwards, so they stay above
+// every valid key, never count in `p` for an accepted key, and are never read (rsize bounds all reads).
 template <int R>
-__device__ __forceinline__ void res_insert(uint64_t (&rk)[R], uint64_t key, uint32_t ef, int lane)
+__device__ __forceinline__ void res_insert(uint64_t (&rk)[R], uint64_t key, int lane)
 {
 	uint32_t p = 0;
 #pragma unroll
@@ -399,11 +403,13 @@ __device__ __forceinline__ void res_insert(uint64_t (&rk)[R], uint64_t key, uint
 #pragma unroll
 	for (int k = R - 1; k >= 0; k--)
 	{
-		const uint64_t fill = (k > 0) ? readlane_u64(rk[k > 0 ? k - 1 : 0], 63) : 0ull;
-		const uint64_t prev = wave_shr1_u64(rk[k], fill);
-		const uint32_t i = (uint32_t) k * 64 + lane;
-		const uint64_t nv = (i < p) ? rk[k] : ((i == p) ? key : prev);
-		rk[k] = (i >= ef) ? ~0ull : nv;
+		if (p < (uint32_t) (k + 1) * 64)          // wave-uniform: registers below the position are untouched
+		{
+			const uint64_t fill = (k > 0) ? readlane_u64(rk[k > 0 ? k - 1 : 0], 63) : 0ull;
+			const uint64_t prev = wave_shr1_u64(rk[k], fill);
+			const uint32_t i = (uint32_t) k * 64 + lane;
+			rk[k] = (i < p) ? rk[k] : ((i == p) ? key : prev);
+		}
 	}
 }
 
@@ -523,7 +529,7 @@ __device__ __forceinline__ bool hash_contains(const uint32_t *tab, uint32_t mask
 }
 
 template <int FUNC, typename SH, int RREG>
-__global__ __launch_bounds__(256) void hnsw_search_kernel_reg(const SearchArgs a)
+__global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(const SearchArgs a)
 {
 	constexpr int CREG = 2 * RREG;
 	constexpr uint32_t CCAP = 64u * CREG;
@@ -589,7 +595,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_reg(const SearchArgs a
 			evals = 1;
 			{
 				const uint64_t hi = (uint64_t) ord_f32(lowerBound) << 32;
-				res_insert<RREG>(rk, hi | ep, ef, lane);
+				res_insert<RREG>(rk, hi | ep, lane);
 				cand_set<CREG>(ck, 0, hi | (uint32_t) ~ep, lane);
 			}
 			if (lane == 0)
@@ -684,7 +690,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_reg(const SearchArgs a
 								cand_set<CREG>(ck, csize, hi | (uint32_t) ~t2, lane);   // :100
 								csize++;
 							}
-							res_insert<RREG>(rk, hi | t2, ef, lane);        // :102-105
+							res_insert<RREG>(rk, hi | t2, lane);            // :102-105
 							rsize = rsize < ef ? rsize + 1 : ef;
 							lowerBound = unord_f32((uint32_t) (res_at<RREG>(rk, rsize - 1) >> 32));   // :107
 						}

@@ -491,7 +491,11 @@ static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t q_st
 	{
 		// [query | hash set (overlaid by the emit step's tie scratch) | newid | newdist]
 		const size_t fixed = off + 64 * 8;
-		uint32_t hcap = 4096;                                  // entries; needs >= 2 four-wave blocks per CU
+		// Rows of >= 1.25 KiB make the traversal HBM-bound, and there the LDS set pays (no L2
+		// atomics, ~10 % less HBM traffic; measured 5.4 -> 7.5 TB/s at 768 dims).  Narrow rows are
+		// issue/latency-bound: more resident waves beat the set, so they keep the bitmap
+		// (profiles/r1g_visited_set_by_dim.txt).
+		uint32_t hcap = ix->stride > 320 ? 4096 : 0;           // entries; needs >= 2 four-wave blocks per CU
 		const char *henv = getenv("HNSW_GPU_HASH_ENTRIES");
 		if (henv) hcap = (uint32_t) atoi(henv);
 		while (hcap >= 512 && 8 * (fixed + std::max<size_t>(hcap * 4, 2 * ef * 8)) > LDS_PER_CU) hcap >>= 1;

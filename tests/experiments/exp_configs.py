@@ -1,7 +1,7 @@
 """Experiment: the other BASELINE configs as parity-style cases at scale (not bench lines):
 build on device, recall@10 vs exhaustive, QPS and algorithmic GB/s, spot-check vs the CPU oracle."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import oracle, pg_embedding_amd as pg
 from pg_embedding_amd.datasets import gmm_torch, recall_at_k
