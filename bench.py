@@ -162,6 +162,19 @@ def main():
     qps = total_queries / elapsed
 
     achieved = bytes_launch / (kms * 1e-3) / 1e9
+    # context for the roof: what a plain device-to-device copy reaches on this GPU (read + write bytes)
+    cp_src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    cp_dst = torch.empty_like(cp_src)
+    cp_dst.copy_(cp_src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        cp_dst.copy_(cp_src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbps = 5 * 2 * cp_src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del cp_src, cp_dst
     result = {
         "metric": "queries/sec at recall@10>=0.95, 1Mx768 L2 efsearch=128",
         "value": qps,
@@ -201,6 +214,7 @@ def main():
             "traffic": pmc_traffic(args),
             "alg_bytes_per_launch": bytes_launch,
             "kernel_ms_per_launch": kms,
+            "measured_copy_GBps": copy_gbps,
         },
         "smaller_launch": small,
     }

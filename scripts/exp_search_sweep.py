@@ -43,6 +43,6 @@ elif mode == "hash":
         for nq in (1, 10000, 40000):
             run(nq, 0, reps=5)
 else:
-    for bpc in (1, 2, 3):
-        for nq in (5000, 10000, 20000):
+    for bpc in (1, 2, 3, 4, 5):
+        for nq in (10000, 40000):
             run(nq, bpc, reps=5)
