@@ -337,6 +337,10 @@ def cpu_baseline(args, ix, Q, gpu_labels, func):
     nt = int(max(threads * 8, min(args.nq, qps1 * threads * args.cpu_seconds * 0.6)))
     rt = cpu.search_many(Qh[:nt], args.ef, nthreads=threads)
     qpst = nt / rt["seconds"]
+    # 8 threads: the figure BASELINE.md §3 plans next to the single-thread one
+    n8 = int(max(64, min(args.nq, qps1 * 8 * args.cpu_seconds * 0.25)))
+    r8 = cpu.search_many(Qh[:n8], args.ef, nthreads=min(8, ncores))
+    qps8 = n8 / r8["seconds"]
     glab = gpu_labels[:n1].cpu().numpy().view(np.uint64)
     agree = float((r1["labels"] == glab).all(axis=1).mean())
     return {
@@ -344,6 +348,7 @@ def cpu_baseline(args, ix, Q, gpu_labels, func):
         "sample": f"{nt} of the {args.nq} queries on {threads} host threads (one query per thread, "
                   f"shared read-only index); single thread: {n1} queries",
         "single_thread_qps": qps1,
+        "eight_thread_qps": qps8,
         "host_cpus": ncores,
         "fraction_of_queries_with_identical_ids": agree,
     }
