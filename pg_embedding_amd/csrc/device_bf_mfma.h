@@ -203,12 +203,12 @@ __global__ __launch_bounds__(256) void bf_rescore_kernel(const float *__restrict
 	const uint32_t wib = threadIdx.x >> 6;
 	const uint32_t qi = blockIdx.x * 4 + wib;
 	if (qi >= nq) return;
-	const size_t wave_bytes = (size_t) qpad_floats * 4 + (size_t) (k + 1) * 8 + 8 * 4;
+	const size_t wave_bytes = (size_t) qpad_floats * 4 + (size_t) (k + 1) * 8 + 128 * 4;
 	unsigned char *my = smem + wib * ((wave_bytes + 15) & ~(size_t) 15);
 	float *qf = reinterpret_cast<float *>(my);
 	const float4 *q4 = reinterpret_cast<const float4 *>(my);
 	uint64_t *top = reinterpret_cast<uint64_t *>(my + (size_t) qpad_floats * 4);
-	float *dist8 = reinterpret_cast<float *>(top + (k + 1));
+	float *sums = reinterpret_cast<float *>(top + (k + 1));
 	for (uint32_t e = lane; e < qpad_floats; e += 64)
 	{
 		const float t = queries[(size_t) qi * dim + (e < dim ? e : dim - 1)];
@@ -222,15 +222,20 @@ __global__ __launch_bounds__(256) void bf_rescore_kernel(const float *__restrict
 	const uint32_t *ids = cand + (size_t) qi * cap;
 	uint32_t tsize = 0;
 	uint64_t worst = ~0ull;
-	for (uint32_t base = 0; base < cnt; base += 8)
+	for (uint32_t base = 0; base < cnt; base += 64)
 	{
-		const uint32_t c8 = min(8u, cnt - base);
+		const uint32_t c64 = min(64u, cnt - base);
 		auto by_id = [ids, base](uint32_t r) { return ids[base + r]; };
-		score_rows<FUNC, 4, 2>(vec, stride, q4, nchunks, kiters, qnorm, by_id, c8, dist8, lane);
+		score_rows<FUNC, 4, 2>(vec, stride, q4, nchunks, kiters, by_id, c64, sums, lane);
 		wave_sync();
-		for (uint32_t r = 0; r < c8; r++)
+		const float dl = finish_dist<FUNC>(sums[lane], sums[OUT2 + lane], qnorm);
+		const uint64_t kl = ((uint64_t) ord_f32(dl) << 32) | ids[base + ((uint32_t) lane < c64 ? lane : 0)];
+		uint64_t todo = __ballot((uint32_t) lane < c64 && (tsize < k || kl < worst));
+		while (todo)
 		{
-			const uint64_t key = ((uint64_t) ord_f32(dist8[r]) << 32) | ids[base + r];
+			const uint32_t r = (uint32_t) __builtin_ctzll(todo);
+			todo &= todo - 1;
+			const uint64_t key = readlane_u64(kl, r);
 			if (tsize < k || key < worst)
 			{
 				tsize = sorted_insert(top, tsize, key, k, lane);

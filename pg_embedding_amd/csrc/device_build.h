@@ -91,14 +91,16 @@ __device__ __forceinline__ uint32_t heuristic_select(const BuildArgs &a, float *
 			float qnorm = 0.f;
 			if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
 			const uint32_t *ids = sel_id;
-			auto by_id = [ids](uint32_t r) { return ids[r]; };
-			score_rows<FUNC, BUILD_KB, 1>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, by_id, nsel, tmpd, lane);
-			wave_sync();
 			bool closer = false;
-			for (uint32_t b = 0; b < nsel; b += 64)
+			for (uint32_t b = 0; b < nsel; b += 64)                   // 64 selected rows per pass
 			{
-				const uint32_t i = b + lane;
-				closer |= (i < nsel) && (tmpd[i] < dist_to_query);    // curdist < dist_to_query, :143
+				const uint32_t nb = nsel - b < 64 ? nsel - b : 64;
+				auto by_id = [ids, b](uint32_t r) { return ids[b + r]; };
+				score_rows<FUNC, BUILD_KB, 1>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nb, tmpd, lane);
+				wave_sync();
+				const float curdist = finish_dist<FUNC>(tmpd[lane], tmpd[OUT2 + lane], qnorm);
+				closer |= ((uint32_t) lane < nb) && (curdist < dist_to_query);   // curdist < dist_to_query, :143
+				wave_sync();
 			}
 			good = __ballot(closer) == 0;
 		}
@@ -121,6 +123,7 @@ __device__ __forceinline__ uint32_t heuristic_select(const BuildArgs &a, float *
 __device__ __forceinline__ uint32_t build_cap(const BuildArgs &a)
 {
 	uint32_t c = a.efc > a.maxM + 1 ? a.efc : a.maxM + 1;
+	if (c < 128) c = 128;               // tmpd doubles as a score_rows output (2 x 64 sums)
 	return (c + 7) & ~7u;
 }
 
@@ -247,15 +250,17 @@ __global__ __launch_bounds__(256) void reverse_links_kernel(const BuildArgs a)
 			stage_row(qf, a.vec + (size_t) t * a.stride, a.stride, a.qpad_floats, lane);
 			float qnorm = 0.f;
 			if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
+			for (uint32_t b = 0; b <= cnt; b += 64)
 			{
+				const uint32_t nb = cnt + 1 - b < 64 ? cnt + 1 - b : 64;
 				const uint32_t *cc = cur;
-				auto by_id = [cc](uint32_t r) { return cc[r]; };
-				score_rows<FUNC, BUILD_KB, 1>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, by_id, cnt + 1, cdist, lane);
+				auto by_id = [cc, b](uint32_t r) { return cc[b + r]; };
+				score_rows<FUNC, BUILD_KB, 1>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nb, tmpd, lane);
+				wave_sync();
+				const float dl = finish_dist<FUNC>(tmpd[lane], tmpd[OUT2 + lane], qnorm);
+				if ((uint32_t) lane < nb) keyA[b + lane] = ((uint64_t) ord_f32(dl) << 32) | (uint32_t) ~cur[b + lane];
+				wave_sync();
 			}
-			wave_sync();
-			for (uint32_t k = lane; k <= cnt; k += 64)
-				keyA[k] = ((uint64_t) ord_f32(cdist[k]) << 32) | (uint32_t) ~cur[k];
-			wave_sync();
 			rank_sort(keyA, keyB, cnt + 1, false, lane);         // pop order of (-dist, idx)
 			const uint32_t nsel = heuristic_select<FUNC>(a, qf, keyB, cnt + 1, a.maxM, keyA, ids, tmpd, lane);
 			rank_sort(keyA, keyB, nsel, true, lane);             // :214-219: farthest first

@@ -100,22 +100,24 @@ __device__ __forceinline__ void acc_step(RowAcc &s, const float4 &q, const float
 	}
 }
 
-// Group-wide finish.  `qnorm` = |q|^2 in the same canonical order (cosine only).
-// Must be executed by all 64 lanes (DPP reads neighbours).
+// Epilogue of one distance from its reduced sums, exactly as the reference writes it
+// (distfunc.c:64,117,129 / :144 / :154).  s0 = sum of squares | dot | sum of |.|; s1 = |x|^2
+// (cosine only); qnorm = |q|^2 in the same canonical order.  Pure per-lane arithmetic, so callers
+// run it once per row with one row per lane instead of once per 16-lane group: the correctly
+// rounded sqrtf costs ~15 instructions and the fp64 divide/sqrt of the cosine form several
+// times that.
 template <int FUNC>
-__device__ __forceinline__ float acc_finish(const RowAcc &s, float qnorm)
+__device__ __forceinline__ float finish_dist(float s0, float s1, float qnorm)
 {
 	if (FUNC == F_L2)
-		return __builtin_sqrtf(row16_sum(fold4(s.a)));             // distfunc.c:64,117,129
+		return __builtin_sqrtf(s0);
 	if (FUNC == F_COSINE)
 	{
-		float dot = row16_sum(fold4(s.a));
-		float nb = row16_sum(fold4(s.b));
-		float prod = qnorm * nb;                                    // float product, distfunc.c:144
-		double r = 1.0 - (double) dot / __builtin_sqrt((double) prod);
+		const float prod = qnorm * s1;                                  // float product, distfunc.c:144
+		const double r = 1.0 - (double) s0 / __builtin_sqrt((double) prod);
 		return (float) r;
 	}
-	return row16_sum(fold4(s.a));                                   // distfunc.c:154
+	return s0;
 }
 
 // |q|^2 of the LDS-staged query, canonical order; all lanes return the same value.
@@ -138,17 +140,20 @@ __device__ __forceinline__ float query_norm(const float4 *q4, uint32_t nchunks, 
 // Score `nrows` rows against the LDS-staged query.
 //   row r lives at vec + rowid(r) * stride (floats; stride % 4 == 0, zero padded)
 //   q4     : query in LDS as float4 chunks, zero padded to a multiple of KB*16 chunks
-//   out[r] : distance, written by the first lane of the owning group
+//   out[r] : REDUCED SUM of row r (sum of squares | dot | sum of |.|), written by the first lane
+//            of the owning group; cosine also writes |x|^2 to out[OUT2 + r].  The caller turns the
+//            sums into distances with finish_dist(), one row per lane.
 // Shape <KB, RPG>: every 16-lane group owns RPG rows per pass (4*RPG rows per wave-pass) and
 // issues KB chunk-steps of ALL its rows before the first use, i.e. KB*RPG independent
 // 16-byte loads per lane (KB*RPG KiB per wave) are in flight per memory round trip.  The
 // traversal is a chain of dependent round trips, so the shape is picked per dimensionality
 // to cover a whole row per trip when it fits: 768 dims = <12,1>, 128 dims = <2,4>.
+constexpr uint32_t OUT2 = 64;      // offset of the second sum (cosine |x|^2) in a score_rows output array
+
 template <int FUNC, int KB, int RPG, typename RowId>
 __device__ __forceinline__ void score_rows(const float *__restrict__ vec, size_t stride,
 										   const float4 *q4, uint32_t nchunks, uint32_t kiters,
-										   float qnorm, RowId rowid, uint32_t nrows,
-										   float *out, int lane)
+										   RowId rowid, uint32_t nrows, float *out, int lane)
 {
 	const uint32_t g = lane >> 4, sub = lane & 15;
 	const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -219,9 +224,15 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ vec, size_t
 #pragma unroll
 		for (int rr = 0; rr < RPG; rr++)
 		{
-			const float d = acc_finish<FUNC>(s[rr], qnorm);
+			const float s0 = row16_sum(fold4(s[rr].a));             // all 64 lanes: DPP reads neighbours
+			float s1 = 0.f;
+			if (FUNC == F_COSINE) s1 = row16_sum(fold4(s[rr].b));
 			const uint32_t r = base + rr * 4 + g;
-			if (sub == 0 && v[rr]) out[r] = d;
+			if (sub == 0 && v[rr])
+			{
+				out[r] = s0;
+				if (FUNC == F_COSINE) out[OUT2 + r] = s1;
+			}
 		}
 	}
 }

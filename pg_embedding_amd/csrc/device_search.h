@@ -173,10 +173,10 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 			const uint32_t ep = a.entry;
 			{
 				auto one = [ep](uint32_t) { return ep; };
-				score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, one, 1u, newdist, lane);
+				score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, one, 1u, newdist, lane);
 			}
 			wave_sync();
-			float lowerBound = newdist[0];
+			float lowerBound = finish_dist<FUNC>(newdist[0], newdist[OUT2], qnorm);
 			evals = 1;
 			if (lane == 0)
 			{
@@ -228,10 +228,16 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 					{                                                    // :95-97, batched
 						const uint32_t *ids = newid;
 						auto by_id = [ids](uint32_t r) { return ids[r]; };
-						score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, by_id, nnew, newdist, lane);
+						score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nnew, newdist, lane);
 					}
 					evals += nnew;
 					wave_sync();
+					{                                                    // sums -> distances, one row per lane
+						const float dl = finish_dist<FUNC>(newdist[lane], newdist[OUT2 + lane], qnorm);
+						wave_sync();
+						newdist[lane] = dl;
+						wave_sync();
+					}
 
 					for (uint32_t r = 0; r < nnew; r++)                  // :99-108, in link order
 					{
@@ -588,10 +594,10 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 			const uint32_t ep = a.entry;                                   // hnswalg.cpp:55-65
 			{
 				auto one = [ep](uint32_t) { return ep; };
-				score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, one, 1u, newdist, lane);
+				score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, one, 1u, newdist, lane);
 			}
 			wave_sync();
-			float lowerBound = newdist[0];
+			float lowerBound = finish_dist<FUNC>(newdist[0], newdist[OUT2], qnorm);
 			evals = 1;
 			{
 				const uint64_t hi = (uint64_t) ord_f32(lowerBound) << 32;
@@ -663,11 +669,11 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 					{                                                       // :95-97, batched
 						const uint32_t *ids = newid;
 						auto by_id = [ids](uint32_t r) { return ids[r]; };
-						score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, qnorm, by_id, nnew, newdist, lane);
+						score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nnew, newdist, lane);
 					}
 					evals += nnew;
 					wave_sync();
-					const float    d_mine = newdist[lane];                  // lane r <- row r
+					const float    d_mine = finish_dist<FUNC>(newdist[lane], newdist[OUT2 + lane], qnorm);   // lane r <- row r
 					const uint32_t t_mine = newid[lane];
 					uint64_t todo = __ballot((uint32_t) lane < nnew && (rsize < ef || lowerBound > d_mine));
 					while (todo)                                            // :99-108, in link order

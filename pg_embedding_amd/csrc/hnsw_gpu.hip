@@ -490,7 +490,7 @@ static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t q_st
 	if (rreg)
 	{
 		// [query | hash set (overlaid by the emit step's tie scratch) | newid | newdist]
-		const size_t fixed = off + 64 * 8;
+		const size_t fixed = off + 64 * 4 + 128 * 4;
 		// Rows of >= 1.25 KiB make the traversal HBM-bound, and there the LDS set pays (no L2
 		// atomics, ~10 % less HBM traffic; measured 5.4 -> 7.5 TB/s at 768 dims).  Narrow rows are
 		// issue/latency-bound: more resident waves beat the set, so they keep the bitmap
@@ -513,7 +513,7 @@ static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t q_st
 		a.off_cand = (uint32_t) off;    off += round_up((2 * ef + 1) * 8, 16);
 	}
 	a.off_newid = (uint32_t) off;   off += 64 * 4;
-	a.off_newdist = (uint32_t) off; off += 64 * 4;
+	a.off_newdist = (uint32_t) off; off += 128 * 4;      // sums + (cosine) |x|^2
 	a.wave_bytes = (uint32_t) round_up(off, 16);
 	if (a.wave_bytes > LDS_PER_CU)
 		return fail(HNSW_GPU_ERR_ARG, "ef=%zu dim=%zu needs %u bytes of LDS per query (> %zu)", ef, ix->meta.dim,
@@ -634,18 +634,27 @@ __global__ __launch_bounds__(256) void dist_batch_kernel(const float *__restrict
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	float *qf = reinterpret_cast<float *>(smem);
 	const float4 *q4 = reinterpret_cast<const float4 *>(smem);
-	for (uint32_t e = threadIdx.x; e < qpad_floats; e += blockDim.x) qf[e] = (e < dim) ? q[e] : 0.f;
+	float *sums = reinterpret_cast<float *>(smem + (size_t) qpad_floats * 4) + (threadIdx.x >> 6) * 128;   // per wave
+	for (uint32_t e = threadIdx.x; e < qpad_floats; e += blockDim.x)
+	{
+		const float t = q[e < dim ? e : dim - 1];
+		qf[e] = (e < dim) ? t : 0.f;
+	}
 	__syncthreads();
 	const int lane = threadIdx.x & 63;
 	const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
 	const uint32_t nwaves = (gridDim.x * blockDim.x) >> 6;
 	float qnorm = 0.f;
 	if (FUNC == F_COSINE) qnorm = query_norm(q4, nchunks, kiters, lane);
-	for (uint32_t base = wave * 8; base < nrows; base += nwaves * 8)
+	for (uint32_t base = wave * 64; base < nrows; base += nwaves * 64)
 	{
-		const uint32_t cnt = min(8u, nrows - base);
+		const uint32_t cnt = min(64u, nrows - base);
 		auto direct = [base](uint32_t r) { return base + r; };
-		score_rows<FUNC, 4, 2>(rows, stride, q4, nchunks, kiters, qnorm, direct, cnt, out + base, lane);
+		score_rows<FUNC, 4, 2>(rows, stride, q4, nchunks, kiters, direct, cnt, sums, lane);
+		wave_sync();
+		const float d = finish_dist<FUNC>(sums[lane], sums[OUT2 + lane], qnorm);
+		if ((uint32_t) lane < cnt) out[base + lane] = d;
+		wave_sync();
 	}
 }
 
@@ -660,9 +669,9 @@ extern "C" int hnsw_gpu_dist_batch_dev(dist_func_t func, const coord_t *d_q, con
 	if (nrows >= 0xFFFFFFF0ull) return fail(HNSW_GPU_ERR_ARG, "too many rows");
 	const uint32_t nchunks = (uint32_t) (row_stride / 4), kiters = (nchunks + 15) / 16;
 	const uint32_t qpad = (uint32_t) round_up(kiters, 4) * 64;
-	const size_t lds = (size_t) qpad * 4;
+	const size_t lds = (size_t) qpad * 4 + 4 * 128 * 4;
 	if (lds > 64 * 1024) return fail(HNSW_GPU_ERR_ARG, "dim %zu too large", dim);
-	const uint32_t blocks = (uint32_t) std::min<size_t>((nrows + 31) / 32, 256 * 8);
+	const uint32_t blocks = (uint32_t) std::min<size_t>((nrows + 255) / 256, 256 * 8);
 	hipStream_t s = (hipStream_t) stream;
 	switch ((int) func)
 	{
@@ -730,22 +739,28 @@ __global__ __launch_bounds__(256) void bruteforce_kernel(const float *__restrict
 	const int lane = threadIdx.x & 63;
 	const uint32_t wib = threadIdx.x >> 6;
 	uint64_t *top = reinterpret_cast<uint64_t *>(smem + (size_t) qpad_floats * 4) + (size_t) wib * (k + 1);
-	float *dist8 = reinterpret_cast<float *>(smem + (size_t) qpad_floats * 4 + (size_t) 4 * (k + 1) * 8) + wib * 8;
+	float *sums = reinterpret_cast<float *>(smem + (size_t) qpad_floats * 4 + (size_t) 4 * (k + 1) * 8) + wib * 128;
 	const uint32_t nw = gridDim.x * 4, w = blockIdx.x * 4 + wib;
 	const uint32_t lo = (uint32_t) ((uint64_t) n * w / nw), hi = (uint32_t) ((uint64_t) n * (w + 1) / nw);
 	float qnorm = 0.f;
 	if (FUNC == F_COSINE) qnorm = query_norm(q4, nchunks, kiters, lane);
 	uint32_t tsize = 0;
 	uint64_t worst = ~0ull;
-	for (uint32_t base = lo; base < hi; base += 8)
+	for (uint32_t base = lo; base < hi; base += 64)
 	{
-		const uint32_t cnt = min(8u, hi - base);
+		const uint32_t cnt = min(64u, hi - base);
 		auto direct = [base](uint32_t r) { return base + r; };
-		score_rows<FUNC, 4, 2>(vec, stride, q4, nchunks, kiters, qnorm, direct, cnt, dist8, lane);
+		score_rows<FUNC, 4, 2>(vec, stride, q4, nchunks, kiters, direct, cnt, sums, lane);
 		wave_sync();
-		for (uint32_t r = 0; r < cnt; r++)
+		const float dl = finish_dist<FUNC>(sums[lane], sums[OUT2 + lane], qnorm);
+		const uint64_t kl = ((uint64_t) ord_f32(dl) << 32) | (base + lane);
+		// only rows that can enter the current top-k are visited one by one
+		uint64_t todo = __ballot((uint32_t) lane < cnt && (tsize < k || kl < worst));
+		while (todo)
 		{
-			const uint64_t key = ((uint64_t) ord_f32(dist8[r]) << 32) | (base + r);
+			const uint32_t r = (uint32_t) __builtin_ctzll(todo);
+			todo &= todo - 1;
+			const uint64_t key = readlane_u64(kl, r);
 			if (tsize < k || key < worst)
 			{
 				tsize = sorted_insert(top, tsize, key, k, lane);
@@ -810,7 +825,7 @@ static int bruteforce_prefix(hnsw_gpu_index *ix, size_t nrows, const coord_t *d_
 	uint32_t splits = (uint32_t) std::max<size_t>(1, std::min<size_t>(64, (size_t) (4 * ix->num_cu) / nq));
 	splits = (uint32_t) std::min<size_t>(splits, std::max<size_t>(1, nrows / 64));
 	const uint32_t nlists = splits * 4;
-	const size_t lds = (size_t) qpad * 4 + (size_t) 4 * (k + 1) * 8 + 4 * 8 * 4;
+	const size_t lds = (size_t) qpad * 4 + (size_t) 4 * (k + 1) * 8 + 4 * 128 * 4;
 	if (lds > 64 * 1024) return fail(HNSW_GPU_ERR_ARG, "k/dim too large for brute force");
 	int rc = ensure_scratch(ix, nq * nlists * k * 8);
 	if (rc) return rc;
@@ -932,7 +947,7 @@ extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d
 
 	// 3. canonical re-score of the survivors
 	const uint32_t qpadf = (uint32_t) round_up(kiters, 4) * 64;
-	const size_t wave_bytes = round_up((size_t) qpadf * 4 + (k + 1) * 8 + 32, 16);
+	const size_t wave_bytes = round_up((size_t) qpadf * 4 + (k + 1) * 8 + 128 * 4, 16);
 	const size_t lds = wave_bytes * 4;
 	if (lds > 64 * 1024) return fail(HNSW_GPU_ERR_ARG, "k/dim too large for the rescoring step");
 #define RS_LAUNCH(F)                                                                                                      \
@@ -1092,7 +1107,7 @@ extern "C" int hnsw_gpu_index_link(hnsw_gpu_index *ix, size_t first, size_t coun
 	a.maxM = (uint32_t) maxM; a.M = (uint32_t) M; a.lstride = ix->lstride; a.efc = (uint32_t) efc;
 	a.cand_idx = cand_idx; a.cand_dist = cand_dist; a.cand_cnt = cand_cnt;
 	a.pairs = pairs; a.npairs = ctr; a.sorted_pairs = sorted; a.seg_start = seg; a.nseg = ctr + 1; a.ticket = ctr + 2;
-	const uint32_t cap = (uint32_t) round_up(std::max(efc, maxM + 1), 8);
+	const uint32_t cap = (uint32_t) round_up(std::max<size_t>(std::max(efc, maxM + 1), 128), 8);   // tmpd holds 2 x 64 sums
 	a.wave_bytes = (uint32_t) round_up((size_t) a.qpad_floats * 4 + (size_t) cap * (8 * 2 + 4 * 3) + (maxM + 2) * 4, 16);
 	if (a.wave_bytes > LDS_PER_CU) return fail(HNSW_GPU_ERR_ARG, "efConstruction/maxM/dim need too much LDS (%u bytes)", a.wave_bytes);
 	uint32_t wpb = 4;
