@@ -77,6 +77,12 @@ int hnsw_gpu_index_export_flat(hnsw_gpu_index *ix, void *elements);
 /* Set / clear the vacuum flag of one element's label (embedding.c:920-926). */
 int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int deleted);
 
+/* Replace / add the elements [first, first+count) from host element images (same layout as
+ * create_from_flat; `elements` points at the image of element `first`).  For a host that knows
+ * which elements changed (new rows, re-linked neighbours, vacuum flags): incremental mirror
+ * maintenance instead of a full re-mirror.  first <= current count. */
+int hnsw_gpu_index_update_from_flat(hnsw_gpu_index *ix, const void *elements, size_t first, size_t count);
+
 /* Grow the mirror's capacity (elements and graph are kept). */
 int hnsw_gpu_index_reserve(hnsw_gpu_index *ix, size_t capacity);
 

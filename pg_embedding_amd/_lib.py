@@ -61,6 +61,7 @@ def gpu_lib():
     L.hnsw_gpu_index_export_flat.argtypes = [vp, vp]
     L.hnsw_gpu_index_link.argtypes = [vp, sz, sz, sz, sz, vp]
     L.hnsw_gpu_index_reserve.argtypes = [vp, sz]
+    L.hnsw_gpu_index_update_from_flat.argtypes = [vp, vp, sz, sz]
     L.hnsw_gpu_index_get_links.argtypes = [vp, C.c_uint32, vp]
     L.hnsw_gpu_index_set_deleted.argtypes = [vp, C.c_uint32, i32]
     L.hnsw_gpu_index_count.restype = sz

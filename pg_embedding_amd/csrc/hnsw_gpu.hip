@@ -269,6 +269,38 @@ __global__ __launch_bounds__(256) void append_rows_kernel(const float *__restric
 
 static const size_t STAGE_BYTES = (size_t) 256 << 20;   // host<->device staging granule
 
+// Re-import `count` host element images into element numbers [first, first+count); the mirror
+// grows to cover them.  n_total bounds the link targets that are accepted.
+static int import_range(hnsw_gpu_index *ix, const void *elements, size_t first, size_t count, size_t n_total)
+{
+	const HnswMetadata *meta = &ix->meta;
+	const size_t esz = meta->size_data_per_element;
+	const size_t per = std::max<size_t>(1, STAGE_BYTES / esz);
+	uint32_t *stage = nullptr;
+	uint32_t *bad = ix->ticket + 8;
+	if (count == 0) return HNSW_GPU_OK;
+	HIPCHK(hipMemset(bad, 0, 4));
+	hipError_t e = hipMalloc(&stage, std::min(per, count) * esz);
+	if (e != hipSuccess) return fail(HNSW_GPU_ERR_NOMEM, "staging allocation failed");
+	for (size_t off = 0; off < count && e == hipSuccess; off += per)
+	{
+		const size_t cnt = std::min(per, count - off);
+		e = hipMemcpy(stage, (const char *) elements + off * esz, cnt * esz, hipMemcpyHostToDevice);
+		if (e != hipSuccess) break;
+		const uint32_t blocks = (uint32_t) ((cnt + 3) / 4);
+		hipLaunchKernelGGL(import_elements_kernel, dim3(blocks), dim3(256), 0, 0, stage, esz / 4, (uint32_t) (first + off),
+						   (uint32_t) cnt, (uint32_t) n_total, (uint32_t) meta->dim, ix->stride, (uint32_t) meta->maxM,
+						   ix->lstride, ix->vec, ix->links, ix->labels, bad);
+		e = hipDeviceSynchronize();
+	}
+	uint32_t nbad = 0;
+	if (e == hipSuccess) e = hipMemcpy(&nbad, bad, 4, hipMemcpyDeviceToHost);
+	(void) hipFree(stage);
+	if (e != hipSuccess) return fail(HNSW_GPU_ERR_HIP, "index upload failed: %s", hipGetErrorString(e));
+	if (nbad) return fail(HNSW_GPU_ERR_ARG, "element image is corrupt: %u bad link counts / link targets", nbad);
+	return HNSW_GPU_OK;
+}
+
 extern "C" int hnsw_gpu_index_create_from_flat(const HnswMetadata *meta, const void *elements, size_t n,
 											   int device, hnsw_gpu_index **out)
 {
@@ -277,36 +309,8 @@ extern "C" int hnsw_gpu_index_create_from_flat(const HnswMetadata *meta, const v
 	hnsw_gpu_index *ix = nullptr;
 	int rc = alloc_index(meta, n, device, &ix);
 	if (rc) return rc;
-	const size_t esz = meta->size_data_per_element;
-	const size_t per = std::max<size_t>(1, STAGE_BYTES / esz);
-	uint32_t *stage = nullptr;
-	uint32_t *bad = ix->ticket + 8;
-	hipError_t e = hipMalloc(&stage, std::min(per, std::max<size_t>(n, 1)) * esz);
-	if (e != hipSuccess) { hnsw_gpu_index_destroy(ix); return fail(HNSW_GPU_ERR_NOMEM, "staging allocation failed"); }
-	for (size_t first = 0; first < n && e == hipSuccess; first += per)
-	{
-		const size_t cnt = std::min(per, n - first);
-		e = hipMemcpy(stage, (const char *) elements + first * esz, cnt * esz, hipMemcpyHostToDevice);
-		if (e != hipSuccess) break;
-		const uint32_t blocks = (uint32_t) ((cnt + 3) / 4);
-		hipLaunchKernelGGL(import_elements_kernel, dim3(blocks), dim3(256), 0, 0, stage, esz / 4, (uint32_t) first,
-						   (uint32_t) cnt, (uint32_t) n, (uint32_t) meta->dim, ix->stride, (uint32_t) meta->maxM,
-						   ix->lstride, ix->vec, ix->links, ix->labels, bad);
-		e = hipDeviceSynchronize();
-	}
-	uint32_t nbad = 0;
-	if (e == hipSuccess) e = hipMemcpy(&nbad, bad, 4, hipMemcpyDeviceToHost);
-	(void) hipFree(stage);
-	if (e != hipSuccess)
-	{
-		hnsw_gpu_index_destroy(ix);
-		return fail(HNSW_GPU_ERR_HIP, "index upload failed: %s", hipGetErrorString(e));
-	}
-	if (nbad)
-	{
-		hnsw_gpu_index_destroy(ix);
-		return fail(HNSW_GPU_ERR_ARG, "element image is corrupt: %u bad link counts / link targets", nbad);
-	}
+	rc = import_range(ix, elements, 0, n, n);
+	if (rc) { hnsw_gpu_index_destroy(ix); return rc; }
 	ix->n = n;
 	*out = ix;
 	return HNSW_GPU_OK;
@@ -1205,5 +1209,29 @@ extern "C" int hnsw_gpu_index_get_links(hnsw_gpu_index *ix, idx_t idx, idx_t *ou
 		if (tmp[j] != LINK_NONE) out[1 + cnt++] = tmp[j];
 	out[0] = cnt;
 	for (size_t j = cnt; j < maxM; j++) out[1 + j] = 0;
+	return HNSW_GPU_OK;
+}
+
+// Refresh part of the mirror from the host: element images of [first, first+count) replace what
+// the mirror holds (links, vector, label); elements past the current end are added.  This is the
+// incremental counterpart of create_from_flat for a host that tracks which pages changed
+// (new elements, re-linked neighbours, vacuum flags) — SURVEY.md §8(f) rank 2.
+extern "C" int hnsw_gpu_index_update_from_flat(hnsw_gpu_index *ix, const void *elements, size_t first, size_t count)
+{
+	if (!ix || (count && !elements)) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	std::unique_lock<std::recursive_mutex> lock_(ix->mu);
+	if (first > ix->n) return fail(HNSW_GPU_ERR_ARG, "update would leave a gap (first %zu > count %zu)", first, ix->n);
+	HIPCHK(hipSetDevice(ix->device));
+	const size_t end = first + count;
+	if (end > ix->cap)
+	{
+		int rc = hnsw_gpu_index_reserve(ix, end + end / 2);
+		if (rc) return rc;
+	}
+	const size_t n_total = std::max(ix->n, end);
+	int rc = import_range(ix, elements, first, count, n_total);
+	if (rc) return rc;
+	ix->n = n_total;
+	ix->xnorm_n = 0;            // cached row norms are stale
 	return HNSW_GPU_OK;
 }

@@ -124,6 +124,14 @@ class GpuIndex:
         155-223, 117-153).  max_batch=1 == the reference's serial inserts, bit for bit."""
         check(self.L.hnsw_gpu_index_link(self._h, first, count, max_batch, ratio, stream), "hnsw_gpu_index_link")
 
+    def update_from_flat(self, elements: np.ndarray, first: int, count: int) -> None:
+        """Replace / add elements [first, first+count) from host element images."""
+        elements = np.ascontiguousarray(elements, dtype=np.uint8)
+        if elements.size != count * self.meta.size_data_per_element:
+            raise ValueError("element image has the wrong size")
+        check(self.L.hnsw_gpu_index_update_from_flat(self._h, elements.ctypes.data, first, count),
+              "hnsw_gpu_index_update_from_flat")
+
     def export_flat(self) -> np.ndarray:
         out = np.empty(self.count * self.meta.size_data_per_element, np.uint8)
         check(self.L.hnsw_gpu_index_export_flat(self._h, out.ctypes.data), "hnsw_gpu_index_export_flat")

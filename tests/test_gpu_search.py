@@ -288,3 +288,28 @@ def test_visited_sets_larger_than_the_lds_table():
     labels, dists, counts = assert_same_as_oracle(ix, port, Q, 256)
     assert port.search_many(Q, 256)["evals"].max() > 3100
     ix.close()
+
+
+def test_incremental_mirror_update_from_changed_elements():
+    """A host that inserts on the CPU pushes only the changed elements (the new ones and the
+    neighbours whose link lists were rewritten) instead of re-mirroring everything."""
+    dim, m, n0, n1 = 40, 6, 3000, 3400
+    X = gmm(n1, dim, k=30, seed=61)
+    port = oracle.PortIndex(dim, m, 32, 64, pg.DIST_L2)
+    port.add(X[:n0])
+    ix = mirror(port, pg.DIST_L2)
+    before = port.raw().reshape(n0, -1).copy()
+    port.add(X[n0:])
+    after = port.raw().reshape(n1, -1)
+    changed = np.nonzero((after[:n0] != before).any(axis=1))[0]
+    assert 0 < changed.size < n0                       # only some old elements were re-linked
+    ix.update_from_flat(after[n0:].ravel(), n0, n1 - n0)          # new elements (grows the mirror)
+    for e in changed:                                             # re-linked neighbours, one by one
+        ix.update_from_flat(after[e].ravel(), int(e), 1)
+    port.set_deleted(5)
+    ix.update_from_flat(port.raw().reshape(n1, -1)[5].ravel(), 5, 1)   # a vacuum flag is an element change too
+    Q = gmm(150, dim, k=30, seed=61, stream=1)
+    assert_same_as_oracle(ix, port, Q, 64)
+    with pytest.raises(RuntimeError, match="gap"):
+        ix.update_from_flat(after[0].ravel(), n1 + 5, 1)
+    ix.close()
