@@ -76,9 +76,11 @@ __global__ __launch_bounds__(256) void bf_mfma_filter_kernel(const BfArgs a)
 	const uint32_t wm = wave >> 1, wn = wave & 1;          // 2 x 2 waves over the block tile
 	const uint32_t kk = lane >> 5, col = lane & 31;
 
-	for (uint32_t ks = 0; ks < a.ksteps; ks++)
+	// Software pipeline: the global loads of K-step ks+1 are issued before the MFMAs of step ks, so
+	// their latency is covered by 64 MFMAs per wave instead of being exposed between two barriers.
+	float4 qa[4], xb[4];
+	auto fetch = [&](uint32_t ks)
 	{
-		float4 qa[4], xb[4];
 #pragma unroll
 		for (int j = 0; j < 4; j++)
 		{
@@ -88,7 +90,11 @@ __global__ __launch_bounds__(256) void bf_mfma_filter_kernel(const BfArgs a)
 			qa[j] = c < nchunks ? tq : make_float4(0.f, 0.f, 0.f, 0.f);
 			xb[j] = c < nchunks ? tx : make_float4(0.f, 0.f, 0.f, 0.f);
 		}
-		__syncthreads();                                            // previous step's reads are done
+	};
+	fetch(0);
+	for (uint32_t ks = 0; ks < a.ksteps; ks++)
+	{
+		__syncthreads();                                            // previous step's operand reads are done
 #pragma unroll
 		for (int j = 0; j < 4; j++)
 		{
@@ -99,6 +105,7 @@ __global__ __launch_bounds__(256) void bf_mfma_filter_kernel(const BfArgs a)
 			Bs[(k + 2) * BF_TR + srow] = xb[j].z; Bs[(k + 3) * BF_TR + srow] = xb[j].w;
 		}
 		__syncthreads();
+		if (ks + 1 < a.ksteps) fetch(ks + 1);                       // in flight during the MFMAs below
 #pragma unroll
 		for (int k2 = 0; k2 < BF_TK; k2 += 2)
 		{
