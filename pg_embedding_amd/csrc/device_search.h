@@ -1,34 +1,41 @@
-// device_search.h — fused traverse + score kernel: searchBaseLayer (hnswalg.cpp:42-114),
+// device_search.h — fused traverse + score kernels: searchBaseLayer (hnswalg.cpp:42-114),
 // searchKnn (hnswalg.cpp:234-252) and the result ordering of hnsw_search
 // (hnswalg.cpp:256-277) for a batch of independent queries.
 //
 // Mapping.  ONE WAVEFRONT = ONE QUERY AT A TIME.  A launch is a fixed set of resident
 // waves ("slots"); each slot pulls query numbers from an atomic ticket until the batch
-// is exhausted, so long and short traversals balance.  Per slot, in LDS:
-//     query (zero padded float4 image) | results[ef+1] | candidates[2ef+1] | hop scratch
-// and in HBM: an exact visited bitmap (N bits) plus a log of the set bits for O(visited)
-// clearing.  Throughput comes from thousands of slots each keeping 4-8 KiB of row
-// reads in flight; a single query is latency-bound by construction (≈ef dependent hops).
+// is exhausted, so long and short traversals balance.  Throughput comes from thousands of
+// slots each keeping up to 24 KiB of row reads in flight; a single query is latency-bound by
+// construction (≈ef dependent hops, two memory round trips each).
+//
+// Two forms of the same algorithm:
+//   hnsw_search_kernel_reg  (ef <= 256, the hot one): result / candidate sets in REGISTERS
+//                           (see the banner further down), visited set = exact hash set in LDS
+//                           with the HBM bitmap as overflow;
+//   hnsw_search_kernel_lds  (any ef): both sets as sorted arrays in LDS, visited set = bitmap.
 //
 // Heaps.  The reference keeps two std::priority_queue<pair<float,idx>>:
 //   topResults  : max-heap on ( dist, idx)   -> worst on top, evicted when size > ef
 //   candidateSet: max-heap on (-dist, idx)   -> best on top, popped to expand
-// Only the extremes of those strict total orders are observable, so the device keeps
-// two SORTED arrays of 64-bit keys instead:
-//   results  : key = ord(dist)<<32 |  idx   ascending; last  = topResults.top()
-//   candidates: key = ord(dist)<<32 | ~idx   ascending; first = candidateSet.top()
-// (ord() maps float order onto unsigned order).  A candidate whose distance exceeds the
-// current bound can never be expanded (the bound only shrinks once results are full,
-// hnswalg.cpp:70,107), so the candidate array may drop its LARGEST key when it is full:
-// live candidates number < 2*ef (<= ef still in results + <= ef-1 evicted at exactly the
-// bound), hence with capacity 2*ef the largest of 2*ef+1 keys is always dead.  This makes
-// the bounded arrays exact, not approximate.
+// Only the extremes of those strict total orders are observable, so any container that
+// yields the same extremes gives the same traversal.  Keys are 64-bit:
+//   results   : ord(dist)<<32 |  idx   (largest key  = topResults.top())
+//   candidates: ord(dist)<<32 | ~idx   (smallest key = candidateSet.top(): nearest, ties by
+//                                       LARGER idx, as the (-dist, idx) pair order dictates)
+// (ord() maps float order onto unsigned order).  The candidate set is BOUNDED without
+// changing the result: a candidate whose distance exceeds the current bound can never be
+// expanded (the bound only shrinks once results are full, hnswalg.cpp:70,107), and live
+// candidates number < 2*ef (<= ef still in results + <= ef-1 evicted at exactly the bound),
+// so with capacity >= 2*ef the largest key of an overfull set is always dead and may be dropped.
 //
-// Visited set.  hnswalg.cpp:45-50,82-93 uses a growable bitmap; here one bitmap per
-// slot.  Marking uses a returning atomic OR, which is the test and the set of :91-93 in
-// one memory round trip and is safe when two neighbours share a word.  Link lists are
-// de-duplicated at upload (first occurrence kept), which is behaviour-preserving because
-// a repeated id is always already visited when reached again in pass 2 (:89-93).
+// Visited set (hnswalg.cpp:45-50,82-93: a growable bitmap in the reference).
+//   * LDS hash set (register form, rows >= 1.25 KiB): open addressing, lock-free ds_cmpst insert
+//     = the test and the set of :91-93 in one LDS operation, no HBM traffic;
+//   * per-slot bitmap in HBM: returning atomic OR (safe when two neighbours share a word), bits
+//     undone through a log after the query.  It is the only set of the LDS form and of narrow rows
+//     (where occupancy matters more), and the overflow of the hash set once that is 3/4 full.
+// Link lists are de-duplicated at upload (first occurrence kept), which is behaviour-preserving
+// because a repeated id is always already visited when reached again in pass 2 (:89-93).
 #pragma once
 #include "device_dist.h"
 
