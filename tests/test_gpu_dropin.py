@@ -178,3 +178,32 @@ def test_index_scan_follows_hnsw_gettuple():
 def sift_like_rows(n, dim):
     from pg_embedding_amd.datasets import sift_like
     return sift_like(n, dim, k=10, seed=6)
+
+
+def test_c_host_linked_against_the_gpu_library(tmp_path):
+    """A C host (storage callbacks + calls to the four symbols only), linked once against the
+    reference objects (oracle/_ref) and once against libembedding_gpu.so: same output."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = [os.path.join(root, "tests", "dropin_c", "dropin_demo.c"), os.path.join(root, "oracle", "flat_host.c")]
+    inc = os.path.join(root, "include")
+    lib = os.path.join(root, "pg_embedding_amd", "lib")
+    gpu_exe = str(tmp_path / "demo_gpu")
+    subprocess.run(["gcc", "-O2", "-std=gnu11", "-I", inc] + src + ["-o", gpu_exe, "-L", lib, "-lembedding_gpu",
+                    "-lhnsw_gpu", f"-Wl,-rpath,{lib}", "-lpthread", "-lm"], check=True)
+    args = ["400", "24", "4", "16", "12", "15"]
+    got = subprocess.run([gpu_exe] + args, capture_output=True, text=True, check=True).stdout
+    assert got.count("\n") == 15 and "d0=0.000000" in got
+    refdir = os.path.join(root, "oracle", "_ref")
+    if os.path.exists(os.path.join(refdir, "hnswalg.o")):
+        ref_exe = str(tmp_path / "demo_ref")
+        objs = []
+        for i, c in enumerate(src):
+            o = str(tmp_path / f"host{i}.o")
+            subprocess.run(["gcc", "-O2", "-std=gnu11", "-I", inc, "-c", c, "-o", o], check=True)
+            objs.append(o)
+        subprocess.run(["g++"] + objs + [os.path.join(refdir, "hnswalg.o"), os.path.join(refdir, "distfunc.o"),
+                        "-o", ref_exe, "-lpthread", "-lm"], check=True)
+        want = subprocess.run([ref_exe] + args, capture_output=True, text=True, check=True).stdout
+        assert got == want
