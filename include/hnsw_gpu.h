@@ -131,6 +131,18 @@ int hnsw_gpu_search_ms(hnsw_gpu_index *ix, unsigned back, float *ms);
 /* Resident query slots (waves) the last search launch used — occupancy figure. */
 int hnsw_gpu_last_search_slots(hnsw_gpu_index *ix, uint32_t *slots);
 
+/* Search contexts.  A mirror serialises its own launches (one visited-set workspace); a context
+ * is an extra workspace bound to the same mirror, so batches launched through different contexts
+ * on different streams run concurrently: while one launch drains (its last, longest queries) the
+ * next one already fills the freed CUs.  The index must not be modified while contexts search it. */
+typedef struct hnsw_gpu_ctx hnsw_gpu_ctx;
+int  hnsw_gpu_ctx_create(hnsw_gpu_index *ix, hnsw_gpu_ctx **out);
+void hnsw_gpu_ctx_destroy(hnsw_gpu_ctx *ctx);
+int  hnsw_gpu_search_batch_ctx(hnsw_gpu_ctx *ctx, const coord_t *d_queries, size_t nq, size_t ef,
+							   label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
+							   void *stream);
+int  hnsw_gpu_ctx_search_ms(hnsw_gpu_ctx *ctx, unsigned back, float *ms);
+
 /* ------------------------------------------------------------------- distances */
 
 /* out[i] = hnsw_dist_func(func, q, rows + i*dim, dim)  (distfunc.c:171-174) for

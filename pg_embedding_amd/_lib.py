@@ -75,6 +75,11 @@ def gpu_lib():
     L.hnsw_gpu_last_search_ms.argtypes = [vp, _f32p]
     L.hnsw_gpu_search_ms.argtypes = [vp, C.c_uint, _f32p]
     L.hnsw_gpu_last_search_slots.argtypes = [vp, _u32p]
+    L.hnsw_gpu_ctx_create.argtypes = [vp, C.POINTER(vp)]
+    L.hnsw_gpu_ctx_destroy.restype = None
+    L.hnsw_gpu_ctx_destroy.argtypes = [vp]
+    L.hnsw_gpu_search_batch_ctx.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp]
+    L.hnsw_gpu_ctx_search_ms.argtypes = [vp, C.c_uint, _f32p]
     L.hnsw_gpu_dist_batch.argtypes = [i32, vp, vp, sz, sz, vp]
     L.hnsw_gpu_dist_batch_dev.argtypes = [i32, vp, vp, sz, sz, sz, vp, vp]
     L.hnsw_gpu_bruteforce_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp]

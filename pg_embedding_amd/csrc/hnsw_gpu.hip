@@ -55,6 +55,45 @@ static inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; 
 // ------------------------------------------------------------------------------------
 // the device mirror
 // ------------------------------------------------------------------------------------
+// Per-stream search state: the slots' visited bitmaps + logs, the ticket word and the HIP-event ring.
+// Every mirror owns one (used by the plain entry points); hnsw_gpu_ctx adds more so that batches on
+// different streams can be in flight at the same time.
+struct SearchWs
+{
+	static const int EV_RING = 64;
+	uint32_t *vis = nullptr;  size_t vis_slots = 0, vis_words = 0;
+	uint32_t *vlog = nullptr; uint32_t logcap = 0;
+	uint32_t *ticket = nullptr;
+	hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};
+	uint64_t launches = 0;
+	uint32_t last_slots = 0;
+};
+
+static int ws_init(SearchWs *w)
+{
+	HIPCHK(hipMalloc(&w->ticket, 64));
+	HIPCHK(hipMemset(w->ticket, 0, 64));
+	for (int i = 0; i < SearchWs::EV_RING; i++)
+	{
+		HIPCHK(hipEventCreate(&w->ev0[i]));
+		HIPCHK(hipEventCreate(&w->ev1[i]));
+	}
+	return HNSW_GPU_OK;
+}
+
+static void ws_free(SearchWs *w)
+{
+	if (w->vis) (void) hipFree(w->vis);
+	if (w->vlog) (void) hipFree(w->vlog);
+	if (w->ticket) (void) hipFree(w->ticket);
+	for (int i = 0; i < SearchWs::EV_RING; i++)
+	{
+		if (w->ev0[i]) (void) hipEventDestroy(w->ev0[i]);
+		if (w->ev1[i]) (void) hipEventDestroy(w->ev1[i]);
+	}
+	*w = SearchWs();
+}
+
 struct hnsw_gpu_index
 {
 	// One search / build / scratch user at a time per mirror: the public entry points that touch
@@ -70,14 +109,9 @@ struct hnsw_gpu_index
 	float    *vec = nullptr;
 	uint32_t *links = nullptr;
 	uint64_t *labels = nullptr;
-	// search workspace (grow-only)
-	uint32_t *vis = nullptr;  size_t vis_slots = 0, vis_words = 0;
-	uint32_t *vlog = nullptr; uint32_t logcap = 0;
-	uint32_t *ticket = nullptr;       // [0] ticket, [1] err
-	static const int EV_RING = 64;           // HIP-event pairs of the most recent search launches
-	hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};
-	uint64_t launches = 0;
-	uint32_t last_slots = 0;
+	SearchWs ws;              // default search state (grow-only)
+	uint64_t generation = 0;  // bumped when capacity changes (bitmap width changes)
+	uint32_t *misc = nullptr; // small device scratch words (import error counter, ...)
 	// scratch for the host-pointer entry points
 	void *scratch = nullptr; size_t scratch_bytes = 0;
 	// builder scratch (hnsw_gpu_index_link)
@@ -85,6 +119,7 @@ struct hnsw_gpu_index
 	// exhaustive MFMA scorer: |row|^2 cache + scratch
 	float *xnorm = nullptr; size_t xnorm_n = 0, xnorm_cap = 0;
 	void *bf = nullptr; size_t bf_bytes = 0;
+	hipEvent_t bf_e0 = nullptr, bf_e1 = nullptr;
 };
 
 static int ensure_scratch(hnsw_gpu_index *ix, size_t bytes)
@@ -133,24 +168,17 @@ static int alloc_index(const HnswMetadata *meta, size_t capacity, int device, hn
 	if ((e = hipMalloc(&ix->vec, ix->cap * ix->stride * sizeof(float))) != hipSuccess ||
 		(e = hipMalloc(&ix->links, ix->cap * ix->lstride * sizeof(uint32_t))) != hipSuccess ||
 		(e = hipMalloc(&ix->labels, ix->cap * sizeof(uint64_t))) != hipSuccess ||
-		(e = hipMalloc(&ix->ticket, 64)) != hipSuccess)
+		(e = hipMalloc(&ix->misc, 64)) != hipSuccess)
 	{
 		hnsw_gpu_index_destroy(ix);
 		return fail(e == hipErrorOutOfMemory ? HNSW_GPU_ERR_NOMEM : HNSW_GPU_ERR_HIP, "index allocation failed: %s",
 					hipGetErrorString(e));
 	}
-	for (int i = 0; i < hnsw_gpu_index::EV_RING && e == hipSuccess; i++)
+	(void) hipMemset(ix->misc, 0, 64);
 	{
-		e = hipEventCreate(&ix->ev0[i]);
-		if (e == hipSuccess) e = hipEventCreate(&ix->ev1[i]);
+		int rc2 = ws_init(&ix->ws);
+		if (rc2) { hnsw_gpu_index_destroy(ix); return rc2; }
 	}
-	if (e != hipSuccess)
-	{
-		hnsw_gpu_index_destroy(ix);
-		return fail(e == hipErrorOutOfMemory ? HNSW_GPU_ERR_NOMEM : HNSW_GPU_ERR_HIP, "index allocation failed: %s",
-					hipGetErrorString(e));
-	}
-	(void) hipMemset(ix->ticket, 0, 64);
 	*out = ix;
 	return HNSW_GPU_OK;
 }
@@ -162,18 +190,14 @@ extern "C" void hnsw_gpu_index_destroy(hnsw_gpu_index *ix)
 	if (ix->vec) (void) hipFree(ix->vec);
 	if (ix->links) (void) hipFree(ix->links);
 	if (ix->labels) (void) hipFree(ix->labels);
-	if (ix->vis) (void) hipFree(ix->vis);
-	if (ix->vlog) (void) hipFree(ix->vlog);
-	if (ix->ticket) (void) hipFree(ix->ticket);
+	ws_free(&ix->ws);
+	if (ix->misc) (void) hipFree(ix->misc);
 	if (ix->scratch) (void) hipFree(ix->scratch);
 	if (ix->bld) (void) hipFree(ix->bld);
 	if (ix->xnorm) (void) hipFree(ix->xnorm);
 	if (ix->bf) (void) hipFree(ix->bf);
-	for (int i = 0; i < hnsw_gpu_index::EV_RING; i++)
-	{
-		if (ix->ev0[i]) (void) hipEventDestroy(ix->ev0[i]);
-		if (ix->ev1[i]) (void) hipEventDestroy(ix->ev1[i]);
-	}
+	if (ix->bf_e0) (void) hipEventDestroy(ix->bf_e0);
+	if (ix->bf_e1) (void) hipEventDestroy(ix->bf_e1);
 	delete ix;
 }
 
@@ -277,7 +301,7 @@ static int import_range(hnsw_gpu_index *ix, const void *elements, size_t first, 
 	const size_t esz = meta->size_data_per_element;
 	const size_t per = std::max<size_t>(1, STAGE_BYTES / esz);
 	uint32_t *stage = nullptr;
-	uint32_t *bad = ix->ticket + 8;
+	uint32_t *bad = ix->misc;
 	if (count == 0) return HNSW_GPU_OK;
 	HIPCHK(hipMemset(bad, 0, 4));
 	hipError_t e = hipMalloc(&stage, std::min(per, count) * esz);
@@ -458,7 +482,7 @@ static search_kernel_t pick_search_kernel(int func, uint32_t kiters, int rreg)
 static const size_t LDS_PER_CU = 160 * 1024;
 static const size_t VIS_BUDGET_BYTES = (size_t) 24 << 30;     // cap on bitmap workspace
 
-static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t q_stride, size_t nq, size_t ef, int mode,
+static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries, size_t q_stride, size_t nq, size_t ef, int mode,
 						 uint64_t *d_labels, uint32_t *d_idx, float *d_dists, uint32_t *d_counts,
 						 uint32_t *d_stats, hipStream_t stream)
 {
@@ -541,27 +565,27 @@ static int launch_search(hnsw_gpu_index *ix, const float *d_queries, size_t q_st
 	if (blocks * wpb > max_slots) blocks = std::max<size_t>(1, max_slots / wpb);
 	const size_t slots = blocks * wpb;
 	const uint32_t logcap = 8192;
-	if (slots > ix->vis_slots || words != ix->vis_words)
+	if (slots > w->vis_slots || words != w->vis_words)
 	{
-		if (ix->vis) (void) hipFree(ix->vis);
-		if (ix->vlog) (void) hipFree(ix->vlog);
-		ix->vis = nullptr; ix->vlog = nullptr; ix->vis_slots = 0;
-		HIPCHK(hipMalloc(&ix->vis, slots * words * 4));
-		HIPCHK(hipMalloc(&ix->vlog, slots * (size_t) logcap * 4));
-		HIPCHK(hipMemsetAsync(ix->vis, 0, slots * words * 4, stream));
-		ix->vis_slots = slots; ix->vis_words = words; ix->logcap = logcap;
+		if (w->vis) (void) hipFree(w->vis);
+		if (w->vlog) (void) hipFree(w->vlog);
+		w->vis = nullptr; w->vlog = nullptr; w->vis_slots = 0;
+		HIPCHK(hipMalloc(&w->vis, slots * words * 4));
+		HIPCHK(hipMalloc(&w->vlog, slots * (size_t) logcap * 4));
+		HIPCHK(hipMemsetAsync(w->vis, 0, slots * words * 4, stream));
+		w->vis_slots = slots; w->vis_words = words; w->logcap = logcap;
 	}
-	a.vis = ix->vis; a.vis_words = words; a.vlog = ix->vlog; a.logcap = ix->logcap;
-	a.ticket = ix->ticket;
-	HIPCHK(hipMemsetAsync(ix->ticket, 0, 8, stream));
+	a.vis = w->vis; a.vis_words = words; a.vlog = w->vlog; a.logcap = w->logcap;
+	a.ticket = w->ticket;
+	HIPCHK(hipMemsetAsync(w->ticket, 0, 8, stream));
 
-	const int evi = (int) (ix->launches % hnsw_gpu_index::EV_RING);
-	HIPCHK(hipEventRecord(ix->ev0[evi], stream));
+	const int evi = (int) (w->launches % SearchWs::EV_RING);
+	HIPCHK(hipEventRecord(w->ev0[evi], stream));
 	hipLaunchKernelGGL(kern, dim3((uint32_t) blocks), dim3(wpb * 64), lds, stream, a);
 	HIPCHK(hipGetLastError());
-	HIPCHK(hipEventRecord(ix->ev1[evi], stream));
-	ix->launches++;
-	ix->last_slots = (uint32_t) slots;
+	HIPCHK(hipEventRecord(w->ev1[evi], stream));
+	w->launches++;
+	w->last_slots = (uint32_t) slots;
 	return HNSW_GPU_OK;
 }
 
@@ -569,14 +593,14 @@ extern "C" int hnsw_gpu_search_batch_dev(hnsw_gpu_index *ix, const coord_t *d_qu
 										 label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
 										 void *stream)
 {
-	return launch_search(ix, d_queries, ix ? ix->meta.dim : 0, nq, ef, 0, d_labels, nullptr, d_dists, d_counts, d_stats, (hipStream_t) stream);
+	return launch_search(ix, ix ? &ix->ws : nullptr, d_queries, ix ? ix->meta.dim : 0, nq, ef, 0, d_labels, nullptr, d_dists, d_counts, d_stats, (hipStream_t) stream);
 }
 
 extern "C" int hnsw_gpu_search_base_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t ef,
 										idx_t *d_idx, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
 										void *stream)
 {
-	return launch_search(ix, d_queries, ix ? ix->meta.dim : 0, nq, ef, 1, nullptr, d_idx, d_dists, d_counts, d_stats, (hipStream_t) stream);
+	return launch_search(ix, ix ? &ix->ws : nullptr, d_queries, ix ? ix->meta.dim : 0, nq, ef, 1, nullptr, d_idx, d_dists, d_counts, d_stats, (hipStream_t) stream);
 }
 
 extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries, size_t nq, size_t ef,
@@ -598,7 +622,7 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 	float *dq = (float *) p; uint64_t *dl = (uint64_t *) (p + qb); float *dd = (float *) (p + qb + lb);
 	uint32_t *dc = (uint32_t *) (p + qb + lb + db);
 	HIPCHK(hipMemcpy(dq, queries, nq * dim * 4, hipMemcpyHostToDevice));
-	rc = launch_search(ix, dq, dim, nq, ef, 0, dl, nullptr, dd, dc, nullptr, nullptr);
+	rc = launch_search(ix, &ix->ws, dq, dim, nq, ef, 0, dl, nullptr, dd, dc, nullptr, nullptr);
 	if (rc) return rc;
 	HIPCHK(hipMemcpy(labels, dl, nq * ef * 8, hipMemcpyDeviceToHost));
 	if (dists) HIPCHK(hipMemcpy(dists, dd, nq * ef * 4, hipMemcpyDeviceToHost));
@@ -606,16 +630,21 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 	return HNSW_GPU_OK;
 }
 
+static int ws_search_ms(int device, SearchWs *w, unsigned back, float *ms)
+{
+	if (back >= (unsigned) SearchWs::EV_RING || (uint64_t) back >= w->launches)
+		return fail(HNSW_GPU_ERR_ARG, "no record of the search launch %u launches ago", back);
+	HIPCHK(hipSetDevice(device));
+	const int evi = (int) ((w->launches - 1 - back) % SearchWs::EV_RING);
+	HIPCHK(hipEventSynchronize(w->ev1[evi]));
+	HIPCHK(hipEventElapsedTime(ms, w->ev0[evi], w->ev1[evi]));
+	return HNSW_GPU_OK;
+}
+
 extern "C" int hnsw_gpu_search_ms(hnsw_gpu_index *ix, unsigned back, float *ms)
 {
 	if (!ix || !ms) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
-	if (back >= (unsigned) hnsw_gpu_index::EV_RING || (uint64_t) back >= ix->launches)
-		return fail(HNSW_GPU_ERR_ARG, "no record of the search launch %u launches ago", back);
-	HIPCHK(hipSetDevice(ix->device));
-	const int evi = (int) ((ix->launches - 1 - back) % hnsw_gpu_index::EV_RING);
-	HIPCHK(hipEventSynchronize(ix->ev1[evi]));
-	HIPCHK(hipEventElapsedTime(ms, ix->ev0[evi], ix->ev1[evi]));
-	return HNSW_GPU_OK;
+	return ws_search_ms(ix->device, &ix->ws, back, ms);
 }
 
 extern "C" int hnsw_gpu_last_search_ms(hnsw_gpu_index *ix, float *ms) { return hnsw_gpu_search_ms(ix, 0, ms); }
@@ -623,7 +652,7 @@ extern "C" int hnsw_gpu_last_search_ms(hnsw_gpu_index *ix, float *ms) { return h
 extern "C" int hnsw_gpu_last_search_slots(hnsw_gpu_index *ix, uint32_t *slots)
 {
 	if (!ix || !slots) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
-	*slots = ix->last_slots;
+	*slots = ix->ws.last_slots;
 	return HNSW_GPU_OK;
 }
 
@@ -944,7 +973,8 @@ extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d
 	a.cand = cand; a.cand_cnt = cnt; a.cap = cap;
 	a.nqt = (uint32_t) ((nq + BF_TQ - 1) / BF_TQ); a.nrt = (n + BF_TR - 1) / BF_TR;
 	const uint32_t rgroups = (a.nrt + 7) / 8;
-	hipEvent_t e0 = ix->ev0[hnsw_gpu_index::EV_RING - 1], e1 = ix->ev1[hnsw_gpu_index::EV_RING - 1];
+	if (!ix->bf_e0) { HIPCHK(hipEventCreate(&ix->bf_e0)); HIPCHK(hipEventCreate(&ix->bf_e1)); }
+	hipEvent_t e0 = ix->bf_e0, e1 = ix->bf_e1;
 	HIPCHK(hipEventRecord(e0, s));
 	hipLaunchKernelGGL(bf_mfma_filter_kernel, dim3(rgroups * a.nqt * 8), dim3(256), 0, s, a);
 	HIPCHK(hipEventRecord(e1, s));
@@ -1139,7 +1169,7 @@ extern "C" int hnsw_gpu_index_link(hnsw_gpu_index *ix, size_t first, size_t coun
 		HIPCHK(hipMemsetAsync(ctr, 0, 16, stream));
 		HIPCHK(hipMemsetAsync(pairs, 0xFF, bslots * 8, stream));
 		// 1. searchBaseLayer(ef = efConstruction) for every new element (hnswalg.cpp:229)
-		int rc = launch_search(ix, ix->vec + linked * ix->stride, ix->stride, b, efc, 1, nullptr, cand_idx, cand_dist,
+		int rc = launch_search(ix, &ix->ws, ix->vec + linked * ix->stride, ix->stride, b, efc, 1, nullptr, cand_idx, cand_dist,
 							   cand_cnt, nullptr, stream);
 		if (rc) return rc;
 		// 2. choose links, emit reverse pairs
@@ -1189,9 +1219,10 @@ extern "C" int hnsw_gpu_index_reserve(hnsw_gpu_index *ix, size_t capacity)
 	ix->vec = nv; ix->links = nl; ix->labels = nb;
 	ix->cap = capacity;
 	// the visited bitmaps are sized by capacity: drop them, the next search re-creates them
-	if (ix->vis) (void) hipFree(ix->vis);
-	if (ix->vlog) (void) hipFree(ix->vlog);
-	ix->vis = nullptr; ix->vlog = nullptr; ix->vis_slots = 0; ix->vis_words = 0;
+	if (ix->ws.vis) (void) hipFree(ix->ws.vis);
+	if (ix->ws.vlog) (void) hipFree(ix->ws.vlog);
+	ix->ws.vis = nullptr; ix->ws.vlog = nullptr; ix->ws.vis_slots = 0; ix->ws.vis_words = 0;
+	ix->generation++;         // contexts notice and rebuild their bitmaps
 	return HNSW_GPU_OK;
 }
 
@@ -1234,4 +1265,49 @@ extern "C" int hnsw_gpu_index_update_from_flat(hnsw_gpu_index *ix, const void *e
 	ix->n = n_total;
 	ix->xnorm_n = 0;            // cached row norms are stale
 	return HNSW_GPU_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// search contexts: independent batches in flight on different streams
+// ------------------------------------------------------------------------------------
+struct hnsw_gpu_ctx
+{
+	hnsw_gpu_index *ix;
+	SearchWs ws;
+};
+
+extern "C" int hnsw_gpu_ctx_create(hnsw_gpu_index *ix, hnsw_gpu_ctx **out)
+{
+	if (!ix || !out) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	HIPCHK(hipSetDevice(ix->device));
+	hnsw_gpu_ctx *c = new (std::nothrow) hnsw_gpu_ctx();
+	if (!c) return fail(HNSW_GPU_ERR_NOMEM, "out of host memory");
+	c->ix = ix;
+	int rc = ws_init(&c->ws);
+	if (rc) { ws_free(&c->ws); delete c; return rc; }
+	*out = c;
+	return HNSW_GPU_OK;
+}
+
+extern "C" void hnsw_gpu_ctx_destroy(hnsw_gpu_ctx *c)
+{
+	if (!c) return;
+	(void) hipSetDevice(c->ix->device);
+	ws_free(&c->ws);
+	delete c;
+}
+
+extern "C" int hnsw_gpu_search_batch_ctx(hnsw_gpu_ctx *c, const coord_t *d_queries, size_t nq, size_t ef,
+										 label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
+										 void *stream)
+{
+	if (!c) return fail(HNSW_GPU_ERR_ARG, "context is NULL");
+	return launch_search(c->ix, &c->ws, d_queries, c->ix->meta.dim, nq, ef, 0, d_labels, nullptr, d_dists, d_counts, d_stats,
+						 (hipStream_t) stream);
+}
+
+extern "C" int hnsw_gpu_ctx_search_ms(hnsw_gpu_ctx *c, unsigned back, float *ms)
+{
+	if (!c || !ms) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	return ws_search_ms(c->ix->device, &c->ws, back, ms);
 }

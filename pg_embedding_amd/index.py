@@ -213,6 +213,39 @@ class GpuIndex:
         return idx, dst
 
 
+class SearchContext:
+    """An extra search workspace on a mirror: batches launched through different contexts on
+    different torch streams overlap on the GPU (include/hnsw_gpu.h, "Search contexts")."""
+
+    def __init__(self, index: GpuIndex):
+        self.index = index
+        self.L = index.L
+        h = C.c_void_p()
+        check(self.L.hnsw_gpu_ctx_create(index._h, C.byref(h)), "hnsw_gpu_ctx_create")
+        self._h = h
+
+    def close(self) -> None:
+        if self._h:
+            self.L.hnsw_gpu_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search_torch(self, queries, ef: int, out: dict, stream=None):
+        """Enqueue one batch on `stream` (a torch.cuda.Stream; default: the current one)."""
+        torch = _torch()
+        s = (stream or torch.cuda.current_stream(queries.device)).cuda_stream
+        check(self.L.hnsw_gpu_search_batch_ctx(self._h, queries.data_ptr(), queries.shape[0], ef,
+                                               out["labels"].data_ptr(), out["dists"].data_ptr(),
+                                               out["counts"].data_ptr(), _dptr(out.get("stats")), s),
+              "hnsw_gpu_search_batch_ctx")
+        return out
+
+
 # ---------------------------------------------------------------------- distances
 def dist_batch(func: int, q: np.ndarray, rows: np.ndarray) -> np.ndarray:
     """out[i] = hnsw_dist_func(func, q, rows[i]) on the device (distfunc.c:171-174)."""

@@ -313,3 +313,29 @@ def test_incremental_mirror_update_from_changed_elements():
     with pytest.raises(RuntimeError, match="gap"):
         ix.update_from_flat(after[0].ravel(), n1 + 5, 1)
     ix.close()
+
+
+def test_search_contexts_overlap_on_two_streams():
+    """Two contexts on two streams, interleaved launches: every launch gives the oracle's answer."""
+    import torch
+    port, X = build_port(8000, 96, 8, 48, pg.DIST_L2, seed=88)
+    ix = mirror(port, pg.DIST_L2)
+    Qa = torch.from_numpy(gmm(3000, 96, k=50, seed=88, stream=1)).cuda()
+    Qb = torch.from_numpy(gmm(3000, 96, k=50, seed=88, stream=2)).cuda()
+    ctx = [pg.SearchContext(ix), pg.SearchContext(ix)]
+    st = [torch.cuda.Stream(), torch.cuda.Stream()]
+    outs = [ix.search_torch(Qa, 64), ix.search_torch(Qb, 64)]
+    torch.cuda.synchronize()
+    for o in outs:
+        o["labels"].zero_()
+    for rep in range(4):
+        ctx[0].search_torch(Qa, 64, outs[0], st[0])
+        ctx[1].search_torch(Qb, 64, outs[1], st[1])
+    torch.cuda.synchronize()
+    wa = port.search_many(Qa.cpu().numpy(), 64)
+    wb = port.search_many(Qb.cpu().numpy(), 64)
+    assert (outs[0]["labels"].cpu().numpy().view(np.uint64) == wa["labels"]).all()
+    assert (outs[1]["labels"].cpu().numpy().view(np.uint64) == wb["labels"]).all()
+    for c in ctx:
+        c.close()
+    ix.close()
