@@ -39,11 +39,30 @@ def _preload_torch_runtime() -> None:
         pass
 
 
+def _build_once() -> None:
+    """The libraries are normally prebuilt by __graft_entry__.build(); if they are absent, compile
+    them here — under a file lock, because one process per GPU may get here at the same time."""
+    import fcntl
+    os.makedirs(_build.LIBDIR, exist_ok=True)
+    with open(os.path.join(_build.LIBDIR, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if not os.path.exists(_build.GPU_LIB) or not os.path.exists(_build.SHIM_LIB):
+                try:
+                    _build.build()
+                except Exception as e:      # no hipcc: report through LibraryMissing below
+                    raise LibraryMissing(f"cannot build the gfx950 libraries: {e}") from e
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+
+
 def gpu_lib():
     """libhnsw_gpu.so with argtypes set (include/hnsw_gpu.h)."""
     global _gpu
     if _gpu is not None:
         return _gpu
+    if not os.path.exists(_build.GPU_LIB):
+        _build_once()
     if not os.path.exists(_build.GPU_LIB):
         raise LibraryMissing(
             f"{_build.GPU_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
