@@ -339,3 +339,27 @@ def test_search_contexts_overlap_on_two_streams():
     for c in ctx:
         c.close()
     ix.close()
+
+
+def test_nan_distances_do_not_hang_or_crash():
+    """Zero vectors give NaN cosine distances in the reference too (distfunc.c:144, 0/0); they are
+    outside the parity contract but must not hang the kernel or corrupt memory."""
+    X = gmm(3000, 32, k=10, seed=9)
+    X[::7] = 0.0
+    port = oracle.PortIndex(32, 6, 24, 32, pg.DIST_COSINE)
+    port.add(X[:40])                         # a few inserts through the oracle (NaNs included) ...
+    meta = pg.make_meta(32, 6, 24, 32, pg.DIST_COSINE)
+    ix = pg.GpuIndex.empty(meta, 3000)
+    ix.append(X)
+    ix.link(0, 3000)                         # ... and the whole set through the device builder
+    Q = gmm(500, 32, k=10, seed=9, stream=1)
+    Q[::5] = 0.0
+    for ef in (16, 200, 400):
+        labels, dists, counts = ix.search(Q, ef)
+        assert (counts <= ef).all()
+        ok = labels != pg.NO_LABEL
+        assert (labels[ok] < 3000).all()
+    raw = ix.export_flat().reshape(3000, -1)
+    cnt = raw[:, :4].copy().view(np.uint32).ravel()
+    assert cnt.max() <= 12
+    ix.close()
