@@ -57,3 +57,65 @@ def test_sharded_index_world1_builds_and_searches():
     assert int(labels.min()) >= 1000 and int(labels.max()) < 1000 + n
     d = dists.cpu().numpy()
     assert (np.diff(d, axis=1) >= 0).all()
+
+
+def _two_rank_worker(rank, world, port, out_path):
+    import os
+    import sys
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    # two processes share the one GPU of the test box, so the control plane is gloo here; on a
+    # real node each rank owns a GPU and the same code runs over RCCL (backend "nccl")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import pg_embedding_amd as pg
+    from pg_embedding_amd.datasets import gmm
+    from pg_embedding_amd.sharded import ShardedIndex, shard_range
+    n, dim, ef = 24000, 48, 32
+    X = gmm(n, dim, k=60, seed=13)
+    Q = torch.from_numpy(gmm(300, dim, k=60, seed=13, stream=1)).cuda()
+    lo, hi = shard_range(n, world, rank)
+    meta = pg.make_meta(dim, 8, 48, ef, pg.DIST_L2)
+    sh = ShardedIndex.build(torch.from_numpy(X[lo:hi]).cuda(), lo, meta)
+    labels, dists, counts = sh.search(Q, ef)
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.savez(out_path, labels=labels.cpu().numpy(), dists=dists.cpu().numpy(), counts=counts.cpu().numpy(),
+                 raw0=sh.index.export_flat())
+    else:
+        np.savez(out_path + ".r1.npz", raw1=sh.index.export_flat())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_one_collective(tmp_path):
+    """world_size=2 for real (two processes, all-gather, device merge): result == oracle per shard
+    + CPU merge on the shards' exported graphs."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    out = str(tmp_path / "merged.npz")
+    mp.spawn(_two_rank_worker, args=(2, port, out), nprocs=2, join=True)
+    got = np.load(out)
+    raws = [got["raw0"], np.load(out + ".r1.npz")["raw1"]]
+    n, dim, ef = 24000, 48, 32
+    Q = gmm(300, dim, k=60, seed=13, stream=1)
+    per = []
+    for r in range(2):
+        lo, hi = shard_range(n, 2, r)
+        p = oracle.PortIndex(dim, 8, 48, ef, pg.DIST_L2)
+        p.load_raw(raws[r], hi - lo)
+        per.append(p.search_many(Q, ef))
+    for q in range(300):
+        l = np.concatenate([p["labels"][q, :p["counts"][q]] for p in per])
+        d = np.concatenate([p["dists"][q, :p["counts"][q]] for p in per])
+        order = np.lexsort((l, d))[:ef]
+        assert (got["labels"][q].view(np.uint64) == l[order]).all()
+        assert (got["dists"][q].view(np.uint32) == d[order].view(np.uint32)).all()
