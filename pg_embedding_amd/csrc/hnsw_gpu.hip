@@ -376,7 +376,7 @@ extern "C" int hnsw_gpu_index_append(hnsw_gpu_index *ix, const coord_t *vectors,
 	HIPCHK(hipSetDevice(ix->device));
 	const size_t dim = ix->meta.dim;
 	const size_t per = std::max<size_t>(1, STAGE_BYTES / (dim * 4 + 8));
-	int rc = ensure_scratch(ix, std::min(per, n) * (dim * 4 + 8));
+	int rc = ensure_scratch(ix, std::min(per, n) * (dim * 4 + 8) + 8);      // + alignment slack for the label array
 	if (rc) return rc;
 	for (size_t first = 0; first < n; first += per)
 	{
