@@ -22,7 +22,7 @@ def live_image(raw, meta, n):
 
 
 @pytest.mark.parametrize("func", [pg.DIST_L2, pg.DIST_COSINE, pg.DIST_MANHATTAN])
-@pytest.mark.parametrize("dim,m,efc,n", [(24, 4, 16, 1200), (128, 8, 40, 900)])
+@pytest.mark.parametrize("dim,m,efc,n", [(24, 4, 16, 1200), (128, 8, 40, 900), (20, 3, 300, 700), (9, 1, 5, 300), (40, 70, 30, 400)])
 def test_serial_link_reproduces_the_oracle_graph(func, dim, m, efc, n):
     X = gmm(n, dim, k=30, seed=3 * dim + func)
     labels = (np.arange(n, dtype=np.uint64) * 7 + 5)
