@@ -10,6 +10,9 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The oracle must exist before collection: test modules parametrise on oracle.have_ref().
+    import oracle
+    oracle.build_oracle()
 
 
 @pytest.fixture(scope="session", autouse=True)
