@@ -12,6 +12,7 @@ CFG = {
   "C3_1Mx768_cosine_m32":         dict(n=1_000_000, dim=768,  m=32, efc=200, ef=128, func=pg.DIST_COSINE, sift=False),
   "C5_1Mx1536_cosine_m32":        dict(n=1_000_000, dim=1536, m=32, efc=200, ef=128, func=pg.DIST_COSINE, sift=False),
   "M_1Mx768_l2_m32":              dict(n=1_000_000, dim=768,  m=32, efc=200, ef=128, func=pg.DIST_L2,     sift=False),
+  "reference_defaults_1Mx768_m100_efc16_ef64": dict(n=1_000_000, dim=768, m=100, efc=16, ef=64, func=pg.DIST_L2, sift=False),
   "manhattan_1Mx256_m16":         dict(n=1_000_000, dim=256,  m=16, efc=100, ef=128, func=pg.DIST_MANHATTAN, sift=False),
 }
 which = sys.argv[1:] or list(CFG)
