@@ -12,7 +12,7 @@
 //   hnsw_search_kernel_reg  (ef <= 256, the hot one): result / candidate sets in REGISTERS
 //                           (see the banner further down), visited set = exact hash set in LDS
 //                           with the HBM bitmap as overflow;
-//   hnsw_search_kernel_lds  (any ef): both sets as sorted arrays in LDS, visited set = bitmap.
+//   hnsw_search_kernel_lds  (any ef): both sets as unsorted arrays in LDS, visited set = bitmap.
 //
 // Heaps.  The reference keeps two std::priority_queue<pair<float,idx>>:
 //   topResults  : max-heap on ( dist, idx)   -> worst on top, evicted when size > ef
@@ -130,225 +130,6 @@ __device__ __forceinline__ void remove_first(uint64_t *A, uint32_t sz, int lane)
 		if (mv) tmp = A[i + 1];
 		wave_sync();
 		if (mv) A[i] = tmp;
-		wave_sync();
-	}
-}
-
-// Generic form: results / candidates as sorted arrays in LDS, any ef (used when ef > 256).
-template <int FUNC, typename SH>
-__global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a)
-{
-	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-	const int lane = threadIdx.x & 63;
-	const uint32_t wib = threadIdx.x >> 6;
-	unsigned char *my = smem + (size_t) wib * a.wave_bytes;
-	float        *qf      = reinterpret_cast<float *>(my);
-	const float4 *q4      = reinterpret_cast<const float4 *>(my);
-	uint64_t     *res     = reinterpret_cast<uint64_t *>(my + a.off_res);
-	uint64_t     *cand    = reinterpret_cast<uint64_t *>(my + a.off_cand);
-	uint32_t     *newid   = reinterpret_cast<uint32_t *>(my + a.off_newid);
-	float        *newdist = reinterpret_cast<float *>(my + a.off_newdist);
-
-	const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wib;
-	uint32_t *vis  = a.vis + (size_t) slot * a.vis_words;
-	uint32_t *vlog = a.vlog + (size_t) slot * a.logcap;
-	const uint32_t ef = a.ef;
-
-	for (;;)
-	{
-		uint32_t qi = 0;
-		if (lane == 0) qi = atomicAdd(a.ticket, 1u);
-		qi = __builtin_amdgcn_readfirstlane(qi);
-		if (qi >= a.nq) break;
-
-		// ---- stage the query in LDS (zero padded) ---------------------------------
-		const float *qsrc = a.queries + (size_t) qi * a.q_stride;
-		for (uint32_t e = lane; e < a.qpad_floats; e += 64)
-		{
-			const float t = qsrc[e < a.dim ? e : a.dim - 1];     // unconditional load, then select
-			qf[e] = (e < a.dim) ? t : 0.f;
-		}
-		wave_sync();
-		float qnorm = 0.f;
-		if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
-
-		uint32_t rsize = 0, csize = 0, logn = 0, evals = 0, hops = 0;
-
-		if (a.n > 0)      // empty index: hnsw_begin_read(entry) fails, hnswalg.cpp:56-57
-		{
-			// ---- entry point, hnswalg.cpp:55-65 -----------------------------------
-			const uint32_t ep = a.entry;
-			{
-				auto one = [ep](uint32_t) { return ep; };
-				score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, one, 1u, newdist, lane);
-			}
-			wave_sync();
-			float lowerBound = finish_dist<FUNC>(newdist[0], newdist[OUT2], qnorm);
-			evals = 1;
-			if (lane == 0)
-			{
-				const uint32_t o = ord_f32(lowerBound);
-				res[0]  = ((uint64_t) o << 32) | ep;
-				cand[0] = ((uint64_t) o << 32) | (uint32_t) ~ep;
-				vis[ep >> 5] = 1u << (ep & 31);       // slot bitmap is all-zero here
-				vlog[0] = ep;
-			}
-			rsize = csize = logn = 1;
-			wave_sync();
-
-			// ---- main loop, hnswalg.cpp:67-112 ------------------------------------
-			while (csize > 0)
-			{
-				const uint64_t ck = cand[0];
-				if (unord_f32((uint32_t) (ck >> 32)) > lowerBound)     // :70-71
-					break;
-				const uint32_t cur = ~(uint32_t) ck;
-				remove_first(cand, csize, lane);                        // :73
-				csize--;
-				hops++;
-
-				for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)           // link list, :76-77
-				{
-					const uint32_t j = j0 + lane;
-					uint32_t t = LINK_NONE;
-					if (j < a.lstride) t = a.links[(size_t) cur * a.lstride + j];
-					bool isnew = false;
-					if (t != LINK_NONE)                                  // :91-93 test-and-set
-					{
-						const uint32_t bit = 1u << (t & 31);
-						const uint32_t old = atomicOr(&vis[t >> 5], bit);
-						isnew = !(old & bit);
-					}
-					const uint64_t mask = __ballot(isnew);
-					const uint32_t nnew = (uint32_t) __builtin_popcountll(mask);
-					if (nnew == 0) continue;
-					const uint32_t rank = lane_rank(mask);               // keeps link order j
-					if (isnew)
-					{
-						newid[rank] = t;
-						const uint32_t lp = logn + rank;
-						if (lp < a.logcap) vlog[lp] = t;
-					}
-					logn += nnew;
-					wave_sync();
-
-					{                                                    // :95-97, batched
-						const uint32_t *ids = newid;
-						auto by_id = [ids](uint32_t r) { return ids[r]; };
-						score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nnew, newdist, lane);
-					}
-					evals += nnew;
-					wave_sync();
-					{                                                    // sums -> distances, one row per lane
-						const float dl = finish_dist<FUNC>(newdist[lane], newdist[OUT2 + lane], qnorm);
-						wave_sync();
-						newdist[lane] = dl;
-						wave_sync();
-					}
-
-					for (uint32_t r = 0; r < nnew; r++)                  // :99-108, in link order
-					{
-						const float d = newdist[r];
-						if (rsize < ef || lowerBound > d)
-						{
-							const uint32_t t2 = newid[r];
-							const uint64_t hi = (uint64_t) ord_f32(d) << 32;
-							csize = sorted_insert(cand, csize, hi | (uint32_t) ~t2, a.ccap, lane);   // :100
-							rsize = sorted_insert(res, rsize, hi | t2, ef, lane);                   // :102-105
-							lowerBound = unord_f32((uint32_t) (res[rsize - 1] >> 32));               // :107
-						}
-					}
-				}
-			}
-		}
-
-		// ---- emit ---------------------------------------------------------------------
-		const size_t obase = (size_t) qi * ef;
-		uint32_t nout = 0;
-		if (a.mode == 1)
-		{
-			for (uint32_t b = 0; b < ef; b += 64)
-			{
-				const uint32_t i = b + lane;
-				if (i < ef)
-				{
-					const bool ok = i < rsize;
-					const uint64_t k = ok ? res[i] : 0;
-					a.out_idx[obase + i] = ok ? (uint32_t) k : LINK_NONE;
-					if (a.out_dists) a.out_dists[obase + i] = ok ? unord_f32((uint32_t) (k >> 32)) : __builtin_inff();
-				}
-			}
-			nout = rsize;
-		}
-		else
-		{
-			// searchKnn, hnswalg.cpp:241-249: label lookup, vacuum filter, order by (dist, label)
-			uint64_t *lab = cand;                       // candidate array is dead now
-			bool tie = false;
-			for (uint32_t b = 0; b < rsize; b += 64)
-			{
-				const uint32_t i = b + lane;
-				if (i < rsize)
-				{
-					lab[i] = a.labels[(uint32_t) res[i]];
-					if (i + 1 < rsize && (uint32_t) (res[i] >> 32) == (uint32_t) (res[i + 1] >> 32)) tie = true;
-				}
-			}
-			wave_sync();
-			const bool any_tie = __ballot(tie) != 0;
-			for (uint32_t b = 0; b < rsize; b += 64)
-			{
-				const uint32_t i = b + lane;
-				const bool in = i < rsize;
-				const uint64_t li = in ? lab[i] : 0;
-				const uint32_t di = in ? (uint32_t) (res[i] >> 32) : 0;
-				const bool keep = in && !((li >> 48) & 1);           // hnsw_is_deleted, embedding.c:948-953
-				const uint64_t kmask = __ballot(keep);
-				uint32_t rank;
-				if (!any_tie)
-					rank = nout + lane_rank(kmask);                  // already in (dist, idx) = (dist, label) order
-				else
-				{
-					rank = 0;
-					for (uint32_t jx = 0; jx < rsize; jx++)          // rank by (dist, label), hnswalg.cpp:236,246
-					{
-						const uint64_t lj = lab[jx];
-						const uint32_t dj = (uint32_t) (res[jx] >> 32);
-						const bool kj = !((lj >> 48) & 1);
-						rank += (kj && (dj < di || (dj == di && lj < li))) ? 1u : 0u;
-					}
-				}
-				if (keep)
-				{
-					a.out_labels[obase + rank] = li;
-					if (a.out_dists) a.out_dists[obase + rank] = unord_f32(di);
-				}
-				nout += (uint32_t) __builtin_popcountll(kmask);
-			}
-			for (uint32_t i = nout + lane; i < ef; i += 64)          // pad the tail
-			{
-				a.out_labels[obase + i] = ~0ull;
-				if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
-			}
-		}
-		if (lane == 0)
-		{
-			a.out_counts[qi] = nout;
-			if (a.out_stats) { a.out_stats[2 * (size_t) qi] = evals; a.out_stats[2 * (size_t) qi + 1] = hops; }
-		}
-
-		// ---- restore the all-zero bitmap for the next query of this slot --------------
-		wave_sync();
-		if (logn <= a.logcap)
-		{
-			for (uint32_t i = lane; i < logn; i += 64) vis[vlog[i] >> 5] = 0u;
-		}
-		else
-		{
-			for (uint64_t w = lane; w < a.vis_words; w += 64) vis[w] = 0u;
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_s_waitcnt(0);   // drain: the next query's atomics must see the zeros
 		wave_sync();
 	}
 }
@@ -818,6 +599,273 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_s_waitcnt(0);
+		wave_sync();
+	}
+}
+
+
+// =====================================================================================
+// Generic form (any ef; used when ef > 256): both sets as UNSORTED arrays in LDS.
+//   results    : res[0..rsize) + the position of the largest key kept wave-uniformly.  Insert while
+//                not full = append; when full = overwrite the largest and rescan for the new largest
+//                (ceil(ef/64) LDS reads per lane + one DPP wave-min).
+//   candidates : cand[0..csize), capacity 2*ef (exact, see the header).  Append = one LDS write;
+//                pop-best = scan for the smallest key, move the last entry into the hole.
+//   emit       : rank sort by (dist, idx) or (dist, label) — O(ef^2/64) per query, a few percent
+//                of a traversal that long.
+// Visited set = the per-slot HBM bitmap.  Same pre-filtered accept loop as the register form.
+// =====================================================================================
+
+// Smallest (MIN=true) or largest key of A[0..n) and its position; n > 0; wave-uniform result.
+template <bool MIN>
+__device__ __forceinline__ uint64_t lds_extreme(const uint64_t *A, uint32_t n, uint32_t &pos, int lane)
+{
+	uint64_t best = MIN ? ~0ull : 0ull;
+	uint32_t bpos = 0;
+	for (uint32_t i = lane; i < n; i += 64)
+	{
+		const uint64_t k = A[i];
+		const bool better = MIN ? (k < best) : (k > best);
+		best = better ? k : best;
+		bpos = better ? i : bpos;
+	}
+	// reduce on the distance word, then on the low word among the lanes that tie on it
+	const uint32_t h = MIN ? (uint32_t) (best >> 32) : ~(uint32_t) (best >> 32);
+	const uint32_t hmin = wave_min_u32(h);
+	uint64_t eq = __ballot(h == hmin);
+	if (__builtin_popcountll(eq) > 1)
+	{
+		const uint32_t lo = (h == hmin) ? (MIN ? (uint32_t) best : ~(uint32_t) best) : 0xFFFFFFFFu;
+		const uint32_t lomin = wave_min_u32(lo);
+		eq = __ballot(h == hmin && lo == lomin);
+	}
+	const uint32_t L = (uint32_t) __builtin_ctzll(eq);
+	pos = (uint32_t) __builtin_amdgcn_readlane((int) bpos, (int) L);
+	return readlane_u64(best, L);
+}
+
+template <int FUNC, typename SH>
+__global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = threadIdx.x & 63;
+	const uint32_t wib = threadIdx.x >> 6;
+	unsigned char *my = smem + (size_t) wib * a.wave_bytes;
+	float        *qf      = reinterpret_cast<float *>(my);
+	const float4 *q4      = reinterpret_cast<const float4 *>(my);
+	uint64_t     *res     = reinterpret_cast<uint64_t *>(my + a.off_res);
+	uint64_t     *cand    = reinterpret_cast<uint64_t *>(my + a.off_cand);
+	uint32_t     *newid   = reinterpret_cast<uint32_t *>(my + a.off_newid);
+	float        *newdist = reinterpret_cast<float *>(my + a.off_newdist);
+
+	const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wib;
+	uint32_t *vis  = a.vis + (size_t) slot * a.vis_words;
+	uint32_t *vlog = a.vlog + (size_t) slot * a.logcap;
+	const uint32_t ef = a.ef;
+
+	for (;;)
+	{
+		uint32_t qi = 0;
+		if (lane == 0) qi = atomicAdd(a.ticket, 1u);
+		qi = __builtin_amdgcn_readfirstlane(qi);
+		if (qi >= a.nq) break;
+
+		const float *qsrc = a.queries + (size_t) qi * a.q_stride;
+		for (uint32_t e = lane; e < a.qpad_floats; e += 64)
+		{
+			const float t = qsrc[e < a.dim ? e : a.dim - 1];     // unconditional load, then select
+			qf[e] = (e < a.dim) ? t : 0.f;
+		}
+		wave_sync();
+		float qnorm = 0.f;
+		if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
+
+		uint32_t rsize = 0, csize = 0, logn = 0, evals = 0, hops = 0;
+		uint32_t rmax_pos = 0;
+
+		if (a.n > 0)      // empty index: hnsw_begin_read(entry) fails, hnswalg.cpp:56-57
+		{
+			const uint32_t ep = a.entry;                                   // hnswalg.cpp:55-65
+			{
+				auto one = [ep](uint32_t) { return ep; };
+				score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, one, 1u, newdist, lane);
+			}
+			wave_sync();
+			float lowerBound = finish_dist<FUNC>(newdist[0], newdist[OUT2], qnorm);
+			evals = 1;
+			if (lane == 0)
+			{
+				const uint32_t o = ord_f32(lowerBound);
+				res[0]  = ((uint64_t) o << 32) | ep;
+				cand[0] = ((uint64_t) o << 32) | (uint32_t) ~ep;
+				vis[ep >> 5] = 1u << (ep & 31);       // slot bitmap is all-zero here
+				vlog[0] = ep;
+			}
+			rsize = csize = logn = 1;
+			wave_sync();
+
+			while (csize > 0)                                               // hnswalg.cpp:67-112
+			{
+				uint32_t cpos;
+				const uint64_t ck = lds_extreme<true>(cand, csize, cpos, lane);
+				if (unord_f32((uint32_t) (ck >> 32)) > lowerBound)         // :70-71
+					break;
+				const uint32_t cur = ~(uint32_t) ck;
+				csize--;                                                    // :73 pop = last entry into the hole
+				if (lane == 0) cand[cpos] = cand[csize];
+				wave_sync();
+				hops++;
+
+				for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)               // :76-77
+				{
+					const uint32_t j = j0 + lane;
+					const uint32_t t = a.links[(size_t) cur * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
+					bool isnew = false;
+					if (j < a.lstride && t != LINK_NONE)                    // :91-93 test-and-set
+					{
+						const uint32_t bit = 1u << (t & 31);
+						const uint32_t old = atomicOr(&vis[t >> 5], bit);
+						isnew = !(old & bit);
+					}
+					const uint64_t mask = __ballot(isnew);
+					const uint32_t nnew = (uint32_t) __builtin_popcountll(mask);
+					if (nnew == 0) continue;
+					const uint32_t rank = lane_rank(mask);
+					if (isnew)
+					{
+						newid[rank] = t;
+						const uint32_t lp = logn + rank;
+						if (lp < a.logcap) vlog[lp] = t;
+					}
+					logn += nnew;
+					wave_sync();
+					{                                                       // :95-97, batched
+						const uint32_t *ids = newid;
+						auto by_id = [ids](uint32_t r) { return ids[r]; };
+						score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nnew, newdist, lane);
+					}
+					evals += nnew;
+					wave_sync();
+					const float    d_mine = finish_dist<FUNC>(newdist[lane], newdist[OUT2 + lane], qnorm);
+					const uint32_t t_mine = newid[lane];
+					uint64_t todo = __ballot((uint32_t) lane < nnew && (rsize < ef || lowerBound > d_mine));
+					while (todo)                                            // :99-108, in link order
+					{
+						const uint32_t r = (uint32_t) __builtin_ctzll(todo);
+						todo &= todo - 1;
+						const float d = __uint_as_float((uint32_t) __builtin_amdgcn_readlane((int) __float_as_uint(d_mine), (int) r));
+						if (!(rsize < ef || lowerBound > d)) continue;
+						const uint32_t t2 = (uint32_t) __builtin_amdgcn_readlane((int) t_mine, (int) r);
+						const uint64_t hi = (uint64_t) ord_f32(d) << 32;
+						const uint64_t ckey = hi | (uint32_t) ~t2, rkey = hi | t2;
+						if (csize == a.ccap)                                // :100; make room: the largest key is dead
+						{
+							uint32_t mp;
+							const uint64_t mx = lds_extreme<false>(cand, csize, mp, lane);
+							if (ckey < mx && lane == 0) cand[mp] = ckey;
+						}
+						else
+						{
+							if (lane == 0) cand[csize] = ckey;
+							csize++;
+						}
+						if (rsize < ef)                                     // :102
+						{
+							if (lane == 0) res[rsize] = rkey;
+							rsize++;
+							wave_sync();
+							if (rsize == 1 || rkey > res[rmax_pos]) rmax_pos = rsize - 1;
+						}
+						else                                                // :104-105 evict the largest
+						{
+							if (lane == 0) res[rmax_pos] = rkey;
+							wave_sync();
+							(void) lds_extreme<false>(res, rsize, rmax_pos, lane);
+						}
+						wave_sync();
+						lowerBound = unord_f32((uint32_t) (res[rmax_pos] >> 32));          // :107
+					}
+					wave_sync();
+				}
+			}
+		}
+
+		// ---- emit: rank-sort the unsorted result array ----------------------------------------
+		const size_t obase = (size_t) qi * ef;
+		uint32_t nout = 0;
+		if (a.mode == 1)
+		{
+			for (uint32_t b = 0; b < rsize; b += 64)
+			{
+				const uint32_t i = b + lane;
+				if (i < rsize)
+				{
+					const uint64_t k = res[i];
+					uint32_t rank = 0;
+					for (uint32_t jx = 0; jx < rsize; jx++) rank += (res[jx] < k) ? 1u : 0u;
+					a.out_idx[obase + rank] = (uint32_t) k;
+					if (a.out_dists) a.out_dists[obase + rank] = unord_f32((uint32_t) (k >> 32));
+				}
+			}
+			nout = rsize;
+			for (uint32_t i = nout + lane; i < ef; i += 64)
+			{
+				a.out_idx[obase + i] = LINK_NONE;
+				if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
+			}
+		}
+		else
+		{
+			// searchKnn, hnswalg.cpp:241-249: label lookup, vacuum filter, order by (dist, label)
+			uint64_t *lab = cand;                       // candidate array is dead now (capacity 2*ef)
+			for (uint32_t i = lane; i < rsize; i += 64) lab[i] = a.labels[(uint32_t) res[i]];
+			wave_sync();
+			for (uint32_t b = 0; b < rsize; b += 64)
+			{
+				const uint32_t i = b + lane;
+				const bool in = i < rsize;
+				const uint64_t li = in ? lab[i] : 0;
+				const uint32_t di = in ? (uint32_t) (res[i] >> 32) : 0;
+				const bool keep = in && !((li >> 48) & 1);           // hnsw_is_deleted, embedding.c:948-953
+				uint32_t rank = 0;
+				for (uint32_t jx = 0; jx < rsize; jx++)              // rank by (dist, label), hnswalg.cpp:236,246
+				{
+					const uint64_t lj = lab[jx];
+					const uint32_t dj = (uint32_t) (res[jx] >> 32);
+					const bool kj = !((lj >> 48) & 1);
+					rank += (kj && (dj < di || (dj == di && lj < li))) ? 1u : 0u;
+				}
+				if (keep)
+				{
+					a.out_labels[obase + rank] = li;
+					if (a.out_dists) a.out_dists[obase + rank] = unord_f32(di);
+				}
+				nout += (uint32_t) __builtin_popcountll(__ballot(keep));
+			}
+			for (uint32_t i = nout + lane; i < ef; i += 64)          // pad the tail
+			{
+				a.out_labels[obase + i] = ~0ull;
+				if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
+			}
+		}
+		if (lane == 0)
+		{
+			a.out_counts[qi] = nout;
+			if (a.out_stats) { a.out_stats[2 * (size_t) qi] = evals; a.out_stats[2 * (size_t) qi + 1] = hops; }
+		}
+
+		// ---- restore the all-zero bitmap for the next query of this slot --------------
+		wave_sync();
+		if (logn <= a.logcap)
+		{
+			for (uint32_t i = lane; i < logn; i += 64) vis[vlog[i] >> 5] = 0u;
+		}
+		else
+		{
+			for (uint64_t w = lane; w < a.vis_words; w += 64) vis[w] = 0u;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_s_waitcnt(0);   // drain: the next query's atomics must see the zeros
 		wave_sync();
 	}
 }
