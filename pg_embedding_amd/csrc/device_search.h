@@ -88,6 +88,7 @@ __device__ __forceinline__ uint32_t lane_rank(uint64_t mask)
 	return __builtin_amdgcn_mbcnt_hi((uint32_t) (mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) mask, 0u));
 }
 
+// (used by the exhaustive scorers' top-k lists)
 // Insert `key` into ascending A[0..sz); A has cap+1 slots.  If the array was full the
 // largest key falls off.  Wave-cooperative, wave-uniform arguments.  Returns new size.
 __device__ __forceinline__ uint32_t sorted_insert(uint64_t *A, uint32_t sz, uint64_t key, uint32_t cap, int lane)
@@ -119,20 +120,6 @@ __device__ __forceinline__ uint32_t sorted_insert(uint64_t *A, uint32_t sz, uint
 	return sz > cap ? cap : sz;
 }
 
-// Drop A[0] from ascending A[0..sz).
-__device__ __forceinline__ void remove_first(uint64_t *A, uint32_t sz, int lane)
-{
-	for (uint32_t b = 0; b + 1 < sz; b += 64)
-	{
-		uint32_t i = b + lane;
-		bool mv = (i + 1 < sz);
-		uint64_t tmp = 0;
-		if (mv) tmp = A[i + 1];
-		wave_sync();
-		if (mv) A[i] = tmp;
-		wave_sync();
-	}
-}
 
 
 // =====================================================================================
