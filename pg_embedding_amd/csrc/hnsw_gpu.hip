@@ -300,12 +300,13 @@ static int import_range(hnsw_gpu_index *ix, const void *elements, size_t first, 
 	const HnswMetadata *meta = &ix->meta;
 	const size_t esz = meta->size_data_per_element;
 	const size_t per = std::max<size_t>(1, STAGE_BYTES / esz);
-	uint32_t *stage = nullptr;
 	uint32_t *bad = ix->misc;
 	if (count == 0) return HNSW_GPU_OK;
 	HIPCHK(hipMemset(bad, 0, 4));
-	hipError_t e = hipMalloc(&stage, std::min(per, count) * esz);
-	if (e != hipSuccess) return fail(HNSW_GPU_ERR_NOMEM, "staging allocation failed");
+	int rc0 = ensure_scratch(ix, std::min(per, count) * esz);      // staging lives in the mirror's scratch
+	if (rc0) return rc0;
+	uint32_t *stage = (uint32_t *) ix->scratch;
+	hipError_t e = hipSuccess;
 	for (size_t off = 0; off < count && e == hipSuccess; off += per)
 	{
 		const size_t cnt = std::min(per, count - off);
@@ -319,7 +320,6 @@ static int import_range(hnsw_gpu_index *ix, const void *elements, size_t first, 
 	}
 	uint32_t nbad = 0;
 	if (e == hipSuccess) e = hipMemcpy(&nbad, bad, 4, hipMemcpyDeviceToHost);
-	(void) hipFree(stage);
 	if (e != hipSuccess) return fail(HNSW_GPU_ERR_HIP, "index upload failed: %s", hipGetErrorString(e));
 	if (nbad) return fail(HNSW_GPU_ERR_ARG, "element image is corrupt: %u bad link counts / link targets", nbad);
 	return HNSW_GPU_OK;
