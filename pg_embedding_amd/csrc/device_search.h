@@ -71,6 +71,7 @@ struct SearchArgs
 	// register form only: exact visited hash set in LDS (power-of-two entries, 0 = off); ids that
 	// arrive after it is hmax full go to the HBM bitmap instead
 	uint32_t off_hash, hcap, hmax;
+	uint64_t *beam_scratch;     // beam form: per-slot HBM scratch for the (rare) prune compaction, 64*UREG keys
 	int mode;                   // 0 = hnsw_search semantics, 1 = searchBaseLayer only
 };
 
@@ -853,6 +854,442 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_s_waitcnt(0);   // drain: the next query's atomics must see the zeros
+		wave_sync();
+	}
+}
+
+
+// =====================================================================================
+// Beam form (ef <= 64*UREG/2): ONE unsorted set of accepted elements, acceptance by counting.
+//
+// The reference keeps topResults and candidateSet; both are functions of the SET of accepted
+// elements, and every decision it takes can be restated as a count over that set:
+//   * accept x   (hnswalg.cpp:99: top().first > dist || size < ef)
+//         <=>  fewer than ef accepted elements have dist <= dist(x);
+//   * stop       (hnswalg.cpp:70: best candidate > lowerBound)
+//         <=>  at least ef accepted elements have dist < dist(best unexpanded element);
+//   * topResults at the end = the ef smallest (dist, idx) keys of the accepted set;
+//   * candidateSet.top() = the unexpanded accepted element with the smallest (dist, ~idx) key.
+// (The bound only shrinks, so an element rejected or evicted earlier never counts against a later
+// acceptance: it lies at or above the bound of its time, hence above any later accepted distance.
+// The same argument lets the set be PRUNED to the elements at or below the ef-th smallest distance —
+// ties at that distance are kept, so both counts and the live candidates stay exact.)
+// So the kernel keeps `uk[UREG]` = accepted keys ord(dist)<<32 | idx, unsorted, one "expanded" bit per
+// slot, and NO sorted insert and NO second set:
+//   accept test = UREG compares + ballots; append = one slot write; pop = masked min-scan;
+//   prune (when the 64*UREG slots are full): 32-step radix select of the ef-th smallest distance word,
+//   compaction through a per-slot HBM scratch line (once per ~ef accepts).
+// Output order is produced at the end by a rank sort over the <= ef survivors.
+// =====================================================================================
+
+template <int U>
+__device__ __forceinline__ uint32_t beam_count_le(const uint64_t (&uk)[U], uint32_t od)
+{
+	uint32_t c = 0;
+#pragma unroll
+	for (int k = 0; k < U; k++) c += (uint32_t) __builtin_popcountll(__ballot((uint32_t) (uk[k] >> 32) <= od));
+	return c;
+}
+
+template <int U>
+__device__ __forceinline__ uint32_t beam_count_lt(const uint64_t (&uk)[U], uint32_t od)
+{
+	uint32_t c = 0;
+#pragma unroll
+	for (int k = 0; k < U; k++) c += (uint32_t) __builtin_popcountll(__ballot((uint32_t) (uk[k] >> 32) < od));
+	return c;
+}
+
+// Best unexpanded element: smallest (dist, ~idx).  Returns false when none is left.
+template <int U>
+__device__ __forceinline__ bool beam_next(const uint64_t (&uk)[U], uint32_t ex, uint32_t &slot, uint64_t &ckey)
+{
+	uint64_t m = ~0ull;
+	uint32_t mk = 0;
+#pragma unroll
+	for (int k = 0; k < U; k++)
+	{
+		const bool open = !((ex >> k) & 1u) && (uint32_t) (uk[k] >> 32) != 0xFFFFFFFFu;
+		const uint64_t c = open ? (uk[k] ^ 0xFFFFFFFFull) : ~0ull;
+		const bool lt = c < m;
+		m = lt ? c : m;
+		mk = lt ? (uint32_t) k : mk;
+	}
+	const uint32_t h = (uint32_t) (m >> 32);
+	const uint32_t hmin = wave_min_u32(h);
+	if (hmin == 0xFFFFFFFFu) return false;
+	uint64_t eq = __ballot(h == hmin);
+	if (__builtin_popcountll(eq) > 1)
+	{
+		const uint32_t lo = (h == hmin) ? (uint32_t) m : 0xFFFFFFFFu;
+		const uint32_t lomin = wave_min_u32(lo);
+		eq = __ballot(h == hmin && lo == lomin);
+	}
+	const uint32_t L = (uint32_t) __builtin_ctzll(eq);
+	slot = ((uint32_t) __builtin_amdgcn_readlane((int) mk, (int) L) << 6) | L;
+	ckey = readlane_u64(m, L);
+	return true;
+}
+
+// ef-th smallest distance word of the set (set holds >= ef used slots).
+template <int U>
+__device__ __forceinline__ uint32_t beam_select(const uint64_t (&uk)[U], uint32_t ef)
+{
+	uint32_t prefix = 0, need = ef;
+	for (int bit = 31; bit >= 0; bit--)
+	{
+		uint32_t c = 0;
+#pragma unroll
+		for (int k = 0; k < U; k++)
+			c += (uint32_t) __builtin_popcountll(__ballot(((((uint32_t) (uk[k] >> 32)) ^ prefix) >> bit) == 0));
+		if (c < need) { need -= c; prefix |= 1u << bit; }
+	}
+	return prefix;
+}
+
+// Drop every element whose distance word exceeds `v`; survivors keep their expanded bits and are
+// compacted to slots 0..n-1 (through this wave's HBM scratch line).  Returns n.
+template <int U>
+__device__ __forceinline__ uint32_t beam_compact(uint64_t (&uk)[U], uint32_t &ex, uint32_t v, uint64_t *scratch, int lane)
+{
+	uint32_t base = 0;
+#pragma unroll
+	for (int k = 0; k < U; k++)
+	{
+		const bool keep = (uint32_t) (uk[k] >> 32) <= v && (uint32_t) (uk[k] >> 32) != 0xFFFFFFFFu;
+		const uint64_t mask = __ballot(keep);
+		// expanded bit travels in bit 31 of the idx word (element numbers stay below 2^31 in this form)
+		if (keep) scratch[base + lane_rank(mask)] = uk[k] | ((uint64_t) ((ex >> k) & 1u) << 31);
+		base += (uint32_t) __builtin_popcountll(mask);
+	}
+	// same wave, same L2: the stores are acknowledged by L2 once vmcnt drains, and the loads below
+	// bypass L1 — no cache writeback needed (an agent-scope release costs a full L2 writeback on gfx950)
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+	__builtin_amdgcn_s_waitcnt(0);
+	ex = 0;
+#pragma unroll
+	for (int k = 0; k < U; k++)
+	{
+		const uint32_t i = (uint32_t) k * 64 + lane;
+		uint64_t t = ~0ull;
+		if (i < base) t = __hip_atomic_load(&scratch[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L1-bypassing load
+		const bool used = i < base;
+		ex |= (used && ((t >> 31) & 1u)) ? (1u << k) : 0u;
+		uk[k] = used ? (t & ~(1ull << 31)) : ~0ull;
+	}
+	return base;
+}
+
+template <int U>
+__device__ __forceinline__ void beam_set(uint64_t (&uk)[U], uint32_t slot, uint64_t key, int lane)
+{
+#pragma unroll
+	for (int k = 0; k < U; k++)
+	{
+		const bool hit = slot == ((uint32_t) k * 64 + (uint32_t) lane);
+		uk[k] = hit ? key : uk[k];
+	}
+}
+
+template <int FUNC, typename SH, int UREG>
+__global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_beam(const SearchArgs a)
+{
+	constexpr uint32_t UCAP = 64u * UREG;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = threadIdx.x & 63;
+	const uint32_t wib = threadIdx.x >> 6;
+	unsigned char *my = smem + (size_t) wib * a.wave_bytes;
+	float        *qf      = reinterpret_cast<float *>(my);
+	const float4 *q4      = reinterpret_cast<const float4 *>(my);
+	uint64_t     *srt_key = reinterpret_cast<uint64_t *>(my + a.off_res);     // emit scratch (overlays the hash set)
+	uint64_t     *srt_lab = reinterpret_cast<uint64_t *>(my + a.off_cand);
+	uint32_t     *htab    = reinterpret_cast<uint32_t *>(my + a.off_hash);
+	const uint32_t hmask  = a.hcap - 1;
+	uint32_t     *newid   = reinterpret_cast<uint32_t *>(my + a.off_newid);
+	float        *newdist = reinterpret_cast<float *>(my + a.off_newdist);
+
+	const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wib;
+	uint32_t *vis  = a.vis + (size_t) slot * a.vis_words;
+	uint32_t *vlog = a.vlog + (size_t) slot * a.logcap;
+	uint64_t *scratch = a.beam_scratch + (size_t) slot * UCAP;
+	const uint32_t ef = a.ef;
+
+	for (;;)
+	{
+		uint32_t qi = 0;
+		if (lane == 0) qi = atomicAdd(a.ticket, 1u);
+		qi = __builtin_amdgcn_readfirstlane(qi);
+		if (qi >= a.nq) break;
+
+		const float *qsrc = a.queries + (size_t) qi * a.q_stride;
+		for (uint32_t e = lane; e < a.qpad_floats; e += 64)
+		{
+			const float t = qsrc[e < a.dim ? e : a.dim - 1];
+			qf[e] = (e < a.dim) ? t : 0.f;
+		}
+		wave_sync();
+		float qnorm = 0.f;
+		if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
+
+		uint64_t uk[UREG];
+#pragma unroll
+		for (int k = 0; k < UREG; k++) uk[k] = ~0ull;
+		uint32_t ex = 0;                     // bit k: slot k*64+lane has been expanded
+		uint32_t usize = 0, logn = 0, evals = 0, hops = 0, hcount = 0;
+		uint32_t bstale = 0xFFFFFFFFu;       // ord() of a valid upper bound of the reference's lowerBound
+		bool spill = a.hcap == 0;
+		if (a.hcap)
+		{
+			uint4 *h4 = reinterpret_cast<uint4 *>(htab);
+			for (uint32_t i = lane; i < a.hcap / 4; i += 64) h4[i] = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
+			wave_sync();
+		}
+
+		if (a.n > 0)
+		{
+			const uint32_t ep = a.entry;                                   // hnswalg.cpp:55-65
+			{
+				auto one = [ep](uint32_t) { return ep; };
+				score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, one, 1u, newdist, lane);
+			}
+			wave_sync();
+			const float d0 = finish_dist<FUNC>(newdist[0], newdist[OUT2], qnorm);
+			evals = 1;
+			beam_set<UREG>(uk, 0, ((uint64_t) ord_f32(d0) << 32) | ep, lane);
+			usize = 1;
+			if (lane == 0)
+			{
+				if (spill) { vis[ep >> 5] = 1u << (ep & 31); vlog[0] = ep; }
+				else htab[hash_slot(ep, hmask)] = ep;
+			}
+			logn = spill ? 1 : 0;
+			hcount = 1;
+			wave_sync();
+
+			for (;;)                                                        // hnswalg.cpp:67-112
+			{
+				uint32_t cslot;
+				uint64_t ckey;
+				if (!beam_next<UREG>(uk, ex, cslot, ckey)) break;          // candidateSet empty
+				const uint32_t cd = (uint32_t) (ckey >> 32);
+				if (beam_count_lt<UREG>(uk, cd) >= ef) break;              // :70-71  best candidate > lowerBound
+				const uint32_t cur = ~(uint32_t) ckey;
+				ex |= ((uint32_t) lane == (cslot & 63)) ? (1u << (cslot >> 6)) : 0u;   // :73 pop
+				hops++;
+
+				for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)               // :76-77
+				{
+					const uint32_t j = j0 + lane;
+					const uint32_t t = a.links[(size_t) cur * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
+					bool isnew = false;
+					if (j < a.lstride && t != LINK_NONE)                    // :91-93
+					{
+						if (!spill)
+							isnew = hash_test_and_set(htab, hmask, t);
+						else
+						{
+							const uint32_t bit = 1u << (t & 31);
+							const uint32_t old = atomicOr(&vis[t >> 5], bit);
+							isnew = !(old & bit);
+						}
+					}
+					const uint64_t mask = __ballot(isnew);
+					const uint32_t nnew = (uint32_t) __builtin_popcountll(mask);
+					if (nnew == 0) continue;
+					const uint32_t rank = lane_rank(mask);
+					if (isnew)
+					{
+						newid[rank] = t;
+						if (spill)
+						{
+							const uint32_t lp = logn + rank;
+							if (lp < a.logcap) vlog[lp] = t;
+						}
+					}
+					if (spill) logn += nnew;
+					else
+					{
+						hcount += nnew;
+						if (hcount + 64 > a.hmax)
+						{
+							// the LDS set is nearly full: move it to this slot's HBM bitmap once and carry on
+							// there (so a long traversal costs what the bitmap-only form costs)
+							wave_sync();
+							for (uint32_t i0 = 0; i0 < a.hcap; i0 += 64)
+							{
+								const uint32_t h = htab[i0 + lane];
+								const bool used = h != HASH_EMPTY;
+								const uint64_t um = __ballot(used);
+								if (used)
+								{
+									atomicOr(&vis[h >> 5], 1u << (h & 31));
+									const uint32_t lp = logn + lane_rank(um);
+									if (lp < a.logcap) vlog[lp] = h;
+								}
+								logn += (uint32_t) __builtin_popcountll(um);
+							}
+							spill = true;
+						}
+					}
+					wave_sync();
+					{
+						const uint32_t *ids = newid;
+						auto by_id = [ids](uint32_t r) { return ids[r]; };
+						score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nnew, newdist, lane);
+					}
+					evals += nnew;
+					wave_sync();
+					const uint32_t od_mine = ord_f32(finish_dist<FUNC>(newdist[lane], newdist[OUT2 + lane], qnorm));
+					const uint32_t t_mine = newid[lane];
+					// rows at or above a valid upper bound of lowerBound cannot be accepted (:99)
+					uint64_t todo = __ballot((uint32_t) lane < nnew && od_mine < bstale);
+					while (todo)                                            // :99-108, in link order
+					{
+						const uint32_t r = (uint32_t) __builtin_ctzll(todo);
+						todo &= todo - 1;
+						const uint32_t od = (uint32_t) __builtin_amdgcn_readlane((int) od_mine, (int) r);
+						if (beam_count_le<UREG>(uk, od) >= ef)              // top().first <= dist and full: rejected,
+						{                                                   // and od is a fresh upper bound of lowerBound
+							bstale = od < bstale ? od : bstale;
+							todo &= __ballot(od_mine < bstale);
+							continue;
+						}
+						const uint32_t t2 = (uint32_t) __builtin_amdgcn_readlane((int) t_mine, (int) r);
+						if (usize == UCAP)                                  // make room: drop what lies above the bound
+						{
+							const uint32_t v = beam_select<UREG>(uk, ef);
+							usize = beam_compact<UREG>(uk, ex, v, scratch, lane);
+							bstale = v;                                     // lowerBound right now
+						}
+						beam_set<UREG>(uk, usize, ((uint64_t) od << 32) | t2, lane);   // :100,:102
+						usize++;
+					}
+					wave_sync();
+				}
+			}
+		}
+
+		// ---- emit: the ef smallest (dist, idx) keys of the set, then the reference's output order ----
+		uint32_t rsize = usize;
+		if (usize > ef)
+		{
+			const uint32_t v = beam_select<UREG>(uk, ef);
+			rsize = beam_compact<UREG>(uk, ex, v, scratch, lane);          // >= ef, more only with ties at v
+		}
+#pragma unroll
+		for (int k = 0; k < UREG; k++)
+		{
+			const uint32_t i = (uint32_t) k * 64 + lane;
+			if (i < rsize) srt_key[i] = uk[k];
+		}
+		wave_sync();
+		const size_t obase = (size_t) qi * ef;
+		uint32_t nout = 0;
+		// rank by (dist, idx); only ranks < ef are results (topCandidates, hnswalg.cpp:237-240)
+		uint32_t myrank[UREG];
+#pragma unroll
+		for (int k = 0; k < UREG; k++) myrank[k] = 0;
+		for (uint32_t jx = 0; jx < rsize; jx++)
+		{
+			const uint64_t kj = srt_key[jx];
+#pragma unroll
+			for (int k = 0; k < UREG; k++) myrank[k] += (kj < uk[k]) ? 1u : 0u;
+		}
+#pragma unroll
+		for (int k = 0; k < UREG; k++)
+			if ((uint32_t) k * 64 + lane >= rsize) myrank[k] = 0xFFFFFFFFu;
+		const uint32_t nres = rsize < ef ? rsize : ef;
+		if (a.mode == 1)
+		{
+#pragma unroll
+			for (int k = 0; k < UREG; k++)
+				if (myrank[k] < nres)
+				{
+					a.out_idx[obase + myrank[k]] = (uint32_t) uk[k];
+					if (a.out_dists) a.out_dists[obase + myrank[k]] = unord_f32((uint32_t) (uk[k] >> 32));
+				}
+			nout = nres;
+			for (uint32_t i = nout + lane; i < ef; i += 64)
+			{
+				a.out_idx[obase + i] = LINK_NONE;
+				if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
+			}
+		}
+		else
+		{
+			// searchKnn, hnswalg.cpp:241-249: labels of the ef results, vacuum filter, (dist, label) order
+			wave_sync();
+			uint64_t lab[UREG];
+			bool tie = false;
+#pragma unroll
+			for (int k = 0; k < UREG; k++)
+			{
+				const bool in = myrank[k] < nres;
+				lab[k] = 0;
+				if (in)
+				{
+					lab[k] = a.labels[(uint32_t) uk[k]];
+					srt_key[myrank[k]] = uk[k];                         // sorted by (dist, idx)
+					srt_lab[myrank[k]] = lab[k];
+				}
+			}
+			wave_sync();
+			// equal distances among the results? (then idx order and label order may differ)
+			for (uint32_t i = lane; i + 1 < nres; i += 64)
+				if ((uint32_t) (srt_key[i] >> 32) == (uint32_t) (srt_key[i + 1] >> 32)) tie = true;
+			const bool any_tie = __ballot(tie) != 0;
+			for (uint32_t b = 0; b < nres; b += 64)
+			{
+				const uint32_t i = b + lane;
+				const bool in = i < nres;
+				const uint64_t li = in ? srt_lab[i] : 0;
+				const uint32_t di = in ? (uint32_t) (srt_key[i] >> 32) : 0;
+				const bool keep = in && !((li >> 48) & 1);
+				const uint64_t kmask = __ballot(keep);
+				uint32_t rank;
+				if (!any_tie)
+					rank = nout + lane_rank(kmask);
+				else
+				{
+					rank = 0;
+					for (uint32_t jx = 0; jx < nres; jx++)
+					{
+						const uint64_t lj = srt_lab[jx];
+						const uint32_t dj = (uint32_t) (srt_key[jx] >> 32);
+						const bool kj = !((lj >> 48) & 1);
+						rank += (kj && (dj < di || (dj == di && lj < li))) ? 1u : 0u;
+					}
+				}
+				if (keep)
+				{
+					a.out_labels[obase + rank] = li;
+					if (a.out_dists) a.out_dists[obase + rank] = unord_f32(di);
+				}
+				nout += (uint32_t) __builtin_popcountll(kmask);
+			}
+			for (uint32_t i = nout + lane; i < ef; i += 64)
+			{
+				a.out_labels[obase + i] = ~0ull;
+				if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
+			}
+		}
+		if (lane == 0)
+		{
+			a.out_counts[qi] = nout;
+			if (a.out_stats) { a.out_stats[2 * (size_t) qi] = evals; a.out_stats[2 * (size_t) qi + 1] = hops; }
+		}
+
+		wave_sync();
+		if (logn <= a.logcap)
+		{
+			for (uint32_t i = lane; i < logn; i += 64) vis[vlog[i] >> 5] = 0u;
+		}
+		else
+		{
+			for (uint64_t w = lane; w < a.vis_words; w += 64) vis[w] = 0u;
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_s_waitcnt(0);
 		wave_sync();
 	}
 }

@@ -63,6 +63,7 @@ struct SearchWs
 	static const int EV_RING = 64;
 	uint32_t *vis = nullptr;  size_t vis_slots = 0, vis_words = 0;
 	uint32_t *vlog = nullptr; uint32_t logcap = 0;
+	uint64_t *beam = nullptr; size_t beam_keys = 0;      // beam form: prune scratch, 64*UREG keys per slot
 	uint32_t *ticket = nullptr;
 	hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};
 	uint64_t launches = 0;
@@ -84,6 +85,7 @@ static int ws_init(SearchWs *w)
 static void ws_free(SearchWs *w)
 {
 	if (w->vis) (void) hipFree(w->vis);
+	if (w->beam) (void) hipFree(w->beam);
 	if (w->vlog) (void) hipFree(w->vlog);
 	if (w->ticket) (void) hipFree(w->ticket);
 	for (int i = 0; i < SearchWs::EV_RING; i++)
@@ -435,10 +437,21 @@ extern "C" int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int del
 // ------------------------------------------------------------------------------------
 typedef void (*search_kernel_t)(const SearchArgs);
 
-// rreg: 0 = LDS form (any ef), 2 / 4 = register form for ef <= 128 / 256
+// rreg: 0 = LDS form (any ef), 2 / 4 = register form for ef <= 128 / 256,
+//       -2 / -4 / -8 = beam form (counting acceptance) with that many set registers, ef <= 64 / 128 / 256
 template <typename SH, int RREG>
 static search_kernel_t pick_search_kernel_f(int func)
 {
+	if (RREG < 0)
+	{
+		constexpr int U = RREG < 0 ? -RREG : 2;
+		switch (func)
+		{
+			case F_L2:     return hnsw_search_kernel_beam<F_L2, SH, U>;
+			case F_COSINE: return hnsw_search_kernel_beam<F_COSINE, SH, U>;
+			default:       return hnsw_search_kernel_beam<F_MANHATTAN, SH, U>;
+		}
+	}
 	if (RREG == 0)
 		switch (func)
 		{
@@ -446,7 +459,7 @@ static search_kernel_t pick_search_kernel_f(int func)
 			case F_COSINE: return hnsw_search_kernel_lds<F_COSINE, SH>;
 			default:       return hnsw_search_kernel_lds<F_MANHATTAN, SH>;
 		}
-	constexpr int R = RREG == 0 ? 2 : RREG;
+	constexpr int R = RREG <= 0 ? 2 : RREG;
 	switch (func)
 	{
 		case F_L2:     return hnsw_search_kernel_reg<F_L2, SH, R>;
@@ -462,6 +475,9 @@ static search_kernel_t pick_search_kernel_s(int func, int rreg)
 	{
 		case 2:  return pick_search_kernel_f<SH, 2>(func);
 		case 4:  return pick_search_kernel_f<SH, 4>(func);
+		case -2: return pick_search_kernel_f<SH, -2>(func);
+		case -4: return pick_search_kernel_f<SH, -4>(func);
+		case -8: return pick_search_kernel_f<SH, -8>(func);
 		default: return pick_search_kernel_f<SH, 0>(func);
 	}
 }
@@ -514,26 +530,38 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	int rreg = ef <= 128 ? 2 : (ef <= 256 ? 4 : 0);
 	const char *force = getenv("HNSW_GPU_FORCE_LDS_HEAPS");
 	if (force && atoi(force) > 0) rreg = 0;
+	// beam form (one accepted set, acceptance by counting) is the default up to ef = 256; HNSW_GPU_BEAM=0
+	// selects the older two-set register form.  Its prune packs the "expanded" bit into bit 31 of the idx.
+	const char *beam = getenv("HNSW_GPU_BEAM");
+	if (rreg && !(beam && atoi(beam) == 0) && ix->cap < 0x80000000ull) rreg = ef <= 64 ? -2 : (ef <= 128 ? -4 : -8);
+	const size_t ucap = rreg < 0 ? (size_t) 64 * (size_t) -rreg : 0;      // beam form: slots of the accepted set
 	size_t off = (size_t) a.qpad_floats * 4;
 	if (rreg)
 	{
 		// [query | hash set (overlaid by the emit step's tie scratch) | newid | newdist]
 		const size_t fixed = off + 64 * 4 + 128 * 4;
 		// Rows of >= 1.25 KiB make the traversal HBM-bound, and there the LDS set pays (no L2
-		// atomics, ~10 % less HBM traffic; measured 5.4 -> 7.5 TB/s at 768 dims).  Narrow rows are
-		// issue/latency-bound: more resident waves beat the set, so they keep the bitmap
-		// (profiles/r1g_visited_set_by_dim.txt).
-		uint32_t hcap = ix->stride > 320 ? 4096 : 0;           // entries; needs >= 2 four-wave blocks per CU
+		// atomics, ~10 % less HBM traffic; measured 5.4 -> 7.5 TB/s at 768 dims) at 8 waves per CU.
+		// Narrow rows are latency-bound and want 16 waves per CU: the beam form gives them a
+		// 2048-entry set (fits 16 x 10 KiB) and moves to the bitmap when a traversal outgrows it; the
+		// two-set register form keeps the bitmap only (profiles/r1g_visited_set_by_dim.txt,
+		// profiles/r1i_beam_form.md).
+		const bool wide = ix->stride > 320;
+		const size_t want_waves = wide ? 8 : 16;
+		uint32_t hcap = wide ? 4096 : (rreg < 0 ? 2048 : 0);
 		const char *henv = getenv("HNSW_GPU_HASH_ENTRIES");
 		if (henv) hcap = (uint32_t) atoi(henv);
-		while (hcap >= 512 && 8 * (fixed + std::max<size_t>(hcap * 4, 2 * ef * 8)) > LDS_PER_CU) hcap >>= 1;
+		// emit scratch: [keys | labels]; the beam form sorts up to `ucap` survivors (ties at the bound)
+		const size_t nkeys = ucap ? ucap : ef;
+		const size_t emit = round_up(nkeys * 8, 16) + round_up(ef * 8, 16);
+		while (hcap >= 512 && want_waves * (fixed + std::max<size_t>(hcap * 4, emit)) > LDS_PER_CU) hcap >>= 1;
 		if (hcap < 512 || (hcap & (hcap - 1))) hcap = 0;
 		a.hcap = hcap;
 		a.hmax = hcap - hcap / 4;
 		a.off_hash = (uint32_t) off;
 		a.off_res = (uint32_t) off;
-		a.off_cand = (uint32_t) (off + round_up(ef * 8, 16));
-		off += round_up(std::max<size_t>((size_t) hcap * 4, 2 * round_up(ef * 8, 16)), 16);
+		a.off_cand = (uint32_t) (off + round_up(nkeys * 8, 16));
+		off += round_up(std::max<size_t>((size_t) hcap * 4, emit), 16);
 	}
 	else
 	{
@@ -576,6 +604,14 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		w->vis_slots = slots; w->vis_words = words; w->logcap = logcap;
 	}
 	a.vis = w->vis; a.vis_words = words; a.vlog = w->vlog; a.logcap = w->logcap;
+	if (ucap && slots * ucap > w->beam_keys)
+	{
+		if (w->beam) (void) hipFree(w->beam);
+		w->beam = nullptr; w->beam_keys = 0;
+		HIPCHK(hipMalloc(&w->beam, slots * ucap * 8));
+		w->beam_keys = slots * ucap;
+	}
+	a.beam_scratch = w->beam;
 	a.ticket = w->ticket;
 	HIPCHK(hipMemsetAsync(w->ticket, 0, 8, stream));
 

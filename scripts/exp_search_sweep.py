@@ -36,6 +36,20 @@ elif mode == "shape":
         print("shape", sh, flush=True)
         for nq in (1, 2048, 10000, 40000, 160000):
             run(nq, 0, reps=5)
+elif mode == "beam":
+    efs = [int(x) for x in (sys.argv[7].split(",") if len(sys.argv) > 7 else [str(ef)])]
+    for e in efs:
+        ef = e
+        ref = None
+        for b in ("0", "1"):
+            os.environ["HNSW_GPU_BEAM"] = b
+            print("ef", ef, "beam form" if b == "1" else "register form", flush=True)
+            o = ix.search_torch(Qall[:20000].contiguous(), ef, stats=True); torch.cuda.synchronize()
+            cur = (o["labels"].cpu().numpy(), o["dists"].cpu().numpy().view(np.uint32), o["counts"].cpu().numpy(), o["stats"].cpu().numpy())
+            if ref is None: ref = cur
+            else: print("   identical to register form:", all((x == y).all() for x, y in zip(ref, cur)), flush=True)
+            for nq in (1, 10000, 40000, 160000):
+                run(nq, 0, reps=5)
 elif mode == "hash":
     for h in (0, 1024, 2048, 4096):
         os.environ["HNSW_GPU_HASH_ENTRIES"] = str(h)

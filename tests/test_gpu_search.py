@@ -250,17 +250,20 @@ def test_many_queries_reuse_slots():
     {"HNSW_GPU_HASH_ENTRIES": "0"},          # bitmap only
     {"HNSW_GPU_FORCE_LDS_HEAPS": "1"},       # generic kernel (sorted arrays in LDS) at small ef
     {"HNSW_GPU_SHAPE_12X1": "1"},
+    {"HNSW_GPU_BEAM": "0"},                  # two-set register form instead of the beam form
+    {"HNSW_GPU_BEAM": "0", "HNSW_GPU_HASH_ENTRIES": "512"},
     {},
 ])
 def test_every_kernel_variant_is_exact(env, monkeypatch):
     """The visited set may live in LDS, spill to the bitmap half-way through a query, or be the
-    bitmap alone; the heaps may be in registers or in LDS: all must give the oracle's answer."""
+    bitmap alone; the accepted set may be one counted set in registers (beam form), two sets in
+    registers, or sorted arrays in LDS: all must give the oracle's answer."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     port, X = build_port(20000, 768, 16, 64, pg.DIST_L2, k=100, seed=77)
     Q = gmm(300, 768, k=100, seed=77, stream=1)
     ix = mirror(port, pg.DIST_L2)
-    for ef in (100, 256):
+    for ef in (40, 100, 256):
         import torch
         out = ix.search_torch(torch.from_numpy(Q).cuda(), ef, stats=True)
         torch.cuda.synchronize()
@@ -274,6 +277,21 @@ def test_every_kernel_variant_is_exact(env, monkeypatch):
     # a second launch on the same slots: bitmap bits set by the spill path were undone
     labels2, _, _ = ix.search(Q, 100)
     assert (labels2 == port.search_many(Q, 100)["labels"]).all()
+    ix.close()
+
+
+@pytest.mark.parametrize("ef", [1, 5, 64, 128, 256])
+def test_beam_prune_with_ties_at_the_bound(ef):
+    """0/1 vectors in 6 dimensions: only 7 distinct L2 distances, so the ef-th smallest distance is
+    shared by hundreds of elements.  The beam form prunes its accepted set at that distance and must
+    keep every tie (they stay live candidates), then pick the survivors by (dist, idx)."""
+    rng = np.random.default_rng(11)
+    X = rng.integers(0, 2, size=(3000, 6)).astype(np.float32)
+    Q = rng.integers(0, 2, size=(64, 6)).astype(np.float32)
+    port = oracle.PortIndex(6, 8, 40, 64, pg.DIST_L2)
+    port.add(X)
+    ix = mirror(port, pg.DIST_L2)
+    assert_same_as_oracle(ix, port, Q, ef)
     ix.close()
 
 
