@@ -992,7 +992,7 @@ __device__ __forceinline__ void beam_set(uint64_t (&uk)[U], uint32_t slot, uint6
 }
 
 template <int FUNC, typename SH, int UREG>
-__global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_beam(const SearchArgs a)
+__global__ __launch_bounds__(256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MIN_WAVES) void hnsw_search_kernel_beam(const SearchArgs a)
 {
 	constexpr uint32_t UCAP = 64u * UREG;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];

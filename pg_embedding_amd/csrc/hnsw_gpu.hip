@@ -438,7 +438,7 @@ extern "C" int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int del
 typedef void (*search_kernel_t)(const SearchArgs);
 
 // rreg: 0 = LDS form (any ef), 2 / 4 = register form for ef <= 128 / 256,
-//       -2 / -4 / -8 = beam form (counting acceptance) with that many set registers, ef <= 64 / 128 / 256
+//       -2 / -4 / -8 / -16 = beam form (counting acceptance) with that many set registers, ef <= 64 / 128 / 256 / 512
 template <typename SH, int RREG>
 static search_kernel_t pick_search_kernel_f(int func)
 {
@@ -478,6 +478,7 @@ static search_kernel_t pick_search_kernel_s(int func, int rreg)
 		case -2: return pick_search_kernel_f<SH, -2>(func);
 		case -4: return pick_search_kernel_f<SH, -4>(func);
 		case -8: return pick_search_kernel_f<SH, -8>(func);
+		case -16: return pick_search_kernel_f<SH, -16>(func);
 		default: return pick_search_kernel_f<SH, 0>(func);
 	}
 }
@@ -525,15 +526,23 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 
 	// LDS carve per wave
 	a.qpad_floats = (uint32_t) round_up(a.kiters, shape_kb(shape_index(a.kiters))) * 64;
-	// register form keeps results/candidates in VGPRs; its LDS "res"/"cand" areas are only the
-	// (dist,label) tie-break scratch of the emit step
-	int rreg = ef <= 128 ? 2 : (ef <= 256 ? 4 : 0);
-	const char *force = getenv("HNSW_GPU_FORCE_LDS_HEAPS");
-	if (force && atoi(force) > 0) rreg = 0;
-	// beam form (one accepted set, acceptance by counting) is the default up to ef = 256; HNSW_GPU_BEAM=0
-	// selects the older two-set register form.  Its prune packs the "expanded" bit into bit 31 of the idx.
+	// Form of the accepted-set bookkeeping (rreg):
+	//   beam form (one accepted set in registers, acceptance by counting): default up to ef = 256, and up
+	//     to ef = 512 for rows wider than 256 floats — those run at 2 waves/SIMD anyway, so 16 set registers
+	//     beat the LDS form there (+22-28 %, profiles/r1i_beam_form.txt); narrow rows keep the LDS form
+	//     above 256 (it holds 4 waves/SIMD).  Its prune packs the "expanded" bit into bit 31 of the idx.
+	//   two-set register form: HNSW_GPU_BEAM=0, or mirrors of >= 2^31 elements; ef <= 256.
+	//   LDS form: everything else (HNSW_GPU_FORCE_LDS_HEAPS=1 forces it).
+	// The register forms use their LDS "res"/"cand" areas only as scratch of the emit step.
 	const char *beam = getenv("HNSW_GPU_BEAM");
-	if (rreg && !(beam && atoi(beam) == 0) && ix->cap < 0x80000000ull) rreg = ef <= 64 ? -2 : (ef <= 128 ? -4 : -8);
+	const char *b16 = getenv("HNSW_GPU_BEAM16");
+	const char *force = getenv("HNSW_GPU_FORCE_LDS_HEAPS");
+	const bool use_beam = !(beam && atoi(beam) == 0) && ix->cap < 0x80000000ull;
+	const bool beam16 = use_beam && ef > 256 && ef <= 512 && (b16 ? atoi(b16) > 0 : shape_index(a.kiters) >= 2);
+	int rreg;
+	if (force && atoi(force) > 0) rreg = 0;
+	else if (use_beam && (ef <= 256 || beam16)) rreg = ef <= 64 ? -2 : (ef <= 128 ? -4 : (ef <= 256 ? -8 : -16));
+	else rreg = ef <= 128 ? 2 : (ef <= 256 ? 4 : 0);
 	const size_t ucap = rreg < 0 ? (size_t) 64 * (size_t) -rreg : 0;      // beam form: slots of the accepted set
 	size_t off = (size_t) a.qpad_floats * 4;
 	if (rreg)

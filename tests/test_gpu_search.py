@@ -252,6 +252,7 @@ def test_many_queries_reuse_slots():
     {"HNSW_GPU_SHAPE_12X1": "1"},
     {"HNSW_GPU_BEAM": "0"},                  # two-set register form instead of the beam form
     {"HNSW_GPU_BEAM": "0", "HNSW_GPU_HASH_ENTRIES": "512"},
+    {"HNSW_GPU_BEAM16": "0"},                # ef in (256, 512]: LDS form instead of 16 set registers
     {},
 ])
 def test_every_kernel_variant_is_exact(env, monkeypatch):
@@ -263,7 +264,7 @@ def test_every_kernel_variant_is_exact(env, monkeypatch):
     port, X = build_port(20000, 768, 16, 64, pg.DIST_L2, k=100, seed=77)
     Q = gmm(300, 768, k=100, seed=77, stream=1)
     ix = mirror(port, pg.DIST_L2)
-    for ef in (40, 100, 256):
+    for ef in (40, 100, 256, 400):
         import torch
         out = ix.search_torch(torch.from_numpy(Q).cuda(), ef, stats=True)
         torch.cuda.synchronize()
