@@ -237,6 +237,28 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ vec, size_t
 	}
 }
 
+// score_rows with the LAST pass narrowed to the rows that are left: full passes of 4*RPG rows, then one
+// pass with RPG/2 or RPG/4 rows per group when that covers the remainder.  A hop yields 5-9 new rows on
+// average, so without this most passes issue (clamped, L1-hit) loads and arithmetic for absent rows.
+// The per-row summation order does not depend on RPG, so results are unchanged bit for bit.
+template <int FUNC, int KB, int RPG, typename RowId>
+__device__ __forceinline__ void score_rows_fit(const float *__restrict__ vec, size_t stride,
+											   const float4 *q4, uint32_t nchunks, uint32_t kiters,
+											   RowId rowid, uint32_t nrows, float *out, int lane)
+{
+	const uint32_t full = nrows / (4 * RPG) * (4 * RPG);
+	if (full) score_rows<FUNC, KB, RPG>(vec, stride, q4, nchunks, kiters, rowid, full, out, lane);
+	const uint32_t rem = nrows - full;
+	if (rem == 0) return;
+	auto shifted = [rowid, full](uint32_t r) { return rowid(full + r); };
+	if (RPG >= 4 && rem > 8)
+		score_rows<FUNC, KB, RPG>(vec, stride, q4, nchunks, kiters, shifted, rem, out + full, lane);
+	else if (RPG >= 2 && rem > 4)
+		score_rows<FUNC, KB, 2>(vec, stride, q4, nchunks, kiters, shifted, rem, out + full, lane);
+	else
+		score_rows<FUNC, KB, 1>(vec, stride, q4, nchunks, kiters, shifted, rem, out + full, lane);
+}
+
 // Load-batch shapes by chunk-steps per row (kiters = ceil(dim/64)).
 struct Shape2x4  { static constexpr int KB = 2,  RPG = 4, MIN_WAVES = 4; };   // dim <= 128
 struct Shape4x2  { static constexpr int KB = 4,  RPG = 2, MIN_WAVES = 4; };   // dim <= 256

@@ -370,7 +370,7 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 			const uint32_t ep = a.entry;                                   // hnswalg.cpp:55-65
 			{
 				auto one = [ep](uint32_t) { return ep; };
-				score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, one, 1u, newdist, lane);
+				score_rows<FUNC, SH::KB, 1>(a.vec, a.stride, q4, a.nchunks, a.kiters, one, 1u, newdist, lane);
 			}
 			wave_sync();
 			float lowerBound = finish_dist<FUNC>(newdist[0], newdist[OUT2], qnorm);
@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 					{                                                       // :95-97, batched
 						const uint32_t *ids = newid;
 						auto by_id = [ids](uint32_t r) { return ids[r]; };
-						score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nnew, newdist, lane);
+						score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nnew, newdist, lane);
 					}
 					evals += nnew;
 					wave_sync();
@@ -676,7 +676,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 			const uint32_t ep = a.entry;                                   // hnswalg.cpp:55-65
 			{
 				auto one = [ep](uint32_t) { return ep; };
-				score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, one, 1u, newdist, lane);
+				score_rows<FUNC, SH::KB, 1>(a.vec, a.stride, q4, a.nchunks, a.kiters, one, 1u, newdist, lane);
 			}
 			wave_sync();
 			float lowerBound = finish_dist<FUNC>(newdist[0], newdist[OUT2], qnorm);
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 					{                                                       // :95-97, batched
 						const uint32_t *ids = newid;
 						auto by_id = [ids](uint32_t r) { return ids[r]; };
-						score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nnew, newdist, lane);
+						score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nnew, newdist, lane);
 					}
 					evals += nnew;
 					wave_sync();
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MI
 			const uint32_t ep = a.entry;                                   // hnswalg.cpp:55-65
 			{
 				auto one = [ep](uint32_t) { return ep; };
-				score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, one, 1u, newdist, lane);
+				score_rows<FUNC, SH::KB, 1>(a.vec, a.stride, q4, a.nchunks, a.kiters, one, 1u, newdist, lane);
 			}
 			wave_sync();
 			const float d0 = finish_dist<FUNC>(newdist[0], newdist[OUT2], qnorm);
@@ -1135,7 +1135,7 @@ __global__ __launch_bounds__(256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MI
 					{
 						const uint32_t *ids = newid;
 						auto by_id = [ids](uint32_t r) { return ids[r]; };
-						score_rows<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nnew, newdist, lane);
+						score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nnew, newdist, lane);
 					}
 					evals += nnew;
 					wave_sync();
