@@ -50,6 +50,19 @@ elif mode == "beam":
             else: print("   identical to register form:", all((x == y).all() for x, y in zip(ref, cur)), flush=True)
             for nq in (1, 10000, 40000, 160000):
                 run(nq, 0, reps=5)
+elif mode == "env":
+    # A/B of one environment knob: exp_search_sweep.py n dim m efc ef env NAME v1,v2,...
+    name, vals = sys.argv[7], sys.argv[8].split(",")
+    ref = None
+    for v in vals:
+        os.environ[name] = v
+        print(name, "=", v, flush=True)
+        o = ix.search_torch(Qall[:20000].contiguous(), ef, stats=True); torch.cuda.synchronize()
+        cur = (o["labels"].cpu().numpy(), o["dists"].cpu().numpy().view(np.uint32), o["counts"].cpu().numpy(), o["stats"].cpu().numpy())
+        if ref is None: ref = cur
+        else: print("   identical to the first setting:", all((x == y).all() for x, y in zip(ref, cur)), flush=True)
+        for nq in (1, 10000, 40000, 160000):
+            run(nq, 0, reps=5)
 elif mode == "hash":
     for h in (0, 1024, 2048, 4096):
         os.environ["HNSW_GPU_HASH_ENTRIES"] = str(h)
