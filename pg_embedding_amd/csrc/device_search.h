@@ -37,6 +37,7 @@
 // Link lists are de-duplicated at upload (first occurrence kept), which is behaviour-preserving
 // because a repeated id is always already visited when reached again in pass 2 (:89-93).
 #pragma once
+#include <type_traits>
 #include "device_dist.h"
 
 namespace pgemb {
@@ -72,6 +73,9 @@ struct SearchArgs
 	// arrive after it is hmax full go to the HBM bitmap instead
 	uint32_t off_hash, hcap, hmax;
 	uint64_t *beam_scratch;     // beam form: per-slot HBM scratch for the (rare) prune compaction, 64*UREG keys
+	uint64_t *set_scratch;      // generic form with its sets in HBM: per-slot area, set_stride keys apart
+	uint32_t out_stride;        // result slots per query in the output arrays (the caller's ef; a.ef may be clamped to n)
+	size_t set_stride;
 	int mode;                   // 0 = hnsw_search semantics, 1 = searchBaseLayer only
 };
 
@@ -483,7 +487,7 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 		}
 
 		// ---- emit -------------------------------------------------------------------------
-		const size_t obase = (size_t) qi * ef;
+		const size_t obase = (size_t) qi * a.out_stride;
 		uint32_t nout = 0;
 		if (a.mode == 1)
 		{
@@ -497,6 +501,11 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 					a.out_idx[obase + i] = ok ? (uint32_t) rk[k] : LINK_NONE;
 					if (a.out_dists) a.out_dists[obase + i] = ok ? unord_f32((uint32_t) (rk[k] >> 32)) : __builtin_inff();
 				}
+			}
+			for (uint32_t i = ef + lane; i < a.out_stride; i += 64)     // caller's ef larger than the index
+			{
+				a.out_idx[obase + i] = LINK_NONE;
+				if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
 			}
 			nout = rsize;
 		}
@@ -563,7 +572,7 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 					nout += (uint32_t) __builtin_popcountll(__ballot(keep));
 				}
 			}
-			for (uint32_t i = nout + lane; i < ef; i += 64)
+			for (uint32_t i = nout + lane; i < a.out_stride; i += 64)
 			{
 				a.out_labels[obase + i] = ~0ull;
 				if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
@@ -604,18 +613,45 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 // Visited set = the per-slot HBM bitmap.  Same pre-filtered accept loop as the register form.
 // =====================================================================================
 
+// Set-array accessors.  G = false: LDS, plain accesses.  G = true: HBM scratch, accessed with relaxed
+// agent-scope atomics = L1-bypassing loads/stores, so that a wave always reads back its own writes from L2
+// (loads still pipeline: the scans below issue four before the first use).
+template <bool G>
+__device__ __forceinline__ uint64_t ldk(const uint64_t *p)
+{
+	if (G) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return *p;
+}
+template <bool G>
+__device__ __forceinline__ void stk(uint64_t *p, uint64_t v)
+{
+	if (G) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	else *p = v;
+}
+
 // Smallest (MIN=true) or largest key of A[0..n) and its position; n > 0; wave-uniform result.
-template <bool MIN>
+template <bool MIN, bool G>
 __device__ __forceinline__ uint64_t lds_extreme(const uint64_t *A, uint32_t n, uint32_t &pos, int lane)
 {
 	uint64_t best = MIN ? ~0ull : 0ull;
 	uint32_t bpos = 0;
-	for (uint32_t i = lane; i < n; i += 64)
+	for (uint32_t i0 = 0; i0 < n; i0 += 256)
 	{
-		const uint64_t k = A[i];
-		const bool better = MIN ? (k < best) : (k > best);
-		best = better ? k : best;
-		bpos = better ? i : bpos;
+		uint64_t k[4];
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			const uint32_t i = i0 + 64u * u + lane;
+			k[u] = ldk<G>(&A[i < n ? i : n - 1]);
+		}
+#pragma unroll
+		for (int u = 0; u < 4; u++)
+		{
+			const uint32_t i = i0 + 64u * u + lane;
+			const bool better = i < n && (MIN ? (k[u] < best) : (k[u] > best));
+			best = better ? k[u] : best;
+			bpos = better ? i : bpos;
+		}
 	}
 	// reduce on the distance word, then on the low word among the lanes that tie on it
 	const uint32_t h = MIN ? (uint32_t) (best >> 32) : ~(uint32_t) (best >> 32);
@@ -632,7 +668,23 @@ __device__ __forceinline__ uint64_t lds_extreme(const uint64_t *A, uint32_t n, u
 	return readlane_u64(best, L);
 }
 
-template <int FUNC, typename SH>
+// Make this wave's own writes to the set arrays visible to its own later reads.  LDS: program order +
+// lgkmcnt.  HBM (G): the accesses bypass L1 (ldk/stk), so draining vmcnt is enough.
+template <bool G>
+__device__ __forceinline__ void set_sync()
+{
+	if (G)
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_s_waitcnt(0);
+	}
+	wave_sync();
+}
+
+// G = false: result/candidate arrays in LDS (ef up to what 160 KB hold).  G = true: the same arrays in a
+// per-slot HBM scratch area — any ef the API admits (the reference's scan doubles efSearch until the
+// index is exhausted, embedding.c:329-343), at L2 latency per scan instead of LDS latency.
+template <int FUNC, typename SH, bool G>
 __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -641,12 +693,21 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 	unsigned char *my = smem + (size_t) wib * a.wave_bytes;
 	float        *qf      = reinterpret_cast<float *>(my);
 	const float4 *q4      = reinterpret_cast<const float4 *>(my);
-	uint64_t     *res     = reinterpret_cast<uint64_t *>(my + a.off_res);
-	uint64_t     *cand    = reinterpret_cast<uint64_t *>(my + a.off_cand);
 	uint32_t     *newid   = reinterpret_cast<uint32_t *>(my + a.off_newid);
 	float        *newdist = reinterpret_cast<float *>(my + a.off_newdist);
 
 	const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wib;
+	uint64_t *res, *cand;
+	if (G)
+	{
+		res  = a.set_scratch + (size_t) slot * a.set_stride;
+		cand = res + a.off_cand;                        // G: off_cand counts keys inside the slot's area
+	}
+	else
+	{
+		res  = reinterpret_cast<uint64_t *>(my + a.off_res);
+		cand = reinterpret_cast<uint64_t *>(my + a.off_cand);
+	}
 	uint32_t *vis  = a.vis + (size_t) slot * a.vis_words;
 	uint32_t *vlog = a.vlog + (size_t) slot * a.logcap;
 	const uint32_t ef = a.ef;
@@ -664,7 +725,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 			const float t = qsrc[e < a.dim ? e : a.dim - 1];     // unconditional load, then select
 			qf[e] = (e < a.dim) ? t : 0.f;
 		}
-		wave_sync();
+		set_sync<G>();
 		float qnorm = 0.f;
 		if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
 
@@ -678,30 +739,30 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 				auto one = [ep](uint32_t) { return ep; };
 				score_rows<FUNC, SH::KB, 1>(a.vec, a.stride, q4, a.nchunks, a.kiters, one, 1u, newdist, lane);
 			}
-			wave_sync();
+			set_sync<G>();
 			float lowerBound = finish_dist<FUNC>(newdist[0], newdist[OUT2], qnorm);
 			evals = 1;
 			if (lane == 0)
 			{
 				const uint32_t o = ord_f32(lowerBound);
-				res[0]  = ((uint64_t) o << 32) | ep;
-				cand[0] = ((uint64_t) o << 32) | (uint32_t) ~ep;
+				stk<G>(&res[0], ((uint64_t) o << 32) | ep);
+				stk<G>(&cand[0], ((uint64_t) o << 32) | (uint32_t) ~ep);
 				vis[ep >> 5] = 1u << (ep & 31);       // slot bitmap is all-zero here
 				vlog[0] = ep;
 			}
 			rsize = csize = logn = 1;
-			wave_sync();
+			set_sync<G>();
 
 			while (csize > 0)                                               // hnswalg.cpp:67-112
 			{
 				uint32_t cpos;
-				const uint64_t ck = lds_extreme<true>(cand, csize, cpos, lane);
+				const uint64_t ck = lds_extreme<true, G>(cand, csize, cpos, lane);
 				if (unord_f32((uint32_t) (ck >> 32)) > lowerBound)         // :70-71
 					break;
 				const uint32_t cur = ~(uint32_t) ck;
 				csize--;                                                    // :73 pop = last entry into the hole
-				if (lane == 0) cand[cpos] = cand[csize];
-				wave_sync();
+				if (lane == 0) stk<G>(&cand[cpos], ldk<G>(&cand[csize]));
+				set_sync<G>();
 				hops++;
 
 				for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)               // :76-77
@@ -726,14 +787,14 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 						if (lp < a.logcap) vlog[lp] = t;
 					}
 					logn += nnew;
-					wave_sync();
+					set_sync<G>();
 					{                                                       // :95-97, batched
 						const uint32_t *ids = newid;
 						auto by_id = [ids](uint32_t r) { return ids[r]; };
 						score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nnew, newdist, lane);
 					}
 					evals += nnew;
-					wave_sync();
+					set_sync<G>();
 					const float    d_mine = finish_dist<FUNC>(newdist[lane], newdist[OUT2 + lane], qnorm);
 					const uint32_t t_mine = newid[lane];
 					uint64_t todo = __ballot((uint32_t) lane < nnew && (rsize < ef || lowerBound > d_mine));
@@ -749,37 +810,40 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 						if (csize == a.ccap)                                // :100; make room: the largest key is dead
 						{
 							uint32_t mp;
-							const uint64_t mx = lds_extreme<false>(cand, csize, mp, lane);
-							if (ckey < mx && lane == 0) cand[mp] = ckey;
+							const uint64_t mx = lds_extreme<false, G>(cand, csize, mp, lane);
+							if (ckey < mx && lane == 0) stk<G>(&cand[mp], ckey);
 						}
 						else
 						{
-							if (lane == 0) cand[csize] = ckey;
+							if (lane == 0) stk<G>(&cand[csize], ckey);
 							csize++;
 						}
 						if (rsize < ef)                                     // :102
 						{
-							if (lane == 0) res[rsize] = rkey;
+							if (lane == 0) stk<G>(&res[rsize], rkey);
 							rsize++;
-							wave_sync();
-							if (rsize == 1 || rkey > res[rmax_pos]) rmax_pos = rsize - 1;
+							set_sync<G>();
+							if (rsize == 1 || rkey > ldk<G>(&res[rmax_pos])) rmax_pos = rsize - 1;
 						}
 						else                                                // :104-105 evict the largest
 						{
-							if (lane == 0) res[rmax_pos] = rkey;
-							wave_sync();
-							(void) lds_extreme<false>(res, rsize, rmax_pos, lane);
+							if (lane == 0) stk<G>(&res[rmax_pos], rkey);
+							set_sync<G>();
+							(void) lds_extreme<false, G>(res, rsize, rmax_pos, lane);
 						}
-						wave_sync();
-						lowerBound = unord_f32((uint32_t) (res[rmax_pos] >> 32));          // :107
+						set_sync<G>();
+						lowerBound = unord_f32((uint32_t) (ldk<G>(&res[rmax_pos]) >> 32));   // :107
 					}
-					wave_sync();
+					set_sync<G>();
 				}
 			}
 		}
 
 		// ---- emit: rank-sort the unsorted result array ----------------------------------------
-		const size_t obase = (size_t) qi * ef;
+		// (G: the arrays are final now; drop this CU's L1 copies of them once — an earlier query of this slot
+		// read them through L1 here — and read them with plain, freely pipelined loads)
+		if (G) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+		const size_t obase = (size_t) qi * a.out_stride;
 		uint32_t nout = 0;
 		if (a.mode == 1)
 		{
@@ -796,7 +860,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 				}
 			}
 			nout = rsize;
-			for (uint32_t i = nout + lane; i < ef; i += 64)
+			for (uint32_t i = nout + lane; i < a.out_stride; i += 64)
 			{
 				a.out_idx[obase + i] = LINK_NONE;
 				if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
@@ -807,7 +871,8 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 			// searchKnn, hnswalg.cpp:241-249: label lookup, vacuum filter, order by (dist, label)
 			uint64_t *lab = cand;                       // candidate array is dead now (capacity 2*ef)
 			for (uint32_t i = lane; i < rsize; i += 64) lab[i] = a.labels[(uint32_t) res[i]];
-			wave_sync();
+			set_sync<G>();
+			if (G) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");     // lab[] is read through L1 below
 			for (uint32_t b = 0; b < rsize; b += 64)
 			{
 				const uint32_t i = b + lane;
@@ -830,7 +895,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 				}
 				nout += (uint32_t) __builtin_popcountll(__ballot(keep));
 			}
-			for (uint32_t i = nout + lane; i < ef; i += 64)          // pad the tail
+			for (uint32_t i = nout + lane; i < a.out_stride; i += 64)          // pad the tail
 			{
 				a.out_labels[obase + i] = ~0ull;
 				if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
@@ -843,7 +908,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 		}
 
 		// ---- restore the all-zero bitmap for the next query of this slot --------------
-		wave_sync();
+		set_sync<G>();
 		if (logn <= a.logcap)
 		{
 			for (uint32_t i = lane; i < logn; i += 64) vis[vlog[i] >> 5] = 0u;
@@ -854,7 +919,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_s_waitcnt(0);   // drain: the next query's atomics must see the zeros
-		wave_sync();
+		set_sync<G>();
 	}
 }
 
@@ -1183,7 +1248,7 @@ __global__ __launch_bounds__(256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MI
 			if (i < rsize) srt_key[i] = uk[k];
 		}
 		wave_sync();
-		const size_t obase = (size_t) qi * ef;
+		const size_t obase = (size_t) qi * a.out_stride;
 		uint32_t nout = 0;
 		// rank by (dist, idx); only ranks < ef are results (topCandidates, hnswalg.cpp:237-240)
 		uint32_t myrank[UREG];
@@ -1209,7 +1274,7 @@ __global__ __launch_bounds__(256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MI
 					if (a.out_dists) a.out_dists[obase + myrank[k]] = unord_f32((uint32_t) (uk[k] >> 32));
 				}
 			nout = nres;
-			for (uint32_t i = nout + lane; i < ef; i += 64)
+			for (uint32_t i = nout + lane; i < a.out_stride; i += 64)
 			{
 				a.out_idx[obase + i] = LINK_NONE;
 				if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
@@ -1267,7 +1332,7 @@ __global__ __launch_bounds__(256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MI
 				}
 				nout += (uint32_t) __builtin_popcountll(kmask);
 			}
-			for (uint32_t i = nout + lane; i < ef; i += 64)
+			for (uint32_t i = nout + lane; i < a.out_stride; i += 64)
 			{
 				a.out_labels[obase + i] = ~0ull;
 				if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();

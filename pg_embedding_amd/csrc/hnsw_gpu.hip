@@ -64,6 +64,7 @@ struct SearchWs
 	uint32_t *vis = nullptr;  size_t vis_slots = 0, vis_words = 0;
 	uint32_t *vlog = nullptr; uint32_t logcap = 0;
 	uint64_t *beam = nullptr; size_t beam_keys = 0;      // beam form: prune scratch, 64*UREG keys per slot
+	uint64_t *sets = nullptr; size_t set_keys = 0;       // generic form with its sets in HBM: 3*ef+2 keys per slot
 	uint32_t *ticket = nullptr;
 	hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};
 	uint64_t launches = 0;
@@ -86,6 +87,7 @@ static void ws_free(SearchWs *w)
 {
 	if (w->vis) (void) hipFree(w->vis);
 	if (w->beam) (void) hipFree(w->beam);
+	if (w->sets) (void) hipFree(w->sets);
 	if (w->vlog) (void) hipFree(w->vlog);
 	if (w->ticket) (void) hipFree(w->ticket);
 	for (int i = 0; i < SearchWs::EV_RING; i++)
@@ -437,7 +439,7 @@ extern "C" int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int del
 // ------------------------------------------------------------------------------------
 typedef void (*search_kernel_t)(const SearchArgs);
 
-// rreg: 0 = LDS form (any ef), 2 / 4 = register form for ef <= 128 / 256,
+// rreg: 0 = generic form, sets in LDS; 1 = generic form, sets in HBM (any ef); 2 / 4 = register form for ef <= 128 / 256,
 //       -2 / -4 / -8 / -16 = beam form (counting acceptance) with that many set registers, ef <= 64 / 128 / 256 / 512
 template <typename SH, int RREG>
 static search_kernel_t pick_search_kernel_f(int func)
@@ -452,14 +454,21 @@ static search_kernel_t pick_search_kernel_f(int func)
 			default:       return hnsw_search_kernel_beam<F_MANHATTAN, SH, U>;
 		}
 	}
+	if (RREG == 1)          // generic form, sets in HBM
+		switch (func)
+		{
+			case F_L2:     return hnsw_search_kernel_lds<F_L2, SH, true>;
+			case F_COSINE: return hnsw_search_kernel_lds<F_COSINE, SH, true>;
+			default:       return hnsw_search_kernel_lds<F_MANHATTAN, SH, true>;
+		}
 	if (RREG == 0)
 		switch (func)
 		{
-			case F_L2:     return hnsw_search_kernel_lds<F_L2, SH>;
-			case F_COSINE: return hnsw_search_kernel_lds<F_COSINE, SH>;
-			default:       return hnsw_search_kernel_lds<F_MANHATTAN, SH>;
+			case F_L2:     return hnsw_search_kernel_lds<F_L2, SH, false>;
+			case F_COSINE: return hnsw_search_kernel_lds<F_COSINE, SH, false>;
+			default:       return hnsw_search_kernel_lds<F_MANHATTAN, SH, false>;
 		}
-	constexpr int R = RREG <= 0 ? 2 : RREG;
+	constexpr int R = RREG <= 1 ? 2 : RREG;
 	switch (func)
 	{
 		case F_L2:     return hnsw_search_kernel_reg<F_L2, SH, R>;
@@ -479,6 +488,7 @@ static search_kernel_t pick_search_kernel_s(int func, int rreg)
 		case -4: return pick_search_kernel_f<SH, -4>(func);
 		case -8: return pick_search_kernel_f<SH, -8>(func);
 		case -16: return pick_search_kernel_f<SH, -16>(func);
+		case 1:  return pick_search_kernel_f<SH, 1>(func);
 		default: return pick_search_kernel_f<SH, 0>(func);
 	}
 }
@@ -498,6 +508,8 @@ static search_kernel_t pick_search_kernel(int func, uint32_t kiters, int rreg)
 
 static const size_t LDS_PER_CU = 160 * 1024;
 static const size_t VIS_BUDGET_BYTES = (size_t) 24 << 30;     // cap on bitmap workspace
+static const size_t SET_BUDGET_BYTES = (size_t) 8 << 30;      // cap on the HBM result/candidate areas (generic form)
+static const size_t MAX_EF = 65536;                           // effective beam (after clamping to the index size)
 
 static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries, size_t q_stride, size_t nq, size_t ef, int mode,
 						 uint64_t *d_labels, uint32_t *d_idx, float *d_dists, uint32_t *d_counts,
@@ -509,8 +521,15 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	if (nq == 0) return HNSW_GPU_OK;
 	if (!d_queries || !d_counts || (mode == 0 && !d_labels) || (mode == 1 && !d_idx))
 		return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
-	if (ef == 0 || ef > 65536) return fail(HNSW_GPU_ERR_ARG, "ef %zu out of range [1, 65536]", ef);
+	if (ef == 0 || ef >= 0xFFFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "ef %zu out of range", ef);
 	if (nq >= 0xFFFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "too many queries");
+	// A beam wider than the index behaves exactly like a beam of the index size (nothing is ever evicted,
+	// the walk ends when the candidates run out), so the scan's efSearch doubling (embedding.c:334) can go
+	// as far as it likes; the output arrays keep the caller's ef as their row stride.
+	const size_t out_stride = ef;
+	ef = std::min(ef, std::max<size_t>(ix->n, 1));
+	if (ef > MAX_EF)
+		return fail(HNSW_GPU_ERR_ARG, "ef %zu with %zu elements: beams above %zu are not supported", out_stride, ix->n, MAX_EF);
 	HIPCHK(hipSetDevice(ix->device));
 
 	SearchArgs a;
@@ -520,6 +539,7 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	a.nchunks = ix->stride / 4; a.kiters = (a.nchunks + 15) / 16;
 	a.maxM = (uint32_t) ix->meta.maxM; a.lstride = ix->lstride; a.entry = ix->meta.enterpoint_node;
 	a.queries = d_queries; a.q_stride = (uint32_t) q_stride; a.nq = (uint32_t) nq; a.ef = (uint32_t) ef; a.ccap = (uint32_t) (2 * ef);
+	a.out_stride = (uint32_t) out_stride;
 	a.out_labels = d_labels; a.out_idx = d_idx; a.out_dists = d_dists; a.out_counts = d_counts; a.out_stats = d_stats;
 	a.mode = mode;
 	if (a.n > 0 && a.entry >= a.n) return fail(HNSW_GPU_ERR_ARG, "enterpoint_node %u >= count %u", a.entry, a.n);
@@ -574,8 +594,23 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	}
 	else
 	{
-		a.off_res = (uint32_t) off;     off += round_up((ef + 1) * 8, 16);
-		a.off_cand = (uint32_t) off;    off += round_up((2 * ef + 1) * 8, 16);
+		// generic form: [res ef+1 | cand 2ef+1] keys per wave — in LDS while at least HNSW_GPU_LDS_SET_MIN_WAVES
+		// (default 4) waves per CU fit, otherwise in a per-slot HBM area (any ef)
+		const size_t set_bytes = round_up((ef + 1) * 8, 16) + round_up((2 * ef + 1) * 8, 16);
+		const char *mw = getenv("HNSW_GPU_LDS_SET_MIN_WAVES");
+		const size_t min_waves = mw && atoi(mw) > 0 ? (size_t) atoi(mw) : 4;
+		if (min_waves * (off + set_bytes + 64 * 4 + 128 * 4) > LDS_PER_CU)
+		{
+			rreg = 1;
+			a.off_res = 0;
+			a.off_cand = (uint32_t) (ef + 1);                     // in keys, inside the slot's area
+			a.set_stride = 3 * ef + 2;
+		}
+		else
+		{
+			a.off_res = (uint32_t) off;     off += round_up((ef + 1) * 8, 16);
+			a.off_cand = (uint32_t) off;    off += round_up((2 * ef + 1) * 8, 16);
+		}
 	}
 	a.off_newid = (uint32_t) off;   off += 64 * 4;
 	a.off_newdist = (uint32_t) off; off += 128 * 4;      // sums + (cosine) |x|^2
@@ -598,7 +633,8 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 
 	// workspace: one bitmap + log per resident wave
 	const size_t words = std::max<size_t>(1, (ix->cap + 31) / 32);   // by capacity: stable while the index grows
-	const size_t max_slots = std::max<size_t>(wpb, VIS_BUDGET_BYTES / (words * 4));
+	size_t max_slots = std::max<size_t>(wpb, VIS_BUDGET_BYTES / (words * 4));
+	if (rreg == 1) max_slots = std::max<size_t>(wpb, std::min(max_slots, SET_BUDGET_BYTES / (a.set_stride * 8)));
 	if (blocks * wpb > max_slots) blocks = std::max<size_t>(1, max_slots / wpb);
 	const size_t slots = blocks * wpb;
 	const uint32_t logcap = 8192;
@@ -621,6 +657,18 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		w->beam_keys = slots * ucap;
 	}
 	a.beam_scratch = w->beam;
+	if (rreg == 1)
+	{
+		const size_t keys = slots * a.set_stride;
+		if (keys > w->set_keys)
+		{
+			if (w->sets) (void) hipFree(w->sets);
+			w->sets = nullptr; w->set_keys = 0;
+			HIPCHK(hipMalloc(&w->sets, keys * 8));
+			w->set_keys = keys;
+		}
+		a.set_scratch = w->sets;
+	}
 	a.ticket = w->ticket;
 	HIPCHK(hipMemsetAsync(w->ticket, 0, 8, stream));
 
@@ -656,7 +704,7 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
 	if (nq == 0) return HNSW_GPU_OK;
 	if (!queries || !labels || !counts) return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
-	if (ef == 0 || ef > 65536) return fail(HNSW_GPU_ERR_ARG, "ef %zu out of range [1, 65536]", ef);
+	if (ef == 0 || ef >= 0xFFFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "ef %zu out of range", ef);
 	HIPCHK(hipSetDevice(ix->device));
 	const size_t dim = ix->meta.dim;
 	const size_t qb = round_up(nq * dim * 4, 256), lb = round_up(nq * ef * 8, 256), db = round_up(nq * ef * 4, 256),

@@ -19,7 +19,7 @@ from .index import GpuIndex
 class IndexScan:
     """``for label in IndexScan(index, query): ...`` == repeated amgettuple calls."""
 
-    def __init__(self, index: GpuIndex, query, efsearch: Optional[int] = None, max_ef: int = 65536):
+    def __init__(self, index: GpuIndex, query, efsearch: Optional[int] = None, max_ef: Optional[int] = None):
         self.index = index
         self.query = np.ascontiguousarray(query, dtype=np.float32).reshape(1, -1)
         if self.query.shape[1] != index.meta.dim:       # embedding.c:311-315
@@ -44,7 +44,9 @@ class IndexScan:
             self.results = list(r.tolist())
             self.no_more = len(r) < self.ef                        # :322
         if self.curr >= len(self.results):                         # :329
-            if self.no_more or self.ef * 2 > self.max_ef:
+            # (the reference has no cap: the doubling ends when a search comes back short; `max_ef` is an
+            # optional safety valve for callers, the device path itself clamps the beam to the index size)
+            if self.no_more or (self.max_ef is not None and self.ef * 2 > self.max_ef):
                 raise StopIteration
             self.ef *= 2                                           # :334
             r = self._search()

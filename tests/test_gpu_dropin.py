@@ -172,6 +172,12 @@ def test_index_scan_follows_hnsw_gettuple():
             if len(got) == 100:
                 break
         assert got == want and len(got) == 100
+    # LIMIT larger than the table: the scan doubles efSearch past the index size (8 -> ... -> 1024 > 900)
+    # and ends when a search comes back short; every reachable row is returned exactly once
+    q = X[7] + 0.25
+    want = reference_scan(q, 10 ** 9)
+    got = list(IndexScan(ix, q, efs))
+    assert got == want and len(set(got)) == len(got) and len(got) > 800
     ix.close()
 
 

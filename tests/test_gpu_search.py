@@ -167,13 +167,35 @@ def test_exact_ties_follow_the_pair_order(func):
     ix.close()
 
 
-@pytest.mark.parametrize("ef", [200, 512, 1500])
+@pytest.mark.parametrize("ef", [200, 512, 1500, 2800, 8192, 65536])
 def test_large_ef(ef):
-    """efSearch doubling path of the scan (embedding.c:334) reaches large beams."""
+    """efSearch doubling path of the scan (embedding.c:334) reaches large beams — up to "more than the
+    index holds".  Past what LDS can hold at 4 waves per CU the result/candidate arrays live in HBM."""
     port, X = build_port(3000, 48, 8, 32, pg.DIST_L2, seed=13)
     ix = mirror(port, pg.DIST_L2)
-    Q = gmm(40, 48, k=50, seed=13, stream=1)
+    Q = gmm(40 if ef <= 1500 else 8, 48, k=50, seed=13, stream=1)
     assert_same_as_oracle(ix, port, Q, ef)
+    ix.close()
+
+
+@pytest.mark.parametrize("func", FUNCS)
+def test_generic_form_with_sets_in_hbm_is_exact(func, monkeypatch):
+    """Force the HBM-resident arrays at a moderate ef (vacuumed labels and equal distances included)."""
+    monkeypatch.setenv("HNSW_GPU_LDS_SET_MIN_WAVES", "1000")
+    rng = np.random.default_rng(5)
+    X = np.rint(gmm(4000, 20, k=40, seed=9) * 3).astype(np.float32)
+    if func == pg.DIST_COSINE:
+        X[(X * X).sum(axis=1) == 0] = 1.0
+    port = oracle.PortIndex(20, 6, 32, 64, func)
+    port.add(X)
+    for i in rng.choice(4000, 500, replace=False):
+        port.set_deleted(int(i))
+    ix = mirror(port, func)
+    Q = gmm(24, 20, k=40, seed=9, stream=1)
+    if func == pg.DIST_COSINE:
+        Q[(Q * Q).sum(axis=1) == 0] = 1.0
+    for ef in (300, 700):
+        assert_same_as_oracle(ix, port, Q, ef)
     ix.close()
 
 
