@@ -8,11 +8,15 @@
 // slots each keeping up to 24 KiB of row reads in flight; a single query is latency-bound by
 // construction (≈ef dependent hops, two memory round trips each).
 //
-// Two forms of the same algorithm:
-//   hnsw_search_kernel_reg  (ef <= 256, the hot one): result / candidate sets in REGISTERS
-//                           (see the banner further down), visited set = exact hash set in LDS
-//                           with the HBM bitmap as overflow;
-//   hnsw_search_kernel_lds  (any ef): both sets as unsorted arrays in LDS, visited set = bitmap.
+// Three forms of the same algorithm (the host picks one per launch, hnsw_gpu.hip launch_search):
+//   hnsw_search_kernel_beam (ef <= 256; <= 512 on wide rows; the hot one): ONE unordered set of accepted
+//                           elements in registers, every decision of the reference restated as a count
+//                           over it (banner further down); visited set = exact hash set in LDS with
+//                           the HBM bitmap behind it;
+//   hnsw_search_kernel_reg  (ef <= 256, fallback): result set sorted + candidate set unsorted, both in
+//                           registers;
+//   hnsw_search_kernel_lds  (any ef): both sets as unsorted arrays, in LDS or (large ef) in HBM;
+//                           visited set = bitmap.
 //
 // Heaps.  The reference keeps two std::priority_queue<pair<float,idx>>:
 //   topResults  : max-heap on ( dist, idx)   -> worst on top, evicted when size > ef
@@ -29,11 +33,13 @@
 // so with capacity >= 2*ef the largest key of an overfull set is always dead and may be dropped.
 //
 // Visited set (hnswalg.cpp:45-50,82-93: a growable bitmap in the reference).
-//   * LDS hash set (register form, rows >= 1.25 KiB): open addressing, lock-free ds_cmpst insert
-//     = the test and the set of :91-93 in one LDS operation, no HBM traffic;
+//   * LDS hash set (register forms): open addressing, lock-free ds_cmpst insert = the test and the
+//     set of :91-93 in one LDS operation, no HBM traffic.  4096 entries for rows >= 1.25 KiB (8 waves
+//     per CU), 2048 for narrower rows in the beam form (16 waves per CU);
 //   * per-slot bitmap in HBM: returning atomic OR (safe when two neighbours share a word), bits
-//     undone through a log after the query.  It is the only set of the LDS form and of narrow rows
-//     (where occupancy matters more), and the overflow of the hash set once that is 3/4 full.
+//     undone through a log after the query.  It is the only set of the generic form, and takes over
+//     from the hash set once that is 3/4 full (wide rows: both are consulted from then on; narrow rows:
+//     the hash set is flushed into the bitmap once).
 // Link lists are de-duplicated at upload (first occurrence kept), which is behaviour-preserving
 // because a repeated id is always already visited when reached again in pass 2 (:89-93).
 #pragma once
