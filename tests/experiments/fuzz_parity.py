@@ -19,7 +19,7 @@ def one_case(rng, idx):
         m = max(1, m // 2)
     n = int(rng.integers(2, 4000 if dim <= 512 else 1500))
     efc = int(rng.choice([1, 4, 16, 40, 100]))
-    ef = int(rng.choice([1, 2, 7, 16, 64, 100, 128, 129, 200, 256, 257, 400]))
+    ef = int(rng.choice([1, 2, 7, 16, 64, 100, 128, 129, 200, 256, 257, 400, 512, 513, 700, 5000]))
     k = int(rng.integers(1, 40))
     X = gmm(n, dim, k=k, sigma=float(rng.choice([0.05, 0.3, 1.0])), seed=1000 + idx)
     if rng.random() < 0.3:
