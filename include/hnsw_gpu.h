@@ -142,6 +142,15 @@ int  hnsw_gpu_search_batch_ctx(hnsw_gpu_ctx *ctx, const coord_t *d_queries, size
 							   label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
 							   void *stream);
 int  hnsw_gpu_ctx_search_ms(hnsw_gpu_ctx *ctx, unsigned back, float *ms);
+/* Host-pointer form of a context search (same arrays as hnsw_gpu_search_batch): copies and launch
+ * go to a stream the context owns and only that stream is waited for, so several host threads —
+ * one context each — keep several batches in flight (the batching server, hnsw_gpu_server.h).
+ * One caller at a time per context. */
+int  hnsw_gpu_search_batch_ctx_host(hnsw_gpu_ctx *ctx, const coord_t *queries, size_t nq, size_t ef,
+									label_t *labels, dist_t *dists, uint32_t *counts);
+/* Pinned host memory for the host-pointer entry points (NULL on failure). */
+void *hnsw_gpu_host_alloc(size_t bytes);
+void  hnsw_gpu_host_free(void *p);
 
 /* ------------------------------------------------------------------- distances */
 

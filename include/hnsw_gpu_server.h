@@ -1,0 +1,137 @@
+/*
+ * hnsw_gpu_server.h — the GPU-owning search server and its client library.
+ *
+ * Why it exists.  Postgres is one single-threaded process per connection
+ * and every scan hands the hot path ONE query (hnsw_gettuple -> hnsw_search, embedding.c:284-343).
+ * A HIP context plus a multi-GB index mirror per backend cannot work, and one query per launch is
+ * latency-bound (one wavefront walking ~160 dependent hops).  So the deployment shape is:
+ *
+ *   hnsw_gpu_server  (one process per GPU)  owns the device, keeps the HBM mirrors keyed by a
+ *                    caller-chosen (key, generation) — e.g. (relfilenode, metapage LSN) — and
+ *                    coalesces the SEARCH requests of all connected backends that are waiting at
+ *                    the same moment into one hnsw_gpu_search_batch launch per dispatcher
+ *                    (two dispatchers on two HIP streams keep the device full while one drains);
+ *   libembedding_gpuc.so  exports the reference's own four symbols (embedding.h:46-47,55-56 ==
+ *                    hnsw_abi.h) implemented as requests to that server.  It links no HIP and
+ *                    creates no device context: a backend pays one Unix-socket round trip.
+ *
+ * Transport: a Unix stream socket, strictly request -> response per connection (a backend has one
+ * scan in flight).  Bulk element images travel as a memfd passed with SCM_RIGHTS and are mapped by
+ * the server — never copied through the socket.  All integers little-endian (same host).
+ *
+ * The server links libhnsw_gpu.so and nothing else computes: without a gfx950 device it refuses to
+ * start (exit status 3).
+ */
+#ifndef PG_EMBEDDING_AMD_HNSW_GPU_SERVER_H
+#define PG_EMBEDDING_AMD_HNSW_GPU_SERVER_H
+
+#include "hnsw_abi.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ wire format */
+
+#define HGS_MAGIC    0x31534748u          /* "HGS1" */
+#define HGS_VERSION  1u
+#define HGS_MAX_PAYLOAD ((uint32_t) 64 << 20)
+
+typedef struct hgs_hdr
+{
+	uint32_t magic;      /* HGS_MAGIC                                             */
+	uint16_t op;         /* request: HGS_OP_*; the response repeats it            */
+	int16_t  status;     /* response: HGS_OK or a negative HGS_ERR_* / HNSW_GPU_ERR_* */
+	uint32_t len;        /* payload bytes after this header                       */
+	uint32_t aux;        /* op-specific: ef / dist_func / idx / max_batch         */
+	uint64_t key;        /* which mirror                                          */
+	uint64_t gen;        /* its generation (0 in a SEARCH = whatever is current)  */
+	uint64_t a0, a1;     /* op-specific                                           */
+} hgs_hdr;               /* 48 bytes */
+
+enum
+{
+	/* op            request                                              response                         */
+	HGS_OP_HELLO       = 1,  /* a0 = HGS_VERSION                               a0 = version, a1 = devices     */
+	HGS_OP_LOOKUP      = 2,  /* key                                            a0 = count, a1 = 1 present/0 absent, gen = current */
+	HGS_OP_UPLOAD      = 3,  /* key, gen, a0 = n, payload = HnswMetadata,
+	                            fd = memfd holding n element images (embedding.c:222-228); replaces the key's mirror */
+	HGS_OP_UPDATE      = 4,  /* key, gen = NEW generation, a0 = first, a1 = count, payload = u64 expected current
+	                            generation, fd = memfd with `count` images -> hnsw_gpu_index_update_from_flat */
+	HGS_OP_SEARCH      = 5,  /* key, gen (0 = any), aux = ef, a0 = 1 to get distances too, payload = dim floats
+	                            -> a0 = count, payload = count labels (u64) [+ count distances (f32)]:
+	                            the array hnsw_search() returns (hnswalg.cpp:256-277)                */
+	HGS_OP_DROP        = 6,  /* key                                                                            */
+	HGS_OP_STATS       = 7,  /*                                                payload = hgs_stats             */
+	HGS_OP_DIST        = 8,  /* aux = dist_func, a0 = dim, payload = 2*dim floats  payload = one f32 (distfunc.c:171-174) */
+	HGS_OP_BIND        = 9,  /* key, gen (0 = any), aux = idx, a0 = label, a1 = new generation (0 = keep),
+	                            payload = dim floats: hnsw_bind_point (hnswalg.cpp:279-291) in serial mode.
+	                            -> payload = u32 nrec, then nrec records [u32 idx][u32 count][u32 link*maxM]:
+	                            the changed link lists, the touched neighbours first, the new element last  */
+	HGS_OP_LINK        = 10, /* key, a0 = first, a1 = count, aux = max_batch (0 = default): bulk
+	                            hnsw_gpu_index_link (CREATE INDEX offload)                              */
+	HGS_OP_EXPORT      = 11, /* key, fd = writable memfd of count*size_data_per_element bytes -> element images */
+	HGS_OP_SET_DELETED = 12  /* key, aux = idx, a0 = 0/1 (embedding.c:920-926)                                */
+};
+
+enum
+{
+	HGS_OK            =   0,
+	/* -1 … -5 are the HNSW_GPU_ERR_* codes of hnsw_gpu.h, passed through */
+	HGS_ERR_PROTOCOL  = -20,  /* malformed request                                 */
+	HGS_ERR_NOKEY     = -21,  /* no mirror under that key                          */
+	HGS_ERR_STALE     = -22,  /* the mirror's generation differs (gen = current)   */
+	HGS_ERR_IO        = -23,  /* client side: cannot reach / lost the server       */
+	HGS_ERR_SHUTDOWN  = -24   /* the server is stopping                            */
+};
+
+typedef struct hgs_stats
+{
+	uint64_t connections, connections_now;
+	uint64_t searches, batches, max_batch;       /* mean batch = searches / batches */
+	uint64_t search_errors;
+	uint64_t uploads, upload_bytes, updates, binds, evictions;
+	uint64_t mirrors, mirror_elements;
+	uint64_t batch_ns;                           /* host time inside search launches, summed over dispatchers */
+	uint64_t uptime_ns;
+} hgs_stats;
+
+/* ------------------------------------------------- client side (libembedding_gpuc.so) */
+
+/* The library also exports hnsw_search / hnsw_bind_point / hnsw_dist_func / hnsw_init_dist_func
+ * (hnsw_abi.h) and imports the host's storage callbacks like hnswalg.cpp does.  The socket path
+ * comes from hnsw_gpu_remote_connect() or, lazily, from the environment variable
+ * PG_EMBEDDING_GPU_SERVER.  Connections are per thread and are re-made after fork().
+ * All calls return HGS_OK (0) or a negative code; hnsw_gpu_remote_last_error() has the text. */
+
+int  hnsw_gpu_remote_connect(const char *socket_path);
+void hnsw_gpu_remote_disconnect(void);
+const char *hnsw_gpu_remote_last_error(void);
+
+/* Bind `meta` (the per-scan HnswMetadata of embedding.c:254) to the server-side mirror
+ * (key, generation) for the drop-in symbols.  If the server does not hold that generation the
+ * host index is walked through hnsw_begin_read/hnsw_end_read (embedding.c:704-767; one pin at a
+ * time, page-tail holes handled) straight into a memfd and uploaded.  Where embedding.c would
+ * call it: hnsw_beginscan (embedding.c:249-262) with key = relfilenode; detach in hnsw_endscan. */
+int hnsw_gpu_remote_attach(HnswMetadata *meta, uint64_t key, uint64_t generation);
+int hnsw_gpu_remote_detach(HnswMetadata *meta);
+
+/* Lower level, for hosts that manage mirrors themselves. */
+int hnsw_gpu_remote_lookup(uint64_t key, uint64_t *generation, size_t *count, int *present);
+int hnsw_gpu_remote_upload(const HnswMetadata *meta, uint64_t key, uint64_t generation,
+						   const void *elements, size_t n);
+int hnsw_gpu_remote_update(uint64_t key, uint64_t expected_generation, uint64_t new_generation,
+						   const HnswMetadata *meta, const void *elements, size_t first, size_t count);
+/* labels: ef values; dists: ef values or NULL */
+int hnsw_gpu_remote_search(uint64_t key, uint64_t generation, const coord_t *query, size_t dim, size_t ef,
+						   label_t *labels, dist_t *dists, size_t *count);
+int hnsw_gpu_remote_link(uint64_t key, size_t first, size_t count, size_t max_batch);
+int hnsw_gpu_remote_export(uint64_t key, void *elements, size_t bytes);
+int hnsw_gpu_remote_set_deleted(uint64_t key, idx_t idx, int deleted);
+int hnsw_gpu_remote_drop(uint64_t key);
+int hnsw_gpu_remote_stats(hgs_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PG_EMBEDDING_AMD_HNSW_GPU_SERVER_H */

@@ -2,6 +2,8 @@
 
     libhnsw_gpu.so       HIP kernels + additive C API   (include/hnsw_gpu.h)
     libembedding_gpu.so  the reference's four symbols   (include/hnsw_abi.h) on top of it
+    libembedding_gpuc.so the same four symbols as a client of hnsw_gpu_server (no HIP linked)
+    bin/hnsw_gpu_server  the GPU-owning batching server (include/hnsw_gpu_server.h)
 
 hipcc cross-compiles for gfx950 without a GPU.  The .so files are git-ignored but travel
 to the GPU box with the tree.
@@ -20,6 +22,9 @@ INC = os.path.join(ROOT, "include")
 
 GPU_LIB = os.path.join(LIBDIR, "libhnsw_gpu.so")
 SHIM_LIB = os.path.join(LIBDIR, "libembedding_gpu.so")
+CLIENT_LIB = os.path.join(LIBDIR, "libembedding_gpuc.so")
+BINDIR = os.path.join(PKG, "bin")
+SERVER_BIN = os.path.join(BINDIR, "hnsw_gpu_server")
 
 HIPCC_FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
@@ -50,8 +55,9 @@ def _run(cmd) -> None:
 
 def build(force: bool = False, verbose: bool = False) -> None:
     os.makedirs(LIBDIR, exist_ok=True)
-    hdrs = [os.path.join(INC, h) for h in ("hnsw_abi.h", "hnsw_gpu.h", "hnsw_gpu_shim.h")]
-    gpu_src = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + hdrs
+    os.makedirs(BINDIR, exist_ok=True)
+    hdrs = [os.path.join(INC, h) for h in ("hnsw_abi.h", "hnsw_gpu.h", "hnsw_gpu_shim.h", "hnsw_gpu_server.h")]
+    gpu_src = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) and f != "hgs_io.h"] + hdrs
     if force or not _newer(GPU_LIB, gpu_src):
         cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INC, "-I", CSRC,
                                           os.path.join(CSRC, "hnsw_gpu.hip"),
@@ -67,8 +73,24 @@ def build(force: bool = False, verbose: bool = False) -> None:
         if verbose:
             print(" ".join(cmd))
         _run(cmd)
+    io_h = os.path.join(CSRC, "hgs_io.h")
+    client_src = [os.path.join(CSRC, "remote_client.cpp"), io_h] + hdrs
+    if force or not _newer(CLIENT_LIB, client_src):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-I", INC, "-I", CSRC,
+               os.path.join(CSRC, "remote_client.cpp"), "-o", CLIENT_LIB, "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        _run(cmd)
+    server_src = [os.path.join(CSRC, "server_main.cpp"), io_h] + hdrs
+    if force or not _newer(SERVER_BIN, server_src + [GPU_LIB]):
+        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", INC, "-I", CSRC,
+               os.path.join(CSRC, "server_main.cpp"), "-o", SERVER_BIN,
+               "-L", LIBDIR, "-lhnsw_gpu", "-Wl,-rpath,$ORIGIN/../lib", "-lpthread"]
+        if verbose:
+            print(" ".join(cmd))
+        _run(cmd)
 
 
 if __name__ == "__main__":
     build(force=True, verbose=True)
-    print("built", GPU_LIB, SHIM_LIB)
+    print("built", GPU_LIB, SHIM_LIB, CLIENT_LIB, SERVER_BIN)

@@ -228,13 +228,15 @@ extern "C" bool hnsw_search(HnswMetadata *meta, const coord_t *point, size_t *n_
 extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t idx)
 {
 	if (!meta || !point) return false;
-	if (idx == 0) return true;                           // bindPoint: nothing for the first element, hnswalg.cpp:228
 	hnsw_gpu_index *ix = nullptr;
 	bool own = false;
 	{
 		std::lock_guard<std::mutex> lk(g_mu);
 		ix = find_attached(meta);
 	}
+	// bindPoint links nothing for the first element (hnswalg.cpp:228); an attached mirror still has to
+	// receive the row itself.
+	if (idx == 0 && !ix) return true;
 	const size_t maxM = meta->maxM;
 	if (maxM > 4096) return false;
 	static thread_local idx_t mine[4097], other[4097];
@@ -278,6 +280,7 @@ extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t 
 			own = true;
 			if (hnsw_gpu_index_count(ix) != (size_t) idx + 1) break;
 		}
+		if (idx == 0) { ok = true; break; }
 		if (hnsw_gpu_index_link(ix, idx, 1, 1, 0, nullptr) != HNSW_GPU_OK) break;
 		if (hnsw_gpu_index_get_links(ix, idx, mine) != HNSW_GPU_OK) break;
 		bool failed = false;

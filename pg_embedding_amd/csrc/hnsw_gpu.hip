@@ -1367,6 +1367,9 @@ struct hnsw_gpu_ctx
 {
 	hnsw_gpu_index *ix;
 	SearchWs ws;
+	// host-pointer form (hnsw_gpu_search_batch_ctx_host): own stream + device staging, grow-only
+	hipStream_t stream = nullptr;
+	void *stage = nullptr; size_t stage_bytes = 0;
 };
 
 extern "C" int hnsw_gpu_ctx_create(hnsw_gpu_index *ix, hnsw_gpu_ctx **out)
@@ -1387,6 +1390,8 @@ extern "C" void hnsw_gpu_ctx_destroy(hnsw_gpu_ctx *c)
 	if (!c) return;
 	(void) hipSetDevice(c->ix->device);
 	ws_free(&c->ws);
+	if (c->stage) (void) hipFree(c->stage);
+	if (c->stream) (void) hipStreamDestroy(c->stream);
 	delete c;
 }
 
@@ -1403,4 +1408,60 @@ extern "C" int hnsw_gpu_ctx_search_ms(hnsw_gpu_ctx *c, unsigned back, float *ms)
 {
 	if (!c || !ms) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
 	return ws_search_ms(c->ix->device, &c->ws, back, ms);
+}
+
+// Host-pointer form of a context search: copy in, launch, copy out on the context's own stream and
+// wait for that stream only, so host threads that own one context each keep several batches in
+// flight on the device (the batching server's dispatchers, server_main.cpp).  Buffers from
+// hnsw_gpu_host_alloc make the copies true DMA transfers.  One caller at a time per context.
+extern "C" int hnsw_gpu_search_batch_ctx_host(hnsw_gpu_ctx *c, const coord_t *queries, size_t nq, size_t ef,
+											  label_t *labels, dist_t *dists, uint32_t *counts)
+{
+	if (!c) return fail(HNSW_GPU_ERR_ARG, "context is NULL");
+	if (nq == 0) return HNSW_GPU_OK;
+	if (!queries || !labels || !counts) return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
+	if (ef == 0 || ef >= 0xFFFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "ef %zu out of range", ef);
+	hnsw_gpu_index *ix = c->ix;
+	HIPCHK(hipSetDevice(ix->device));
+	if (!c->stream) HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	const size_t dim = ix->meta.dim;
+	const size_t qb = round_up(nq * dim * 4, 256), lb = round_up(nq * ef * 8, 256), db = round_up(nq * ef * 4, 256),
+				 cb = round_up(nq * 4, 256);
+	if (qb + lb + db + cb > c->stage_bytes)
+	{
+		if (c->stage) (void) hipFree(c->stage);
+		c->stage = nullptr; c->stage_bytes = 0;
+		const size_t want = std::max<size_t>(qb + lb + db + cb, (size_t) 1 << 20);
+		HIPCHK(hipMalloc(&c->stage, want));
+		c->stage_bytes = want;
+	}
+	char *p = (char *) c->stage;
+	float *dq = (float *) p; uint64_t *dl = (uint64_t *) (p + qb); float *dd = (float *) (p + qb + lb);
+	uint32_t *dc = (uint32_t *) (p + qb + lb + db);
+	HIPCHK(hipMemcpyAsync(dq, queries, nq * dim * 4, hipMemcpyHostToDevice, c->stream));
+	int rc = launch_search(ix, &c->ws, dq, dim, nq, ef, 0, dl, nullptr, dd, dc, nullptr, c->stream);
+	if (rc) return rc;
+	HIPCHK(hipMemcpyAsync(labels, dl, nq * ef * 8, hipMemcpyDeviceToHost, c->stream));
+	if (dists) HIPCHK(hipMemcpyAsync(dists, dd, nq * ef * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipMemcpyAsync(counts, dc, nq * 4, hipMemcpyDeviceToHost, c->stream));
+	HIPCHK(hipStreamSynchronize(c->stream));
+	return HNSW_GPU_OK;
+}
+
+// Pinned host memory for the host-pointer entry points (NULL when there is no device / no memory).
+extern "C" void *hnsw_gpu_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess)
+	{
+		(void) hipGetLastError();
+		fail(HNSW_GPU_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+		return nullptr;
+	}
+	return p;
+}
+
+extern "C" void hnsw_gpu_host_free(void *p)
+{
+	if (p) (void) hipHostFree(p);
 }

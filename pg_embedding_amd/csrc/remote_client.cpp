@@ -1,0 +1,506 @@
+// remote_client.cpp — libembedding_gpuc.so: the four symbols embedding.c links against
+// (embedding.h:46-47,55-56), implemented as requests to hnsw_gpu_server (hnsw_gpu_server.h).
+//
+//   hnsw_search          hnswalg.cpp:256-277  -> SEARCH  (batched with the other backends' scans)
+//   hnsw_bind_point      hnswalg.cpp:279-291  -> BIND    (serial device insert on the server's mirror)
+//                                                + write-back of the changed lists via hnsw_begin_write
+//   hnsw_dist_func       distfunc.c:171-174   -> DIST
+//   hnsw_init_dist_func  distfunc.c:159-169   -> reads PG_EMBEDDING_GPU_SERVER
+//
+// No HIP is linked and nothing is computed here: when the server cannot be reached every call
+// fails (false / NaN) with a message on stderr.  It imports the host's storage callbacks
+// (embedding.h:44,48-53) like hnswalg.cpp does, for the index walk of an upload and the write-back
+// of an insert.
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/un.h>
+
+#include "hgs_io.h"
+#include "hnsw_gpu.h"      // error codes only: nothing of libhnsw_gpu.so is linked
+
+namespace {
+
+std::mutex g_mu;
+std::string g_path;                       // socket path (connect() or PG_EMBEDDING_GPU_SERVER)
+
+thread_local int   t_fd = -1;
+thread_local pid_t t_pid = 0;
+thread_local char  t_err[512] = "";
+thread_local std::vector<char> t_resp;    // payload of the last response
+
+struct Attachment { HnswMetadata *meta; uint64_t key, gen; };
+std::vector<Attachment> g_attached;
+std::atomic<uint64_t> g_ephemeral{0};
+
+int fail(int code, const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	vsnprintf(t_err, sizeof(t_err), fmt, ap);
+	va_end(ap);
+	return code;
+}
+
+void drop_connection()
+{
+	if (t_fd >= 0) close(t_fd);
+	t_fd = -1;
+}
+
+int ensure_connected()
+{
+	if (t_fd >= 0 && t_pid == getpid()) return HGS_OK;
+	if (t_fd >= 0) drop_connection();             // inherited across fork(): the parent's conversation
+	std::string path;
+	{
+		std::lock_guard<std::mutex> lk(g_mu);
+		if (g_path.empty())
+		{
+			const char *env = getenv("PG_EMBEDDING_GPU_SERVER");
+			if (env && *env) g_path = env;
+		}
+		path = g_path;
+	}
+	if (path.empty())
+		return fail(HGS_ERR_IO, "no server socket: set PG_EMBEDDING_GPU_SERVER or call hnsw_gpu_remote_connect()");
+	struct sockaddr_un addr;
+	memset(&addr, 0, sizeof(addr));
+	addr.sun_family = AF_UNIX;
+	if (path.size() >= sizeof(addr.sun_path)) return fail(HGS_ERR_IO, "socket path too long");
+	strncpy(addr.sun_path, path.c_str(), sizeof(addr.sun_path) - 1);
+	int fd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+	if (fd < 0) return fail(HGS_ERR_IO, "socket(): %s", strerror(errno));
+	if (connect(fd, (struct sockaddr *) &addr, sizeof(addr)) != 0)
+	{
+		int e = errno;
+		close(fd);
+		return fail(HGS_ERR_IO, "cannot reach hnsw_gpu_server at %s: %s", path.c_str(), strerror(e));
+	}
+	t_fd = fd;
+	t_pid = getpid();
+	hgs_hdr h, r;
+	memset(&h, 0, sizeof(h));
+	h.magic = HGS_MAGIC; h.op = HGS_OP_HELLO; h.a0 = HGS_VERSION;
+	if (hgs::send_msg(t_fd, &h, nullptr, 0, nullptr, 0) != 0 || hgs::recv_exact(t_fd, &r, sizeof(r), nullptr) != 0 ||
+		r.magic != HGS_MAGIC || r.status != HGS_OK || r.len != 0)
+	{
+		drop_connection();
+		return fail(HGS_ERR_IO, "handshake with hnsw_gpu_server at %s failed", path.c_str());
+	}
+	return HGS_OK;
+}
+
+// One request -> one response.  The response header lands in *r, its payload in t_resp.
+int rpc(hgs_hdr *h, const void *p1, size_t l1, const void *p2, size_t l2, int pass_fd, hgs_hdr *r)
+{
+	int rc = ensure_connected();
+	if (rc != HGS_OK) return rc;
+	h->magic = HGS_MAGIC;
+	h->len = (uint32_t) ((p1 ? l1 : 0) + (p2 ? l2 : 0));
+	if (hgs::send_msg(t_fd, h, p1, l1, p2, l2, pass_fd) != 0 || hgs::recv_exact(t_fd, r, sizeof(*r), nullptr) != 0)
+	{
+		drop_connection();
+		return fail(HGS_ERR_IO, "lost the connection to hnsw_gpu_server");
+	}
+	if (r->magic != HGS_MAGIC || r->len > HGS_MAX_PAYLOAD || r->op != h->op)
+	{
+		drop_connection();
+		return fail(HGS_ERR_PROTOCOL, "bad response from hnsw_gpu_server");
+	}
+	t_resp.resize(r->len);
+	if (r->len && hgs::recv_exact(t_fd, t_resp.data(), r->len, nullptr) != 0)
+	{
+		drop_connection();
+		return fail(HGS_ERR_IO, "lost the connection to hnsw_gpu_server");
+	}
+	if (r->status != HGS_OK)
+		return fail(r->status, "hnsw_gpu_server refused request %u: status %d", (unsigned) h->op, (int) r->status);
+	return HGS_OK;
+}
+
+// An anonymous shared-memory file of `bytes` bytes, mapped.  The server maps the same pages.
+struct Shm
+{
+	int fd = -1; void *p = nullptr; size_t bytes = 0;
+	~Shm()
+	{
+		if (p) munmap(p, bytes);
+		if (fd >= 0) close(fd);
+	}
+	bool create(size_t nbytes)
+	{
+		fd = memfd_create("hnsw_gpu_elements", MFD_CLOEXEC);
+		if (fd < 0) return false;
+		if (nbytes == 0) nbytes = 1;
+		if (ftruncate(fd, (off_t) nbytes) != 0) return false;
+		void *m = mmap(nullptr, nbytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+		if (m == MAP_FAILED) return false;
+		p = m; bytes = nbytes;
+		return true;
+	}
+	void release()
+	{
+		if (p) munmap(p, bytes);
+		if (fd >= 0) close(fd);
+		p = nullptr; bytes = 0; fd = -1;
+	}
+	bool grow(size_t nbytes)
+	{
+		if (nbytes <= bytes) return true;
+		size_t nb = bytes;
+		while (nb < nbytes) nb *= 2;
+		if (ftruncate(fd, (off_t) nb) != 0) return false;
+		void *m = mremap(p, bytes, nb, MREMAP_MAYMOVE);
+		if (m == MAP_FAILED) return false;
+		p = m; bytes = nb;
+		return true;
+	}
+};
+
+bool find_attached(HnswMetadata *meta, Attachment *out)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	for (const Attachment &a : g_attached)
+		if (a.meta == meta) { *out = a; return true; }
+	return false;
+}
+
+// Copy every element of the host index into shared memory by the accessor the reference search
+// uses (hnsw_begin_read, embedding.c:704-757), one pin at a time.  Element numbers may have holes at
+// the tail of a page (idx = blk*elems_per_page + off-1, embedding.c:229,693): a miss inside a page
+// skips to the next page, a miss at a page start ends the walk; holes become zero-linked,
+// vacuum-flagged placeholders nothing links to (same walk as hnsw_gpu_shim_snapshot).
+int walk_and_upload(HnswMetadata *meta, uint64_t key, uint64_t gen)
+{
+	const size_t esz = meta->size_data_per_element;
+	const size_t epp = meta->elems_per_page ? meta->elems_per_page : 1;
+	// Per-thread and reused: a host callback that leaves by longjmp (elog(ERROR), embedding.c:715)
+	// must not leak the area — the next walk takes it back.
+	static thread_local Shm shm;
+	shm.release();
+	if (!shm.create((size_t) 1 << 20)) return fail(HGS_ERR_IO, "memfd_create/mmap failed: %s", strerror(errno));
+	size_t n = 0;
+	for (size_t idx = 0; idx < 0xFFFFFFFEull;)
+	{
+		idx_t *links = nullptr;
+		if (hnsw_begin_read(meta, (idx_t) idx, &links, nullptr, nullptr))
+		{
+			if (!shm.grow((idx + 1) * esz)) { hnsw_end_read(meta); return fail(HGS_ERR_IO, "cannot grow the upload area"); }
+			for (size_t hole = n; hole < idx; hole++)
+			{
+				char *p = (char *) shm.p + hole * esz;
+				memset(p, 0, esz);
+				const label_t dead = (label_t) 1 << HNSW_LABEL_DELETED_BIT;
+				memcpy(p + meta->offset_label, &dead, sizeof(dead));
+			}
+			memcpy((char *) shm.p + idx * esz, links, esz);      // the element image is contiguous
+			hnsw_end_read(meta);
+			n = idx + 1;
+			idx++;
+		}
+		else
+		{
+			if (idx % epp == 0) break;
+			idx = (idx / epp + 1) * epp;
+		}
+	}
+	hgs_hdr h, r;
+	memset(&h, 0, sizeof(h));
+	h.op = HGS_OP_UPLOAD; h.key = key; h.gen = gen; h.a0 = n;
+	int rc = rpc(&h, meta, sizeof(*meta), nullptr, 0, n ? shm.fd : -1, &r);
+	shm.release();
+	return rc;
+}
+
+uint64_t ephemeral_key()
+{
+	// high bit set: never collides with a relfilenode-style key; unique per process and call
+	return 0x8000000000000000ull | ((uint64_t) getpid() << 24) | (g_ephemeral++ & 0xFFFFFF);
+}
+
+int simple(uint16_t op, uint64_t key, uint32_t aux, uint64_t a0, uint64_t a1, hgs_hdr *r)
+{
+	hgs_hdr h;
+	memset(&h, 0, sizeof(h));
+	h.op = op; h.key = key; h.aux = aux; h.a0 = a0; h.a1 = a1;
+	return rpc(&h, nullptr, 0, nullptr, 0, -1, r);
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------------
+// additive client calls
+// ---------------------------------------------------------------------------------------
+extern "C" const char *hnsw_gpu_remote_last_error(void) { return t_err; }
+
+extern "C" int hnsw_gpu_remote_connect(const char *socket_path)
+{
+	if (!socket_path || !*socket_path) return fail(HGS_ERR_IO, "empty socket path");
+	{
+		std::lock_guard<std::mutex> lk(g_mu);
+		g_path = socket_path;
+	}
+	drop_connection();
+	return ensure_connected();
+}
+
+extern "C" void hnsw_gpu_remote_disconnect(void) { drop_connection(); }
+
+extern "C" int hnsw_gpu_remote_lookup(uint64_t key, uint64_t *generation, size_t *count, int *present)
+{
+	hgs_hdr r;
+	int rc = simple(HGS_OP_LOOKUP, key, 0, 0, 0, &r);
+	if (rc != HGS_OK) return rc;
+	if (generation) *generation = r.gen;
+	if (count) *count = (size_t) r.a0;
+	if (present) *present = (int) r.a1;
+	return HGS_OK;
+}
+
+extern "C" int hnsw_gpu_remote_upload(const HnswMetadata *meta, uint64_t key, uint64_t generation,
+									  const void *elements, size_t n)
+{
+	if (!meta || (n && !elements)) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	Shm shm;
+	const size_t bytes = n * meta->size_data_per_element;
+	if (n)
+	{
+		if (!shm.create(bytes)) return fail(HGS_ERR_IO, "memfd_create/mmap failed: %s", strerror(errno));
+		memcpy(shm.p, elements, bytes);
+	}
+	hgs_hdr h, r;
+	memset(&h, 0, sizeof(h));
+	h.op = HGS_OP_UPLOAD; h.key = key; h.gen = generation; h.a0 = n;
+	return rpc(&h, meta, sizeof(*meta), nullptr, 0, n ? shm.fd : -1, &r);
+}
+
+extern "C" int hnsw_gpu_remote_update(uint64_t key, uint64_t expected_generation, uint64_t new_generation,
+									  const HnswMetadata *meta, const void *elements, size_t first, size_t count)
+{
+	if (!meta || !elements || count == 0) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	Shm shm;
+	const size_t bytes = count * meta->size_data_per_element;
+	if (!shm.create(bytes)) return fail(HGS_ERR_IO, "memfd_create/mmap failed: %s", strerror(errno));
+	memcpy(shm.p, elements, bytes);
+	hgs_hdr h, r;
+	memset(&h, 0, sizeof(h));
+	h.op = HGS_OP_UPDATE; h.key = key; h.gen = new_generation; h.a0 = first; h.a1 = count;
+	return rpc(&h, &expected_generation, 8, nullptr, 0, shm.fd, &r);
+}
+
+extern "C" int hnsw_gpu_remote_search(uint64_t key, uint64_t generation, const coord_t *query, size_t dim, size_t ef,
+									  label_t *labels, dist_t *dists, size_t *count)
+{
+	if (!query || !labels || !count) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	if (ef == 0 || ef > 0xFFFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "ef out of range");
+	hgs_hdr h, r;
+	memset(&h, 0, sizeof(h));
+	h.op = HGS_OP_SEARCH; h.key = key; h.gen = generation; h.aux = (uint32_t) ef; h.a0 = dists ? 1 : 0;
+	int rc = rpc(&h, query, dim * 4, nullptr, 0, -1, &r);
+	if (rc != HGS_OK) return rc;
+	const size_t cnt = (size_t) r.a0;
+	if (cnt > ef || t_resp.size() != cnt * (dists ? 12 : 8)) return fail(HGS_ERR_PROTOCOL, "bad SEARCH response");
+	memcpy(labels, t_resp.data(), cnt * 8);
+	if (dists) memcpy(dists, t_resp.data() + cnt * 8, cnt * 4);
+	*count = cnt;
+	return HGS_OK;
+}
+
+extern "C" int hnsw_gpu_remote_link(uint64_t key, size_t first, size_t count, size_t max_batch)
+{
+	hgs_hdr r;
+	return simple(HGS_OP_LINK, key, (uint32_t) max_batch, first, count, &r);
+}
+
+extern "C" int hnsw_gpu_remote_export(uint64_t key, void *elements, size_t bytes)
+{
+	if (!elements) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	Shm shm;
+	if (!shm.create(bytes)) return fail(HGS_ERR_IO, "memfd_create/mmap failed: %s", strerror(errno));
+	hgs_hdr h, r;
+	memset(&h, 0, sizeof(h));
+	h.op = HGS_OP_EXPORT; h.key = key;
+	int rc = rpc(&h, nullptr, 0, nullptr, 0, shm.fd, &r);
+	if (rc != HGS_OK) return rc;
+	memcpy(elements, shm.p, bytes);
+	return HGS_OK;
+}
+
+extern "C" int hnsw_gpu_remote_set_deleted(uint64_t key, idx_t idx, int deleted)
+{
+	hgs_hdr r;
+	return simple(HGS_OP_SET_DELETED, key, idx, deleted ? 1 : 0, 0, &r);
+}
+
+extern "C" int hnsw_gpu_remote_drop(uint64_t key)
+{
+	hgs_hdr r;
+	return simple(HGS_OP_DROP, key, 0, 0, 0, &r);
+}
+
+extern "C" int hnsw_gpu_remote_stats(hgs_stats *out)
+{
+	if (!out) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	hgs_hdr r;
+	int rc = simple(HGS_OP_STATS, 0, 0, 0, 0, &r);
+	if (rc != HGS_OK) return rc;
+	if (t_resp.size() != sizeof(*out)) return fail(HGS_ERR_PROTOCOL, "bad STATS response");
+	memcpy(out, t_resp.data(), sizeof(*out));
+	return HGS_OK;
+}
+
+extern "C" int hnsw_gpu_remote_attach(HnswMetadata *meta, uint64_t key, uint64_t generation)
+{
+	if (!meta) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	uint64_t have_gen = 0;
+	int present = 0;
+	int rc = hnsw_gpu_remote_lookup(key, &have_gen, nullptr, &present);
+	if (rc != HGS_OK) return rc;
+	if (!present || have_gen != generation)
+	{
+		rc = walk_and_upload(meta, key, generation);
+		if (rc != HGS_OK) return rc;
+	}
+	std::lock_guard<std::mutex> lk(g_mu);
+	for (Attachment &a : g_attached)
+		if (a.meta == meta) { a.key = key; a.gen = generation; return HGS_OK; }
+	g_attached.push_back(Attachment{ meta, key, generation });
+	return HGS_OK;
+}
+
+extern "C" int hnsw_gpu_remote_detach(HnswMetadata *meta)
+{
+	std::lock_guard<std::mutex> lk(g_mu);
+	for (size_t i = 0; i < g_attached.size(); i++)
+		if (g_attached[i].meta == meta)
+		{
+			g_attached[i] = g_attached.back();
+			g_attached.pop_back();
+			return HGS_OK;
+		}
+	return fail(HNSW_GPU_ERR_ARG, "meta is not attached");
+}
+
+// ---------------------------------------------------------------------------------------
+// the drop-in symbols
+// ---------------------------------------------------------------------------------------
+extern "C" void hnsw_init_dist_func(void)
+{
+	// _PG_init (embedding.c:150) may run in the postmaster: remember the path, connect lazily in
+	// the backend that searches.
+	std::lock_guard<std::mutex> lk(g_mu);
+	const char *env = getenv("PG_EMBEDDING_GPU_SERVER");
+	if (g_path.empty() && env && *env) g_path = env;
+}
+
+extern "C" dist_t hnsw_dist_func(dist_func_t dist, coord_t const *ax, coord_t const *bx, size_t dim)
+{
+	hgs_hdr h, r;
+	memset(&h, 0, sizeof(h));
+	h.op = HGS_OP_DIST; h.aux = (uint32_t) dist; h.a0 = dim;
+	if (!ax || !bx || dim == 0 || rpc(&h, ax, dim * 4, bx, dim * 4, -1, &r) != HGS_OK || t_resp.size() != sizeof(dist_t))
+	{
+		fprintf(stderr, "pg_embedding_amd: hnsw_dist_func failed: %s\n", t_err);
+		return NAN;
+	}
+	dist_t out;
+	memcpy(&out, t_resp.data(), sizeof(out));
+	return out;
+}
+
+extern "C" bool hnsw_search(HnswMetadata *meta, const coord_t *point, size_t *n_results, label_t **results)
+{
+	if (!meta || !point || !n_results || !results) return false;
+	const size_t ef = meta->efSearch;
+	Attachment at;
+	bool own = false;
+	if (!find_attached(meta, &at))
+	{
+		// No identity for this index (HnswMetadata has none, embedding.c:254): mirror it under a
+		// throw-away key for this one call — always correct, O(N) per call, like the in-process shim.
+		at.meta = meta; at.key = ephemeral_key(); at.gen = 1;
+		if (walk_and_upload(meta, at.key, at.gen) != HGS_OK)
+		{
+			fprintf(stderr, "pg_embedding_amd: hnsw_search: cannot mirror the index: %s\n", t_err);
+			return false;
+		}
+		own = true;
+	}
+	label_t *buf = (label_t *) malloc(ef ? ef * sizeof(label_t) : 1);        // caller frees (embedding.c:327)
+	bool ok = buf != nullptr;
+	size_t cnt = 0;
+	if (ok && ef > 0)                    // ef = 0: searchKnn trims to zero results (hnswalg.cpp:238-240)
+	{
+		ok = hnsw_gpu_remote_search(at.key, own ? 0 : at.gen, point, meta->dim, ef, buf, nullptr, &cnt) == HGS_OK;
+		if (!ok) fprintf(stderr, "pg_embedding_amd: hnsw_search failed: %s\n", t_err);
+	}
+	if (own) (void) hnsw_gpu_remote_drop(at.key);
+	if (!ok) { free(buf); return false; }
+	*n_results = cnt;
+	*results = buf;
+	return true;
+}
+
+// hnsw_bind_point (hnswalg.cpp:279-291).  The host has already stored element `idx` zero-linked
+// (embedding.c:619-621,670).  The server appends it to its mirror if the mirror is one element
+// behind, runs the reference's insert in serial form and returns the changed link lists, which go
+// back to the host's pages through hnsw_begin_write/hnsw_end_write: the touched neighbours first,
+// then the new element (hnswalg.cpp:169-222), one write pin at a time (embedding.c:780-781).
+extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t idx)
+{
+	if (!meta || !point) return false;
+	Attachment at;
+	bool own = false;
+	if (!find_attached(meta, &at))
+	{
+		if (idx == 0) return true;                               // bindPoint links nothing, hnswalg.cpp:228
+		at.meta = meta; at.key = ephemeral_key(); at.gen = 1;
+		if (walk_and_upload(meta, at.key, at.gen) != HGS_OK)
+		{
+			fprintf(stderr, "pg_embedding_amd: hnsw_bind_point: cannot mirror the index: %s\n", t_err);
+			return false;
+		}
+		own = true;
+	}
+	bool ok = false;
+	do
+	{
+		label_t label = 0;
+		if (!hnsw_begin_read(meta, idx, nullptr, nullptr, &label)) { fail(HNSW_GPU_ERR_ARG, "element %u is not stored", (unsigned) idx); break; }
+		hnsw_end_read(meta);
+		hgs_hdr h, r;
+		memset(&h, 0, sizeof(h));
+		h.op = HGS_OP_BIND; h.key = at.key; h.gen = 0; h.aux = idx; h.a0 = label;
+		if (rpc(&h, point, meta->dim * 4, nullptr, 0, -1, &r) != HGS_OK) break;
+		const size_t rec = 1 + meta->maxM + 1;                   // [idx][count][links * maxM]
+		if (t_resp.size() < 4) { fail(HGS_ERR_PROTOCOL, "bad BIND response"); break; }
+		uint32_t nrec;
+		memcpy(&nrec, t_resp.data(), 4);
+		if (t_resp.size() != 4 + (size_t) nrec * rec * 4) { fail(HGS_ERR_PROTOCOL, "bad BIND response"); break; }
+		// copy out first: a host callback may longjmp (elog(ERROR)) and t_resp is reused by the next call
+		std::vector<uint32_t> recs((size_t) nrec * rec);
+		memcpy(recs.data(), t_resp.data() + 4, recs.size() * 4);
+		for (uint32_t i = 0; i < nrec; i++)
+		{
+			const uint32_t *p = recs.data() + (size_t) i * rec;
+			idx_t *dst = nullptr;
+			hnsw_begin_write(meta, p[0], &dst, nullptr, nullptr);
+			memcpy(dst, p + 1, (meta->maxM + 1) * sizeof(idx_t));
+			hnsw_end_write(meta);
+		}
+		ok = true;
+	} while (0);
+	if (!ok) fprintf(stderr, "pg_embedding_amd: hnsw_bind_point(%u) failed: %s\n", (unsigned) idx, t_err);
+	if (own) (void) hnsw_gpu_remote_drop(at.key);
+	return ok;
+}

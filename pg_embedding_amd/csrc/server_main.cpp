@@ -1,0 +1,874 @@
+// server_main.cpp — hnsw_gpu_server: the GPU-owning process behind libembedding_gpuc.so
+// (include/hnsw_gpu_server.h has the why and the wire format).
+//
+//   readers      epoll threads: parse requests; answer the trivial ones; SEARCH goes to the batch
+//                queue, everything that changes a mirror goes to the control thread
+//   dispatchers  (default 2) take every queued SEARCH for one (mirror, ef) — up to --max-batch —
+//                pack the queries into a pinned buffer and run ONE hnsw_gpu_search_batch_ctx_host
+//                (own context = own visited-set workspace and HIP stream per dispatcher, so the
+//                next batch fills the CUs the previous one frees while it drains), then answer
+//                each backend.  Requests gather while the device is busy: no artificial delay
+//                unless --linger-us is given.
+//   control      one thread: UPLOAD / UPDATE / BIND / LINK / EXPORT / DROP / SET_DELETED / DIST.
+//                Mirror changes take the mirror's write lock (writer-preferring), searches its
+//                read lock.
+//
+// All device work goes through the C API of libhnsw_gpu.so (hnsw_gpu.h); this file has no HIP in
+// it and no arithmetic.  No device, no service: exit status 3.
+#include <atomic>
+#include <cerrno>
+#include <chrono>
+#include <condition_variable>
+#include <csignal>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <unordered_map>
+#include <vector>
+
+#include <fcntl.h>
+#include <pthread.h>
+#include <sys/epoll.h>
+#include <sys/eventfd.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <sys/un.h>
+
+#include "hgs_io.h"
+#include "hnsw_gpu.h"
+
+namespace {
+
+// ----------------------------------------------------------------------------- options / globals
+struct Options
+{
+	std::string path;
+	int device = 0;
+	int readers = 4;
+	int dispatchers = 2;
+	size_t max_batch = 16384;
+	long linger_us = 0;
+	size_t min_batch = 1;          // with --linger-us: wait while fewer requests than this are queued
+	int backlog = 1024;
+	bool verbose = false;
+	int ready_fd = -1;
+} g_opt;
+
+std::atomic<bool> g_stop{false};
+int g_wake_fd = -1;                // eventfd: wakes every epoll loop at shutdown
+std::chrono::steady_clock::time_point g_t0;
+
+struct Counters
+{
+	std::atomic<uint64_t> connections{0}, connections_now{0}, searches{0}, batches{0}, max_batch{0},
+		search_errors{0}, uploads{0}, upload_bytes{0}, updates{0}, binds{0}, evictions{0}, batch_ns{0};
+} g_cnt;
+
+uint64_t now_ns()
+{
+	return (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(
+		std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+void logf(const char *fmt, ...)
+{
+	va_list ap;
+	va_start(ap, fmt);
+	fprintf(stderr, "hnsw_gpu_server: ");
+	vfprintf(stderr, fmt, ap);
+	fputc('\n', stderr);
+	va_end(ap);
+}
+#define VLOG(...) do { if (g_opt.verbose) logf(__VA_ARGS__); } while (0)
+
+// ----------------------------------------------------------------------------- mirrors
+struct Entry
+{
+	uint64_t key = 0;
+	std::atomic<uint64_t> gen{0};
+	HnswMetadata meta;
+	hnsw_gpu_index *ix = nullptr;
+	pthread_rwlock_t rw;                         // searches: read; BIND/UPDATE/LINK/...: write
+	std::mutex cmu;
+	std::vector<hnsw_gpu_ctx *> ctx;             // one per dispatcher, made on first use
+	std::atomic<uint64_t> last_used{0};
+	std::atomic<size_t> count{0};
+
+	Entry()
+	{
+		pthread_rwlockattr_t a;
+		pthread_rwlockattr_init(&a);
+		pthread_rwlockattr_setkind_np(&a, PTHREAD_RWLOCK_PREFER_WRITER_NONRECURSIVE_NP);
+		pthread_rwlock_init(&rw, &a);
+		pthread_rwlockattr_destroy(&a);
+		memset(&meta, 0, sizeof(meta));
+	}
+	~Entry()
+	{
+		for (hnsw_gpu_ctx *c : ctx) if (c) hnsw_gpu_ctx_destroy(c);
+		if (ix) hnsw_gpu_index_destroy(ix);
+		pthread_rwlock_destroy(&rw);
+	}
+	hnsw_gpu_ctx *context(int d)
+	{
+		std::lock_guard<std::mutex> lk(cmu);
+		if (ctx.size() <= (size_t) d) ctx.resize((size_t) d + 1, nullptr);
+		if (!ctx[d] && hnsw_gpu_ctx_create(ix, &ctx[d]) != HNSW_GPU_OK) ctx[d] = nullptr;
+		return ctx[d];
+	}
+};
+using EntryP = std::shared_ptr<Entry>;
+
+std::mutex g_map_mu;
+std::unordered_map<uint64_t, EntryP> g_map;
+
+EntryP find_entry(uint64_t key)
+{
+	std::lock_guard<std::mutex> lk(g_map_mu);
+	auto it = g_map.find(key);
+	return it == g_map.end() ? EntryP() : it->second;
+}
+
+// Drop the least recently used mirror nobody else holds (not `keep`).  True if one was dropped.
+bool evict_one(uint64_t keep)
+{
+	EntryP victim;
+	{
+		std::lock_guard<std::mutex> lk(g_map_mu);
+		uint64_t best = ~0ull;
+		for (auto &kv : g_map)
+			if (kv.first != keep && kv.second.use_count() == 1 && kv.second->last_used.load() < best)
+			{
+				best = kv.second->last_used.load();
+				victim = kv.second;
+			}
+		if (victim) g_map.erase(victim->key);
+	}
+	if (!victim) return false;
+	logf("evicting mirror %llx (%zu elements) to make room", (unsigned long long) victim->key, victim->count.load());
+	g_cnt.evictions++;
+	return true;        // freed when `victim` goes out of scope here
+}
+
+// ----------------------------------------------------------------------------- connections
+struct Conn
+{
+	int fd = -1;
+	std::vector<char> in;
+	std::deque<int> fds;          // descriptors received and not yet claimed by a request
+	std::mutex wmu;
+	std::atomic<bool> closed{false};
+	~Conn()
+	{
+		for (int f : fds) close(f);
+		if (fd >= 0) close(fd);
+	}
+	void respond(const hgs_hdr &req, int status, uint64_t a0 = 0, uint64_t a1 = 0, const void *p1 = nullptr,
+				 size_t l1 = 0, const void *p2 = nullptr, size_t l2 = 0, uint64_t gen = 0)
+	{
+		if (closed.load()) return;
+		hgs_hdr h;
+		memset(&h, 0, sizeof(h));
+		h.magic = HGS_MAGIC; h.op = req.op; h.status = (int16_t) status;
+		h.len = (uint32_t) ((p1 ? l1 : 0) + (p2 ? l2 : 0));
+		h.key = req.key; h.gen = gen ? gen : req.gen; h.a0 = a0; h.a1 = a1;
+		std::lock_guard<std::mutex> lk(wmu);
+		if (hgs::send_msg(fd, &h, p1, l1, p2, l2) != 0) closed.store(true);
+	}
+};
+using ConnP = std::shared_ptr<Conn>;
+
+// ----------------------------------------------------------------------------- queues
+struct SReq            // one backend's hnsw_search
+{
+	ConnP c;
+	EntryP e;
+	hgs_hdr h;
+	std::vector<float> q;
+};
+std::mutex g_q_mu;
+std::condition_variable g_q_cv;
+std::deque<SReq> g_q;
+
+struct CReq            // a control request
+{
+	ConnP c;
+	hgs_hdr h;
+	std::vector<char> payload;
+	int fd = -1;
+};
+std::mutex g_c_mu;
+std::condition_variable g_c_cv;
+std::deque<CReq> g_c;
+
+// ----------------------------------------------------------------------------- dispatchers
+struct Pinned
+{
+	void *p = nullptr; size_t bytes = 0;
+	~Pinned() { if (p) hnsw_gpu_host_free(p); }
+	bool reserve(size_t want)
+	{
+		if (want <= bytes) return true;
+		if (p) hnsw_gpu_host_free(p);
+		p = nullptr; bytes = 0;
+		size_t nb = (size_t) 1 << 20;
+		while (nb < want) nb *= 2;
+		p = hnsw_gpu_host_alloc(nb);
+		if (!p) return false;
+		bytes = nb;
+		return true;
+	}
+};
+
+void run_batch(int d, std::vector<SReq> &batch, Pinned &pin)
+{
+	Entry *e = batch[0].e.get();
+	const size_t nq = batch.size(), ef = batch[0].h.aux, dim = e->meta.dim;
+	const size_t qb = (nq * dim * 4 + 255) & ~(size_t) 255, lb = (nq * ef * 8 + 255) & ~(size_t) 255,
+				 db = (nq * ef * 4 + 255) & ~(size_t) 255, cb = nq * 4;
+	int rc = HNSW_GPU_OK;
+	if (!pin.reserve(qb + lb + db + cb)) rc = HNSW_GPU_ERR_NOMEM;
+	char *base = (char *) pin.p;
+	float *Q = (float *) base;
+	label_t *L = (label_t *) (base + qb);
+	dist_t *D = (dist_t *) (base + qb + lb);
+	uint32_t *C = (uint32_t *) (base + qb + lb + db);
+	const uint64_t t0 = now_ns();
+	if (rc == HNSW_GPU_OK)
+	{
+		for (size_t i = 0; i < nq; i++) memcpy(Q + i * dim, batch[i].q.data(), dim * 4);
+		pthread_rwlock_rdlock(&e->rw);
+		hnsw_gpu_ctx *ctx = e->context(d);
+		if (!ctx) rc = HNSW_GPU_ERR_HIP;
+		else rc = hnsw_gpu_search_batch_ctx_host(ctx, Q, nq, ef, L, D, C);
+		pthread_rwlock_unlock(&e->rw);
+		if (rc != HNSW_GPU_OK) logf("search batch of %zu (ef %zu) failed: %s", nq, ef, hnsw_gpu_last_error());
+	}
+	e->last_used.store(now_ns());
+	g_cnt.batch_ns += now_ns() - t0;
+	g_cnt.batches++;
+	g_cnt.searches += nq;
+	uint64_t mb = g_cnt.max_batch.load();
+	while (nq > mb && !g_cnt.max_batch.compare_exchange_weak(mb, nq)) {}
+	if (rc != HNSW_GPU_OK) g_cnt.search_errors += nq;
+	for (size_t i = 0; i < nq; i++)
+	{
+		SReq &r = batch[i];
+		if (rc != HNSW_GPU_OK) { r.c->respond(r.h, rc); continue; }
+		const size_t cnt = C[i];
+		r.c->respond(r.h, HGS_OK, cnt, 0, L + i * ef, cnt * 8, r.h.a0 ? D + i * ef : nullptr, cnt * 4, e->gen.load());
+	}
+}
+
+void dispatcher_main(int d)
+{
+	Pinned pin;
+	std::vector<SReq> batch;
+	while (true)
+	{
+		batch.clear();
+		{
+			std::unique_lock<std::mutex> lk(g_q_mu);
+			g_q_cv.wait(lk, [] { return g_stop.load() || !g_q.empty(); });
+			if (g_stop.load()) break;
+			if (g_opt.linger_us > 0 && g_q.size() < g_opt.min_batch)
+				g_q_cv.wait_for(lk, std::chrono::microseconds(g_opt.linger_us),
+								[] { return g_stop.load() || g_q.size() >= g_opt.min_batch; });
+			if (g_q.empty()) continue;
+			Entry *e = g_q.front().e.get();
+			const uint32_t ef = g_q.front().h.aux;
+			for (auto it = g_q.begin(); it != g_q.end() && batch.size() < g_opt.max_batch;)
+			{
+				if (it->e.get() == e && it->h.aux == ef) { batch.push_back(std::move(*it)); it = g_q.erase(it); }
+				else ++it;
+			}
+		}
+		run_batch(d, batch, pin);
+	}
+	// answer what is still queued
+	std::lock_guard<std::mutex> lk(g_q_mu);
+	for (SReq &r : g_q) r.c->respond(r.h, HGS_ERR_SHUTDOWN);
+	g_q.clear();
+}
+
+// ----------------------------------------------------------------------------- control thread
+struct Mapping            // a received memfd, mapped
+{
+	void *p = nullptr; size_t bytes = 0; int fd = -1;
+	~Mapping()
+	{
+		if (p) munmap(p, bytes);
+		if (fd >= 0) close(fd);
+	}
+	bool map(int f, bool writable)
+	{
+		fd = f;
+		struct stat st;
+		if (f < 0 || fstat(f, &st) != 0 || st.st_size <= 0) return false;
+		void *m = mmap(nullptr, (size_t) st.st_size, writable ? PROT_READ | PROT_WRITE : PROT_READ, MAP_SHARED, f, 0);
+		if (m == MAP_FAILED) return false;
+		p = m; bytes = (size_t) st.st_size;
+		return true;
+	}
+};
+
+bool meta_sane(const HnswMetadata &m)
+{
+	if (m.dim == 0 || m.dim > (1u << 20) || m.maxM == 0 || m.maxM > 4096) return false;
+	if (m.offset_data != (m.maxM + 1) * 4 || m.offset_label != m.offset_data + m.dim * 4) return false;
+	if (m.size_data_per_element != m.offset_label + 8) return false;            // embedding.c:225-228
+	if ((unsigned) m.dist_func > 2) return false;
+	return true;
+}
+
+void do_upload(CReq &r)
+{
+	HnswMetadata meta;
+	if (r.payload.size() != sizeof(meta)) { r.c->respond(r.h, HGS_ERR_PROTOCOL); return; }
+	memcpy(&meta, r.payload.data(), sizeof(meta));
+	const size_t n = (size_t) r.h.a0;
+	if (!meta_sane(meta) || n > 0xFFFFFFFEull) { r.c->respond(r.h, HNSW_GPU_ERR_ARG); return; }
+	Mapping m;
+	const void *elements = nullptr;
+	if (n > 0)
+	{
+		int fd = r.fd; r.fd = -1;
+		if (!m.map(fd, false) || m.bytes / meta.size_data_per_element < n) { r.c->respond(r.h, HGS_ERR_PROTOCOL); return; }
+		elements = m.p;
+	}
+	EntryP e = std::make_shared<Entry>();
+	e->key = r.h.key; e->gen.store(r.h.gen); e->meta = meta;
+	int rc;
+	bool dropped_own = false;
+	while (true)
+	{
+		rc = hnsw_gpu_index_create_from_flat(&meta, elements, n, g_opt.device, &e->ix);
+		if (rc == HNSW_GPU_OK || (rc != HNSW_GPU_ERR_HIP && rc != HNSW_GPU_ERR_NOMEM)) break;
+		// out of device memory?  first the generation this upload replaces, then idle mirrors, LRU first
+		if (!dropped_own)
+		{
+			dropped_own = true;
+			bool had;
+			{
+				std::lock_guard<std::mutex> lk(g_map_mu);
+				had = g_map.erase(r.h.key) > 0;
+			}
+			if (had) continue;
+		}
+		if (!evict_one(r.h.key)) break;
+	}
+	if (rc != HNSW_GPU_OK)
+	{
+		logf("upload of key %llx (%zu elements) failed: %s", (unsigned long long) r.h.key, n, hnsw_gpu_last_error());
+		r.c->respond(r.h, rc);
+		return;
+	}
+	e->count.store(n);
+	e->last_used.store(now_ns());
+	{
+		std::lock_guard<std::mutex> lk(g_map_mu);
+		g_map[r.h.key] = e;          // an older generation is freed when its last batch lets go
+	}
+	g_cnt.uploads++;
+	g_cnt.upload_bytes += n * meta.size_data_per_element;
+	VLOG("mirror %llx gen %llu: %zu elements x %zu dims", (unsigned long long) r.h.key, (unsigned long long) r.h.gen, n,
+		 (size_t) meta.dim);
+	r.c->respond(r.h, HGS_OK, n);
+}
+
+struct WriteLock
+{
+	Entry *e;
+	explicit WriteLock(Entry *e_) : e(e_) { pthread_rwlock_wrlock(&e->rw); }
+	~WriteLock() { pthread_rwlock_unlock(&e->rw); }
+};
+
+void do_update(CReq &r)
+{
+	EntryP e = find_entry(r.h.key);
+	if (!e) { r.c->respond(r.h, HGS_ERR_NOKEY); return; }
+	uint64_t expect = 0;
+	if (r.payload.size() != 8) { r.c->respond(r.h, HGS_ERR_PROTOCOL); return; }
+	memcpy(&expect, r.payload.data(), 8);
+	if (expect != e->gen.load()) { r.c->respond(r.h, HGS_ERR_STALE, 0, 0, nullptr, 0, nullptr, 0, e->gen.load()); return; }
+	const size_t first = (size_t) r.h.a0, count = (size_t) r.h.a1, esz = e->meta.size_data_per_element;
+	Mapping m;
+	int fd = r.fd; r.fd = -1;
+	if (count == 0 || !m.map(fd, false) || m.bytes / esz < count) { r.c->respond(r.h, HGS_ERR_PROTOCOL); return; }
+	int rc;
+	{
+		WriteLock wl(e.get());
+		rc = hnsw_gpu_index_update_from_flat(e->ix, m.p, first, count);
+		if (rc == HNSW_GPU_OK) { e->count.store(hnsw_gpu_index_count(e->ix)); e->gen.store(r.h.gen); }
+	}
+	if (rc != HNSW_GPU_OK) logf("update of key %llx failed: %s", (unsigned long long) r.h.key, hnsw_gpu_last_error());
+	g_cnt.updates++;
+	r.c->respond(r.h, rc, e->count.load());
+}
+
+// hnsw_bind_point on the server's mirror: same steps as the in-process shim (embedding_shim.cpp).
+void do_bind(CReq &r)
+{
+	EntryP e = find_entry(r.h.key);
+	if (!e) { r.c->respond(r.h, HGS_ERR_NOKEY); return; }
+	if (r.h.gen && r.h.gen != e->gen.load()) { r.c->respond(r.h, HGS_ERR_STALE, 0, 0, nullptr, 0, nullptr, 0, e->gen.load()); return; }
+	const size_t dim = e->meta.dim, maxM = e->meta.maxM;
+	const idx_t idx = r.h.aux;
+	if (r.payload.size() != dim * 4) { r.c->respond(r.h, HGS_ERR_PROTOCOL); return; }
+	const coord_t *point = (const coord_t *) r.payload.data();
+	std::vector<uint32_t> out;
+	int rc = HNSW_GPU_OK;
+	{
+		WriteLock wl(e.get());
+		size_t have = hnsw_gpu_index_count(e->ix);
+		if (have < (size_t) idx)              // page-tail holes (embedding.c:229,693): dead placeholders
+		{
+			const size_t gap = (size_t) idx - have;
+			std::vector<coord_t> zeros(gap * dim, 0.f);
+			std::vector<label_t> dead(gap, (label_t) 1 << HNSW_LABEL_DELETED_BIT);
+			rc = hnsw_gpu_index_reserve(e->ix, (size_t) idx + 1 + (size_t) idx / 2);
+			if (rc == HNSW_GPU_OK) rc = hnsw_gpu_index_append(e->ix, zeros.data(), dead.data(), gap);
+			have = (size_t) idx;
+		}
+		if (rc == HNSW_GPU_OK && have == (size_t) idx)
+		{
+			label_t label = (label_t) r.h.a0;
+			rc = hnsw_gpu_index_reserve(e->ix, (size_t) idx + 1 + (size_t) idx / 2);
+			if (rc == HNSW_GPU_OK) rc = hnsw_gpu_index_append(e->ix, point, &label, 1);
+		}
+		else if (rc == HNSW_GPU_OK && have != (size_t) idx + 1)
+			rc = HNSW_GPU_ERR_ARG;
+		out.push_back(0);
+		if (rc == HNSW_GPU_OK && idx != 0)       // bindPoint: nothing to do for the first element, hnswalg.cpp:228
+		{
+			std::vector<idx_t> mine(maxM + 1), other(maxM + 1);
+			rc = hnsw_gpu_index_link(e->ix, idx, 1, 1, 0, nullptr);
+			if (rc == HNSW_GPU_OK) rc = hnsw_gpu_index_get_links(e->ix, idx, mine.data());
+			for (uint32_t j = 0; rc == HNSW_GPU_OK && j < mine[0]; j++)
+			{
+				rc = hnsw_gpu_index_get_links(e->ix, mine[1 + j], other.data());
+				out.push_back(mine[1 + j]);
+				out.insert(out.end(), other.begin(), other.end());
+				out[0]++;
+			}
+			out.push_back(idx);
+			out.insert(out.end(), mine.begin(), mine.end());
+			out[0]++;
+		}
+		e->count.store(hnsw_gpu_index_count(e->ix));
+		if (rc == HNSW_GPU_OK && r.h.a1) e->gen.store(r.h.a1);
+	}
+	g_cnt.binds++;
+	if (rc != HNSW_GPU_OK)
+	{
+		logf("bind of element %u into key %llx failed: %s", (unsigned) idx, (unsigned long long) r.h.key, hnsw_gpu_last_error());
+		r.c->respond(r.h, rc);
+		return;
+	}
+	r.c->respond(r.h, HGS_OK, e->count.load(), 0, out.data(), out.size() * 4, nullptr, 0, e->gen.load());
+}
+
+void do_control(CReq &r)
+{
+	switch (r.h.op)
+	{
+	case HGS_OP_UPLOAD: do_upload(r); break;
+	case HGS_OP_UPDATE: do_update(r); break;
+	case HGS_OP_BIND:   do_bind(r); break;
+	case HGS_OP_DROP:
+	{
+		EntryP e;
+		{
+			std::lock_guard<std::mutex> lk(g_map_mu);
+			auto it = g_map.find(r.h.key);
+			if (it != g_map.end()) { e = it->second; g_map.erase(it); }
+		}
+		r.c->respond(r.h, e ? HGS_OK : HGS_ERR_NOKEY);
+		break;
+	}
+	case HGS_OP_LINK:
+	{
+		EntryP e = find_entry(r.h.key);
+		if (!e) { r.c->respond(r.h, HGS_ERR_NOKEY); break; }
+		int rc;
+		{
+			WriteLock wl(e.get());
+			rc = hnsw_gpu_index_link(e->ix, (size_t) r.h.a0, (size_t) r.h.a1, r.h.aux, 0, nullptr);
+			idx_t probe[4097];
+			if (rc == HNSW_GPU_OK && hnsw_gpu_index_count(e->ix) > 0)
+				rc = hnsw_gpu_index_get_links(e->ix, 0, probe);          // waits for the build
+		}
+		if (rc != HNSW_GPU_OK) logf("link failed: %s", hnsw_gpu_last_error());
+		r.c->respond(r.h, rc);
+		break;
+	}
+	case HGS_OP_EXPORT:
+	{
+		EntryP e = find_entry(r.h.key);
+		int fd = r.fd; r.fd = -1;
+		Mapping m;
+		if (!e) { if (fd >= 0) close(fd); r.c->respond(r.h, HGS_ERR_NOKEY); break; }
+		const size_t need = e->count.load() * e->meta.size_data_per_element;
+		if (need == 0) { if (fd >= 0) close(fd); r.c->respond(r.h, HGS_OK, 0); break; }
+		if (!m.map(fd, true) || m.bytes < need) { r.c->respond(r.h, HGS_ERR_PROTOCOL); break; }
+		int rc;
+		{
+			WriteLock wl(e.get());
+			rc = hnsw_gpu_index_export_flat(e->ix, m.p);
+		}
+		r.c->respond(r.h, rc, e->count.load());
+		break;
+	}
+	case HGS_OP_SET_DELETED:
+	{
+		EntryP e = find_entry(r.h.key);
+		if (!e) { r.c->respond(r.h, HGS_ERR_NOKEY); break; }
+		int rc;
+		{
+			WriteLock wl(e.get());
+			rc = hnsw_gpu_index_set_deleted(e->ix, r.h.aux, r.h.a0 ? 1 : 0);
+		}
+		r.c->respond(r.h, rc);
+		break;
+	}
+	case HGS_OP_DIST:
+	{
+		const size_t dim = (size_t) r.h.a0;
+		if (dim == 0 || r.payload.size() != 2 * dim * 4 || r.h.aux > 2) { r.c->respond(r.h, HGS_ERR_PROTOCOL); break; }
+		const coord_t *a = (const coord_t *) r.payload.data();
+		dist_t out = 0;
+		int rc = hnsw_gpu_dist_batch((dist_func_t) r.h.aux, a, a + dim, 1, dim, &out);
+		r.c->respond(r.h, rc, 0, 0, &out, sizeof(out));
+		break;
+	}
+	default:
+		r.c->respond(r.h, HGS_ERR_PROTOCOL);
+	}
+	if (r.fd >= 0) { close(r.fd); r.fd = -1; }
+}
+
+void control_main()
+{
+	while (true)
+	{
+		CReq r;
+		{
+			std::unique_lock<std::mutex> lk(g_c_mu);
+			g_c_cv.wait(lk, [] { return g_stop.load() || !g_c.empty(); });
+			if (g_stop.load()) break;
+			r = std::move(g_c.front());
+			g_c.pop_front();
+		}
+		do_control(r);
+	}
+	std::lock_guard<std::mutex> lk(g_c_mu);
+	for (CReq &r : g_c)
+	{
+		if (r.fd >= 0) close(r.fd);
+		r.c->respond(r.h, HGS_ERR_SHUTDOWN);
+	}
+	g_c.clear();
+}
+
+// ----------------------------------------------------------------------------- readers
+void fill_stats(hgs_stats *s)
+{
+	memset(s, 0, sizeof(*s));
+	s->connections = g_cnt.connections; s->connections_now = g_cnt.connections_now;
+	s->searches = g_cnt.searches; s->batches = g_cnt.batches; s->max_batch = g_cnt.max_batch;
+	s->search_errors = g_cnt.search_errors;
+	s->uploads = g_cnt.uploads; s->upload_bytes = g_cnt.upload_bytes; s->updates = g_cnt.updates;
+	s->binds = g_cnt.binds; s->evictions = g_cnt.evictions; s->batch_ns = g_cnt.batch_ns;
+	{
+		std::lock_guard<std::mutex> lk(g_map_mu);
+		s->mirrors = g_map.size();
+		for (auto &kv : g_map) s->mirror_elements += kv.second->count.load();
+	}
+	s->uptime_ns = (uint64_t) std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - g_t0).count();
+}
+
+bool needs_fd(uint16_t op, const hgs_hdr &h)
+{
+	return (op == HGS_OP_UPLOAD && h.a0 > 0) || op == HGS_OP_UPDATE || op == HGS_OP_EXPORT;
+}
+
+// One complete request.  False = protocol violation, drop the connection.
+bool handle_message(const ConnP &c, const hgs_hdr &h, const char *payload)
+{
+	switch (h.op)
+	{
+	case HGS_OP_HELLO:
+		if (h.a0 != HGS_VERSION) { c->respond(h, HGS_ERR_PROTOCOL, HGS_VERSION); return false; }
+		c->respond(h, HGS_OK, HGS_VERSION, (uint64_t) hnsw_gpu_device_count());
+		return true;
+	case HGS_OP_LOOKUP:
+	{
+		EntryP e = find_entry(h.key);
+		if (e) c->respond(h, HGS_OK, e->count.load(), 1, nullptr, 0, nullptr, 0, e->gen.load());
+		else c->respond(h, HGS_OK, 0, 0);
+		return true;
+	}
+	case HGS_OP_STATS:
+	{
+		hgs_stats s;
+		fill_stats(&s);
+		c->respond(h, HGS_OK, 0, 0, &s, sizeof(s));
+		return true;
+	}
+	case HGS_OP_SEARCH:
+	{
+		EntryP e = find_entry(h.key);
+		if (!e) { c->respond(h, HGS_ERR_NOKEY); return true; }
+		const uint64_t gen = e->gen.load();
+		if (h.gen && h.gen != gen) { c->respond(h, HGS_ERR_STALE, 0, 0, nullptr, 0, nullptr, 0, gen); return true; }
+		if (h.len != e->meta.dim * 4 || h.aux == 0) { c->respond(h, HNSW_GPU_ERR_ARG); return true; }
+		SReq r;
+		r.c = c; r.e = std::move(e); r.h = h;
+		r.q.resize(h.len / 4);
+		memcpy(r.q.data(), payload, h.len);
+		{
+			std::lock_guard<std::mutex> lk(g_q_mu);
+			g_q.push_back(std::move(r));
+		}
+		g_q_cv.notify_one();
+		return true;
+	}
+	case HGS_OP_UPLOAD: case HGS_OP_UPDATE: case HGS_OP_BIND: case HGS_OP_DROP: case HGS_OP_LINK:
+	case HGS_OP_EXPORT: case HGS_OP_SET_DELETED: case HGS_OP_DIST:
+	{
+		CReq r;
+		r.c = c; r.h = h;
+		r.payload.assign(payload, payload + h.len);
+		if (needs_fd(h.op, h))
+		{
+			if (c->fds.empty()) { c->respond(h, HGS_ERR_PROTOCOL); return false; }
+			r.fd = c->fds.front();
+			c->fds.pop_front();
+		}
+		{
+			std::lock_guard<std::mutex> lk(g_c_mu);
+			g_c.push_back(std::move(r));
+		}
+		g_c_cv.notify_one();
+		return true;
+	}
+	default:
+		c->respond(h, HGS_ERR_PROTOCOL);
+		return false;
+	}
+}
+
+// Drain the socket; false when the connection is finished.
+bool on_readable(const ConnP &c)
+{
+	while (true)
+	{
+		char buf[65536];
+		struct iovec iov = { buf, sizeof(buf) };
+		struct msghdr mh;
+		memset(&mh, 0, sizeof(mh));
+		mh.msg_iov = &iov; mh.msg_iovlen = 1;
+		alignas(struct cmsghdr) char cbuf[CMSG_SPACE(8 * sizeof(int))];
+		mh.msg_control = cbuf; mh.msg_controllen = sizeof(cbuf);
+		ssize_t n = recvmsg(c->fd, &mh, MSG_CMSG_CLOEXEC | MSG_DONTWAIT);
+		if (n < 0)
+		{
+			if (errno == EINTR) continue;
+			if (errno == EAGAIN || errno == EWOULDBLOCK) break;
+			return false;
+		}
+		if (n == 0) return false;
+		for (struct cmsghdr *cm = CMSG_FIRSTHDR(&mh); cm; cm = CMSG_NXTHDR(&mh, cm))
+			if (cm->cmsg_level == SOL_SOCKET && cm->cmsg_type == SCM_RIGHTS)
+			{
+				size_t cnt = (cm->cmsg_len - CMSG_LEN(0)) / sizeof(int);
+				for (size_t i = 0; i < cnt; i++)
+				{
+					int f;
+					memcpy(&f, CMSG_DATA(cm) + i * sizeof(int), sizeof(int));
+					if (c->fds.size() < 4) c->fds.push_back(f); else close(f);
+				}
+			}
+		c->in.insert(c->in.end(), buf, buf + n);
+		size_t off = 0;
+		while (c->in.size() - off >= sizeof(hgs_hdr))
+		{
+			hgs_hdr h;
+			memcpy(&h, c->in.data() + off, sizeof(h));
+			if (h.magic != HGS_MAGIC || h.len > HGS_MAX_PAYLOAD) return false;
+			if (c->in.size() - off < sizeof(h) + h.len) break;
+			if (!handle_message(c, h, c->in.data() + off + sizeof(h))) return false;
+			off += sizeof(h) + h.len;
+		}
+		if (off) c->in.erase(c->in.begin(), c->in.begin() + (long) off);
+		if ((size_t) n < sizeof(buf)) break;
+	}
+	return !c->closed.load();
+}
+
+void reader_main(int epfd)
+{
+	std::vector<struct epoll_event> evs(256);
+	while (!g_stop.load())
+	{
+		int n = epoll_wait(epfd, evs.data(), (int) evs.size(), -1);
+		if (n < 0) { if (errno == EINTR) continue; break; }
+		for (int i = 0; i < n; i++)
+		{
+			if (evs[i].data.ptr == nullptr) continue;            // the wake-up eventfd
+			ConnP *holder = (ConnP *) evs[i].data.ptr;
+			bool keep = !(evs[i].events & EPOLLERR);
+			if (keep && (evs[i].events & (EPOLLIN | EPOLLHUP))) keep = on_readable(*holder);
+			if (!keep)
+			{
+				epoll_ctl(epfd, EPOLL_CTL_DEL, (*holder)->fd, nullptr);
+				(*holder)->closed.store(true);
+				shutdown((*holder)->fd, SHUT_RDWR);
+				g_cnt.connections_now--;
+				delete holder;               // the descriptor closes when the last pending request lets go
+			}
+		}
+	}
+}
+
+void on_signal(int)
+{
+	g_stop.store(true);
+	uint64_t one = 1;
+	if (g_wake_fd >= 0) { ssize_t w = write(g_wake_fd, &one, sizeof(one)); (void) w; }
+}
+
+void usage()
+{
+	fprintf(stderr,
+			"usage: hnsw_gpu_server --socket PATH [--device N] [--dispatchers N] [--readers N]\n"
+			"                       [--max-batch N] [--linger-us N --min-batch N] [--verbose] [--ready-fd N]\n");
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+	for (int i = 1; i < argc; i++)
+	{
+		std::string a = argv[i];
+		auto val = [&](const char *name) -> const char * {
+			if (i + 1 >= argc) { fprintf(stderr, "%s needs a value\n", name); exit(2); }
+			return argv[++i];
+		};
+		if (a == "--socket") g_opt.path = val("--socket");
+		else if (a == "--device") g_opt.device = atoi(val("--device"));
+		else if (a == "--dispatchers") g_opt.dispatchers = atoi(val("--dispatchers"));
+		else if (a == "--readers") g_opt.readers = atoi(val("--readers"));
+		else if (a == "--max-batch") g_opt.max_batch = (size_t) atol(val("--max-batch"));
+		else if (a == "--linger-us") g_opt.linger_us = atol(val("--linger-us"));
+		else if (a == "--min-batch") g_opt.min_batch = (size_t) atol(val("--min-batch"));
+		else if (a == "--ready-fd") g_opt.ready_fd = atoi(val("--ready-fd"));
+		else if (a == "--verbose") g_opt.verbose = true;
+		else { usage(); return 2; }
+	}
+	if (g_opt.path.empty() || g_opt.dispatchers < 1 || g_opt.readers < 1 || g_opt.max_batch < 1) { usage(); return 2; }
+	if (g_opt.path.size() >= sizeof(((struct sockaddr_un *) nullptr)->sun_path)) { logf("socket path too long"); return 2; }
+
+	const int ndev = hnsw_gpu_device_count();
+	if (ndev <= 0 || g_opt.device < 0 || g_opt.device >= ndev)
+	{
+		logf("no usable gfx950 device (visible: %d, asked for %d); there is no CPU path", ndev, g_opt.device);
+		return 3;
+	}
+	g_t0 = std::chrono::steady_clock::now();
+
+	signal(SIGPIPE, SIG_IGN);
+	struct sigaction sa;
+	memset(&sa, 0, sizeof(sa));
+	sa.sa_handler = on_signal;
+	sigaction(SIGTERM, &sa, nullptr);
+	sigaction(SIGINT, &sa, nullptr);
+	g_wake_fd = eventfd(0, EFD_CLOEXEC | EFD_NONBLOCK);
+
+	int lfd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC | SOCK_NONBLOCK, 0);
+	if (lfd < 0) { logf("socket: %s", strerror(errno)); return 1; }
+	struct sockaddr_un addr;
+	memset(&addr, 0, sizeof(addr));
+	addr.sun_family = AF_UNIX;
+	strncpy(addr.sun_path, g_opt.path.c_str(), sizeof(addr.sun_path) - 1);
+	unlink(g_opt.path.c_str());
+	mode_t old = umask(0077);                       // the socket belongs to the server's user only
+	int brc = bind(lfd, (struct sockaddr *) &addr, sizeof(addr));
+	umask(old);
+	if (brc != 0 || listen(lfd, g_opt.backlog) != 0) { logf("bind/listen %s: %s", g_opt.path.c_str(), strerror(errno)); return 1; }
+
+	std::vector<int> epfds;
+	std::vector<std::thread> threads;
+	for (int r = 0; r < g_opt.readers; r++)
+	{
+		int ep = epoll_create1(EPOLL_CLOEXEC);
+		struct epoll_event ev;
+		memset(&ev, 0, sizeof(ev));
+		ev.events = EPOLLIN; ev.data.ptr = nullptr;
+		epoll_ctl(ep, EPOLL_CTL_ADD, g_wake_fd, &ev);
+		epfds.push_back(ep);
+		threads.emplace_back(reader_main, ep);
+	}
+	for (int d = 0; d < g_opt.dispatchers; d++) threads.emplace_back(dispatcher_main, d);
+	threads.emplace_back(control_main);
+
+	logf("listening on %s (device %d of %d, %d dispatchers, max batch %zu)", g_opt.path.c_str(), g_opt.device, ndev,
+		 g_opt.dispatchers, g_opt.max_batch);
+	if (g_opt.ready_fd >= 0)
+	{
+		ssize_t w = write(g_opt.ready_fd, "READY\n", 6); (void) w;
+		if (g_opt.ready_fd > 2) close(g_opt.ready_fd);
+	}
+
+	size_t next = 0;
+	while (!g_stop.load())
+	{
+		struct pollfd pf[2] = { { lfd, POLLIN, 0 }, { g_wake_fd, POLLIN, 0 } };
+		int pr = poll(pf, 2, -1);
+		if (pr < 0) { if (errno == EINTR) continue; break; }
+		if (pf[1].revents) break;
+		while (true)
+		{
+			int fd = accept4(lfd, nullptr, nullptr, SOCK_CLOEXEC | SOCK_NONBLOCK);
+			if (fd < 0) break;
+			ConnP c = std::make_shared<Conn>();
+			c->fd = fd;
+			g_cnt.connections++;
+			g_cnt.connections_now++;
+			struct epoll_event ev;
+			memset(&ev, 0, sizeof(ev));
+			ev.events = EPOLLIN;
+			ev.data.ptr = new ConnP(c);
+			if (epoll_ctl(epfds[next % epfds.size()], EPOLL_CTL_ADD, fd, &ev) != 0)
+			{
+				delete (ConnP *) ev.data.ptr;
+				g_cnt.connections_now--;
+			}
+			next++;
+		}
+	}
+
+	g_stop.store(true);
+	on_signal(0);
+	g_q_cv.notify_all();
+	g_c_cv.notify_all();
+	for (std::thread &t : threads) t.join();
+	close(lfd);
+	unlink(g_opt.path.c_str());
+	{
+		std::lock_guard<std::mutex> lk(g_map_mu);
+		g_map.clear();                               // frees the device mirrors
+	}
+	hgs_stats s;
+	fill_stats(&s);
+	logf("stopped: %llu searches in %llu batches (largest %llu)", (unsigned long long) s.searches,
+		 (unsigned long long) s.batches, (unsigned long long) s.max_batch);
+	return 0;
+}

@@ -1,0 +1,178 @@
+/*
+ * tests/double/engine_double.c — TEST INFRASTRUCTURE ONLY.
+ *
+ * A stand-in for the part of libhnsw_gpu.so's C API (include/hnsw_gpu.h) that hnsw_gpu_server
+ * calls, implemented on the CPU oracle (oracle/hnsw_port.c).  tests/server_util.py links the
+ * server's own source (pg_embedding_amd/csrc/server_main.cpp) against this file INSTEAD of the
+ * HIP library, into tests/_build/hnsw_gpu_server_double, so that the server's protocol, batching,
+ * locking and the client library can be tested in the CPU-only container.  The product binary
+ * (pg_embedding_amd/bin/hnsw_gpu_server) links libhnsw_gpu.so and has no switch to get here.
+ *
+ * HGS_DOUBLE_SLEEP_US makes every search batch take at least that long, so that requests pile up
+ * behind it the way they do behind a busy device.
+ */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "hnsw_gpu.h"
+
+/* oracle/hnsw_port.c */
+typedef struct PortIndex PortIndex;
+PortIndex *port_create(size_t dim, size_t M, size_t efc, size_t efs, int func, size_t capacity);
+void   port_destroy(PortIndex *ix);
+size_t port_count(PortIndex *ix);
+void  *port_data(PortIndex *ix);
+size_t port_elem_size(PortIndex *ix);
+int    port_load_raw(PortIndex *ix, const void *bytes, size_t n);
+void   port_set_deleted(PortIndex *ix, uint32_t idx, int deleted);
+int    port_search(PortIndex *ix, const float *q, size_t ef, uint64_t *label_out, float *dist_out,
+				   size_t *n_out, uint32_t *evals, uint32_t *hops);
+int    port_bind_point(PortIndex *ix, const float *point, uint32_t cur_c);
+float  port_dist(int func, const float *q, const float *x, size_t dim);
+
+struct hnsw_gpu_index { PortIndex *p; HnswMetadata meta; };
+struct hnsw_gpu_ctx { hnsw_gpu_index *ix; };
+
+static __thread char t_err[256] = "";
+const char *hnsw_gpu_last_error(void) { return t_err; }
+int hnsw_gpu_device_count(void) { return 1; }
+
+int hnsw_gpu_index_create_from_flat(const HnswMetadata *meta, const void *elements, size_t n, int device,
+									hnsw_gpu_index **out)
+{
+	(void) device;
+	hnsw_gpu_index *ix = (hnsw_gpu_index *) calloc(1, sizeof(*ix));
+	if (!ix) return HNSW_GPU_ERR_NOMEM;
+	ix->meta = *meta;
+	ix->p = port_create(meta->dim, meta->M, meta->efConstruction, meta->efSearch, (int) meta->dist_func, n ? n : 16);
+	if (!ix->p || (n && port_load_raw(ix->p, elements, n) != 0))
+	{
+		snprintf(t_err, sizeof(t_err), "double: cannot load %zu elements", n);
+		if (ix->p) port_destroy(ix->p);
+		free(ix);
+		return HNSW_GPU_ERR_NOMEM;
+	}
+	*out = ix;
+	return HNSW_GPU_OK;
+}
+
+void hnsw_gpu_index_destroy(hnsw_gpu_index *ix)
+{
+	if (!ix) return;
+	port_destroy(ix->p);
+	free(ix);
+}
+
+size_t hnsw_gpu_index_count(const hnsw_gpu_index *ix) { return ix ? port_count(ix->p) : 0; }
+
+int hnsw_gpu_index_update_from_flat(hnsw_gpu_index *ix, const void *elements, size_t first, size_t count)
+{
+	const size_t esz = port_elem_size(ix->p), have = port_count(ix->p);
+	if (first > have) { snprintf(t_err, sizeof(t_err), "double: first %zu > count %zu", first, have); return HNSW_GPU_ERR_ARG; }
+	const size_t total = first + count > have ? first + count : have;
+	char *img = (char *) malloc(total * esz ? total * esz : 1);
+	if (!img) return HNSW_GPU_ERR_NOMEM;
+	memcpy(img, port_data(ix->p), have * esz);
+	memcpy(img + first * esz, elements, count * esz);
+	int rc = port_load_raw(ix->p, img, total);
+	free(img);
+	return rc == 0 ? HNSW_GPU_OK : HNSW_GPU_ERR_NOMEM;
+}
+
+int hnsw_gpu_index_reserve(hnsw_gpu_index *ix, size_t capacity) { (void) ix; (void) capacity; return HNSW_GPU_OK; }
+
+int hnsw_gpu_index_append(hnsw_gpu_index *ix, const coord_t *vectors, const label_t *labels, size_t n)
+{
+	const size_t esz = port_elem_size(ix->p), have = port_count(ix->p), dim = ix->meta.dim;
+	char *img = (char *) calloc(n ? n : 1, esz);
+	if (!img) return HNSW_GPU_ERR_NOMEM;
+	for (size_t i = 0; i < n; i++)
+	{
+		label_t l = labels ? labels[i] : (label_t) (have + i);
+		memcpy(img + i * esz + ix->meta.offset_data, vectors + i * dim, dim * 4);
+		memcpy(img + i * esz + ix->meta.offset_label, &l, 8);
+	}
+	int rc = hnsw_gpu_index_update_from_flat(ix, img, have, n);
+	free(img);
+	return rc;
+}
+
+int hnsw_gpu_index_link(hnsw_gpu_index *ix, size_t first, size_t count, size_t max_batch, size_t ratio, void *stream)
+{
+	(void) max_batch; (void) ratio; (void) stream;       /* always the reference's serial order */
+	const size_t esz = port_elem_size(ix->p);
+	for (size_t i = first; i < first + count; i++)
+	{
+		const float *v = (const float *) ((char *) port_data(ix->p) + i * esz + ix->meta.offset_data);
+		if (port_bind_point(ix->p, v, (uint32_t) i) != 0) return HNSW_GPU_ERR_INTERNAL;
+	}
+	return HNSW_GPU_OK;
+}
+
+int hnsw_gpu_index_get_links(hnsw_gpu_index *ix, idx_t idx, idx_t *out)
+{
+	if (idx >= port_count(ix->p)) return HNSW_GPU_ERR_ARG;
+	memcpy(out, (char *) port_data(ix->p) + (size_t) idx * port_elem_size(ix->p), (ix->meta.maxM + 1) * 4);
+	return HNSW_GPU_OK;
+}
+
+int hnsw_gpu_index_export_flat(hnsw_gpu_index *ix, void *elements)
+{
+	memcpy(elements, port_data(ix->p), port_count(ix->p) * port_elem_size(ix->p));
+	return HNSW_GPU_OK;
+}
+
+int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int deleted)
+{
+	if (idx >= port_count(ix->p)) return HNSW_GPU_ERR_ARG;
+	port_set_deleted(ix->p, idx, deleted);
+	return HNSW_GPU_OK;
+}
+
+int hnsw_gpu_ctx_create(hnsw_gpu_index *ix, hnsw_gpu_ctx **out)
+{
+	hnsw_gpu_ctx *c = (hnsw_gpu_ctx *) calloc(1, sizeof(*c));
+	if (!c) return HNSW_GPU_ERR_NOMEM;
+	c->ix = ix;
+	*out = c;
+	return HNSW_GPU_OK;
+}
+
+void hnsw_gpu_ctx_destroy(hnsw_gpu_ctx *c) { free(c); }
+
+int hnsw_gpu_search_batch_ctx_host(hnsw_gpu_ctx *c, const coord_t *queries, size_t nq, size_t ef, label_t *labels,
+								   dist_t *dists, uint32_t *counts)
+{
+	const char *fail_at = getenv("HGS_DOUBLE_FAIL_EF");       /* error-path tests */
+	if (fail_at && (size_t) atol(fail_at) == ef)
+	{
+		snprintf(t_err, sizeof(t_err), "double: asked to fail at ef %zu", ef);
+		return HNSW_GPU_ERR_INTERNAL;
+	}
+	const char *us = getenv("HGS_DOUBLE_SLEEP_US");
+	if (us && atol(us) > 0)
+	{
+		struct timespec ts = { atol(us) / 1000000, (atol(us) % 1000000) * 1000 };
+		nanosleep(&ts, NULL);
+	}
+	const size_t dim = c->ix->meta.dim;
+	for (size_t q = 0; q < nq; q++)
+	{
+		size_t n = 0;
+		for (size_t i = 0; i < ef; i++) { labels[q * ef + i] = ~(label_t) 0; if (dists) dists[q * ef + i] = 1.0f / 0.0f; }
+		port_search(c->ix->p, queries + q * dim, ef, labels + q * ef, dists ? dists + q * ef : NULL, &n, NULL, NULL);
+		counts[q] = (uint32_t) n;
+	}
+	return HNSW_GPU_OK;
+}
+
+void *hnsw_gpu_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
+void  hnsw_gpu_host_free(void *p) { free(p); }
+
+int hnsw_gpu_dist_batch(dist_func_t func, const coord_t *q, const coord_t *rows, size_t nrows, size_t dim, dist_t *out)
+{
+	for (size_t i = 0; i < nrows; i++) out[i] = port_dist((int) func, q, rows + i * dim, dim);
+	return HNSW_GPU_OK;
+}

@@ -6,7 +6,10 @@
  * four symbols of embedding.h:46-47,55-56.  It is linked against libembedding_gpu.so where the
  * reference links hnswalg.o + distfunc.o — nothing else changes.
  *
- *   usage: dropin_demo <n> <dim> <m> <efc> <efs> <nq>
+ *   usage: dropin_demo <n> <dim> <m> <efc> <efs> <nq> [key]
+ * With a key — and only when linked against the server client library, libembedding_gpuc.so — the
+ * (still empty) index is first attached to the server-side mirror of that key, the way
+ * hnsw_beginscan / hnsw_insert would (hnsw_gpu_server.h): inserts then extend that one mirror.
  * Rows/queries come from a fixed LCG; output: for every query the labels hnsw_search() returns.
  */
 #include <stdio.h>
@@ -18,6 +21,9 @@ typedef struct FlatIndex FlatIndex;
 FlatIndex *flat_create(size_t dim, size_t M, size_t efc, size_t efs, int dist_func, size_t capacity);
 long flat_add(FlatIndex *f, const coord_t *vec, label_t label);
 HnswMetadata *flat_meta(FlatIndex *f);
+
+/* libembedding_gpuc.so only (weak: absent in the other two link arrangements) */
+extern int hnsw_gpu_remote_attach(HnswMetadata *meta, uint64_t key, uint64_t generation) __attribute__((weak));
 
 static unsigned long long lcg = 88172645463325252ull;
 static float rnd(void)
@@ -34,6 +40,11 @@ int main(int argc, char **argv)
 	hnsw_init_dist_func();                                  /* _PG_init, embedding.c:150 */
 	FlatIndex *f = flat_create(dim, m, efc, efs, DIST_L2, n);
 	float *v = (float *) malloc(dim * sizeof(float));
+	if (argc > 7 && hnsw_gpu_remote_attach && hnsw_gpu_remote_attach(flat_meta(f), strtoull(argv[7], NULL, 0), 1) != 0)
+	{
+		fprintf(stderr, "attach failed\n");
+		return 1;
+	}
 	for (size_t i = 0; i < n; i++)
 	{
 		for (size_t d = 0; d < dim; d++) v[d] = rnd() + (float) (i % 7);

@@ -1,0 +1,88 @@
+"""Helpers for the hnsw_gpu_server tests: build the server's own source against the CPU test
+double (tests/double/engine_double.c + oracle/hnsw_port.c) and build the C client programs."""
+import fcntl
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include")
+CSRC = os.path.join(ROOT, "pg_embedding_amd", "csrc")
+LIB = os.path.join(ROOT, "pg_embedding_amd", "lib")
+OUT = os.path.join(ROOT, "tests", "_build")
+DOUBLE_BIN = os.path.join(OUT, "hnsw_gpu_server_double")
+FLAT_HOST = os.path.join(ROOT, "oracle", "flat_host.c")
+
+
+def _stale(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("build failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
+
+
+class _Lock:
+    def __enter__(self):
+        os.makedirs(OUT, exist_ok=True)
+        self.f = open(os.path.join(OUT, ".lock"), "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+
+    def __exit__(self, *a):
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
+
+
+def build_double_server() -> str:
+    """server_main.cpp linked against the oracle-backed engine double instead of libhnsw_gpu.so."""
+    src = [os.path.join(CSRC, "server_main.cpp"), os.path.join(CSRC, "hgs_io.h"),
+           os.path.join(ROOT, "tests", "double", "engine_double.c"), os.path.join(ROOT, "oracle", "hnsw_port.c"),
+           os.path.join(INC, "hnsw_gpu_server.h"), os.path.join(INC, "hnsw_gpu.h")]
+    with _Lock():
+        if _stale(DOUBLE_BIN, src):
+            objs = []
+            for name, c, flags in (
+                    ("engine_double.o", src[2], ["-O2", "-std=gnu11"]),
+                    ("hnsw_port.o", src[3], ["-O3", "-mavx2", "-mfma", "-ffp-contract=off", "-fno-fast-math", "-std=gnu11"])):
+                o = os.path.join(OUT, name)
+                _run(["gcc"] + flags + ["-I", INC, "-c", c, "-o", o])
+                objs.append(o)
+            _run(["g++", "-O2", "-std=c++17", "-Wall", "-I", INC, "-I", CSRC, src[0]] + objs +
+                 ["-o", DOUBLE_BIN, "-lpthread", "-lm"])
+    return DOUBLE_BIN
+
+
+def build_c_client(name: str, link_client_lib: bool = True) -> str:
+    """tests/dropin_c/<name>.c + the flat host, linked against libembedding_gpuc.so (the four
+    reference symbols as a client of the server)."""
+    src = [os.path.join(ROOT, "tests", "dropin_c", name + ".c"), FLAT_HOST]
+    exe = os.path.join(OUT, name + "_remote")
+    client = os.path.join(LIB, "libembedding_gpuc.so")
+    with _Lock():
+        if _stale(exe, src + [client, os.path.join(INC, "hnsw_gpu_server.h")]):
+            _run(["gcc", "-O2", "-std=gnu11", "-I", INC] + src + ["-o", exe, "-L", LIB, "-lembedding_gpuc",
+                                                               f"-Wl,-rpath,{LIB}", "-lpthread", "-lm"])
+    return exe
+
+
+def build_c_reference(name: str):
+    """The same C host linked against the reference's own objects (oracle/_ref), or None."""
+    refdir = os.path.join(ROOT, "oracle", "_ref")
+    if not os.path.exists(os.path.join(refdir, "hnswalg.o")):
+        return None
+    src = [os.path.join(ROOT, "tests", "dropin_c", name + ".c"), FLAT_HOST]
+    exe = os.path.join(OUT, name + "_ref")
+    with _Lock():
+        if _stale(exe, src):
+            objs = []
+            for i, c in enumerate(src):
+                o = os.path.join(OUT, f"{name}_ref{i}.o")
+                _run(["gcc", "-O2", "-std=gnu11", "-I", INC, "-c", c, "-o", o])
+                objs.append(o)
+            _run(["g++"] + objs + [os.path.join(refdir, "hnswalg.o"), os.path.join(refdir, "distfunc.o"),
+                                   "-o", exe, "-lpthread", "-lm"])
+    return exe

@@ -1,0 +1,326 @@
+"""hnsw_gpu_server + libembedding_gpuc.so without a GPU: the server's own source linked against the
+oracle-backed engine double (tests/double/engine_double.c).  What is under test here is the part
+that has no arithmetic in it — wire protocol, batching, per-mirror locking, generations, the
+client library's drop-in symbols and their failure behaviour; the device path behind the same
+server is covered by tests/test_gpu_server.py."""
+import json
+import os
+import socket
+import struct
+import subprocess
+import threading
+
+import numpy as np
+import pytest
+
+import oracle
+import pg_embedding_amd as pg
+from pg_embedding_amd.datasets import gmm
+from pg_embedding_amd.server import HGS_ERR_NOKEY, HGS_ERR_STALE, RemoteClient, RemoteError, ServerProcess
+import server_util as SU
+
+
+@pytest.fixture(scope="module")
+def double_bin():
+    return SU.build_double_server()
+
+
+@pytest.fixture()
+def srv(double_bin):
+    with ServerProcess(binary=double_bin) as s:
+        yield s
+
+
+def port_index(n, dim, m, efc, efs, func, seed):
+    X = gmm(n, dim, k=20, seed=seed)
+    p = oracle.PortIndex(dim, m, efc, efs, func)
+    p.add(X, np.arange(n, dtype=np.uint64) + 500)
+    return p, X
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def test_product_server_refuses_to_start_without_a_device():
+    """No device, no service: the shipped binary has no CPU engine behind it."""
+    from pg_embedding_amd._lib import gpu_lib
+    if gpu_lib().hnsw_gpu_device_count() > 0:
+        pytest.skip("a device is present")
+    with pytest.raises(RuntimeError, match="status 3"):
+        ServerProcess().start()
+
+
+def test_client_fails_loudly_without_a_server(tmp_path):
+    with pytest.raises(RemoteError) as e:
+        RemoteClient(str(tmp_path / "nobody-listens"))
+    assert e.value.code == -23
+    exe = SU.build_c_client("dropin_demo")
+    env = dict(os.environ, PG_EMBEDDING_GPU_SERVER=str(tmp_path / "nobody-listens"))
+    r = subprocess.run([exe, "50", "8", "3", "8", "8", "2"], capture_output=True, text=True, env=env)
+    assert r.returncode != 0 and "cannot reach hnsw_gpu_server" in r.stderr
+
+
+@pytest.mark.parametrize("func", [pg.DIST_L2, pg.DIST_COSINE, pg.DIST_MANHATTAN])
+def test_remote_calls_round_trip(srv, func):
+    dim, m, n, efs = 40, 6, 1200, 48
+    port, X = port_index(n, dim, m, 32, efs, func, seed=11 + func)
+    meta = pg.make_meta(dim, m, 32, efs, func)
+    c = RemoteClient(srv.socket_path)
+    key = 4242
+    assert c.lookup(key) == (False, 0, 0)
+    with pytest.raises(RemoteError) as e:
+        c.search(key, X[0], efs)
+    assert e.value.code == HGS_ERR_NOKEY
+    c.upload(meta, key, 7, port.raw(), n)
+    assert c.lookup(key) == (True, 7, n)
+    Q = gmm(25, dim, k=20, seed=11 + func, stream=1)
+    for q in Q:
+        lab, dst = c.search(key, q, efs)
+        wl, wd = port.search(q, efs)[:2]
+        assert (lab == wl).all() and (bits(dst) == bits(wd)).all()
+    # a generation the server does not hold is refused, 0 means "whatever is current"
+    with pytest.raises(RemoteError) as e:
+        c.search(key, Q[0], efs, gen=8)
+    assert e.value.code == HGS_ERR_STALE
+    assert (c.search(key, Q[0], efs, gen=7)[0] == port.search(Q[0], efs)[0]).all()
+    # other beams, including one wider than... the doubling of embedding.c:334
+    for ef in (1, 5, 2 * efs):
+        assert (c.search(key, Q[1], ef)[0] == port.search(Q[1], ef)[0]).all()
+    # vacuum flag (embedding.c:920-926)
+    first = int(c.search(key, Q[2], efs)[0][0])
+    idx = first - 500
+    c.set_deleted(key, idx, True)
+    port.set_deleted(idx, True)
+    assert first not in c.search(key, Q[2], efs)[0].tolist()
+    assert (c.search(key, Q[2], efs)[0] == port.search(Q[2], efs)[0]).all()
+    # incremental update: new rows linked by the host, only the changed elements travel
+    more = gmm(30, dim, k=20, seed=99)
+    before = port.raw().reshape(n, -1).copy()
+    port.add(more, np.arange(30, dtype=np.uint64) + 9000)
+    after = port.raw().reshape(n + 30, -1)
+    changed = np.flatnonzero((after[:n] != before).any(axis=1))
+    with pytest.raises(RemoteError) as e:
+        c.update(meta, key, 6, 8, after[n:].reshape(-1), n, 30)       # wrong expected generation
+    assert e.value.code == HGS_ERR_STALE
+    c.update(meta, key, 7, 8, after[n:].reshape(-1), n, 30)
+    for i in changed:
+        c.update(meta, key, 8, 8, after[i], int(i), 1)
+    assert c.lookup(key) == (True, 8, n + 30)
+    for q in Q[:10]:
+        assert (c.search(key, q, efs)[0] == port.search(q, efs)[0]).all()
+    # the mirror comes back as the host's element images
+    img = c.export(key, (n + 30) * meta.size_data_per_element)
+    assert (img == port.raw()).all()
+    st = c.stats()
+    assert st["mirrors"] == 1 and st["mirror_elements"] == n + 30 and st["uploads"] == 1 and st["search_errors"] == 0
+    c.drop(key)
+    assert c.lookup(key)[0] is False
+    with pytest.raises(RemoteError):
+        c.drop(key)
+    c.close()
+
+
+def test_bulk_link_on_the_server_matches_serial_inserts(srv):
+    """UPLOAD of zero-linked rows + LINK (the CREATE INDEX offload) in serial mode = the oracle's graph."""
+    dim, m, n = 16, 4, 300
+    port, X = port_index(n, dim, m, 16, 20, pg.DIST_L2, seed=3)
+    meta = pg.make_meta(dim, m, 16, 20, pg.DIST_L2)
+    img = port.raw().reshape(n, -1).copy()
+    img[:, :meta.offset_data] = 0                         # forget the links
+    c = RemoteClient(srv.socket_path)
+    c.upload(meta, 9, 1, img.reshape(-1), n)
+    c.link(9, 0, n, 1)
+    assert (c.export(9, n * meta.size_data_per_element) == port.raw()).all()
+    c.close()
+
+
+def run_clients(sock, key, gen, dim, m, efc, efs, func, Q, nproc, tmp_path, rounds=1):
+    exe = SU.build_c_client("server_clients")
+    qf, of = str(tmp_path / "q.f32"), str(tmp_path / "out.u64")
+    np.ascontiguousarray(Q, np.float32).tofile(qf)
+    env = dict(os.environ, PG_EMBEDDING_GPU_SERVER=sock)
+    r = subprocess.run([exe, str(key), str(gen), str(dim), str(m), str(efc), str(efs), str(func), qf, str(len(Q)),
+                        str(nproc), of, str(rounds)], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stderr
+    out = np.fromfile(of, np.uint64)
+    nq = len(Q)
+    return json.loads(r.stdout), out[:nq * efs].reshape(nq, efs), out[nq * efs:]
+
+
+def test_many_backends_are_batched_and_each_gets_its_own_answer(double_bin, tmp_path):
+    """48 single-threaded processes call hnsw_search() one query at a time (embedding.c:317); the
+    server turns what is waiting into batches; every call returns exactly the oracle's array."""
+    dim, m, n, efs = 32, 5, 2000, 24
+    port, X = port_index(n, dim, m, 24, efs, pg.DIST_L2, seed=21)
+    meta = pg.make_meta(dim, m, 24, efs, pg.DIST_L2)
+    Q = gmm(960, dim, k=20, seed=21, stream=1)
+    with ServerProcess(binary=double_bin, env={"HGS_DOUBLE_SLEEP_US": "3000"}) as s:
+        c = RemoteClient(s.socket_path)
+        c.upload(meta, 77, 3, port.raw(), n)
+        info, labels, counts = run_clients(s.socket_path, 77, 3, dim, m, 24, efs, pg.DIST_L2, Q, 48, tmp_path)
+        want = port.search_many(Q, efs)
+        assert (counts == want["counts"]).all()
+        for q in range(len(Q)):
+            k = int(counts[q])
+            assert (labels[q, :k] == want["labels"][q, :k]).all()
+        st = c.stats()
+        assert st["searches"] == len(Q) and st["search_errors"] == 0
+        assert st["max_batch"] > 8 and st["batches"] < len(Q) // 4, st       # really coalesced
+        assert st["connections"] >= 49
+        c.close()
+
+
+def test_batches_never_mix_beams_or_mirrors(srv):
+    """Concurrent searches with different efSearch on two mirrors: batches are per (mirror, ef)."""
+    dim, m, efs = 24, 4, 16
+    pa, Xa = port_index(900, dim, m, 16, efs, pg.DIST_L2, seed=31)
+    pb, Xb = port_index(700, dim, m, 16, efs, pg.DIST_COSINE, seed=32)
+    c0 = RemoteClient(srv.socket_path)
+    c0.upload(pg.make_meta(dim, m, 16, efs, pg.DIST_L2), 1, 1, pa.raw(), 900)
+    c0.upload(pg.make_meta(dim, m, 16, efs, pg.DIST_COSINE), 2, 1, pb.raw(), 700)
+    Q = gmm(64, dim, k=20, seed=33, stream=1)
+    errors = []
+
+    def worker(t):
+        try:
+            c = RemoteClient(srv.socket_path)          # connections are per thread
+            key, port = (1, pa) if t % 2 == 0 else (2, pb)
+            ef = (8, 16, 40)[t % 3]
+            for q in Q:
+                lab, dst = c.search(key, q, ef)
+                wl, wd = port.search(q, ef)[:2]
+                if not ((lab == wl).all() and (bits(dst) == bits(wd)).all()):
+                    errors.append((t, "mismatch"))
+            c.close()
+        except Exception as ex:            # noqa: BLE001
+            errors.append((t, repr(ex)))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(12)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errors, errors
+    assert c0.stats()["searches"] == 12 * len(Q)
+    c0.close()
+
+
+def test_searches_and_mirror_changes_interleave_safely(srv):
+    """Writers (SET_DELETED toggles under the mirror's write lock) while readers search: every answer
+    equals the oracle's answer for one of the two states."""
+    dim, m, n, efs = 24, 4, 800, 16
+    port, X = port_index(n, dim, m, 16, efs, pg.DIST_L2, seed=41)
+    meta = pg.make_meta(dim, m, 16, efs, pg.DIST_L2)
+    c0 = RemoteClient(srv.socket_path)
+    c0.upload(meta, 5, 1, port.raw(), n)
+    q = X[10] + 0.01
+    alive = port.search(q, efs)[0]
+    victim = int(alive[0]) - 500
+    port.set_deleted(victim, True)
+    dead = port.search(q, efs)[0]
+    stop = threading.Event()
+    bad = []
+
+    def reader():
+        c = RemoteClient(srv.socket_path)
+        while not stop.is_set():
+            got = c.search(5, q, efs)[0]
+            if not (np.array_equal(got, alive) or np.array_equal(got, dead)):
+                bad.append(got)
+        c.close()
+
+    th = [threading.Thread(target=reader) for _ in range(6)]
+    [t.start() for t in th]
+    for i in range(200):
+        c0.set_deleted(5, victim, i % 2 == 0)
+    stop.set()
+    [t.join() for t in th]
+    assert not bad
+    c0.close()
+
+
+def test_dropin_symbols_from_c_match_the_reference(srv):
+    """The C host of tests/dropin_c (storage callbacks + the four symbols only) linked against
+    libembedding_gpuc.so: inserts through hnsw_bind_point (BIND + write-back), searches through
+    hnsw_search, same bytes on stdout as the same host linked against the reference's objects —
+    un-attached (throw-away mirrors per call) and attached to one server-side mirror."""
+    exe = SU.build_c_client("dropin_demo")
+    ref = SU.build_c_reference("dropin_demo")
+    args = ["300", "24", "4", "16", "12", "15"]
+    env = dict(os.environ, PG_EMBEDDING_GPU_SERVER=srv.socket_path)
+    plain = subprocess.run([exe] + args, capture_output=True, text=True, env=env, check=True).stdout
+    attached = subprocess.run([exe] + args + ["123"], capture_output=True, text=True, env=env, check=True).stdout
+    assert plain.count("\n") == 15 and "d0=0.000000" in plain
+    assert attached == plain
+    if ref:
+        want = subprocess.run([ref] + args, capture_output=True, text=True, check=True).stdout
+        assert plain == want
+    c = RemoteClient(srv.socket_path)
+    st = c.stats()
+    assert st["binds"] >= 2 * 299                       # both runs inserted through the server
+    assert c.lookup(123) == (True, 1, 300)              # the attached run left its mirror behind, complete
+    assert st["mirrors"] == 1                           # the throw-away mirrors are gone
+    c.close()
+
+
+def test_a_failing_batch_is_reported_and_the_server_goes_on(double_bin):
+    dim, m, n = 16, 4, 200
+    port, X = port_index(n, dim, m, 16, 10, pg.DIST_L2, seed=51)
+    with ServerProcess(binary=double_bin, env={"HGS_DOUBLE_FAIL_EF": "13"}) as s:
+        c = RemoteClient(s.socket_path)
+        c.upload(pg.make_meta(dim, m, 16, 10, pg.DIST_L2), 1, 1, port.raw(), n)
+        with pytest.raises(RemoteError) as e:
+            c.search(1, X[0], 13)
+        assert e.value.code == -4                       # HNSW_GPU_ERR_INTERNAL passed through
+        assert (c.search(1, X[0], 10)[0] == port.search(X[0], 10)[0]).all()
+        assert c.stats()["search_errors"] == 1
+        c.close()
+
+
+def test_malformed_traffic_only_costs_the_sender_its_connection(srv):
+    dim, m, n = 16, 4, 200
+    port, X = port_index(n, dim, m, 16, 10, pg.DIST_L2, seed=61)
+    c = RemoteClient(srv.socket_path)
+    c.upload(pg.make_meta(dim, m, 16, 10, pg.DIST_L2), 1, 1, port.raw(), n)
+
+    def raw():
+        s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        s.settimeout(5)
+        s.connect(srv.socket_path)
+        return s
+
+    hdr = struct.Struct("<IHhIIQQQQ")
+    assert hdr.size == 48
+    s = raw()                                            # wrong magic
+    s.sendall(b"\x00" * 48)
+    assert s.recv(64) == b""
+    s = raw()                                            # absurd length
+    s.sendall(hdr.pack(0x31534748, 5, 0, 0xFFFFFFF0, 10, 1, 0, 0, 0))
+    assert s.recv(64) == b""
+    s = raw()                                            # unknown op: an error response, then closed
+    s.sendall(hdr.pack(0x31534748, 99, 0, 0, 0, 0, 0, 0, 0))
+    r = hdr.unpack(s.recv(48))
+    assert r[2] == -20
+    s = raw()                                            # wrong query size: refused, connection stays usable
+    s.sendall(hdr.pack(0x31534748, 5, 0, 8, 10, 1, 0, 0, 0) + b"\x00" * 8)
+    assert hdr.unpack(s.recv(48))[2] == -2
+    s.sendall(hdr.pack(0x31534748, 2, 0, 0, 0, 1, 0, 0, 0))
+    r = hdr.unpack(s.recv(48))
+    assert r[2] == 0 and r[7] == n
+    s = raw()                                            # UPLOAD that promises a descriptor and sends none
+    s.sendall(hdr.pack(0x31534748, 3, 0, 88, 0, 9, 1, 5, 0) + b"\x00" * 88)
+    assert hdr.unpack(s.recv(48))[2] == -20
+    s = raw()                                            # a backend that dies mid-request
+    s.sendall(hdr.pack(0x31534748, 5, 0, dim * 4, 10, 1, 0, 0, 0) + b"\x00" * 10)
+    s.close()
+    assert (c.search(1, X[3], 10)[0] == port.search(X[3], 10)[0]).all()     # everybody else is fine
+    c.close()
+
+
+def test_server_stops_cleanly_on_sigterm(double_bin):
+    s = ServerProcess(binary=double_bin).start()
+    c = RemoteClient(s.socket_path)
+    assert c.stats()["connections_now"] == 1
+    assert s.stop() == 0
+    with pytest.raises(RemoteError):
+        c.stats()
+    c.close()
