@@ -1,0 +1,127 @@
+"""Throughput of the drop-in symbol hnsw_search() when many single-threaded backends share one
+hnsw_gpu_server (the Postgres deployment shape, include/hnsw_gpu_server.h).
+
+  * rows are generated on the host, uploaded zero-linked and linked on the server (LINK, batched
+    device build) — the CREATE INDEX offload;
+  * for each process count P, tests/dropin_c/server_clients.c forks P backends that each call
+    hnsw_search() one query at a time; the server coalesces what is waiting into batch launches;
+  * a sample of the returned arrays is compared with the reference's own code (oracle/_ref, or the
+    C restatement) searching the exported graph bytes.
+
+Usage: python scripts/server_bench.py [--rows 1000000 --dims 768 --m 16 --efc 200 --efs 128]
+                                      [--procs 1,16,64,256,1024] [--queries 20480] [--dispatchers 2]
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=1000000)
+    ap.add_argument("--dims", type=int, default=768)
+    ap.add_argument("--m", type=int, default=16)
+    ap.add_argument("--efc", type=int, default=200)
+    ap.add_argument("--efs", type=int, default=128)
+    ap.add_argument("--procs", default="1,16,64,256,1024")
+    ap.add_argument("--queries", type=int, default=20480)
+    ap.add_argument("--target-seconds", type=float, default=4.0)
+    ap.add_argument("--dispatchers", type=int, default=2)
+    ap.add_argument("--readers", type=int, default=8)
+    ap.add_argument("--binary", default=None, help="server binary (default: the shipped one)")
+    ap.add_argument("--check", type=int, default=200, help="queries compared with the CPU reference")
+    a = ap.parse_args()
+
+    import oracle
+    import pg_embedding_amd as pg
+    from pg_embedding_amd.datasets import gmm
+    from pg_embedding_amd.server import RemoteClient, ServerProcess
+    import server_util as SU
+
+    exe = SU.build_c_client("server_clients")
+    meta = pg.make_meta(a.dims, a.m, a.efc, a.efs, pg.DIST_L2)
+    esz = meta.size_data_per_element
+    t = time.time()
+    X = gmm(a.rows, a.dims, k=1000, seed=42)
+    Q = gmm(a.queries, a.dims, k=1000, seed=42, stream=1)
+    img = np.zeros((a.rows, esz), np.uint8)
+    img[:, meta.offset_data:meta.offset_label] = X.view(np.uint8).reshape(a.rows, a.dims * 4)
+    img[:, meta.offset_label:] = np.arange(a.rows, dtype=np.uint64).view(np.uint8).reshape(a.rows, 8)
+    del X
+    print(f"# data: {a.rows} x {a.dims} GMM(1000, 0.3) in {time.time() - t:.1f} s", flush=True)
+
+    tmp = tempfile.mkdtemp(prefix="hgs_bench_")
+    qf, of = os.path.join(tmp, "q.f32"), os.path.join(tmp, "out.u64")
+    Q.tofile(qf)
+    key, gen = 1, 1
+    srv = ServerProcess(dispatchers=a.dispatchers, readers=a.readers, binary=a.binary)
+    with srv:
+        c = RemoteClient(srv.socket_path)
+        t = time.time()
+        c.upload(meta, key, gen, img.reshape(-1), a.rows)
+        t_up = time.time() - t
+        t = time.time()
+        c.link(key, 0, a.rows, 0)
+        t_link = time.time() - t
+        print(f"# upload {img.nbytes / 1e9:.2f} GB through a memfd: {t_up:.2f} s; device build (LINK): {t_link:.2f} s", flush=True)
+        env = dict(os.environ, PG_EMBEDDING_GPU_SERVER=srv.socket_path)
+        rows = []
+        labels = None
+        for P in [int(x) for x in a.procs.split(",")]:
+            nq = max(P, min(a.queries, max(P * 8, 512)))
+            # short calibration run, then as many rounds as fill the target time
+            args = [exe, str(key), str(gen), str(a.dims), str(a.m), str(a.efc), str(a.efs), "0", qf, str(nq), str(P), of]
+            r = subprocess.run(args + ["1"], capture_output=True, text=True, env=env, timeout=600)
+            assert r.returncode == 0, r.stderr
+            cal = json.loads(r.stdout)
+            rounds = int(max(1, min(200, a.target_seconds * cal["qps"] / nq)))
+            before = c.stats()
+            r = subprocess.run(args + [str(rounds)], capture_output=True, text=True, env=env, timeout=600)
+            assert r.returncode == 0, r.stderr
+            info = json.loads(r.stdout)
+            st = c.stats()
+            d = {k: st[k] - before[k] for k in ("searches", "batches", "batch_ns")}
+            info.update(mean_batch=d["searches"] / max(1, d["batches"]), batches=d["batches"],
+                        ms_per_batch=d["batch_ns"] / 1e6 / max(1, d["batches"]),
+                        latency_ms=1e3 * P / info["qps"])
+            rows.append(info)
+            print(json.dumps(info), flush=True)
+            out = np.fromfile(of, np.uint64)
+            labels = (nq, out[:nq * a.efs].reshape(nq, a.efs).copy(), out[nq * a.efs:].copy())
+        # parity of what the backends received, against the reference's code on the same graph bytes
+        graph = c.export(key, a.rows * esz)
+        nq, lab, cnt = labels
+        ncheck = min(a.check, nq)
+        checks = [("C restatement in the device's summation order (oracle/hnsw_port.c)", oracle.PortIndex)]
+        if oracle.have_ref():
+            checks.append(("reference binary, -Ofast summation order (oracle/_ref)", oracle.RefIndex))
+        for kind, cls in checks:
+            cpu = cls(a.dims, a.m, a.efc, a.efs, pg.DIST_L2)
+            cpu.load_raw(graph, a.rows)
+            same = 0
+            for q in range(ncheck):
+                w = cpu.search(Q[q], a.efs)
+                w = w[0] if isinstance(w, tuple) else w
+                same += int(cnt[q] == len(w) and (lab[q, :len(w)] == w).all())
+            print(f"# parity: {same}/{ncheck} sampled hnsw_search() answers identical to the {kind} on the exported graph", flush=True)
+            del cpu
+        st = c.stats()
+        print("# server totals:", json.dumps({k: st[k] for k in ("connections", "searches", "batches", "max_batch", "search_errors")}))
+        c.close()
+    print("\n| backends | queries/s | mean batch | ms per batch | round trip ms |\n|---|---|---|---|---|")
+    for r in rows:
+        print(f"| {r['nproc']} | {r['qps']:.0f} | {r['mean_batch']:.1f} | {r['ms_per_batch']:.2f} | {r['latency_ms']:.2f} |")
+
+
+if __name__ == "__main__":
+    main()
