@@ -148,6 +148,18 @@ int  hnsw_gpu_ctx_search_ms(hnsw_gpu_ctx *ctx, unsigned back, float *ms);
  * One caller at a time per context. */
 int  hnsw_gpu_search_batch_ctx_host(hnsw_gpu_ctx *ctx, const coord_t *queries, size_t nq, size_t ef,
 									label_t *labels, dist_t *dists, uint32_t *counts);
+/* Streamed completion.  Device-pointer launch on a stream the context owns, plus nq completion
+ * flags: when query i's outputs are complete the kernel makes them visible system-wide and then stores
+ * 1 to d_done[i].  With d_done and the output arrays in pinned host memory (hnsw_gpu_host_alloc: the
+ * device writes it directly) a host thread can hand out each answer when that query's own walk ends
+ * instead of when the slowest query of the batch does — a walk is ~160 dependent hops and the slowest
+ * of a batch takes 2-3x the mean.  The queries may live in pinned host memory too.  The caller zeroes
+ * d_done before the call; nothing is waited for.  hnsw_gpu_ctx_idle: 1 once the context's last launch
+ * has left the device, 0 while it runs, < 0 on error. */
+int  hnsw_gpu_search_batch_ctx_flags(hnsw_gpu_ctx *ctx, const coord_t *d_queries, size_t nq, size_t ef,
+									 label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
+									 uint32_t *d_done);
+int  hnsw_gpu_ctx_idle(hnsw_gpu_ctx *ctx);
 /* Pinned host memory for the host-pointer entry points (NULL on failure). */
 void *hnsw_gpu_host_alloc(size_t bytes);
 void  hnsw_gpu_host_free(void *p);

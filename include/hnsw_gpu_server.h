@@ -93,6 +93,7 @@ typedef struct hgs_stats
 	uint64_t uploads, upload_bytes, updates, binds, evictions;
 	uint64_t mirrors, mirror_elements;
 	uint64_t batch_ns;                           /* host time inside search launches, summed over dispatchers */
+	uint64_t kernel_ns;                          /* device time of the search kernels (HIP events), summed     */
 	uint64_t uptime_ns;
 } hgs_stats;
 

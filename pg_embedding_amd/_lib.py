@@ -99,6 +99,13 @@ def gpu_lib():
     L.hnsw_gpu_ctx_destroy.argtypes = [vp]
     L.hnsw_gpu_search_batch_ctx.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp]
     L.hnsw_gpu_ctx_search_ms.argtypes = [vp, C.c_uint, _f32p]
+    L.hnsw_gpu_search_batch_ctx_host.argtypes = [vp, vp, sz, sz, vp, vp, vp]
+    L.hnsw_gpu_search_batch_ctx_flags.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp]
+    L.hnsw_gpu_ctx_idle.argtypes = [vp]
+    L.hnsw_gpu_host_alloc.restype = vp
+    L.hnsw_gpu_host_alloc.argtypes = [sz]
+    L.hnsw_gpu_host_free.restype = None
+    L.hnsw_gpu_host_free.argtypes = [vp]
     L.hnsw_gpu_dist_batch.argtypes = [i32, vp, vp, sz, sz, vp]
     L.hnsw_gpu_dist_batch_dev.argtypes = [i32, vp, vp, sz, sz, sz, vp, vp]
     L.hnsw_gpu_bruteforce_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp]

@@ -67,6 +67,8 @@ struct SearchArgs
 	float    *out_dists;        // nq*ef or null
 	uint32_t *out_counts;       // nq
 	uint32_t *out_stats;        // nq*2 {evals, hops} or null
+	uint32_t *done;             // null, or nq completion flags (host-visible): 1 is stored with system scope
+	                            // once query i's outputs are complete (hnsw_gpu_search_batch_ctx_flags)
 	// per-slot workspace
 	uint32_t *vis;              // slots * vis_words, all zero between queries
 	uint32_t *vlog;             // slots * logcap
@@ -84,6 +86,14 @@ struct SearchArgs
 	size_t set_stride;
 	int mode;                   // 0 = hnsw_search semantics, 1 = searchBaseLayer only
 };
+
+// Streamed completion: everything this wave wrote for the query becomes visible system-wide, then
+// the flag.  Once per query, outside the hop loop.
+__device__ __forceinline__ void signal_done(uint32_t *flag, int lane)
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope
+	if (lane == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 __device__ __forceinline__ uint32_t ord_f32(float f)
 {
@@ -589,6 +599,7 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 			a.out_counts[qi] = nout;
 			if (a.out_stats) { a.out_stats[2 * (size_t) qi] = evals; a.out_stats[2 * (size_t) qi + 1] = hops; }
 		}
+		if (a.done) signal_done(a.done + qi, lane);
 
 		// ---- restore the all-zero bitmap ---------------------------------------------------
 		wave_sync();
@@ -912,6 +923,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 			a.out_counts[qi] = nout;
 			if (a.out_stats) { a.out_stats[2 * (size_t) qi] = evals; a.out_stats[2 * (size_t) qi + 1] = hops; }
 		}
+		if (a.done) signal_done(a.done + qi, lane);
 
 		// ---- restore the all-zero bitmap for the next query of this slot --------------
 		set_sync<G>();
@@ -1349,6 +1361,7 @@ __global__ __launch_bounds__(256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MI
 			a.out_counts[qi] = nout;
 			if (a.out_stats) { a.out_stats[2 * (size_t) qi] = evals; a.out_stats[2 * (size_t) qi + 1] = hops; }
 		}
+		if (a.done) signal_done(a.done + qi, lane);
 
 		wave_sync();
 		if (logn <= a.logcap)

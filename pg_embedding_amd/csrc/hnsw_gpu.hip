@@ -69,6 +69,7 @@ struct SearchWs
 	hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};
 	uint64_t launches = 0;
 	uint32_t last_slots = 0;
+	uint32_t *done_next = nullptr;                       // completion flags for the next launch only
 };
 
 static int ws_init(SearchWs *w)
@@ -670,6 +671,8 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		a.set_scratch = w->sets;
 	}
 	a.ticket = w->ticket;
+	a.done = w->done_next;
+	w->done_next = nullptr;
 	HIPCHK(hipMemsetAsync(w->ticket, 0, 8, stream));
 
 	const int evi = (int) (w->launches % SearchWs::EV_RING);
@@ -1446,6 +1449,36 @@ extern "C" int hnsw_gpu_search_batch_ctx_host(hnsw_gpu_ctx *c, const coord_t *qu
 	HIPCHK(hipMemcpyAsync(counts, dc, nq * 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
 	return HNSW_GPU_OK;
+}
+
+// Streamed completion (hnsw_gpu.h): device-pointer launch on the context's own stream with per-query
+// completion flags.  Nothing is copied and nothing is waited for here.
+extern "C" int hnsw_gpu_search_batch_ctx_flags(hnsw_gpu_ctx *c, const coord_t *d_queries, size_t nq, size_t ef,
+											   label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
+											   uint32_t *d_done)
+{
+	if (!c) return fail(HNSW_GPU_ERR_ARG, "context is NULL");
+	if (!d_done) return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
+	HIPCHK(hipSetDevice(c->ix->device));
+	if (!c->stream) HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	std::unique_lock<std::recursive_mutex> lock_(c->ix->mu);      // done_next -> launch is one step
+	c->ws.done_next = d_done;
+	int rc = launch_search(c->ix, &c->ws, d_queries, c->ix->meta.dim, nq, ef, 0, d_labels, nullptr, d_dists, d_counts, d_stats,
+						   c->stream);
+	c->ws.done_next = nullptr;
+	return rc;
+}
+
+// 1 = the context's last launch has left the device, 0 = still running, < 0 = error.
+extern "C" int hnsw_gpu_ctx_idle(hnsw_gpu_ctx *c)
+{
+	if (!c) return fail(HNSW_GPU_ERR_ARG, "context is NULL");
+	if (c->ws.launches == 0) return 1;
+	const int evi = (int) ((c->ws.launches - 1) % SearchWs::EV_RING);
+	hipError_t e = hipEventQuery(c->ws.ev1[evi]);
+	if (e == hipSuccess) return 1;
+	if (e == hipErrorNotReady) { (void) hipGetLastError(); return 0; }
+	return fail(HNSW_GPU_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
 }
 
 // Pinned host memory for the host-pointer entry points (NULL when there is no device / no memory).

@@ -53,6 +53,7 @@ struct Options
 	int readers = 4;
 	int dispatchers = 2;
 	size_t max_batch = 16384;
+	int lanes = 2;                 // launches in flight per dispatcher (0 = one blocking launch at a time)
 	long linger_us = 0;
 	size_t min_batch = 1;          // with --linger-us: wait while fewer requests than this are queued
 	int backlog = 1024;
@@ -67,7 +68,7 @@ std::chrono::steady_clock::time_point g_t0;
 struct Counters
 {
 	std::atomic<uint64_t> connections{0}, connections_now{0}, searches{0}, batches{0}, max_batch{0},
-		search_errors{0}, uploads{0}, upload_bytes{0}, updates{0}, binds{0}, evictions{0}, batch_ns{0};
+		search_errors{0}, uploads{0}, upload_bytes{0}, updates{0}, binds{0}, evictions{0}, batch_ns{0}, kernel_ns{0};
 } g_cnt;
 
 uint64_t now_ns()
@@ -94,26 +95,55 @@ struct Entry
 	std::atomic<uint64_t> gen{0};
 	HnswMetadata meta;
 	hnsw_gpu_index *ix = nullptr;
-	pthread_rwlock_t rw;                         // searches: read; BIND/UPDATE/LINK/...: write
+	// searches: readers (several launches of one dispatcher thread may hold it at once, so this is a
+	// counting gate, not a pthread rwlock); BIND/UPDATE/LINK/...: one writer, and a waiting writer
+	// keeps new searches out
+	std::mutex gmu;
+	std::condition_variable gcv;
+	int readers = 0, writers_waiting = 0;
+	bool writing = false;
 	std::mutex cmu;
-	std::vector<hnsw_gpu_ctx *> ctx;             // one per dispatcher, made on first use
+	std::vector<hnsw_gpu_ctx *> ctx;             // one per dispatcher lane, made on first use
 	std::atomic<uint64_t> last_used{0};
 	std::atomic<size_t> count{0};
 
-	Entry()
-	{
-		pthread_rwlockattr_t a;
-		pthread_rwlockattr_init(&a);
-		pthread_rwlockattr_setkind_np(&a, PTHREAD_RWLOCK_PREFER_WRITER_NONRECURSIVE_NP);
-		pthread_rwlock_init(&rw, &a);
-		pthread_rwlockattr_destroy(&a);
-		memset(&meta, 0, sizeof(meta));
-	}
+	Entry() { memset(&meta, 0, sizeof(meta)); }
 	~Entry()
 	{
 		for (hnsw_gpu_ctx *c : ctx) if (c) hnsw_gpu_ctx_destroy(c);
 		if (ix) hnsw_gpu_index_destroy(ix);
-		pthread_rwlock_destroy(&rw);
+	}
+	bool try_read()
+	{
+		std::lock_guard<std::mutex> lk(gmu);
+		if (writing || writers_waiting) return false;
+		readers++;
+		return true;
+	}
+	void begin_read()
+	{
+		std::unique_lock<std::mutex> lk(gmu);
+		gcv.wait(lk, [this] { return !writing && !writers_waiting; });
+		readers++;
+	}
+	void end_read()
+	{
+		std::lock_guard<std::mutex> lk(gmu);
+		if (--readers == 0) gcv.notify_all();
+	}
+	void begin_write()
+	{
+		std::unique_lock<std::mutex> lk(gmu);
+		writers_waiting++;
+		gcv.wait(lk, [this] { return readers == 0 && !writing; });
+		writers_waiting--;
+		writing = true;
+	}
+	void end_write()
+	{
+		std::lock_guard<std::mutex> lk(gmu);
+		writing = false;
+		gcv.notify_all();
 	}
 	hnsw_gpu_ctx *context(int d)
 	{
@@ -243,11 +273,13 @@ void run_batch(int d, std::vector<SReq> &batch, Pinned &pin)
 	if (rc == HNSW_GPU_OK)
 	{
 		for (size_t i = 0; i < nq; i++) memcpy(Q + i * dim, batch[i].q.data(), dim * 4);
-		pthread_rwlock_rdlock(&e->rw);
+		e->begin_read();
 		hnsw_gpu_ctx *ctx = e->context(d);
 		if (!ctx) rc = HNSW_GPU_ERR_HIP;
 		else rc = hnsw_gpu_search_batch_ctx_host(ctx, Q, nq, ef, L, D, C);
-		pthread_rwlock_unlock(&e->rw);
+		float kms = 0.f;
+		if (rc == HNSW_GPU_OK && hnsw_gpu_ctx_search_ms(ctx, 0, &kms) == HNSW_GPU_OK) g_cnt.kernel_ns += (uint64_t) (kms * 1e6f);
+		e->end_read();
 		if (rc != HNSW_GPU_OK) logf("search batch of %zu (ef %zu) failed: %s", nq, ef, hnsw_gpu_last_error());
 	}
 	e->last_used.store(now_ns());
@@ -266,7 +298,28 @@ void run_batch(int d, std::vector<SReq> &batch, Pinned &pin)
 	}
 }
 
-void dispatcher_main(int d)
+// Take every queued SEARCH for the (mirror, ef) of the oldest one, up to --max-batch.  g_q_mu held.
+void take_batch(std::vector<SReq> &batch)
+{
+	Entry *e = g_q.front().e.get();
+	const uint32_t ef = g_q.front().h.aux;
+	for (auto it = g_q.begin(); it != g_q.end() && batch.size() < g_opt.max_batch;)
+	{
+		if (it->e.get() == e && it->h.aux == ef) { batch.push_back(std::move(*it)); it = g_q.erase(it); }
+		else ++it;
+	}
+}
+
+void answer_leftovers()
+{
+	std::lock_guard<std::mutex> lk(g_q_mu);
+	for (SReq &r : g_q) r.c->respond(r.h, HGS_ERR_SHUTDOWN);
+	g_q.clear();
+}
+
+// --lanes 0: one blocking launch at a time per dispatcher; every answer of a batch leaves when the
+// slowest query of the batch is done.
+void dispatcher_blocking(int d)
 {
 	Pinned pin;
 	std::vector<SReq> batch;
@@ -281,20 +334,198 @@ void dispatcher_main(int d)
 				g_q_cv.wait_for(lk, std::chrono::microseconds(g_opt.linger_us),
 								[] { return g_stop.load() || g_q.size() >= g_opt.min_batch; });
 			if (g_q.empty()) continue;
-			Entry *e = g_q.front().e.get();
-			const uint32_t ef = g_q.front().h.aux;
-			for (auto it = g_q.begin(); it != g_q.end() && batch.size() < g_opt.max_batch;)
-			{
-				if (it->e.get() == e && it->h.aux == ef) { batch.push_back(std::move(*it)); it = g_q.erase(it); }
-				else ++it;
-			}
+			take_batch(batch);
 		}
 		run_batch(d, batch, pin);
 	}
-	// answer what is still queued
-	std::lock_guard<std::mutex> lk(g_q_mu);
-	for (SReq &r : g_q) r.c->respond(r.h, HGS_ERR_SHUTDOWN);
-	g_q.clear();
+	answer_leftovers();
+}
+
+// Streamed completion (default).  A lane = one launch in flight: its queries, result arrays and
+// completion flags live in pinned host memory that the kernel reads and writes directly
+// (hnsw_gpu_search_batch_ctx_flags), so nothing is copied and nothing is waited for: the dispatcher
+// polls the flags and answers each backend the moment ITS walk has ended — not when the slowest of
+// the batch has — while new requests go out on the next free lane.
+struct Lane
+{
+	Pinned pin;
+	std::vector<SReq> batch;
+	std::vector<uint32_t> pending;           // positions in `batch` not answered yet
+	EntryP e;
+	hnsw_gpu_ctx *ctx = nullptr;
+	size_t ef = 0;
+	label_t *L = nullptr; dist_t *D = nullptr; uint32_t *C = nullptr;
+	volatile uint32_t *F = nullptr;
+	uint64_t t0 = 0, t_check = 0;
+	bool active = false;
+};
+
+const uint64_t LANE_TIMEOUT_NS = 60ull * 1000000000ull;
+
+bool lane_launch(int ctx_slot, Lane &ln)
+{
+	Entry *e = ln.batch[0].e.get();
+	if (!e->try_read())                      // a writer is waiting or working: put the requests back, in order
+	{
+		std::lock_guard<std::mutex> lk(g_q_mu);
+		for (size_t i = ln.batch.size(); i-- > 0;) g_q.push_front(std::move(ln.batch[i]));
+		ln.batch.clear();
+		return false;
+	}
+	const size_t nq = ln.batch.size(), ef = ln.batch[0].h.aux, dim = e->meta.dim;
+	const size_t qb = (nq * dim * 4 + 255) & ~(size_t) 255, lb = (nq * ef * 8 + 255) & ~(size_t) 255,
+				 db = (nq * ef * 4 + 255) & ~(size_t) 255, cb = (nq * 4 + 255) & ~(size_t) 255, fb = nq * 4;
+	int rc = ln.pin.reserve(qb + lb + db + cb + fb) ? HNSW_GPU_OK : HNSW_GPU_ERR_NOMEM;
+	if (rc == HNSW_GPU_OK)
+	{
+		char *base = (char *) ln.pin.p;
+		float *Q = (float *) base;
+		ln.L = (label_t *) (base + qb);
+		ln.D = (dist_t *) (base + qb + lb);
+		ln.C = (uint32_t *) (base + qb + lb + db);
+		ln.F = (volatile uint32_t *) (base + qb + lb + db + cb);
+		for (size_t i = 0; i < nq; i++) memcpy(Q + i * dim, ln.batch[i].q.data(), dim * 4);
+		memset((void *) ln.F, 0, fb);
+		ln.ctx = e->context(ctx_slot);
+		rc = ln.ctx ? hnsw_gpu_search_batch_ctx_flags(ln.ctx, Q, nq, ef, ln.L, ln.D, ln.C, nullptr, (uint32_t *) ln.F)
+					: HNSW_GPU_ERR_HIP;
+	}
+	if (rc != HNSW_GPU_OK)
+	{
+		logf("search launch of %zu (ef %zu) failed: %s", nq, ef, hnsw_gpu_last_error());
+		e->end_read();
+		g_cnt.search_errors += nq;
+		g_cnt.searches += nq;
+		g_cnt.batches++;
+		for (SReq &r : ln.batch) r.c->respond(r.h, rc);
+		ln.batch.clear();
+		return false;
+	}
+	ln.e = ln.batch[0].e;
+	ln.ef = ef;
+	ln.pending.resize(nq);
+	for (size_t i = 0; i < nq; i++) ln.pending[i] = (uint32_t) i;
+	ln.t0 = ln.t_check = now_ns();
+	ln.active = true;
+	g_cnt.batches++;
+	g_cnt.searches += nq;
+	uint64_t mb = g_cnt.max_batch.load();
+	while (nq > mb && !g_cnt.max_batch.compare_exchange_weak(mb, nq)) {}
+	return true;
+}
+
+// Answer what has completed; retire the lane when everything has.  True if anything happened.
+bool lane_poll(Lane &ln)
+{
+	bool progress = false;
+	const uint64_t gen = ln.e->gen.load();
+	for (size_t k = 0; k < ln.pending.size();)
+	{
+		const uint32_t i = ln.pending[k];
+		if (__atomic_load_n((const uint32_t *) &ln.F[i], __ATOMIC_ACQUIRE))
+		{
+			SReq &r = ln.batch[i];
+			const size_t cnt = ln.C[i] <= ln.ef ? ln.C[i] : 0;
+			r.c->respond(r.h, HGS_OK, cnt, 0, ln.L + (size_t) i * ln.ef, cnt * 8, r.h.a0 ? ln.D + (size_t) i * ln.ef : nullptr, cnt * 4,
+						 gen);
+			ln.pending[k] = ln.pending.back();
+			ln.pending.pop_back();
+			progress = true;
+		}
+		else k++;
+	}
+	// Has the launch left the device?  Asked when every flag is in, and every 2 ms as the failure detector.
+	int idle = 0;
+	const uint64_t now = now_ns();
+	if (ln.pending.empty() || now - ln.t_check > 2000000ull)
+	{
+		idle = hnsw_gpu_ctx_idle(ln.ctx);
+		ln.t_check = now;
+	}
+	bool fail = idle < 0 || (idle == 1 && !ln.pending.empty() && [&] {
+		// the launch has left the device: every flag is visible by now — look once more before giving up
+		for (uint32_t i : ln.pending) if (!__atomic_load_n((const uint32_t *) &ln.F[i], __ATOMIC_ACQUIRE)) return true;
+		return false;
+	}());
+	if (!fail && !ln.pending.empty() && now_ns() - ln.t0 > LANE_TIMEOUT_NS) fail = true;
+	if (fail)
+	{
+		logf("search launch lost %zu of %zu queries: %s", ln.pending.size(), ln.batch.size(), hnsw_gpu_last_error());
+		g_cnt.search_errors += ln.pending.size();
+		for (uint32_t i : ln.pending) ln.batch[i].c->respond(ln.batch[i].h, HNSW_GPU_ERR_INTERNAL);
+		ln.pending.clear();
+		progress = true;
+	}
+	if (ln.pending.empty() && (idle == 1 || fail))
+	{
+		float kms = 0.f;
+		if (!fail && hnsw_gpu_ctx_search_ms(ln.ctx, 0, &kms) == HNSW_GPU_OK) g_cnt.kernel_ns += (uint64_t) (kms * 1e6f);
+		g_cnt.batch_ns += now_ns() - ln.t0;
+		ln.e->last_used.store(now_ns());
+		ln.e->end_read();
+		ln.e.reset();
+		ln.batch.clear();
+		ln.active = false;
+		progress = true;
+	}
+	return progress;
+}
+
+void dispatcher_lanes(int d)
+{
+	std::vector<Lane> lanes((size_t) g_opt.lanes);
+	unsigned idle_spins = 0;
+	while (!g_stop.load())
+	{
+		bool progress = false;
+		size_t active = 0;
+		for (Lane &ln : lanes) active += ln.active ? 1 : 0;
+		for (size_t li = 0; li < lanes.size(); li++)
+		{
+			Lane &ln = lanes[li];
+			if (ln.active) continue;
+			{
+				std::unique_lock<std::mutex> lk(g_q_mu);
+				if (active == 0)           // nothing in flight here: sleep until there is work
+				{
+					g_q_cv.wait(lk, [] { return g_stop.load() || !g_q.empty(); });
+					if (g_stop.load()) break;
+					if (g_opt.linger_us > 0 && g_q.size() < g_opt.min_batch)
+						g_q_cv.wait_for(lk, std::chrono::microseconds(g_opt.linger_us),
+										[] { return g_stop.load() || g_q.size() >= g_opt.min_batch; });
+				}
+				if (g_q.empty()) break;
+				take_batch(ln.batch);
+			}
+			if (lane_launch(d * g_opt.lanes + (int) li, ln)) { active++; progress = true; }
+			else if (active == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));   // writer at work
+			break;                         // poll before filling another lane: requests gather meanwhile
+		}
+		for (Lane &ln : lanes)
+			if (ln.active && lane_poll(ln)) progress = true;
+		if (progress) idle_spins = 0;
+		else if (++idle_spins > 64) { std::this_thread::yield(); }
+		else __builtin_ia32_pause();
+	}
+	// stopping: let what is in flight finish (bounded), then refuse the rest
+	const uint64_t t_end = now_ns() + 5ull * 1000000000ull;
+	for (Lane &ln : lanes)
+		while (ln.active && now_ns() < t_end)
+			if (!lane_poll(ln)) std::this_thread::yield();
+	for (Lane &ln : lanes)
+		if (ln.active)
+		{
+			for (uint32_t i : ln.pending) ln.batch[i].c->respond(ln.batch[i].h, HGS_ERR_SHUTDOWN);
+			ln.e->end_read();
+			ln.active = false;
+		}
+	answer_leftovers();
+}
+
+void dispatcher_main(int d)
+{
+	if (g_opt.lanes > 0) dispatcher_lanes(d);
+	else dispatcher_blocking(d);
 }
 
 // ----------------------------------------------------------------------------- control thread
@@ -385,8 +616,8 @@ void do_upload(CReq &r)
 struct WriteLock
 {
 	Entry *e;
-	explicit WriteLock(Entry *e_) : e(e_) { pthread_rwlock_wrlock(&e->rw); }
-	~WriteLock() { pthread_rwlock_unlock(&e->rw); }
+	explicit WriteLock(Entry *e_) : e(e_) { e->begin_write(); }
+	~WriteLock() { e->end_write(); }
 };
 
 void do_update(CReq &r)
@@ -584,7 +815,7 @@ void fill_stats(hgs_stats *s)
 	s->searches = g_cnt.searches; s->batches = g_cnt.batches; s->max_batch = g_cnt.max_batch;
 	s->search_errors = g_cnt.search_errors;
 	s->uploads = g_cnt.uploads; s->upload_bytes = g_cnt.upload_bytes; s->updates = g_cnt.updates;
-	s->binds = g_cnt.binds; s->evictions = g_cnt.evictions; s->batch_ns = g_cnt.batch_ns;
+	s->binds = g_cnt.binds; s->evictions = g_cnt.evictions; s->batch_ns = g_cnt.batch_ns; s->kernel_ns = g_cnt.kernel_ns;
 	{
 		std::lock_guard<std::mutex> lk(g_map_mu);
 		s->mirrors = g_map.size();
@@ -748,7 +979,7 @@ void usage()
 {
 	fprintf(stderr,
 			"usage: hnsw_gpu_server --socket PATH [--device N] [--dispatchers N] [--readers N]\n"
-			"                       [--max-batch N] [--linger-us N --min-batch N] [--verbose] [--ready-fd N]\n");
+			"                       [--max-batch N] [--lanes N] [--linger-us N --min-batch N] [--verbose] [--ready-fd N]\n");
 }
 
 }  // namespace
@@ -767,13 +998,14 @@ int main(int argc, char **argv)
 		else if (a == "--dispatchers") g_opt.dispatchers = atoi(val("--dispatchers"));
 		else if (a == "--readers") g_opt.readers = atoi(val("--readers"));
 		else if (a == "--max-batch") g_opt.max_batch = (size_t) atol(val("--max-batch"));
+		else if (a == "--lanes") g_opt.lanes = atoi(val("--lanes"));
 		else if (a == "--linger-us") g_opt.linger_us = atol(val("--linger-us"));
 		else if (a == "--min-batch") g_opt.min_batch = (size_t) atol(val("--min-batch"));
 		else if (a == "--ready-fd") g_opt.ready_fd = atoi(val("--ready-fd"));
 		else if (a == "--verbose") g_opt.verbose = true;
 		else { usage(); return 2; }
 	}
-	if (g_opt.path.empty() || g_opt.dispatchers < 1 || g_opt.readers < 1 || g_opt.max_batch < 1) { usage(); return 2; }
+	if (g_opt.path.empty() || g_opt.dispatchers < 1 || g_opt.readers < 1 || g_opt.max_batch < 1 || g_opt.lanes < 0 || g_opt.lanes > 16) { usage(); return 2; }
 	if (g_opt.path.size() >= sizeof(((struct sockaddr_un *) nullptr)->sun_path)) { logf("socket path too long"); return 2; }
 
 	const int ndev = hnsw_gpu_device_count();
@@ -819,8 +1051,8 @@ int main(int argc, char **argv)
 	for (int d = 0; d < g_opt.dispatchers; d++) threads.emplace_back(dispatcher_main, d);
 	threads.emplace_back(control_main);
 
-	logf("listening on %s (device %d of %d, %d dispatchers, max batch %zu)", g_opt.path.c_str(), g_opt.device, ndev,
-		 g_opt.dispatchers, g_opt.max_batch);
+	logf("listening on %s (device %d of %d, %d dispatchers x %d lanes, max batch %zu)", g_opt.path.c_str(), g_opt.device, ndev,
+		 g_opt.dispatchers, g_opt.lanes, g_opt.max_batch);
 	if (g_opt.ready_fd >= 0)
 	{
 		ssize_t w = write(g_opt.ready_fd, "READY\n", 6); (void) w;

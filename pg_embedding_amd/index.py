@@ -245,6 +245,54 @@ class SearchContext:
               "hnsw_gpu_search_batch_ctx")
         return out
 
+    def search_host(self, Q: np.ndarray, ef: int):
+        """Host arrays in and out on the context's own stream (hnsw_gpu_search_batch_ctx_host)."""
+        Q = np.ascontiguousarray(Q, dtype=np.float32).reshape(-1, int(self.index.meta.dim))
+        nq = Q.shape[0]
+        lab = np.empty((nq, ef), np.uint64)
+        dst = np.empty((nq, ef), np.float32)
+        cnt = np.empty(nq, np.uint32)
+        check(self.L.hnsw_gpu_search_batch_ctx_host(self._h, Q.ctypes.data, nq, ef, lab.ctypes.data, dst.ctypes.data,
+                                                    cnt.ctypes.data), "hnsw_gpu_search_batch_ctx_host")
+        return lab, dst, cnt
+
+    def search_streamed(self, Q: np.ndarray, ef: int, timeout: float = 60.0):
+        """Streamed completion (hnsw_gpu_search_batch_ctx_flags): queries, results and per-query
+        completion flags live in pinned host memory the kernel reads and writes directly.  Returns
+        (labels, dists, counts, order) where `order` lists the queries in the order their flags
+        were seen — what a server uses to answer each caller as soon as its walk has ended."""
+        import time
+        Q = np.ascontiguousarray(Q, dtype=np.float32).reshape(-1, int(self.index.meta.dim))
+        nq, dim = Q.shape
+        sizes = [nq * dim * 4, nq * ef * 8, nq * ef * 4, nq * 4, nq * 4]
+        offs = np.cumsum([0] + [(b + 255) // 256 * 256 for b in sizes])
+        base = self.L.hnsw_gpu_host_alloc(int(offs[-1]))
+        if not base:
+            raise MemoryError("hnsw_gpu_host_alloc")
+        try:
+            view = lambda i, dt, shape: np.frombuffer((C.c_uint8 * sizes[i]).from_address(base + int(offs[i])), dtype=dt).reshape(shape)
+            q, lab, dst = view(0, np.float32, (nq, dim)), view(1, np.uint64, (nq, ef)), view(2, np.float32, (nq, ef))
+            cnt, flg = view(3, np.uint32, (nq,)), view(4, np.uint32, (nq,))
+            q[:] = Q
+            flg[:] = 0
+            check(self.L.hnsw_gpu_search_batch_ctx_flags(self._h, q.ctypes.data, nq, ef, lab.ctypes.data, dst.ctypes.data,
+                                                         cnt.ctypes.data, None, flg.ctypes.data),
+                  "hnsw_gpu_search_batch_ctx_flags")
+            order, seen = [], np.zeros(nq, bool)
+            t_end = time.time() + timeout
+            while len(order) < nq:
+                new = np.flatnonzero((flg != 0) & ~seen)
+                seen[new] = True
+                order.extend(new.tolist())
+                if time.time() > t_end:
+                    raise TimeoutError("completion flags did not arrive")
+            while self.L.hnsw_gpu_ctx_idle(self._h) == 0:
+                if time.time() > t_end:
+                    raise TimeoutError("launch did not retire")
+            return lab.copy(), dst.copy(), cnt.copy(), np.array(order)
+        finally:
+            self.L.hnsw_gpu_host_free(base)
+
 
 # ---------------------------------------------------------------------- distances
 def dist_batch(func: int, q: np.ndarray, rows: np.ndarray) -> np.ndarray:

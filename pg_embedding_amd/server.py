@@ -30,7 +30,7 @@ class hgs_stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "connections", "connections_now", "searches", "batches", "max_batch", "search_errors",
         "uploads", "upload_bytes", "updates", "binds", "evictions", "mirrors", "mirror_elements",
-        "batch_ns", "uptime_ns")]
+        "batch_ns", "kernel_ns", "uptime_ns")]
 
 
 HGS_ERR_NOKEY, HGS_ERR_STALE, HGS_ERR_IO = -21, -22, -23
@@ -140,7 +140,7 @@ class ServerProcess:
     and stops it (SIGTERM) on exit.  `binary` lets the CPU tests substitute their test double."""
 
     def __init__(self, socket_path: Optional[str] = None, device: int = 0, dispatchers: int = 2,
-                 max_batch: int = 16384, linger_us: int = 0, min_batch: int = 1, readers: int = 4, binary: Optional[str] = None,
+                 max_batch: int = 16384, linger_us: int = 0, min_batch: int = 1, readers: int = 4, lanes: int = 2, binary: Optional[str] = None,
                  env: Optional[dict] = None, verbose: bool = False, start_timeout: float = 120.0):
         self.binary = binary or _build.SERVER_BIN
         if not os.path.exists(self.binary):
@@ -153,7 +153,7 @@ class ServerProcess:
             socket_path = os.path.join(self._tmp, "s")
         self.socket_path = socket_path
         self.args = [self.binary, "--socket", socket_path, "--device", str(device), "--dispatchers", str(dispatchers),
-                     "--max-batch", str(max_batch), "--readers", str(readers)]
+                     "--max-batch", str(max_batch), "--readers", str(readers), "--lanes", str(lanes)]
         if linger_us:
             self.args += ["--linger-us", str(linger_us), "--min-batch", str(min_batch)]
         if verbose:

@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--target-seconds", type=float, default=4.0)
     ap.add_argument("--dispatchers", type=int, default=2)
     ap.add_argument("--readers", type=int, default=8)
+    ap.add_argument("--lanes", type=int, default=2, help="launches in flight per dispatcher (0 = blocking batches)")
     ap.add_argument("--binary", default=None, help="server binary (default: the shipped one)")
     ap.add_argument("--check", type=int, default=200, help="queries compared with the CPU reference")
     a = ap.parse_args()
@@ -64,7 +65,7 @@ def main():
     qf, of = os.path.join(tmp, "q.f32"), os.path.join(tmp, "out.u64")
     Q.tofile(qf)
     key, gen = 1, 1
-    srv = ServerProcess(dispatchers=a.dispatchers, readers=a.readers, binary=a.binary)
+    srv = ServerProcess(dispatchers=a.dispatchers, readers=a.readers, lanes=a.lanes, binary=a.binary)
     with srv:
         c = RemoteClient(srv.socket_path)
         t = time.time()
@@ -90,9 +91,10 @@ def main():
             assert r.returncode == 0, r.stderr
             info = json.loads(r.stdout)
             st = c.stats()
-            d = {k: st[k] - before[k] for k in ("searches", "batches", "batch_ns")}
+            d = {k: st[k] - before[k] for k in ("searches", "batches", "batch_ns", "kernel_ns")}
             info.update(mean_batch=d["searches"] / max(1, d["batches"]), batches=d["batches"],
                         ms_per_batch=d["batch_ns"] / 1e6 / max(1, d["batches"]),
+                        kernel_ms_per_batch=d["kernel_ns"] / 1e6 / max(1, d["batches"]),
                         latency_ms=1e3 * P / info["qps"])
             rows.append(info)
             print(json.dumps(info), flush=True)
@@ -118,9 +120,9 @@ def main():
         st = c.stats()
         print("# server totals:", json.dumps({k: st[k] for k in ("connections", "searches", "batches", "max_batch", "search_errors")}))
         c.close()
-    print("\n| backends | queries/s | mean batch | ms per batch | round trip ms |\n|---|---|---|---|---|")
+    print("\n| backends | queries/s | mean batch | ms per batch (host) | kernel ms per batch | round trip ms |\n|---|---|---|---|---|---|")
     for r in rows:
-        print(f"| {r['nproc']} | {r['qps']:.0f} | {r['mean_batch']:.1f} | {r['ms_per_batch']:.2f} | {r['latency_ms']:.2f} |")
+        print(f"| {r['nproc']} | {r['qps']:.0f} | {r['mean_batch']:.1f} | {r['ms_per_batch']:.2f} | {r['kernel_ms_per_batch']:.2f} | {r['latency_ms']:.2f} |")
 
 
 if __name__ == "__main__":

@@ -11,6 +11,7 @@
  * HGS_DOUBLE_SLEEP_US makes every search batch take at least that long, so that requests pile up
  * behind it the way they do behind a busy device.
  */
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -33,7 +34,13 @@ int    port_bind_point(PortIndex *ix, const float *point, uint32_t cur_c);
 float  port_dist(int func, const float *q, const float *x, size_t dim);
 
 struct hnsw_gpu_index { PortIndex *p; HnswMetadata meta; };
-struct hnsw_gpu_ctx { hnsw_gpu_index *ix; };
+struct hnsw_gpu_ctx
+{
+	hnsw_gpu_index *ix;
+	/* the "launch" of hnsw_gpu_search_batch_ctx_flags: a thread that walks the queries one by one */
+	volatile int busy;
+	const coord_t *q; size_t nq, ef; label_t *labels; dist_t *dists; uint32_t *counts; uint32_t *done;
+};
 
 static __thread char t_err[256] = "";
 const char *hnsw_gpu_last_error(void) { return t_err; }
@@ -140,7 +147,12 @@ int hnsw_gpu_ctx_create(hnsw_gpu_index *ix, hnsw_gpu_ctx **out)
 	return HNSW_GPU_OK;
 }
 
-void hnsw_gpu_ctx_destroy(hnsw_gpu_ctx *c) { free(c); }
+void hnsw_gpu_ctx_destroy(hnsw_gpu_ctx *c)
+{
+	if (!c) return;
+	while (c->busy) { struct timespec ts = { 0, 100000 }; nanosleep(&ts, NULL); }
+	free(c);
+}
 
 int hnsw_gpu_search_batch_ctx_host(hnsw_gpu_ctx *c, const coord_t *queries, size_t nq, size_t ef, label_t *labels,
 								   dist_t *dists, uint32_t *counts)
@@ -167,6 +179,54 @@ int hnsw_gpu_search_batch_ctx_host(hnsw_gpu_ctx *c, const coord_t *queries, size
 	}
 	return HNSW_GPU_OK;
 }
+
+int hnsw_gpu_ctx_search_ms(hnsw_gpu_ctx *c, unsigned back, float *ms) { (void) c; (void) back; *ms = 0.f; return HNSW_GPU_OK; }
+
+static void *flags_worker(void *arg)
+{
+	hnsw_gpu_ctx *c = (hnsw_gpu_ctx *) arg;
+	const size_t dim = c->ix->meta.dim, ef = c->ef;
+	const char *us = getenv("HGS_DOUBLE_SLEEP_US");
+	for (size_t q = 0; q < c->nq; q++)
+	{
+		if (us && atol(us) > 0 && q % 8 == 0)                /* walks end at different times */
+		{
+			struct timespec ts = { 0, (atol(us) % 1000000) * 1000 / 4 };
+			nanosleep(&ts, NULL);
+		}
+		size_t n = 0;
+		for (size_t i = 0; i < ef; i++) { c->labels[q * ef + i] = ~(label_t) 0; if (c->dists) c->dists[q * ef + i] = 1.0f / 0.0f; }
+		port_search(c->ix->p, c->q + q * dim, ef, c->labels + q * ef, c->dists ? c->dists + q * ef : NULL, &n, NULL, NULL);
+		c->counts[q] = (uint32_t) n;
+		__atomic_store_n(&c->done[q], 1u, __ATOMIC_RELEASE);
+	}
+	__atomic_store_n(&c->busy, 0, __ATOMIC_RELEASE);
+	return NULL;
+}
+
+int hnsw_gpu_search_batch_ctx_flags(hnsw_gpu_ctx *c, const coord_t *d_queries, size_t nq, size_t ef, label_t *d_labels,
+									dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats, uint32_t *d_done)
+{
+	(void) d_stats;
+	const char *fail_at = getenv("HGS_DOUBLE_FAIL_EF");
+	if (fail_at && (size_t) atol(fail_at) == ef)
+	{
+		snprintf(t_err, sizeof(t_err), "double: asked to fail at ef %zu", ef);
+		return HNSW_GPU_ERR_INTERNAL;
+	}
+	if (c->busy) { snprintf(t_err, sizeof(t_err), "double: context busy"); return HNSW_GPU_ERR_INTERNAL; }
+	c->q = d_queries; c->nq = nq; c->ef = ef; c->labels = d_labels; c->dists = d_dists; c->counts = d_counts; c->done = d_done;
+	c->busy = 1;
+	pthread_t th;
+	pthread_attr_t at;
+	pthread_attr_init(&at);
+	pthread_attr_setdetachstate(&at, PTHREAD_CREATE_DETACHED);
+	if (pthread_create(&th, &at, flags_worker, c) != 0) { c->busy = 0; return HNSW_GPU_ERR_NOMEM; }
+	pthread_attr_destroy(&at);
+	return HNSW_GPU_OK;
+}
+
+int hnsw_gpu_ctx_idle(hnsw_gpu_ctx *c) { return __atomic_load_n(&c->busy, __ATOMIC_ACQUIRE) ? 0 : 1; }
 
 void *hnsw_gpu_host_alloc(size_t bytes) { return malloc(bytes ? bytes : 1); }
 void  hnsw_gpu_host_free(void *p) { free(p); }

@@ -382,6 +382,30 @@ def test_search_contexts_overlap_on_two_streams():
     ix.close()
 
 
+@pytest.mark.parametrize("func", [pg.DIST_L2, pg.DIST_COSINE, pg.DIST_MANHATTAN])
+def test_streamed_completion_and_host_context_forms(func):
+    """hnsw_gpu_search_batch_ctx_flags: the kernel writes results and per-query completion flags
+    straight into pinned host memory; hnsw_gpu_search_batch_ctx_host: host arrays on the context's own
+    stream.  Same bits as the oracle in every kernel form (beam, beam with 16 registers / LDS, generic)."""
+    port, X = build_port(6000, 72, 6, 40, func, seed=120 + func)
+    ix = mirror(port, func)
+    ctx = pg.SearchContext(ix)
+    Q = gmm(700, 72, k=50, seed=120 + func, stream=1)
+    for ef in (48, 300, 700):
+        want = port.search_many(Q, ef)
+        lab, dst, cnt, order = ctx.search_streamed(Q, ef)
+        assert sorted(order.tolist()) == list(range(len(Q)))           # every flag arrived, once
+        assert (cnt == want["counts"]).all()
+        for q in range(len(Q)):
+            k = int(cnt[q])
+            assert (lab[q, :k] == want["labels"][q, :k]).all()
+            assert (bits(dst[q, :k]) == bits(want["dists"][q, :k])).all()
+        lab2, dst2, cnt2 = ctx.search_host(Q, ef)
+        assert (lab2 == lab).all() and (bits(dst2) == bits(dst)).all() and (cnt2 == cnt).all()
+    ctx.close()
+    ix.close()
+
+
 def test_nan_distances_do_not_hang_or_crash():
     """Zero vectors give NaN cosine distances in the reference too (distfunc.c:144, 0/0); they are
     outside the parity contract but must not hang the kernel or corrupt memory."""

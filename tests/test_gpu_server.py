@@ -17,9 +17,11 @@ from test_server_cpu import bits, port_index, run_clients
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def srv():
-    with ServerProcess() as s:
+@pytest.fixture(scope="module", params=[2, 0], ids=["streamed", "blocking"])
+def srv(request):
+    """Both dispatcher forms: streamed completion (kernel writes results + per-query flags straight into
+    pinned host memory, answers leave as their walks end) and one blocking launch at a time."""
+    with ServerProcess(lanes=request.param) as s:
         yield s
 
 

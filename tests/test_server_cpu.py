@@ -25,9 +25,11 @@ def double_bin():
     return SU.build_double_server()
 
 
-@pytest.fixture()
-def srv(double_bin):
-    with ServerProcess(binary=double_bin) as s:
+@pytest.fixture(params=[2, 0], ids=["streamed", "blocking"])
+def srv(double_bin, request):
+    """Both dispatcher forms: streamed completion (2 launches in flight per dispatcher, answers leave as
+    their walks end) and one blocking launch at a time."""
+    with ServerProcess(binary=double_bin, lanes=request.param) as s:
         yield s
 
 
@@ -148,14 +150,15 @@ def run_clients(sock, key, gen, dim, m, efc, efs, func, Q, nproc, tmp_path, roun
     return json.loads(r.stdout), out[:nq * efs].reshape(nq, efs), out[nq * efs:]
 
 
-def test_many_backends_are_batched_and_each_gets_its_own_answer(double_bin, tmp_path):
+@pytest.mark.parametrize("lanes", [2, 0])
+def test_many_backends_are_batched_and_each_gets_its_own_answer(double_bin, tmp_path, lanes):
     """48 single-threaded processes call hnsw_search() one query at a time (embedding.c:317); the
     server turns what is waiting into batches; every call returns exactly the oracle's array."""
     dim, m, n, efs = 32, 5, 2000, 24
     port, X = port_index(n, dim, m, 24, efs, pg.DIST_L2, seed=21)
     meta = pg.make_meta(dim, m, 24, efs, pg.DIST_L2)
     Q = gmm(960, dim, k=20, seed=21, stream=1)
-    with ServerProcess(binary=double_bin, env={"HGS_DOUBLE_SLEEP_US": "3000"}) as s:
+    with ServerProcess(binary=double_bin, lanes=lanes, env={"HGS_DOUBLE_SLEEP_US": "3000"}) as s:
         c = RemoteClient(s.socket_path)
         c.upload(meta, 77, 3, port.raw(), n)
         info, labels, counts = run_clients(s.socket_path, 77, 3, dim, m, 24, efs, pg.DIST_L2, Q, 48, tmp_path)
@@ -262,10 +265,11 @@ def test_dropin_symbols_from_c_match_the_reference(srv):
     c.close()
 
 
-def test_a_failing_batch_is_reported_and_the_server_goes_on(double_bin):
+@pytest.mark.parametrize("lanes", [2, 0])
+def test_a_failing_batch_is_reported_and_the_server_goes_on(double_bin, lanes):
     dim, m, n = 16, 4, 200
     port, X = port_index(n, dim, m, 16, 10, pg.DIST_L2, seed=51)
-    with ServerProcess(binary=double_bin, env={"HGS_DOUBLE_FAIL_EF": "13"}) as s:
+    with ServerProcess(binary=double_bin, lanes=lanes, env={"HGS_DOUBLE_FAIL_EF": "13"}) as s:
         c = RemoteClient(s.socket_path)
         c.upload(pg.make_meta(dim, m, 16, 10, pg.DIST_L2), 1, 1, port.raw(), n)
         with pytest.raises(RemoteError) as e:
