@@ -9,8 +9,10 @@
  *   hnsw_gpu_server  (one process per GPU)  owns the device, keeps the HBM mirrors keyed by a
  *                    caller-chosen (key, generation) — e.g. (relfilenode, metapage LSN) — and
  *                    coalesces the SEARCH requests of all connected backends that are waiting at
- *                    the same moment into one hnsw_gpu_search_batch launch per dispatcher
- *                    (two dispatchers on two HIP streams keep the device full while one drains);
+ *                    the same moment into one launch of the fused search kernel; several launches
+ *                    are in flight on their own HIP streams, the kernel writes each query's result
+ *                    and a completion flag straight into pinned host memory, and a backend is
+ *                    answered when ITS walk has ended, not when the slowest of the batch has;
  *   libembedding_gpuc.so  exports the reference's own four symbols (embedding.h:46-47,55-56 ==
  *                    hnsw_abi.h) implemented as requests to that server.  It links no HIP and
  *                    creates no device context: a backend pays one Unix-socket round trip.

@@ -3,18 +3,23 @@
 //
 //   readers      epoll threads: parse requests; answer the trivial ones; SEARCH goes to the batch
 //                queue, everything that changes a mirror goes to the control thread
-//   dispatchers  (default 2) take every queued SEARCH for one (mirror, ef) — up to --max-batch —
-//                pack the queries into a pinned buffer and run ONE hnsw_gpu_search_batch_ctx_host
-//                (own context = own visited-set workspace and HIP stream per dispatcher, so the
-//                next batch fills the CUs the previous one frees while it drains), then answer
-//                each backend.  Requests gather while the device is busy: no artificial delay
-//                unless --linger-us is given.
+//   dispatchers  (default 2) each keep up to --lanes (default 3) launches in flight.  A free lane
+//                takes every queued SEARCH for one (mirror, ef) — up to --max-batch — packs the
+//                queries into the lane's pinned host buffer and launches the fused search kernel on
+//                the lane's own context (own visited-set workspace, own HIP stream) with the result
+//                arrays and one completion flag per query IN that pinned buffer
+//                (hnsw_gpu_search_batch_ctx_flags): nothing is copied, nothing is waited for.  The
+//                dispatcher polls the flags and answers each backend the moment ITS walk has ended —
+//                a walk is ~160 dependent hops and the slowest of a batch takes 2-3x the mean.
+//                Requests gather while the lanes are busy: no artificial delay unless --linger-us
+//                is given.  --lanes 0 = one blocking launch at a time per dispatcher.
 //   control      one thread: UPLOAD / UPDATE / BIND / LINK / EXPORT / DROP / SET_DELETED / DIST.
-//                Mirror changes take the mirror's write lock (writer-preferring), searches its
-//                read lock.
+//                Mirror changes wait for the mirror's searches in flight and keep new ones out
+//                (counting gate, writer first).
 //
 // All device work goes through the C API of libhnsw_gpu.so (hnsw_gpu.h); this file has no HIP in
 // it and no arithmetic.  No device, no service: exit status 3.
+#include <algorithm>
 #include <atomic>
 #include <cerrno>
 #include <chrono>
@@ -53,7 +58,7 @@ struct Options
 	int readers = 4;
 	int dispatchers = 2;
 	size_t max_batch = 16384;
-	int lanes = 2;                 // launches in flight per dispatcher (0 = one blocking launch at a time)
+	int lanes = 3;                 // launches in flight per dispatcher (0 = one blocking launch at a time)
 	long linger_us = 0;
 	size_t min_batch = 1;          // with --linger-us: wait while fewer requests than this are queued
 	int backlog = 1024;
@@ -1008,6 +1013,15 @@ int main(int argc, char **argv)
 	if (g_opt.path.empty() || g_opt.dispatchers < 1 || g_opt.readers < 1 || g_opt.max_batch < 1 || g_opt.lanes < 0 || g_opt.lanes > 16) { usage(); return 2; }
 	if (g_opt.path.size() >= sizeof(((struct sockaddr_un *) nullptr)->sun_path)) { logf("socket path too long"); return 2; }
 
+	// Every lane launches on its own HIP stream.  The runtime spreads streams over GPU_MAX_HW_QUEUES
+	// hardware queues (4 by default) and launches that share a queue run one after the other: with
+	// 8 lanes on 4 queues a launch waited 2.0 ms for 1.0 ms of kernel (profiles/r1k_server_backends.txt).
+	// One queue per lane, plus the null stream's; must be in the environment before the first HIP call.
+	{
+		char hwq[16];
+		snprintf(hwq, sizeof(hwq), "%d", std::max(4, g_opt.dispatchers * std::max(1, g_opt.lanes) + 2));
+		setenv("GPU_MAX_HW_QUEUES", hwq, 0);
+	}
 	const int ndev = hnsw_gpu_device_count();
 	if (ndev <= 0 || g_opt.device < 0 || g_opt.device >= ndev)
 	{

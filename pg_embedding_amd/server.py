@@ -140,7 +140,7 @@ class ServerProcess:
     and stops it (SIGTERM) on exit.  `binary` lets the CPU tests substitute their test double."""
 
     def __init__(self, socket_path: Optional[str] = None, device: int = 0, dispatchers: int = 2,
-                 max_batch: int = 16384, linger_us: int = 0, min_batch: int = 1, readers: int = 4, lanes: int = 2, binary: Optional[str] = None,
+                 max_batch: int = 16384, linger_us: int = 0, min_batch: int = 1, readers: int = 4, lanes: int = 3, binary: Optional[str] = None,
                  env: Optional[dict] = None, verbose: bool = False, start_timeout: float = 120.0):
         self.binary = binary or _build.SERVER_BIN
         if not os.path.exists(self.binary):

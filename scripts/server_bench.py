@@ -38,7 +38,8 @@ def main():
     ap.add_argument("--target-seconds", type=float, default=4.0)
     ap.add_argument("--dispatchers", type=int, default=2)
     ap.add_argument("--readers", type=int, default=8)
-    ap.add_argument("--lanes", type=int, default=2, help="launches in flight per dispatcher (0 = blocking batches)")
+    ap.add_argument("--lanes", type=int, default=3, help="launches in flight per dispatcher (0 = blocking batches)")
+    ap.add_argument("--hwq", type=int, default=0, help="GPU_MAX_HW_QUEUES for the server process (0 = leave it alone)")
     ap.add_argument("--binary", default=None, help="server binary (default: the shipped one)")
     ap.add_argument("--check", type=int, default=200, help="queries compared with the CPU reference")
     a = ap.parse_args()
@@ -65,7 +66,8 @@ def main():
     qf, of = os.path.join(tmp, "q.f32"), os.path.join(tmp, "out.u64")
     Q.tofile(qf)
     key, gen = 1, 1
-    srv = ServerProcess(dispatchers=a.dispatchers, readers=a.readers, lanes=a.lanes, binary=a.binary)
+    srv = ServerProcess(dispatchers=a.dispatchers, readers=a.readers, lanes=a.lanes, binary=a.binary,
+                        env={"GPU_MAX_HW_QUEUES": str(a.hwq)} if a.hwq else None)
     with srv:
         c = RemoteClient(srv.socket_path)
         t = time.time()
