@@ -112,10 +112,22 @@ def test_libraries_export_every_declared_symbol():
     assert {"hnsw_begin_read", "hnsw_end_read"} <= und
     # and the core library must be host-independent
     assert not any(s.startswith("hnsw_begin") or s.startswith("hnsw_end") for s in undefined(B.GPU_LIB))
+    # the server's client library: the same four symbols + the calls of hnsw_gpu_server.h, the host's
+    # callbacks imported, and nothing of HIP or of libhnsw_gpu.so linked
+    client = exported(B.CLIENT_LIB)
+    assert {"hnsw_search", "hnsw_bind_point", "hnsw_dist_func", "hnsw_init_dist_func"} <= client
+    assert {d for d in declared("hnsw_gpu_server.h") if d.startswith("hnsw_gpu_remote_")} <= client
+    assert len([d for d in declared("hnsw_gpu_server.h") if d.startswith("hnsw_gpu_remote_")]) >= 13
+    und = undefined(B.CLIENT_LIB)
+    assert {"hnsw_begin_read", "hnsw_end_read", "hnsw_begin_write", "hnsw_end_write"} <= und
+    assert not any(s.startswith("hip") or s.startswith("hnsw_gpu_") for s in und)
+    # the server binary gets its arithmetic from libhnsw_gpu.so only
+    srv = undefined(B.SERVER_BIN)
+    assert {"hnsw_gpu_search_batch_ctx_flags", "hnsw_gpu_index_create_from_flat", "hnsw_gpu_index_link"} <= srv
 
 
 def test_no_cpu_fallback_product_never_links_the_oracle():
-    for lib in (B.GPU_LIB, B.SHIM_LIB):
+    for lib in (B.GPU_LIB, B.SHIM_LIB, B.CLIENT_LIB, B.SERVER_BIN):
         und = undefined(lib) | exported(lib)
         assert not any(s.startswith("port_") or s.startswith("flat_") for s in und)
     pkg = os.path.join(ROOT, "pg_embedding_amd")
