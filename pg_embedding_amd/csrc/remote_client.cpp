@@ -105,6 +105,8 @@ int rpc(hgs_hdr *h, const void *p1, size_t l1, const void *p2, size_t l2, int pa
 {
 	int rc = ensure_connected();
 	if (rc != HGS_OK) return rc;
+	if (pass_fd >= 0 && fcntl(pass_fd, F_ADD_SEALS, F_SEAL_SHRINK) != 0)      // see Shm::seal
+		return fail(HGS_ERR_IO, "cannot seal the shared memory file: %s", strerror(errno));
 	h->magic = HGS_MAGIC;
 	h->len = (uint32_t) ((p1 ? l1 : 0) + (p2 ? l2 : 0));
 	if (hgs::send_msg(t_fd, h, p1, l1, p2, l2, pass_fd) != 0 || hgs::recv_exact(t_fd, r, sizeof(*r), nullptr) != 0)
@@ -139,7 +141,7 @@ struct Shm
 	}
 	bool create(size_t nbytes)
 	{
-		fd = memfd_create("hnsw_gpu_elements", MFD_CLOEXEC);
+		fd = memfd_create("hnsw_gpu_elements", MFD_CLOEXEC | MFD_ALLOW_SEALING);
 		if (fd < 0) return false;
 		if (nbytes == 0) nbytes = 1;
 		if (ftruncate(fd, (off_t) nbytes) != 0) return false;
@@ -148,6 +150,8 @@ struct Shm
 		p = m; bytes = nbytes;
 		return true;
 	}
+	// The server only maps files that can no longer shrink under it (it would die of SIGBUS).
+	bool seal() { return fcntl(fd, F_ADD_SEALS, F_SEAL_SHRINK) == 0; }
 	void release()
 	{
 		if (p) munmap(p, bytes);

@@ -192,6 +192,8 @@ bool evict_one(uint64_t keep)
 }
 
 // ----------------------------------------------------------------------------- connections
+const int MAX_INFLIGHT_PER_CONN = 64;
+
 struct Conn
 {
 	int fd = -1;
@@ -199,6 +201,7 @@ struct Conn
 	std::deque<int> fds;          // descriptors received and not yet claimed by a request
 	std::mutex wmu;
 	std::atomic<bool> closed{false};
+	std::atomic<int> inflight{0};  // SEARCH requests not answered yet (a backend has one; the cap stops a flood)
 	~Conn()
 	{
 		for (int f : fds) close(f);
@@ -207,6 +210,7 @@ struct Conn
 	void respond(const hgs_hdr &req, int status, uint64_t a0 = 0, uint64_t a1 = 0, const void *p1 = nullptr,
 				 size_t l1 = 0, const void *p2 = nullptr, size_t l2 = 0, uint64_t gen = 0)
 	{
+		if (req.op == HGS_OP_SEARCH) inflight--;
 		if (closed.load()) return;
 		hgs_hdr h;
 		memset(&h, 0, sizeof(h));
@@ -214,7 +218,8 @@ struct Conn
 		h.len = (uint32_t) ((p1 ? l1 : 0) + (p2 ? l2 : 0));
 		h.key = req.key; h.gen = gen ? gen : req.gen; h.a0 = a0; h.a1 = a1;
 		std::lock_guard<std::mutex> lk(wmu);
-		if (hgs::send_msg(fd, &h, p1, l1, p2, l2) != 0) closed.store(true);
+		// a backend that does not read its answer may hold a dispatcher for 2 s, once: then it is cut off
+		if (hgs::send_msg(fd, &h, p1, l1, p2, l2, -1, 2000) != 0) { closed.store(true); shutdown(fd, SHUT_RDWR); }
 	}
 };
 using ConnP = std::shared_ptr<Conn>;
@@ -547,6 +552,10 @@ struct Mapping            // a received memfd, mapped
 		fd = f;
 		struct stat st;
 		if (f < 0 || fstat(f, &st) != 0 || st.st_size <= 0) return false;
+		// only a memfd sealed against shrinking: a client that truncates the file under our mapping
+		// would otherwise take the server down with SIGBUS
+		const int seals = fcntl(f, F_GET_SEALS);
+		if (seals < 0 || !(seals & F_SEAL_SHRINK)) return false;
 		void *m = mmap(nullptr, (size_t) st.st_size, writable ? PROT_READ | PROT_WRITE : PROT_READ, MAP_SHARED, f, 0);
 		if (m == MAP_FAILED) return false;
 		p = m; bytes = (size_t) st.st_size;
@@ -859,6 +868,7 @@ bool handle_message(const ConnP &c, const hgs_hdr &h, const char *payload)
 	}
 	case HGS_OP_SEARCH:
 	{
+		if (c->inflight.fetch_add(1) >= MAX_INFLIGHT_PER_CONN) { c->respond(h, HGS_ERR_PROTOCOL); return false; }
 		EntryP e = find_entry(h.key);
 		if (!e) { c->respond(h, HGS_ERR_NOKEY); return true; }
 		const uint64_t gen = e->gen.load();

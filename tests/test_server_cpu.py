@@ -313,6 +313,32 @@ def test_malformed_traffic_only_costs_the_sender_its_connection(srv):
     s = raw()                                            # UPLOAD that promises a descriptor and sends none
     s.sendall(hdr.pack(0x31534748, 3, 0, 88, 0, 9, 1, 5, 0) + b"\x00" * 88)
     assert hdr.unpack(s.recv(48))[2] == -20
+    # an UPLOAD whose file could still shrink under the server's mapping (no F_SEAL_SHRINK) is refused
+    fd = os.memfd_create("unsealed", os.MFD_CLOEXEC)
+    os.ftruncate(fd, 5 * (9 * 4 + dim * 4 + 8))
+    meta = pg.make_meta(dim, m, 16, 10, pg.DIST_L2)
+    s = raw()
+    socket.send_fds(s, [hdr.pack(0x31534748, 3, 0, 88, 0, 9, 1, 5, 0) + bytes(meta)], [fd])
+    assert hdr.unpack(s.recv(48))[2] == -20
+    os.close(fd)
+    assert c.lookup(9)[0] is False
+    # a connection may pipeline a little (a backend has one scan in flight), not flood the queue
+    s = raw()
+    one = hdr.pack(0x31534748, 5, 0, dim * 4, 10, 1, 0, 0, 0) + X[0].tobytes()
+    s.sendall(one * 8)
+    got = b""
+    while len(got) < 8 * (48 + 10 * 8):
+        got += s.recv(65536)
+    assert all(hdr.unpack(got[i * 128:i * 128 + 48])[2] == 0 for i in range(8))
+    s = raw()
+    s.settimeout(10)
+    try:
+        s.sendall(one * 400)
+        data = b"x"
+        while data:
+            data = s.recv(65536)                         # ... answers, then EOF: cut off
+    except (BrokenPipeError, ConnectionResetError):
+        pass
     s = raw()                                            # a backend that dies mid-request
     s.sendall(hdr.pack(0x31534748, 5, 0, dim * 4, 10, 1, 0, 0, 0) + b"\x00" * 10)
     s.close()
