@@ -33,7 +33,7 @@ int    port_search(PortIndex *ix, const float *q, size_t ef, uint64_t *label_out
 int    port_bind_point(PortIndex *ix, const float *point, uint32_t cur_c);
 float  port_dist(int func, const float *q, const float *x, size_t dim);
 
-struct hnsw_gpu_index { PortIndex *p; HnswMetadata meta; };
+struct hnsw_gpu_index { PortIndex *p; HnswMetadata meta; size_t charged; };
 struct hnsw_gpu_ctx
 {
 	hnsw_gpu_index *ix;
@@ -46,10 +46,20 @@ static __thread char t_err[256] = "";
 const char *hnsw_gpu_last_error(void) { return t_err; }
 int hnsw_gpu_device_count(void) { return 1; }
 
+/* HGS_DOUBLE_CAPACITY = elements the "device" holds over all mirrors: beyond it an upload fails with
+ * HNSW_GPU_ERR_NOMEM like a failed hipMalloc, which is what makes the server evict idle mirrors. */
+static size_t g_live_elements = 0;
+
 int hnsw_gpu_index_create_from_flat(const HnswMetadata *meta, const void *elements, size_t n, int device,
 									hnsw_gpu_index **out)
 {
 	(void) device;
+	const char *cap = getenv("HGS_DOUBLE_CAPACITY");
+	if (cap && __atomic_load_n(&g_live_elements, __ATOMIC_RELAXED) + n > (size_t) atol(cap))
+	{
+		snprintf(t_err, sizeof(t_err), "double: out of device memory");
+		return HNSW_GPU_ERR_NOMEM;
+	}
 	hnsw_gpu_index *ix = (hnsw_gpu_index *) calloc(1, sizeof(*ix));
 	if (!ix) return HNSW_GPU_ERR_NOMEM;
 	ix->meta = *meta;
@@ -61,6 +71,8 @@ int hnsw_gpu_index_create_from_flat(const HnswMetadata *meta, const void *elemen
 		free(ix);
 		return HNSW_GPU_ERR_NOMEM;
 	}
+	ix->charged = n;
+	__atomic_fetch_add(&g_live_elements, n, __ATOMIC_RELAXED);
 	*out = ix;
 	return HNSW_GPU_OK;
 }
@@ -68,6 +80,7 @@ int hnsw_gpu_index_create_from_flat(const HnswMetadata *meta, const void *elemen
 void hnsw_gpu_index_destroy(hnsw_gpu_index *ix)
 {
 	if (!ix) return;
+	__atomic_fetch_sub(&g_live_elements, ix->charged, __ATOMIC_RELAXED);
 	port_destroy(ix->p);
 	free(ix);
 }

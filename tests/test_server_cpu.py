@@ -346,6 +346,30 @@ def test_malformed_traffic_only_costs_the_sender_its_connection(srv):
     c.close()
 
 
+def test_an_upload_that_does_not_fit_evicts_idle_mirrors_lru_first(double_bin):
+    dim, m, efs = 16, 4, 10
+    meta = pg.make_meta(dim, m, 16, efs, pg.DIST_L2)
+    ports = [port_index(400, dim, m, 16, efs, pg.DIST_L2, seed=70 + i) for i in range(4)]
+    with ServerProcess(binary=double_bin, env={"HGS_DOUBLE_CAPACITY": "1000"}) as s:
+        c = RemoteClient(s.socket_path)
+        c.upload(meta, 1, 1, ports[0][0].raw(), 400)
+        c.upload(meta, 2, 1, ports[1][0].raw(), 400)
+        c.search(1, ports[0][1][0], efs)                 # key 1 is now the more recently used one
+        c.upload(meta, 3, 1, ports[2][0].raw(), 400)     # 1200 > 1000: key 2 has to go
+        assert [c.lookup(k)[0] for k in (1, 2, 3)] == [True, False, True]
+        assert c.stats()["evictions"] == 1
+        # a new generation of a key that is already there replaces it without touching the others
+        c.upload(meta, 3, 2, ports[3][0].raw(), 400)
+        assert [c.lookup(k)[:2] for k in (1, 3)] == [(True, 1), (True, 2)] and c.stats()["evictions"] == 1
+        assert (c.search(3, ports[3][1][5], efs)[0] == ports[3][0].search(ports[3][1][5], efs)[0]).all()
+        # something that cannot fit at all: refused (HNSW_GPU_ERR_NOMEM), everything idle was given up for it
+        big = port_index(1100, dim, m, 16, efs, pg.DIST_L2, seed=99)[0]
+        with pytest.raises(RemoteError) as e:
+            c.upload(meta, 9, 1, big.raw(), 1100)
+        assert e.value.code == -3
+        c.close()
+
+
 def test_server_stops_cleanly_on_sigterm(double_bin):
     s = ServerProcess(binary=double_bin).start()
     c = RemoteClient(s.socket_path)
