@@ -26,6 +26,7 @@
 
 #include "hnsw_gpu.h"
 #include "hnsw_gpu_shim.h"
+#include "host_walk.h"
 
 namespace {
 
@@ -76,12 +77,13 @@ bool stage_reserve(size_t bytes)
 
 }  // namespace
 
-// Copy every element of the host index into one contiguous image by the same accessor the
-// reference search uses (hnsw_begin_read, embedding.c:704-757).  Element numbers may have
-// holes at the tail of a page (idx = blk*elems_per_page + off-1 with un-aligned
-// elems_per_page, embedding.c:229,693 / SURVEY.md §0.8): a miss inside a page skips to the
-// next page; a miss at a page start ends the walk.  Holes become zero-linked, vacuum-flagged
-// placeholders that nothing links to.
+// Copy the host index into one contiguous image by the same accessor the reference search uses
+// (hnsw_begin_read, embedding.c:704-757), following the links from the entry point — see
+// host_walk.h for why it must not probe element numbers past the end (the real host raises ERROR
+// there) and why leaving out unreachable elements changes no answer.  Element numbers that were
+// not reached, among them the holes at the tail of a page (idx = blk*elems_per_page + off-1 with
+// un-aligned elems_per_page, embedding.c:229,693 / SURVEY.md §0.8), become zero-linked,
+// vacuum-flagged placeholders that nothing links to.
 extern "C" int hnsw_gpu_shim_snapshot(HnswMetadata *meta, hnsw_gpu_index **out)
 {
 	if (!meta || !out) return HNSW_GPU_ERR_ARG;
@@ -91,37 +93,9 @@ extern "C" int hnsw_gpu_shim_snapshot(HnswMetadata *meta, hnsw_gpu_index **out)
 		fprintf(stderr, "pg_embedding_amd: no HIP device visible; the GPU hot path has no CPU fallback\n");
 		return HNSW_GPU_ERR_NODEVICE;
 	}
-	const size_t esz = meta->size_data_per_element;
-	const size_t epp = meta->elems_per_page ? meta->elems_per_page : 1;
-	size_t n = 0;
-	for (size_t idx = 0; idx < 0xFFFFFFFEull;)
-	{
-		idx_t *links = nullptr;
-		if (hnsw_begin_read(meta, (idx_t) idx, &links, nullptr, nullptr))
-		{
-			if (!stage_reserve((idx + 1) * esz)) { hnsw_end_read(meta); return HNSW_GPU_ERR_NOMEM; }
-			if (idx > n)        // holes skipped since the last real element
-			{
-				for (size_t h = n; h < idx; h++)
-				{
-					char *p = t_stage + h * esz;
-					memset(p, 0, esz);
-					const label_t dead = (label_t) 1 << HNSW_LABEL_DELETED_BIT;
-					memcpy(p + meta->offset_label, &dead, sizeof(dead));
-				}
-			}
-			memcpy(t_stage + idx * esz, links, esz);     // the element image is contiguous
-			hnsw_end_read(meta);
-			n = idx + 1;
-			idx++;
-		}
-		else
-		{
-			if (idx % epp == 0) break;                    // page does not exist: end of index
-			idx = (idx / epp + 1) * epp;                  // tail hole: continue on the next page
-		}
-	}
-	return hnsw_gpu_index_create_from_flat(meta, t_stage, n, dev, out);
+	const long n = hostwalk::copy_reachable(meta, [](size_t bytes) -> char * { return stage_reserve(bytes) ? t_stage : nullptr; });
+	if (n < 0) return HNSW_GPU_ERR_NOMEM;
+	return hnsw_gpu_index_create_from_flat(meta, t_stage, (size_t) n, dev, out);
 }
 
 extern "C" int hnsw_gpu_shim_attach(HnswMetadata *meta, hnsw_gpu_index *ix)
@@ -243,11 +217,15 @@ extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t 
 	bool ok = false;
 	do
 	{
-		if (ix)
+		if (!ix)                                         // no attached mirror: mirror what the search can reach;
+		{                                                // the new element is not linked yet, so it is added below
+			if (hnsw_gpu_shim_snapshot(meta, &ix) != HNSW_GPU_OK) break;
+			own = true;
+		}
 		{
 			size_t have = hnsw_gpu_index_count(ix);
-			if (have < (size_t) idx)                     // element numbers skipped a page-tail hole
-			{                                            // (embedding.c:229,693): dead placeholders
+			if (have < (size_t) idx)                     // element numbers skipped a page-tail hole (embedding.c:229,693)
+			{                                            // or the tail was not reachable: dead placeholders
 				const size_t gap = (size_t) idx - have;
 				if (hnsw_gpu_index_reserve(ix, (size_t) idx + 1 + (size_t) idx / 2) != HNSW_GPU_OK) break;
 				coord_t *zeros = (coord_t *) calloc(gap * meta->dim, sizeof(coord_t));
@@ -273,12 +251,6 @@ extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t 
 						(unsigned) idx, have);
 				break;
 			}
-		}
-		else
-		{
-			if (hnsw_gpu_shim_snapshot(meta, &ix) != HNSW_GPU_OK) break;
-			own = true;
-			if (hnsw_gpu_index_count(ix) != (size_t) idx + 1) break;
 		}
 		if (idx == 0) { ok = true; break; }
 		if (hnsw_gpu_index_link(ix, idx, 1, 1, 0, nullptr) != HNSW_GPU_OK) break;

@@ -26,6 +26,7 @@
 #include <sys/un.h>
 
 #include "hgs_io.h"
+#include "host_walk.h"
 #include "hnsw_gpu.h"      // error codes only: nothing of libhnsw_gpu.so is linked
 
 namespace {
@@ -179,45 +180,21 @@ bool find_attached(HnswMetadata *meta, Attachment *out)
 	return false;
 }
 
-// Copy every element of the host index into shared memory by the accessor the reference search
-// uses (hnsw_begin_read, embedding.c:704-757), one pin at a time.  Element numbers may have holes at
-// the tail of a page (idx = blk*elems_per_page + off-1, embedding.c:229,693): a miss inside a page
-// skips to the next page, a miss at a page start ends the walk; holes become zero-linked,
-// vacuum-flagged placeholders nothing links to (same walk as hnsw_gpu_shim_snapshot).
+// Copy the host index into shared memory by the accessor the reference search uses (hnsw_begin_read,
+// embedding.c:704-757), following the links from the entry point, one pin at a time — host_walk.h
+// explains why the walk must not probe element numbers past the end (the real host raises ERROR there)
+// and why leaving out unreachable elements changes no answer; element numbers that were not reached
+// (page-tail holes of embedding.c:229,693 among them) become vacuum-flagged placeholders.
 int walk_and_upload(HnswMetadata *meta, uint64_t key, uint64_t gen)
 {
-	const size_t esz = meta->size_data_per_element;
-	const size_t epp = meta->elems_per_page ? meta->elems_per_page : 1;
 	// Per-thread and reused: a host callback that leaves by longjmp (elog(ERROR), embedding.c:715)
 	// must not leak the area — the next walk takes it back.
 	static thread_local Shm shm;
 	shm.release();
 	if (!shm.create((size_t) 1 << 20)) return fail(HGS_ERR_IO, "memfd_create/mmap failed: %s", strerror(errno));
-	size_t n = 0;
-	for (size_t idx = 0; idx < 0xFFFFFFFEull;)
-	{
-		idx_t *links = nullptr;
-		if (hnsw_begin_read(meta, (idx_t) idx, &links, nullptr, nullptr))
-		{
-			if (!shm.grow((idx + 1) * esz)) { hnsw_end_read(meta); return fail(HGS_ERR_IO, "cannot grow the upload area"); }
-			for (size_t hole = n; hole < idx; hole++)
-			{
-				char *p = (char *) shm.p + hole * esz;
-				memset(p, 0, esz);
-				const label_t dead = (label_t) 1 << HNSW_LABEL_DELETED_BIT;
-				memcpy(p + meta->offset_label, &dead, sizeof(dead));
-			}
-			memcpy((char *) shm.p + idx * esz, links, esz);      // the element image is contiguous
-			hnsw_end_read(meta);
-			n = idx + 1;
-			idx++;
-		}
-		else
-		{
-			if (idx % epp == 0) break;
-			idx = (idx / epp + 1) * epp;
-		}
-	}
+	const long walked = hostwalk::copy_reachable(meta, [](size_t bytes) -> char * { return shm.grow(bytes) ? (char *) shm.p : nullptr; });
+	if (walked < 0) return fail(HGS_ERR_IO, "cannot grow the upload area");
+	const size_t n = (size_t) walked;
 	hgs_hdr h, r;
 	memset(&h, 0, sizeof(h));
 	h.op = HGS_OP_UPLOAD; h.key = key; h.gen = gen; h.a0 = n;

@@ -86,3 +86,27 @@ def build_c_reference(name: str):
             _run(["g++"] + objs + [os.path.join(refdir, "hnswalg.o"), os.path.join(refdir, "distfunc.o"),
                                    "-o", exe, "-lpthread", "-lm"])
     return exe
+
+
+# ---------------------------------------------------------------------------------------------
+# The reference's own Postgres glue (embedding.c, compiled unmodified by oracle/Makefile `pgmock`
+# into oracle/_ref/embedding.o) + the mini-Postgres of oracle/pgmock, linked against the product.
+PG_GLUE_OBJS = [os.path.join(ROOT, "oracle", "_ref", "embedding.o"),
+                os.path.join(ROOT, "oracle", "_build", "pgmock.o"),
+                os.path.join(ROOT, "oracle", "_build", "regress_mini.o")]
+PG_REGRESS_REF = os.path.join(ROOT, "oracle", "_ref", "pg_regress_ref")
+
+
+def have_pg_glue() -> bool:
+    return all(os.path.exists(o) for o in PG_GLUE_OBJS)
+
+
+def build_pg_regress(variant: str) -> str:
+    """variant 'gpu': libembedding_gpu.so (in-process device); 'client': libembedding_gpuc.so (hnsw_gpu_server)."""
+    libs = {"gpu": ["-lembedding_gpu", "-lhnsw_gpu"], "client": ["-lembedding_gpuc"]}[variant]
+    exe = os.path.join(OUT, "pg_regress_" + variant)
+    deps = PG_GLUE_OBJS + [os.path.join(LIB, "libembedding_gpu.so" if variant == "gpu" else "libembedding_gpuc.so")]
+    with _Lock():
+        if _stale(exe, deps):
+            _run(["g++"] + PG_GLUE_OBJS + ["-o", exe, "-L", LIB] + libs + [f"-Wl,-rpath,{LIB}", "-lpthread", "-lm"])
+    return exe

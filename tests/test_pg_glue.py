@@ -1,0 +1,109 @@
+"""The drop-in claim at the level the north star states it: the reference's Postgres glue stays
+intact.  embedding.c is compiled UNMODIFIED where it lies (oracle/Makefile `pgmock`) against a
+single-process stand-in for the server API it uses (oracle/pgmock: real page arithmetic, pin/lock
+tracking, generic WAL, reloptions, IndexAmRoutine) and driven through its own access-method routine
+by a mini psql (oracle/pgmock/regress_mini.c).  Only what is linked underneath the four symbols of
+embedding.h:46-47,55-56 changes:
+
+  reference   hnswalg.o + distfunc.o              -> must reproduce the reference's test/expected/*.out
+  product     libembedding_gpuc.so + hnsw_gpu_server (CPU: the server's test double; GPU: the device)
+              libembedding_gpu.so (GPU, in-process)  -> must print the same bytes
+
+Scripts: tests/golden/pg_regress/*.cmd (knn / gh-2 / gh-3 = the reference's test/sql files statement
+by statement; scenario = a 1 650-row session with inserts, deletes, VACUUM, TID reuse, LIMIT above
+efsearch, all three operator classes).  *.expected = output of the reference-linked driver
+(tests/golden/make_pg_regress_golden.py)."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from pg_embedding_amd.server import ServerProcess
+import server_util as SU
+
+GOLD = os.path.join(SU.ROOT, "tests", "golden", "pg_regress")
+REF_EXPECTED = "/root/reference/test/expected"
+SCRIPTS = ["knn", "gh-2", "gh-3", "scenario"]
+
+needs_glue = pytest.mark.skipif(not SU.have_pg_glue(), reason="oracle/_ref/embedding.o is built only where /root/reference exists")
+
+
+def run_driver(exe, name, env=None):
+    cmd = open(os.path.join(GOLD, name + ".cmd")).read()
+    r = subprocess.run([exe], input=cmd, capture_output=True, text=True, env=env, timeout=900)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    return r.stdout
+
+
+def expected(name):
+    return open(os.path.join(GOLD, name + ".expected")).read()
+
+
+def select_blocks(text):
+    """{statement: result block} for the SELECT statements of a psql transcript (explain excluded)."""
+    out, lines, i = {}, text.splitlines(), 0
+    while i < len(lines):
+        if re.match(r"SELECT ", lines[i], re.I):
+            j = i + 1
+            while j < len(lines) and not re.match(r"\(\d+ rows?\)$", lines[j]):
+                j += 1
+            out.setdefault(lines[i], []).append("\n".join(lines[i + 1:j + 1]))
+            i = j
+        i += 1
+    return out
+
+
+@needs_glue
+@pytest.mark.skipif(not os.path.isdir(REF_EXPECTED), reason="reference not mounted")
+@pytest.mark.parametrize("name", ["knn", "gh-2", "gh-3"])
+def test_reference_glue_on_the_mock_reproduces_the_references_expected_output(name):
+    """Validates the harness itself: embedding.c + hnswalg.cpp + distfunc.c, all unmodified, on the
+    mini-Postgres give the result tables of the reference's own pg_regress expectations — the NULL row,
+    the Manhattan tie, delete + vacuum + reinsert, TRUNCATE, the empty index, ctid/id output."""
+    got = select_blocks(run_driver(SU.PG_REGRESS_REF, name))
+    want = select_blocks(open(os.path.join(REF_EXPECTED, name + ".out")).read())
+    assert want and got == want
+    assert run_driver(SU.PG_REGRESS_REF, name) == expected(name)          # and the committed golden is current
+    if name == "knn":                                                     # the plan's startup cost, knn.out:11
+        assert "startup cost 256.00" in expected(name) and "(cost=256.00.." in open(os.path.join(REF_EXPECTED, "knn.out")).read()
+
+
+@needs_glue
+@pytest.mark.skipif(not os.path.exists(SU.PG_REGRESS_REF), reason="reference-linked driver not built")
+def test_scenario_golden_is_current():
+    assert run_driver(SU.PG_REGRESS_REF, "scenario") == expected("scenario")
+    blocks = expected("scenario")
+    assert blocks.count("(60 rows)") == 4                                 # LIMIT 60 > efsearch 24: the scan doubled efSearch
+    assert "ERROR:  Wrong number of dimensions: 5 instead of 16 expected" in blocks
+
+
+@needs_glue
+@pytest.mark.parametrize("name", SCRIPTS)
+def test_glue_over_the_server_client_library(name):
+    """embedding.c + libembedding_gpuc.so; the server here is the CPU test double (protocol, BIND
+    write-back through hnsw_begin_write into real pages, uploads walked through hnsw_begin_read with
+    its pins and locks).  No attach calls: embedding.c is unmodified, so every call mirrors the index."""
+    exe = SU.build_pg_regress("client")
+    with ServerProcess(binary=SU.build_double_server()) as s:
+        got = run_driver(exe, name, env=dict(os.environ, PG_EMBEDDING_GPU_SERVER=s.socket_path))
+    assert got == expected(name)
+
+
+@needs_glue
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SCRIPTS)
+def test_glue_over_the_device_in_process(name):
+    """embedding.c + libembedding_gpu.so: CREATE INDEX, INSERT, ordered scans, DELETE + VACUUM, the SQL
+    distance functions — same bytes as with the reference's hnswalg.o + distfunc.o underneath."""
+    assert run_driver(SU.build_pg_regress("gpu"), name) == expected(name)
+
+
+@needs_glue
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SCRIPTS)
+def test_glue_over_the_device_through_the_server(name):
+    exe = SU.build_pg_regress("client")
+    with ServerProcess() as s:
+        got = run_driver(exe, name, env=dict(os.environ, PG_EMBEDDING_GPU_SERVER=s.socket_path))
+    assert got == expected(name)
