@@ -73,7 +73,9 @@ enum
 	HGS_OP_LINK        = 10, /* key, a0 = first, a1 = count, aux = max_batch (0 = default): bulk
 	                            hnsw_gpu_index_link (CREATE INDEX offload)                              */
 	HGS_OP_EXPORT      = 11, /* key, fd = writable memfd of count*size_data_per_element bytes -> element images */
-	HGS_OP_SET_DELETED = 12  /* key, aux = idx, a0 = 0/1 (embedding.c:920-926)                                */
+	HGS_OP_SET_DELETED = 12, /* key, aux = idx, a0 = 0/1 (embedding.c:920-926)                                */
+	HGS_OP_SETGEN      = 13  /* key, gen = NEW generation, payload = u64 expected current generation: the mirror
+	                            already holds the new state (it was changed through BIND), only its name moves   */
 };
 
 enum
@@ -118,6 +120,11 @@ const char *hnsw_gpu_remote_last_error(void);
  * call it: hnsw_beginscan (embedding.c:249-262) with key = relfilenode; detach in hnsw_endscan. */
 int hnsw_gpu_remote_attach(HnswMetadata *meta, uint64_t key, uint64_t generation);
 int hnsw_gpu_remote_detach(HnswMetadata *meta);
+/* After inserts through hnsw_bind_point() on an attached meta the server-side mirror already holds the
+ * new elements; this gives that state the generation the host now computes for its index (so that the
+ * next attach — in this or any other backend — finds it current instead of uploading).  Where
+ * embedding.c would call it: at the end of hnsw_insert / hnsw_build (integration/embedding_gpu_server.patch). */
+int hnsw_gpu_remote_advance(HnswMetadata *meta, uint64_t new_generation);
 
 /* Lower level, for hosts that manage mirrors themselves. */
 int hnsw_gpu_remote_lookup(uint64_t key, uint64_t *generation, size_t *count, int *present);

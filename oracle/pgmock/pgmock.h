@@ -168,6 +168,7 @@ typedef struct RelationData
 } RelationData;
 typedef RelationData *Relation;
 #define RelationNeedsWAL(rel) ((rel)->needs_wal)
+#define RelationGetRelid(rel) ((rel)->rd_id)
 #define RelationGetSmgr(rel) (rel)
 BlockNumber RelationGetNumberOfBlocksInFork(Relation rel, ForkNumber fork);
 #define RelationGetNumberOfBlocks(rel) RelationGetNumberOfBlocksInFork(rel, MAIN_FORKNUM)

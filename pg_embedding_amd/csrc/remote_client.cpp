@@ -359,6 +359,24 @@ extern "C" int hnsw_gpu_remote_attach(HnswMetadata *meta, uint64_t key, uint64_t
 	return HGS_OK;
 }
 
+extern "C" int hnsw_gpu_remote_advance(HnswMetadata *meta, uint64_t new_generation)
+{
+	Attachment at;
+	if (!meta || !find_attached(meta, &at)) return fail(HNSW_GPU_ERR_ARG, "meta is not attached");
+	if (at.gen == new_generation) return HGS_OK;
+	hgs_hdr h, r;
+	memset(&h, 0, sizeof(h));
+	h.op = HGS_OP_SETGEN; h.key = at.key; h.gen = new_generation;
+	int rc = rpc(&h, &at.gen, 8, nullptr, 0, -1, &r);
+	if (rc != HGS_OK && rc != HGS_ERR_STALE) return rc;
+	// STALE: somebody else renamed it first (two inserters cannot overlap — the host serialises them,
+	// embedding.c:624-629 — but an uploader can): the next attach settles it by comparing generations.
+	std::lock_guard<std::mutex> lk(g_mu);
+	for (Attachment &a : g_attached)
+		if (a.meta == meta) a.gen = new_generation;
+	return HGS_OK;
+}
+
 extern "C" int hnsw_gpu_remote_detach(HnswMetadata *meta)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
@@ -422,7 +440,14 @@ extern "C" bool hnsw_search(HnswMetadata *meta, const coord_t *point, size_t *n_
 	size_t cnt = 0;
 	if (ok && ef > 0)                    // ef = 0: searchKnn trims to zero results (hnswalg.cpp:238-240)
 	{
-		ok = hnsw_gpu_remote_search(at.key, own ? 0 : at.gen, point, meta->dim, ef, buf, nullptr, &cnt) == HGS_OK;
+		// Generation 0 = whatever the server holds now: the generation decided at attach time whether to
+		// upload; after that another backend may have inserted (and renamed the mirror), and the newest
+		// state is what this backend's own pages show too.  A mirror that was dropped meanwhile (VACUUM
+		// invalidates it) is uploaded again, once.
+		int rc = hnsw_gpu_remote_search(at.key, 0, point, meta->dim, ef, buf, nullptr, &cnt);
+		if (rc == HGS_ERR_NOKEY && !own && walk_and_upload(meta, at.key, at.gen) == HGS_OK)
+			rc = hnsw_gpu_remote_search(at.key, 0, point, meta->dim, ef, buf, nullptr, &cnt);
+		ok = rc == HGS_OK;
 		if (!ok) fprintf(stderr, "pg_embedding_amd: hnsw_search failed: %s\n", t_err);
 	}
 	if (own) (void) hnsw_gpu_remote_drop(at.key);
@@ -462,7 +487,10 @@ extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t 
 		hgs_hdr h, r;
 		memset(&h, 0, sizeof(h));
 		h.op = HGS_OP_BIND; h.key = at.key; h.gen = 0; h.aux = idx; h.a0 = label;
-		if (rpc(&h, point, meta->dim * 4, nullptr, 0, -1, &r) != HGS_OK) break;
+		int rc = rpc(&h, point, meta->dim * 4, nullptr, 0, -1, &r);
+		if (rc == HGS_ERR_NOKEY && !own && walk_and_upload(meta, at.key, at.gen) == HGS_OK)   // dropped meanwhile
+			rc = rpc(&h, point, meta->dim * 4, nullptr, 0, -1, &r);
+		if (rc != HGS_OK) break;
 		const size_t rec = 1 + meta->maxM + 1;                   // [idx][count][links * maxM]
 		if (t_resp.size() < 4) { fail(HGS_ERR_PROTOCOL, "bad BIND response"); break; }
 		uint32_t nrec;

@@ -770,6 +770,21 @@ void do_control(CReq &r)
 		r.c->respond(r.h, rc, e->count.load());
 		break;
 	}
+	case HGS_OP_SETGEN:
+	{
+		EntryP e = find_entry(r.h.key);
+		uint64_t expect = 0;
+		if (!e) { r.c->respond(r.h, HGS_ERR_NOKEY); break; }
+		if (r.payload.size() != 8) { r.c->respond(r.h, HGS_ERR_PROTOCOL); break; }
+		memcpy(&expect, r.payload.data(), 8);
+		if (!e->gen.compare_exchange_strong(expect, r.h.gen))
+		{
+			r.c->respond(r.h, HGS_ERR_STALE, 0, 0, nullptr, 0, nullptr, 0, expect);
+			break;
+		}
+		r.c->respond(r.h, HGS_OK, e->count.load());
+		break;
+	}
 	case HGS_OP_SET_DELETED:
 	{
 		EntryP e = find_entry(r.h.key);
@@ -886,7 +901,7 @@ bool handle_message(const ConnP &c, const hgs_hdr &h, const char *payload)
 		return true;
 	}
 	case HGS_OP_UPLOAD: case HGS_OP_UPDATE: case HGS_OP_BIND: case HGS_OP_DROP: case HGS_OP_LINK:
-	case HGS_OP_EXPORT: case HGS_OP_SET_DELETED: case HGS_OP_DIST:
+	case HGS_OP_EXPORT: case HGS_OP_SET_DELETED: case HGS_OP_DIST: case HGS_OP_SETGEN:
 	{
 		CReq r;
 		r.c = c; r.h = h;

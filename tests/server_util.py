@@ -101,12 +101,17 @@ def have_pg_glue() -> bool:
     return all(os.path.exists(o) for o in PG_GLUE_OBJS)
 
 
+PG_GLUE_PATCHED = os.path.join(ROOT, "oracle", "_ref", "embedding_patched.o")
+
+
 def build_pg_regress(variant: str) -> str:
-    """variant 'gpu': libembedding_gpu.so (in-process device); 'client': libembedding_gpuc.so (hnsw_gpu_server)."""
-    libs = {"gpu": ["-lembedding_gpu", "-lhnsw_gpu"], "client": ["-lembedding_gpuc"]}[variant]
+    """variant 'gpu': libembedding_gpu.so (in-process device); 'client': libembedding_gpuc.so (hnsw_gpu_server);
+    'patched': the glue with integration/embedding_gpu_server.patch applied + libembedding_gpuc.so."""
+    libs = {"gpu": ["-lembedding_gpu", "-lhnsw_gpu"], "client": ["-lembedding_gpuc"], "patched": ["-lembedding_gpuc"]}[variant]
+    objs = [PG_GLUE_PATCHED] + PG_GLUE_OBJS[1:] if variant == "patched" else PG_GLUE_OBJS
     exe = os.path.join(OUT, "pg_regress_" + variant)
-    deps = PG_GLUE_OBJS + [os.path.join(LIB, "libembedding_gpu.so" if variant == "gpu" else "libembedding_gpuc.so")]
+    deps = objs + [os.path.join(LIB, "libembedding_gpu.so" if variant == "gpu" else "libembedding_gpuc.so")]
     with _Lock():
         if _stale(exe, deps):
-            _run(["g++"] + PG_GLUE_OBJS + ["-o", exe, "-L", LIB] + libs + [f"-Wl,-rpath,{LIB}", "-lpthread", "-lm"])
+            _run(["g++"] + objs + ["-o", exe, "-L", LIB] + libs + [f"-Wl,-rpath,{LIB}", "-lpthread", "-lm"])
     return exe

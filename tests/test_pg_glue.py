@@ -90,6 +90,37 @@ def test_glue_over_the_server_client_library(name):
     assert got == expected(name)
 
 
+def run_patched(name, server):
+    from pg_embedding_amd.server import RemoteClient
+    exe = SU.build_pg_regress("patched")
+    with server as s:
+        got = run_driver(exe, name, env=dict(os.environ, PG_EMBEDDING_GPU_SERVER=s.socket_path))
+        c = RemoteClient(s.socket_path)
+        st = c.stats()
+        c.close()
+    return got, st
+
+
+needs_patched = pytest.mark.skipif(not os.path.exists(SU.PG_GLUE_PATCHED), reason="patched glue is built only where /root/reference exists")
+
+
+@needs_glue
+@needs_patched
+@pytest.mark.parametrize("name", SCRIPTS)
+def test_patched_glue_attaches_and_keeps_one_mirror_in_step(name):
+    """integration/embedding_gpu_server.patch applied to the reference's embedding.c (attach in
+    beginscan/build/insert, advance after inserts, drop after VACUUM): same result tables, but scans are
+    single requests and every insert extends the one server-side mirror."""
+    got, st = run_patched(name, ServerProcess(binary=SU.build_double_server()))
+    assert got == expected(name)
+    if name == "scenario":
+        # 1 CREATE INDEX upload of the empty index per index (3) + 1 re-upload after the VACUUM drop for
+        # the l2 index; every other call found the mirror current.  Un-patched the same session uploads
+        # the index for every one of its ~1 900 inserts and scans.
+        assert st["uploads"] <= 6, st
+        assert st["binds"] >= 1500 + 150 + 40 - 3 and st["search_errors"] == 0, st
+
+
 @needs_glue
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", SCRIPTS)
@@ -107,3 +138,13 @@ def test_glue_over_the_device_through_the_server(name):
     with ServerProcess() as s:
         got = run_driver(exe, name, env=dict(os.environ, PG_EMBEDDING_GPU_SERVER=s.socket_path))
     assert got == expected(name)
+
+
+@needs_glue
+@needs_patched
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SCRIPTS)
+def test_patched_glue_over_the_device_through_the_server(name):
+    got, st = run_patched(name, ServerProcess())
+    assert got == expected(name)
+    assert st["search_errors"] == 0
