@@ -126,6 +126,19 @@ int hnsw_gpu_remote_detach(HnswMetadata *meta);
  * embedding.c would call it: at the end of hnsw_insert / hnsw_build (integration/embedding_gpu_server.patch). */
 int hnsw_gpu_remote_advance(HnswMetadata *meta, uint64_t new_generation);
 
+/* CREATE INDEX offload (hnsw_build, embedding.c:489-537).  After begin_build, hnsw_bind_point(meta, ...)
+ * only reports success — the host has stored the row zero-linked (embedding.c:619-621,670).  finish_build
+ * uploads the n_slots stored elements (numbers that do not exist, i.e. page-tail holes, become
+ * vacuum-flagged placeholders), links them all on the device and writes every link list back into the
+ * host's pages through hnsw_begin_write/hnsw_end_write (the caller holds the index-wide writer lock, as
+ * for any hnsw_bind_point).  max_batch = 1: the reference's serial insert order, bit-identical graph;
+ * 0: batched bulk build — a different, equally good graph (same degree / recall,
+ * profiles/r1_build_quality.txt) in seconds instead of minutes.  The mirror stays on the server as
+ * (key, generation), so the first scan attaches without an upload. */
+int hnsw_gpu_remote_begin_build(HnswMetadata *meta);
+int hnsw_gpu_remote_finish_build(HnswMetadata *meta, uint64_t key, uint64_t generation, size_t n_slots,
+								 size_t max_batch);
+
 /* Lower level, for hosts that manage mirrors themselves. */
 int hnsw_gpu_remote_lookup(uint64_t key, uint64_t *generation, size_t *count, int *present);
 int hnsw_gpu_remote_upload(const HnswMetadata *meta, uint64_t key, uint64_t generation,

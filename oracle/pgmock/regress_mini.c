@@ -14,6 +14,7 @@
  *   seqscan on|off                          SET enable_seqscan
  *   create_table T [serial]                 CREATE TABLE T (val real[])  /  (id SERIAL PRIMARY KEY, val REAL[])
  *   insert T {a,b,c} | NULL                 one row
+ *   generate T N DIM SEED                   N clustered rows of DIM values k/8 (INSERT ... SELECT from a generator)
  *   create_index T NAME l2|cos|manhattan OPTS   CREATE INDEX NAME ON T USING hnsw (val <opclass>) WITH (OPTS)
  *   select T OP {a,b,c} COLS LIMIT ; TEXT   SELECT COLS FROM T ORDER BY val OP {..} [LIMIT n]; OP is <-> <=> <~>;
  *                                           COLS is val | ctid,id | ctid ; LIMIT 0 = none; TEXT is echoed first
@@ -390,6 +391,45 @@ static void run(char *line)
 		pgmock_error("too many tables");
 	}
 	else if (strcmp(tok[0], "insert") == 0 && n == 3) cmd_insert(table(tok[1]), tok[2]);
+	else if (strcmp(tok[0], "generate") == 0 && n == 5)
+	{
+		/* N rows of DIM values k/8, k < 64, clustered: INSERT ... SELECT from a generator (rows go through
+		 * the indexes like any insert) */
+		Table *t = table(tok[1]);
+		const long rows = atol(tok[2]), dim = atol(tok[3]);
+		unsigned long long lcg = strtoull(tok[4], NULL, 0) * 2862933555777941757ull + 3037000493ull;
+		float4 centre[64][256], v[256];
+		if (dim < 1 || dim > 256) pgmock_error("generate: 1..256 dimensions");
+		for (int c = 0; c < 64; c++)
+			for (long d = 0; d < dim; d++)
+			{
+				lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+				centre[c][d] = (float4) ((lcg >> 40) % 40);
+			}
+		for (long r = 0; r < rows; r++)
+		{
+			lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+			const int c = (int) ((lcg >> 33) % 64);
+			for (long d = 0; d < dim; d++)
+			{
+				lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
+				v[d] = (centre[c][d] + (float4) ((lcg >> 40) % 24)) / 8.0f;
+			}
+			ArrayType *val = pgmock_make_array(v, (int) dim);
+			const size_t row = heap_insert(t, val);
+			ItemPointerData tid;
+			tid_of(row, &tid);
+			for (int i = 0; i < t->nidx; i++)
+			{
+				Datum values[1] = { PointerGetDatum(val) };
+				bool isnull[1] = { false };
+				IndexInfo *ii = BuildIndexInfo(t->idx[i].rel);
+				g_am->aminsert(t->idx[i].rel, values, isnull, &tid, NULL, UNIQUE_CHECK_NO, false, ii);
+				pfree(ii);
+			}
+		}
+		after_am_call("generate");
+	}
 	else if (strcmp(tok[0], "create_index") == 0 && n == 5) cmd_create_index(table(tok[1]), tok[2], tok[3], tok[4]);
 	else if (strcmp(tok[0], "select") == 0 && n == 6) cmd_select(table(tok[1]), tok[2], tok[3], tok[4], atol(tok[5]));
 	else if (strcmp(tok[0], "count") == 0 && n == 2)

@@ -41,6 +41,7 @@ thread_local std::vector<char> t_resp;    // payload of the last response
 
 struct Attachment { HnswMetadata *meta; uint64_t key, gen; };
 std::vector<Attachment> g_attached;
+std::vector<HnswMetadata *> g_building;   // metas between hnsw_gpu_remote_begin_build and ..._finish_build
 std::atomic<uint64_t> g_ephemeral{0};
 
 int fail(int code, const char *fmt, ...)
@@ -359,6 +360,89 @@ extern "C" int hnsw_gpu_remote_attach(HnswMetadata *meta, uint64_t key, uint64_t
 	return HGS_OK;
 }
 
+// CREATE INDEX offload.  Between begin_build and finish_build hnsw_bind_point(meta, ...) only reports
+// success: the host has stored the row zero-linked (embedding.c:619-621,670), nothing is linked yet.
+extern "C" int hnsw_gpu_remote_begin_build(HnswMetadata *meta)
+{
+	if (!meta) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	std::lock_guard<std::mutex> lk(g_mu);
+	for (HnswMetadata *b : g_building)
+		if (b == meta) return HGS_OK;
+	g_building.push_back(meta);
+	return HGS_OK;
+}
+
+// Upload the stored rows (element numbers [0, n_slots); numbers that do not exist — page-tail holes —
+// become vacuum-flagged placeholders), link them all on the device (hnsw_gpu_index_link: max_batch 1 =
+// the reference's serial order, bit-identical graph; 0 = batched bulk build, an equally good graph in a
+// fraction of the time), and write every element's link list back into the host's pages through
+// hnsw_begin_write/hnsw_end_write.  The caller holds the index-wide writer lock (embedding.c:624-629),
+// as for any hnsw_bind_point.  The mirror stays on the server as (key, generation).
+extern "C" int hnsw_gpu_remote_finish_build(HnswMetadata *meta, uint64_t key, uint64_t generation, size_t n_slots,
+											size_t max_batch)
+{
+	if (!meta) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	{
+		std::lock_guard<std::mutex> lk(g_mu);
+		for (size_t i = 0; i < g_building.size(); i++)
+			if (g_building[i] == meta) { g_building[i] = g_building.back(); g_building.pop_back(); break; }
+	}
+	const size_t esz = meta->size_data_per_element, lbytes = (meta->maxM + 1) * sizeof(idx_t);
+	const label_t dead = (label_t) 1 << HNSW_LABEL_DELETED_BIT;
+	static thread_local Shm shm;                   // reused: a callback may leave by longjmp (see walk_and_upload)
+	static thread_local std::vector<uint64_t> real;
+	shm.release();
+	real.assign((n_slots + 63) / 64, 0);
+	if (!shm.create(n_slots ? n_slots * esz : 1)) return fail(HGS_ERR_IO, "memfd_create/mmap failed: %s", strerror(errno));
+	for (size_t idx = 0; idx < n_slots; idx++)
+	{
+		char *dst = (char *) shm.p + idx * esz;
+		idx_t *links = nullptr;
+		if (hnsw_begin_read(meta, (idx_t) idx, &links, nullptr, nullptr))
+		{
+			memcpy(dst, links, esz);
+			hnsw_end_read(meta);
+			memset(dst, 0, lbytes);                  // whatever the pages hold, the build starts un-linked
+			real[idx / 64] |= 1ull << (idx % 64);
+		}
+		else
+		{
+			memset(dst, 0, esz);
+			memcpy(dst + meta->offset_label, &dead, sizeof(dead));
+		}
+	}
+	hgs_hdr h, r;
+	memset(&h, 0, sizeof(h));
+	h.op = HGS_OP_UPLOAD; h.key = key; h.gen = generation; h.a0 = n_slots;
+	int rc = rpc(&h, meta, sizeof(*meta), nullptr, 0, n_slots ? shm.fd : -1, &r);
+	// link the stored elements run by run: a placeholder must stay what it is in the host, absent
+	for (size_t first = 0; rc == HGS_OK && first < n_slots;)
+	{
+		if (!((real[first / 64] >> (first % 64)) & 1)) { first++; continue; }
+		size_t end = first;
+		while (end < n_slots && ((real[end / 64] >> (end % 64)) & 1)) end++;
+		rc = hnsw_gpu_remote_link(key, first, end - first, max_batch);
+		first = end;
+	}
+	shm.release();
+	if (rc != HGS_OK || n_slots == 0) return rc;
+	// the graph comes back as element images; only the link lists go into the pages
+	if (!shm.create(n_slots * esz)) return fail(HGS_ERR_IO, "memfd_create/mmap failed: %s", strerror(errno));
+	memset(&h, 0, sizeof(h));
+	h.op = HGS_OP_EXPORT; h.key = key;
+	rc = rpc(&h, nullptr, 0, nullptr, 0, shm.fd, &r);
+	for (size_t idx = 0; rc == HGS_OK && idx < n_slots; idx++)
+	{
+		if (!((real[idx / 64] >> (idx % 64)) & 1)) continue;
+		idx_t *dst = nullptr;
+		hnsw_begin_write(meta, (idx_t) idx, &dst, nullptr, nullptr);
+		memcpy(dst, (char *) shm.p + idx * esz, lbytes);
+		hnsw_end_write(meta);
+	}
+	shm.release();
+	return rc;
+}
+
 extern "C" int hnsw_gpu_remote_advance(HnswMetadata *meta, uint64_t new_generation)
 {
 	Attachment at;
@@ -465,6 +549,11 @@ extern "C" bool hnsw_search(HnswMetadata *meta, const coord_t *point, size_t *n_
 extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t idx)
 {
 	if (!meta || !point) return false;
+	{
+		std::lock_guard<std::mutex> lk(g_mu);                      // CREATE INDEX offload: rows are only stored now,
+		for (HnswMetadata *b : g_building)                         // hnsw_gpu_remote_finish_build links them all
+			if (b == meta) return true;
+	}
 	Attachment at;
 	bool own = false;
 	if (!find_attached(meta, &at))

@@ -109,16 +109,16 @@ needs_patched = pytest.mark.skipif(not os.path.exists(SU.PG_GLUE_PATCHED), reaso
 @pytest.mark.parametrize("name", SCRIPTS)
 def test_patched_glue_attaches_and_keeps_one_mirror_in_step(name):
     """integration/embedding_gpu_server.patch applied to the reference's embedding.c (attach in
-    beginscan/build/insert, advance after inserts, drop after VACUUM): same result tables, but scans are
-    single requests and every insert extends the one server-side mirror."""
+    beginscan/insert, advance after inserts, deferred bulk link in CREATE INDEX, drop after VACUUM): same
+    result tables — the double links in the reference's serial order — but scans are single requests and
+    every insert extends the one server-side mirror."""
     got, st = run_patched(name, ServerProcess(binary=SU.build_double_server()))
     assert got == expected(name)
     if name == "scenario":
-        # 1 CREATE INDEX upload of the empty index per index (3) + 1 re-upload after the VACUUM drop for
-        # the l2 index; every other call found the mirror current.  Un-patched the same session uploads
-        # the index for every one of its ~1 900 inserts and scans.
-        assert st["uploads"] <= 6, st
-        assert st["binds"] >= 1500 + 150 + 40 - 3 and st["search_errors"] == 0, st
+        # 3 CREATE INDEX (rows stored during the table scan, then ONE upload + link + write-back each) and
+        # 1 re-upload after the VACUUM drop of the l2 index; the 190 later inserts extend that mirror (BIND).
+        # Un-patched the same session uploads the index 4 667 times (405 MB).
+        assert st["uploads"] == 4 and st["binds"] == 190 and st["search_errors"] == 0, st
 
 
 @needs_glue
@@ -144,7 +144,56 @@ def test_glue_over_the_device_through_the_server(name):
 @needs_patched
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", SCRIPTS)
-def test_patched_glue_over_the_device_through_the_server(name):
+def test_patched_glue_over_the_device_through_the_server(name, monkeypatch):
+    """PG_EMBEDDING_GPU_BUILD_BATCH=1: CREATE INDEX links in the reference's serial order on the device,
+    so the bytes must match; the default batched build is measured by quality below."""
+    monkeypatch.setenv("PG_EMBEDDING_GPU_BUILD_BATCH", "1")
     got, st = run_patched(name, ServerProcess())
     assert got == expected(name)
     assert st["search_errors"] == 0
+
+
+def build_script(n, dim, nq, opts):
+    rows = ["# CREATE INDEX over generated rows, then index scans and the same queries as exact sequential scans",
+            "create_table t serial", f"generate t {n} {dim} 12345", f"create_index t t_l2 l2 {opts}"]
+    import numpy as np
+    rng = np.random.default_rng(5)
+    qs = rng.integers(0, 64, (nq, dim)) / 8.0
+    for i, q in enumerate(qs):
+        lit = "{" + ",".join(f"{x:g}" for x in q) + "}"
+        rows += ["seqscan off", f"select t <-> {lit} id 10 ; ann {i}", "seqscan on", f"select t <-> {lit} id 10 ; exact {i}"]
+    return "\n".join(rows) + "\n"
+
+
+def ids_by_statement(text):
+    out, cur = {}, None
+    for ln in text.splitlines():
+        if ln.startswith(("ann ", "exact ")):
+            cur = ln
+            out[cur] = []
+        elif cur and re.fullmatch(r"\s*\d+", ln):
+            out[cur].append(int(ln))
+    return out
+
+
+@needs_glue
+@needs_patched
+@pytest.mark.gpu
+def test_create_index_offload_builds_a_good_graph_fast(tmp_path):
+    """CREATE INDEX through the patched glue with the default batched device build: 20 000 x 64 rows are
+    stored by the table scan, linked in one go on the device and written back into the pages; the index
+    scans that follow (pages -> mirror already on the server) find the exact neighbours."""
+    import time
+    n, dim, nq = 20000, 64, 20
+    script = build_script(n, dim, nq, f"dims={dim},m=8,efconstruction=64,efsearch=64")
+    exe = SU.build_pg_regress("patched")
+    with ServerProcess() as s:
+        t = time.time()
+        r = subprocess.run([exe], input=script, capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, PG_EMBEDDING_GPU_SERVER=s.socket_path))
+        dt = time.time() - t
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = ids_by_statement(r.stdout)
+    hits = sum(len(set(res[f"ann {i}"]) & set(res[f"exact {i}"])) for i in range(nq))
+    print(f"CREATE INDEX offload: {n} x {dim}, whole session {dt:.1f} s, recall@10 {hits / (10 * nq):.3f}")
+    assert hits / (10 * nq) >= 0.9
