@@ -24,6 +24,7 @@
  *   cost T NAME                             startup cost the access method reports for an ordered scan
  */
 #include <math.h>
+#include <time.h>
 
 #include "pgmock.h"
 
@@ -225,7 +226,17 @@ static void cmd_select(Table *t, const char *opstr, const char *lit, const char 
 	int op = -1;
 	for (int i = 0; i < 3; i++) if (strcmp(opstr, g_opname[i]) == 0) op = i;
 	if (op < 0) pgmock_error("operator does not exist: real[] %s real[]", opstr);
-	ArrayType *q = parse_array(lit);
+	ArrayType *q;
+	if (lit[0] == '@')                     /* @ROWNO: that stored row, every component moved by 1/8 */
+	{
+		const size_t r = (size_t) atol(lit + 1);
+		if (r >= t->heap.n || !t->heap.rows[r].val) pgmock_error("row %zu does not exist", r);
+		q = DatumGetArrayTypePCopy(PointerGetDatum(t->heap.rows[r].val));
+		float4 *v = (float4 *) ARR_DATA_PTR(q);
+		for (int i = 0; i < ArrayGetNItems(ARR_NDIM(q), ARR_DIMS(q)); i++) v[i] += 0.125f;
+	}
+	else
+		q = parse_array(lit);
 	size_t nout = 0, cap = 64;
 	size_t *rows = (size_t *) palloc(cap * sizeof(size_t));
 	Relation index = NULL;
@@ -484,7 +495,17 @@ int main(void)
 		line[strcspn(line, "\n")] = 0;
 		pgmock_error_jmp = &trap;
 		if (setjmp(trap) == 0)
+		{
+			struct timespec t0, t1;
+			const bool timed = strncmp(line, "create_index", 12) == 0 || strncmp(line, "generate", 8) == 0;
+			char what[64];
+			snprintf(what, sizeof(what), "%.60s", line);
+			clock_gettime(CLOCK_MONOTONIC, &t0);
 			run(line);
+			clock_gettime(CLOCK_MONOTONIC, &t1);
+			if (timed)                                              /* psql's \timing, on stderr */
+				fprintf(stderr, "Time: %.3f ms  %s\n", 1e3 * (double) (t1.tv_sec - t0.tv_sec) + 1e-6 * (double) (t1.tv_nsec - t0.tv_nsec), what);
+		}
 		else
 		{
 			printf("ERROR:  %s\n", pgmock_last_error);              /* transaction abort: pins and locks are dropped */

@@ -156,11 +156,8 @@ def test_patched_glue_over_the_device_through_the_server(name, monkeypatch):
 def build_script(n, dim, nq, opts):
     rows = ["# CREATE INDEX over generated rows, then index scans and the same queries as exact sequential scans",
             "create_table t serial", f"generate t {n} {dim} 12345", f"create_index t t_l2 l2 {opts}"]
-    import numpy as np
-    rng = np.random.default_rng(5)
-    qs = rng.integers(0, 64, (nq, dim)) / 8.0
-    for i, q in enumerate(qs):
-        lit = "{" + ",".join(f"{x:g}" for x in q) + "}"
+    for i in range(nq):
+        lit = f"@{(i * 7919 + 13) % n}"                       # a stored row, nudged: an in-distribution query
         rows += ["seqscan off", f"select t <-> {lit} id 10 ; ann {i}", "seqscan on", f"select t <-> {lit} id 10 ; exact {i}"]
     return "\n".join(rows) + "\n"
 
@@ -182,18 +179,23 @@ def ids_by_statement(text):
 def test_create_index_offload_builds_a_good_graph_fast(tmp_path):
     """CREATE INDEX through the patched glue with the default batched device build: 20 000 x 64 rows are
     stored by the table scan, linked in one go on the device and written back into the pages; the index
-    scans that follow (pages -> mirror already on the server) find the exact neighbours."""
-    import time
-    n, dim, nq = 20000, 64, 20
+    scans that follow (mirror already on the server) find the exact neighbours.  The same statements
+    through the reference's own objects (row-by-row inserts on the CPU) are timed next to it."""
+    n, dim, nq = 20000, 64, 8
     script = build_script(n, dim, nq, f"dims={dim},m=8,efconstruction=64,efsearch=64")
     exe = SU.build_pg_regress("patched")
     with ServerProcess() as s:
-        t = time.time()
         r = subprocess.run([exe], input=script, capture_output=True, text=True, timeout=900,
                            env=dict(os.environ, PG_EMBEDDING_GPU_SERVER=s.socket_path))
-        dt = time.time() - t
     assert r.returncode == 0, r.stderr[-2000:]
     res = ids_by_statement(r.stdout)
     hits = sum(len(set(res[f"ann {i}"]) & set(res[f"exact {i}"])) for i in range(nq))
-    print(f"CREATE INDEX offload: {n} x {dim}, whole session {dt:.1f} s, recall@10 {hits / (10 * nq):.3f}")
+    ms = float(re.search(r"Time: ([0-9.]+) ms  create_index", r.stderr).group(1))
+    line = f"CREATE INDEX offload: {n} x {dim} m=8 efconstruction=64: {ms:.0f} ms through the patched glue, recall@10 {hits / (10 * nq):.3f}"
+    if os.path.exists(SU.PG_REGRESS_REF):
+        head = "\n".join(script.splitlines()[:4]) + "\n"          # create_table, generate, create_index only
+        rr = subprocess.run([SU.PG_REGRESS_REF], input=head, capture_output=True, text=True, timeout=900)
+        ref_ms = float(re.search(r"Time: ([0-9.]+) ms  create_index", rr.stderr).group(1))
+        line += f"; reference glue + hnswalg.o on the host CPU: {ref_ms:.0f} ms"
+    print(line)
     assert hits / (10 * nq) >= 0.9
