@@ -12,6 +12,10 @@
  *
  * Commands (one per line on stdin; '#' starts a comment):
  *   seqscan on|off                          SET enable_seqscan
+ *   needs_wal on|off                        RelationNeedsWAL() of the indexes created from now on.  The glue
+ *                                           sets unlogged = RelationNeedsWAL() (embedding.c:241), so "off" is what
+ *                                           sends its page updates through generic WAL records (a COPY of the page,
+ *                                           applied on finish) — the write-back of link lists has to work on both
  *   create_table T [serial]                 CREATE TABLE T (val real[])  /  (id SERIAL PRIMARY KEY, val REAL[])
  *   insert T {a,b,c} | NULL                 one row
  *   generate T N DIM SEED                   N clustered rows of DIM values k/8 (INSERT ... SELECT from a generator)
@@ -53,6 +57,7 @@ typedef struct
 static Table g_tables[MAX_TABLES];
 static IndexAmRoutine *g_am;
 static bool g_seqscan = true;
+static bool g_needs_wal = true;       /* RelationNeedsWAL() of the indexes created from now on */
 static const PGFunction g_distfn[3] = { l2_distance, cosine_distance, manhattan_distance };
 static const char *g_opname[3] = { "<->", "<=>", "<~>" };
 
@@ -200,7 +205,7 @@ static void cmd_create_index(Table *t, const char *name, const char *opclass, co
 	const int op = strcmp(opclass, "l2") == 0 ? 0 : strcmp(opclass, "cos") == 0 ? 1 : strcmp(opclass, "manhattan") == 0 ? 2 : -1;
 	if (op < 0 || t->nidx == MAX_INDEXES) pgmock_error("operator class \"%s\" does not exist for access method \"hnsw\"", opclass);
 	bytea *parsed = g_am->amoptions(PointerGetDatum(opts), true);
-	Relation rel = pgmock_create_index_relation(name, &t->heap, g_distfn[op], true);
+	Relation rel = pgmock_create_index_relation(name, &t->heap, g_distfn[op], g_needs_wal);
 	rel->rd_options = parsed;
 	IndexInfo *ii = BuildIndexInfo(rel);
 	IndexBuildResult *res = g_am->ambuild(NULL, rel, ii);
@@ -387,6 +392,7 @@ static void run(char *line)
 	if (n == 0) return;
 	if (echo) printf("%s\n", echo);
 	if (strcmp(tok[0], "seqscan") == 0 && n == 2) g_seqscan = strcmp(tok[1], "on") == 0;
+	else if (strcmp(tok[0], "needs_wal") == 0 && n == 2) g_needs_wal = strcmp(tok[1], "on") == 0;
 	else if (strcmp(tok[0], "create_table") == 0 && n >= 2)
 	{
 		for (int i = 0; i < MAX_TABLES; i++)

@@ -78,6 +78,34 @@ def test_scenario_golden_is_current():
     assert "ERROR:  Wrong number of dimensions: 5 instead of 16 expected" in blocks
 
 
+def with_generic_wal(name):
+    """the same script with the glue's page updates going through generic WAL records"""
+    return "needs_wal off\n" + open(os.path.join(GOLD, name + ".cmd")).read()
+
+
+@needs_glue
+@pytest.mark.parametrize("variant", ["ref", "client", "patched"])
+def test_page_updates_through_generic_wal_records(variant):
+    """embedding.c:241 sets unlogged = RelationNeedsWAL(), so a relation that "does not need WAL" is the one
+    whose updates go through GenericXLogRegisterBuffer: hnsw_begin_write then hands out pointers into a
+    COPY of the page that GenericXLogFinish applies.  The link lists written back by hnsw_bind_point and by
+    the CREATE INDEX offload must land either way."""
+    if variant == "ref":
+        if not os.path.exists(SU.PG_REGRESS_REF):
+            pytest.skip("reference-linked driver not built")
+        r = subprocess.run([SU.PG_REGRESS_REF], input=with_generic_wal("scenario"), capture_output=True, text=True)
+        assert r.returncode == 0 and r.stdout == expected("scenario")
+        return
+    if variant == "patched" and not os.path.exists(SU.PG_GLUE_PATCHED):
+        pytest.skip("patched glue not built")
+    exe = SU.build_pg_regress(variant)
+    with ServerProcess(binary=SU.build_double_server()) as s:
+        r = subprocess.run([exe], input=with_generic_wal("scenario"), capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, PG_EMBEDDING_GPU_SERVER=s.socket_path))
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout == expected("scenario")
+
+
 @needs_glue
 @pytest.mark.parametrize("name", SCRIPTS)
 def test_glue_over_the_server_client_library(name):
