@@ -587,7 +587,7 @@ extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t 
 		if (t_resp.size() != 4 + (size_t) nrec * rec * 4) { fail(HGS_ERR_PROTOCOL, "bad BIND response"); break; }
 		// copy out first: a host callback may longjmp (elog(ERROR)) and t_resp is reused by the next call
 		std::vector<uint32_t> recs((size_t) nrec * rec);
-		memcpy(recs.data(), t_resp.data() + 4, recs.size() * 4);
+		if (!recs.empty()) memcpy(recs.data(), t_resp.data() + 4, recs.size() * 4);
 		for (uint32_t i = 0; i < nrec; i++)
 		{
 			const uint32_t *p = recs.data() + (size_t) i * rec;
