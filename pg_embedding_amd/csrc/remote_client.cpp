@@ -75,6 +75,25 @@ int ensure_connected()
 	}
 	if (path.empty())
 		return fail(HGS_ERR_IO, "no server socket: set PG_EMBEDDING_GPU_SERVER or call hnsw_gpu_remote_connect()");
+	// Several GPUs = several servers (one process per GPU), sockets separated by ','.  A backend stays with
+	// one of them (by process id): every server mirrors the indexes its backends use — replicas, so
+	// read throughput scales with the GPUs; a mirror on another server that an insert here made stale is
+	// noticed by its generation at the next attach there and uploaded again.
+	if (path.find(',') != std::string::npos)
+	{
+		std::vector<std::string> all;
+		size_t a = 0;
+		while (a <= path.size())
+		{
+			const size_t b = path.find(',', a);
+			const std::string one = path.substr(a, b == std::string::npos ? std::string::npos : b - a);
+			if (!one.empty()) all.push_back(one);
+			if (b == std::string::npos) break;
+			a = b + 1;
+		}
+		if (all.empty()) return fail(HGS_ERR_IO, "no server socket in \"%s\"", path.c_str());
+		path = all[(size_t) getpid() % all.size()];
+	}
 	struct sockaddr_un addr;
 	memset(&addr, 0, sizeof(addr));
 	addr.sun_family = AF_UNIX;

@@ -346,6 +346,32 @@ def test_malformed_traffic_only_costs_the_sender_its_connection(srv):
     c.close()
 
 
+def test_several_servers_one_per_gpu_backends_spread_by_pid(double_bin, tmp_path):
+    """PG_EMBEDDING_GPU_SERVER = "sockA,sockB": one server per GPU, every backend sticks to one of them (pid
+    modulo), each server mirrors what its backends use — replicas.  All answers are still the oracle's."""
+    dim, m, n, efs = 24, 4, 1200, 16
+    port, X = port_index(n, dim, m, 16, efs, pg.DIST_L2, seed=88)
+    meta = pg.make_meta(dim, m, 16, efs, pg.DIST_L2)
+    Q = gmm(640, dim, k=20, seed=88, stream=1)
+    with ServerProcess(binary=double_bin) as a, ServerProcess(binary=double_bin) as b:
+        for s in (a, b):                                   # what the first attach of a backend on each would do
+            c = RemoteClient(s.socket_path)
+            c.upload(meta, 5, 1, port.raw(), n)
+            c.close()
+        both = a.socket_path + "," + b.socket_path
+        info, labels, counts = run_clients(both, 5, 1, dim, m, 16, efs, pg.DIST_L2, Q, 32, tmp_path)
+        want = port.search_many(Q, efs)
+        assert (counts == want["counts"]).all()
+        for q in range(len(Q)):
+            assert (labels[q, :int(counts[q])] == want["labels"][q, :int(counts[q])]).all()
+        served = []
+        for s in (a, b):
+            c = RemoteClient(s.socket_path)
+            served.append(c.stats()["searches"])
+            c.close()
+        assert sum(served) == len(Q) and min(served) > 0, served      # both took part
+
+
 def test_an_upload_that_does_not_fit_evicts_idle_mirrors_lru_first(double_bin):
     dim, m, efs = 16, 4, 10
     meta = pg.make_meta(dim, m, 16, efs, pg.DIST_L2)
