@@ -234,9 +234,13 @@ int pgmock_locks_outstanding(void)
 	return n;
 }
 
+long pgmock_fail_read_countdown = 0;      /* fault injection: the N-th page read from now raises ERROR */
+
 Buffer ReadBufferExtended(Relation rel, ForkNumber fork, BlockNumber blk, ReadBufferMode mode, BufferAccessStrategy strategy)
 {
 	(void) mode; (void) strategy;
+	if (pgmock_fail_read_countdown > 0 && --pgmock_fail_read_countdown == 0)
+		pgmock_error("could not read block %u in file \"%s\": Input/output error (injected)", blk, rel->name);
 	if (blk == P_NEW)
 	{
 		blk = rel->npages[fork];

@@ -16,6 +16,8 @@
  *                                           sets unlogged = RelationNeedsWAL() (embedding.c:241), so "off" is what
  *                                           sends its page updates through generic WAL records (a COPY of the page,
  *                                           applied on finish) — the write-back of link lists has to work on both
+ *   fail_read_after N                       fault injection: the N-th page read from now raises ERROR (an I/O error
+ *                                           inside a storage callback: the hot path is left by longjmp)
  *   create_table T [serial]                 CREATE TABLE T (val real[])  /  (id SERIAL PRIMARY KEY, val REAL[])
  *   insert T {a,b,c} | NULL                 one row
  *   generate T N DIM SEED                   N clustered rows of DIM values k/8 (INSERT ... SELECT from a generator)
@@ -38,6 +40,7 @@ extern Datum l2_distance(PG_FUNCTION_ARGS);
 extern Datum cosine_distance(PG_FUNCTION_ARGS);
 extern Datum manhattan_distance(PG_FUNCTION_ARGS);
 void pgmock_reset_pins(void);
+extern long pgmock_fail_read_countdown;
 
 #define ROWS_PER_HEAP_PAGE 200          /* must match table_index_build_scan in pgmock.c */
 #define MAX_INDEXES 8
@@ -393,6 +396,7 @@ static void run(char *line)
 	if (echo) printf("%s\n", echo);
 	if (strcmp(tok[0], "seqscan") == 0 && n == 2) g_seqscan = strcmp(tok[1], "on") == 0;
 	else if (strcmp(tok[0], "needs_wal") == 0 && n == 2) g_needs_wal = strcmp(tok[1], "on") == 0;
+	else if (strcmp(tok[0], "fail_read_after") == 0 && n == 2) pgmock_fail_read_countdown = atol(tok[1]);
 	else if (strcmp(tok[0], "create_table") == 0 && n >= 2)
 	{
 		for (int i = 0; i < MAX_TABLES; i++)

@@ -106,6 +106,61 @@ def test_page_updates_through_generic_wal_records(variant):
     assert r.stdout == expected("scenario")
 
 
+FAULT_SCRIPT = """seqscan off
+create_table t serial
+generate t 600 16 7
+create_index t t_l2 l2 dims=16,m=4,efconstruction=32,efsearch=24
+select t <-> @17 id 5 ; before
+fail_read_after 40
+select t <-> @17 id 5 ; a page read fails inside a storage callback
+select t <-> @17 id 5 ; after the aborted statement
+fail_read_after 3
+insert t {1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1}
+select t <-> @17 id 5 ; after the aborted insert
+insert t {1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1}
+select t <-> {1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1} id 2 ; the row inserted after the failure is found
+"""
+
+
+@needs_glue
+@pytest.mark.parametrize("variant", ["ref", "client", "patched"])
+def test_an_error_inside_a_storage_callback_leaves_everything_usable(variant):
+    """The host's callbacks may leave by longjmp (elog(ERROR), e.g. an I/O error in ReadBuffer): the hot
+    path must hold nothing that the abort does not reclaim.  A failing statement prints ERROR; the next
+    ones give the same answers as before, for the reference's objects and for the client library (walks
+    and write-backs in progress, connection and attachment state)."""
+    if variant == "ref":
+        if not os.path.exists(SU.PG_REGRESS_REF):
+            pytest.skip("reference-linked driver not built")
+        r = subprocess.run([SU.PG_REGRESS_REF], input=FAULT_SCRIPT, capture_output=True, text=True)
+    else:
+        if variant == "patched" and not os.path.exists(SU.PG_GLUE_PATCHED):
+            pytest.skip("patched glue not built")
+        with ServerProcess(binary=SU.build_double_server()) as s:
+            r = subprocess.run([SU.build_pg_regress(variant)], input=FAULT_SCRIPT, capture_output=True, text=True, timeout=600,
+                               env=dict(os.environ, PG_EMBEDDING_GPU_SERVER=s.socket_path))
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-1500:])
+    labels = [ln.split(" ; ", 1)[1] for ln in FAULT_SCRIPT.splitlines() if " ; " in ln]
+    by, cur = {}, None
+    for ln in r.stdout.splitlines():
+        if ln in labels:
+            cur = ln
+            by[cur] = ln
+        elif cur:
+            by[cur] += "\n" + ln
+    assert "(5 rows)" in by["before"]
+    def table(b):                                             # the result table alone (an un-echoed ERROR may follow it)
+        lines = by[b].splitlines()[1:]
+        end = next((i for i, ln in enumerate(lines) if re.fullmatch(r"\(\d+ rows?\)", ln)), len(lines) - 1)
+        return "\n".join(lines[:end + 1])
+    if variant != "patched":                                  # the patched glue's scan is one request: no page reads to fail
+        assert "ERROR:" in by["a page read fails inside a storage callback"]
+    assert table("after the aborted statement") == table("before")
+    assert "ERROR:" in by["after the aborted statement"]      # the insert that follows it failed too (injected)
+    assert "(5 rows)" in table("after the aborted insert")
+    assert "(2 rows)" in by["the row inserted after the failure is found"]
+
+
 @needs_glue
 @pytest.mark.parametrize("name", SCRIPTS)
 def test_glue_over_the_server_client_library(name):
