@@ -829,6 +829,42 @@ extern "C" int hnsw_gpu_dist_batch(dist_func_t func, const coord_t *q, const coo
 	if (dim == 0) return fail(HNSW_GPU_ERR_ARG, "dim is 0");
 	if (hnsw_gpu_device_count() <= 0) return fail(HNSW_GPU_ERR_NODEVICE, "no HIP device visible (this library has no CPU path)");
 	const size_t stride = round_up(dim, 4);
+	// Small calls — the SQL operators hand over ONE pair per call (embedding.c:1037) — go through a
+	// per-thread pinned staging area that the kernel reads and writes directly: no allocation, no copy
+	// engine, one launch + one stream wait.
+	const size_t small_bytes = (1 + nrows) * stride * 4 + round_up(nrows * 4, 16);
+	if (small_bytes <= ((size_t) 256 << 10))
+	{
+		static thread_local char *pin = nullptr;
+		static thread_local size_t pin_bytes = 0;
+		static thread_local hipStream_t pin_stream = nullptr;
+		static thread_local int pin_device = -1;
+		int dev = 0;
+		HIPCHK(hipGetDevice(&dev));
+		if (pin_device != dev || pin_bytes < small_bytes)
+		{
+			if (pin) (void) hipHostFree(pin);
+			if (pin_stream) (void) hipStreamDestroy(pin_stream);
+			pin = nullptr; pin_bytes = 0; pin_stream = nullptr; pin_device = -1;
+			HIPCHK(hipHostMalloc((void **) &pin, (size_t) 256 << 10, hipHostMallocDefault));
+			HIPCHK(hipStreamCreateWithFlags(&pin_stream, hipStreamNonBlocking));
+			pin_bytes = (size_t) 256 << 10;
+			pin_device = dev;
+		}
+		float *hq = (float *) pin, *hr = hq + stride, *ho = (float *) (pin + (1 + nrows) * stride * 4);
+		memcpy(hq, q, dim * 4);
+		for (size_t d = dim; d < stride; d++) hq[d] = 0.f;
+		for (size_t r = 0; r < nrows; r++)
+		{
+			memcpy(hr + r * stride, rows + r * dim, dim * 4);
+			for (size_t d = dim; d < stride; d++) hr[r * stride + d] = 0.f;
+		}
+		int rc2 = hnsw_gpu_dist_batch_dev(func, hq, hr, nrows, dim, stride, ho, pin_stream);
+		if (rc2) return rc2;
+		HIPCHK(hipStreamSynchronize(pin_stream));
+		memcpy(out, ho, nrows * 4);
+		return HNSW_GPU_OK;
+	}
 	float *dq = nullptr, *dr = nullptr, *dout = nullptr;
 	hipError_t e = hipSuccess;
 	int rc = HNSW_GPU_OK;
