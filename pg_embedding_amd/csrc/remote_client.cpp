@@ -130,10 +130,15 @@ int rpc(hgs_hdr *h, const void *p1, size_t l1, const void *p2, size_t l2, int pa
 		return fail(HGS_ERR_IO, "cannot seal the shared memory file: %s", strerror(errno));
 	h->magic = HGS_MAGIC;
 	h->len = (uint32_t) ((p1 ? l1 : 0) + (p2 ? l2 : 0));
-	if (hgs::send_msg(t_fd, h, p1, l1, p2, l2, pass_fd) != 0 || hgs::recv_exact(t_fd, r, sizeof(*r), nullptr) != 0)
+	// A connection that was fine at the last call may have died since (the server was restarted): one
+	// fresh connection, one retry — for everything that can be repeated without harm, i.e. all but BIND
+	// (an insert that may or may not have been applied is the caller's to sort out: it fails).
+	for (int attempt = 0;; attempt++)
 	{
+		if (hgs::send_msg(t_fd, h, p1, l1, p2, l2, pass_fd) == 0 && hgs::recv_exact(t_fd, r, sizeof(*r), nullptr) == 0) break;
 		drop_connection();
-		return fail(HGS_ERR_IO, "lost the connection to hnsw_gpu_server");
+		if (attempt == 1 || h->op == HGS_OP_BIND || ensure_connected() != HGS_OK)
+			return fail(HGS_ERR_IO, "lost the connection to hnsw_gpu_server");
 	}
 	if (r->magic != HGS_MAGIC || r->len > HGS_MAX_PAYLOAD || r->op != h->op)
 	{

@@ -396,6 +396,39 @@ def test_an_upload_that_does_not_fit_evicts_idle_mirrors_lru_first(double_bin):
         c.close()
 
 
+def test_a_restarted_server_is_picked_up_again(double_bin, tmp_path):
+    """The server goes away and comes back on the same socket (its mirrors are gone with it): the next
+    request of a connected client reconnects by itself; a search on a mirror the new server does not
+    have says so (NOKEY) and works again after the upload."""
+    dim, m, n, efs = 16, 4, 300, 10
+    port, X = port_index(n, dim, m, 16, efs, pg.DIST_L2, seed=95)
+    meta = pg.make_meta(dim, m, 16, efs, pg.DIST_L2)
+    path = str(tmp_path / "sock")
+    s1 = ServerProcess(socket_path=path, binary=double_bin).start()
+    c = RemoteClient(path)
+    c.upload(meta, 1, 1, port.raw(), n)
+    assert (c.search(1, X[0], efs)[0] == port.search(X[0], efs)[0]).all()
+    s1.stop()
+    with pytest.raises(RemoteError) as e:                 # nobody there at all: an I/O error, not a hang
+        c.stats()
+    assert e.value.code == -23
+    s2 = ServerProcess(socket_path=path, binary=double_bin).start()
+    try:
+        assert c.stats()["mirrors"] == 0                  # reconnected without being told to
+        with pytest.raises(RemoteError) as e:
+            c.search(1, X[0], efs)
+        assert e.value.code == HGS_ERR_NOKEY
+        c.upload(meta, 1, 1, port.raw(), n)
+        assert (c.search(1, X[0], efs)[0] == port.search(X[0], efs)[0]).all()
+        # and with the connection still open on the client side when the server is replaced
+        s2.stop()
+        s2 = ServerProcess(socket_path=path, binary=double_bin).start()
+        assert c.lookup(1) == (False, 0, 0)               # first call after the restart: one silent retry
+    finally:
+        s2.stop()
+        c.close()
+
+
 def test_server_stops_cleanly_on_sigterm(double_bin):
     s = ServerProcess(binary=double_bin).start()
     c = RemoteClient(s.socket_path)
