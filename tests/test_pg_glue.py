@@ -24,7 +24,7 @@ import server_util as SU
 
 GOLD = os.path.join(SU.ROOT, "tests", "golden", "pg_regress")
 REF_EXPECTED = "/root/reference/test/expected"
-SCRIPTS = ["knn", "gh-2", "gh-3", "scenario"]
+SCRIPTS = ["knn", "gh-2", "gh-3", "scenario", "exhaust"]
 
 needs_glue = pytest.mark.skipif(not SU.have_pg_glue(), reason="oracle/_ref/embedding.o is built only where /root/reference exists")
 
