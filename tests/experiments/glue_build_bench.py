@@ -1,13 +1,13 @@
 """CREATE INDEX through the reference's own glue (embedding.c on the mini-Postgres of oracle/pgmock):
 the patched glue + libembedding_gpuc.so + hnsw_gpu_server (rows stored by the table scan, one device
 build, link lists written back into the pages) next to the reference's objects on the host CPU
-(row-by-row hnsw_bind_point).  Usage: python scripts/glue_build_bench.py [rows dims m efconstruction]"""
+(row-by-row hnsw_bind_point).  Usage: python tests/experiments/glue_build_bench.py [rows dims m efconstruction]"""
 import os
 import re
 import subprocess
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import server_util as SU                                   # noqa: E402

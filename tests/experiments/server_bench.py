@@ -8,7 +8,7 @@ hnsw_gpu_server (the Postgres deployment shape, include/hnsw_gpu_server.h).
   * a sample of the returned arrays is compared with the reference's own code (oracle/_ref, or the
     C restatement) searching the exported graph bytes.
 
-Usage: python scripts/server_bench.py [--rows 1000000 --dims 768 --m 16 --efc 200 --efs 128]
+Usage: python tests/experiments/server_bench.py [--rows 1000000 --dims 768 --m 16 --efc 200 --efs 128]
                                       [--procs 1,16,64,256,1024] [--queries 20480] [--dispatchers 2]
 """
 import argparse
@@ -21,7 +21,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
