@@ -136,6 +136,12 @@ def test_no_cpu_fallback_product_never_links_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "import oracle" not in txt and "from oracle" not in txt, f
+    # nor do the scripts: drivers that check against the oracle live under tests/experiments
+    for dp, _, files in os.walk(os.path.join(ROOT, "scripts")):
+        for f in files:
+            if f.endswith(".py"):
+                txt = open(os.path.join(dp, f)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "server_util" not in txt, f
 
 
 def test_fails_loudly_without_a_device(gpu_count):
