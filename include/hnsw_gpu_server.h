@@ -27,6 +27,8 @@
 #ifndef PG_EMBEDDING_AMD_HNSW_GPU_SERVER_H
 #define PG_EMBEDDING_AMD_HNSW_GPU_SERVER_H
 
+/* Inside the reference's own embedding.c the types come from its embedding.h: define
+ * PG_EMBEDDING_AMD_HNSW_ABI_H before including this header (integration/embedding_gpu_server.patch does). */
 #include "hnsw_abi.h"
 
 #ifdef __cplusplus
