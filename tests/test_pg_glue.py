@@ -161,6 +161,74 @@ def test_an_error_inside_a_storage_callback_leaves_everything_usable(variant):
     assert "(2 rows)" in by["the row inserted after the failure is found"]
 
 
+def random_session(seed):
+    """A random psql session: small odd dimensionalities (page-tail holes: 3 dims -> 156 of 157 slots per page),
+    random m / efconstruction / efsearch, interleaved inserts, NULLs, deletes, VACUUM, TRUNCATE, a second index
+    with another operator class, scans with and without LIMIT.  Values are multiples of 1/8 (exact sums)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    dim = int(rng.choice([3, 5, 8, 13, 16]))
+    m = int(rng.integers(2, 7))
+    opts = f"dims={dim},m={m},efconstruction={int(rng.integers(4, 40))},efsearch={int(rng.integers(2, 30))}"
+    lit = lambda v: "{" + ",".join(f"{x:g}" for x in v) + "}"
+    centres = rng.integers(0, 30, (6, dim))
+    row = lambda: (centres[rng.integers(0, 6)] + rng.integers(0, 16, dim)) / 8.0
+    ops = ["<->", "<=>", "<~>"]
+    L = [f"# random session {seed}", "seqscan off", "create_table t serial"]
+    n_rows = 0
+    for _ in range(int(rng.integers(0, 250))):
+        L.append(f"insert t {lit(row())}")
+        n_rows += 1
+    first = int(rng.integers(0, 3))
+    L.append(f"create_index t i0 {['l2', 'cos', 'manhattan'][first]} {opts}")
+    have = [first]
+    for step in range(int(rng.integers(20, 60))):
+        r = rng.random()
+        if r < 0.45:
+            for _ in range(int(rng.integers(1, 40))):
+                L.append("insert t NULL" if rng.random() < 0.03 else f"insert t {lit(row())}")
+                n_rows += 1
+        elif r < 0.75:
+            op = int(rng.choice(have))
+            lim = int(rng.choice([0, 1, 5, 20, 100]))
+            q = f"@{int(rng.integers(0, n_rows))}" if n_rows and rng.random() < 0.5 else lit(row())
+            L.append(f"select t {ops[op]} {q} ctid,id {lim} ; step {step}: {ops[op]} limit {lim}")
+        elif r < 0.85 and n_rows:
+            for _ in range(int(rng.integers(1, 30))):
+                L.append(f"delete t {int(rng.integers(0, n_rows))}")
+            if rng.random() < 0.7:
+                L.append("vacuum t")
+        elif r < 0.9 and len(have) < 3:
+            op = [o for o in range(3) if o not in have][0]
+            L.append(f"create_index t i{len(have)} {['l2', 'cos', 'manhattan'][op]} {opts}")
+            have.append(op)
+        elif r < 0.93:
+            L.append("truncate t")
+            n_rows = 0
+        else:
+            L.append("needs_wal " + ("off" if rng.random() < 0.5 else "on"))
+    L.append("drop_table t")
+    return "\n".join(L) + "\n"
+
+
+@needs_glue
+@pytest.mark.skipif(not os.path.exists(SU.PG_REGRESS_REF), reason="reference-linked driver not built")
+@pytest.mark.parametrize("seed", range(12))
+def test_random_sessions_print_the_same_bytes_as_the_reference(seed):
+    """Differential fuzz through the real glue: the reference's objects vs libembedding_gpuc.so + server
+    (un-patched and patched glue) on random sessions; '@ROWNO' queries of deleted rows give the same ERROR."""
+    script = random_session(1000 + seed)
+    want = subprocess.run([SU.PG_REGRESS_REF], input=script, capture_output=True, text=True, timeout=600)
+    assert want.returncode == 0, want.stderr[-1500:]
+    variants = ["client"] + (["patched"] if os.path.exists(SU.PG_GLUE_PATCHED) else [])
+    with ServerProcess(binary=SU.build_double_server()) as s:
+        for v in variants:
+            got = subprocess.run([SU.build_pg_regress(v)], input=script, capture_output=True, text=True, timeout=600,
+                                 env=dict(os.environ, PG_EMBEDDING_GPU_SERVER=s.socket_path))
+            assert got.returncode == 0, (v, got.stdout[-1500:], got.stderr[-1500:])
+            assert got.stdout == want.stdout, v
+
+
 @needs_glue
 @pytest.mark.parametrize("name", SCRIPTS)
 def test_glue_over_the_server_client_library(name):
@@ -282,3 +350,23 @@ def test_create_index_offload_builds_a_good_graph_fast(tmp_path):
         line += f"; reference glue + hnswalg.o on the host CPU: {ref_ms:.0f} ms"
     print(line)
     assert hits / (10 * nq) >= 0.9
+
+
+@needs_glue
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(SU.PG_REGRESS_REF), reason="reference-linked driver not built")
+@pytest.mark.parametrize("seed", range(8))
+def test_random_sessions_on_the_device(seed, monkeypatch):
+    """The differential fuzz of test_random_sessions_… with the device underneath: in process, through the
+    server, and through the server with the patched glue (serial build order, so the bytes must match)."""
+    monkeypatch.setenv("PG_EMBEDDING_GPU_BUILD_BATCH", "1")
+    script = random_session(2000 + seed)
+    want = subprocess.run([SU.PG_REGRESS_REF], input=script, capture_output=True, text=True, timeout=600)
+    assert want.returncode == 0
+    got = subprocess.run([SU.build_pg_regress("gpu")], input=script, capture_output=True, text=True, timeout=900)
+    assert got.returncode == 0 and got.stdout == want.stdout, got.stderr[-1500:]
+    with ServerProcess() as s:
+        for v in ["client"] + (["patched"] if os.path.exists(SU.PG_GLUE_PATCHED) else []):
+            got = subprocess.run([SU.build_pg_regress(v)], input=script, capture_output=True, text=True, timeout=900,
+                                 env=dict(os.environ, PG_EMBEDDING_GPU_SERVER=s.socket_path))
+            assert got.returncode == 0 and got.stdout == want.stdout, (v, got.stderr[-1500:])
