@@ -11,8 +11,11 @@ embedding.h:46-47,55-56 changes:
 
 Scripts: tests/golden/pg_regress/*.cmd (knn / gh-2 / gh-3 = the reference's test/sql files statement
 by statement; scenario = a 1 650-row session with inserts, deletes, VACUUM, TID reuse, LIMIT above
-efsearch, all three operator classes).  *.expected = output of the reference-linked driver
-(tests/golden/make_pg_regress_golden.py)."""
+efsearch, all three operator classes; exhaust = scans without LIMIT: efSearch doubling to exhaustion).
+*.expected = output of the reference-linked driver (tests/golden/make_pg_regress_golden.py).
+Beyond the fixed scripts: the maintainer patch (integration/embedding_gpu_server.patch) applied to a scratch
+copy of the glue, page updates through generic WAL records, an injected I/O ERROR inside a storage callback
+(longjmp through the hot path), the CREATE INDEX offload, and a differential fuzz over random sessions."""
 import os
 import re
 import subprocess
