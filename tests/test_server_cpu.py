@@ -396,6 +396,31 @@ def test_an_upload_that_does_not_fit_evicts_idle_mirrors_lru_first(double_bin):
         c.close()
 
 
+@pytest.mark.parametrize("lanes", [3, 0])
+def test_linger_gathers_a_batch_before_launching(double_bin, lanes):
+    """--linger-us N --min-batch M: a dispatcher that finds fewer than M requests waits up to N us for more."""
+    dim, m, n, efs = 16, 4, 400, 10
+    port, X = port_index(n, dim, m, 16, efs, pg.DIST_L2, seed=97)
+    with ServerProcess(binary=double_bin, lanes=lanes, linger_us=200000, min_batch=6) as s:
+        c0 = RemoteClient(s.socket_path)
+        c0.upload(pg.make_meta(dim, m, 16, efs, pg.DIST_L2), 1, 1, port.raw(), n)
+        bad = []
+
+        def one(i):
+            c = RemoteClient(s.socket_path)
+            if not (c.search(1, X[i], efs)[0] == port.search(X[i], efs)[0]).all():
+                bad.append(i)
+            c.close()
+
+        th = [threading.Thread(target=one, args=(i,)) for i in range(6)]
+        [t.start() for t in th]
+        [t.join() for t in th]
+        st = c0.stats()
+        assert not bad and st["searches"] == 6
+        assert st["max_batch"] >= 4 and st["batches"] <= 3, st       # gathered, not six launches of one
+        c0.close()
+
+
 def test_a_restarted_server_is_picked_up_again(double_bin, tmp_path):
     """The server goes away and comes back on the same socket (its mirrors are gone with it): the next
     request of a connected client reconnects by itself; a search on a mirror the new server does not
