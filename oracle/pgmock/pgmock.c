@@ -179,6 +179,7 @@ void pgmock_truncate_relation(Relation rel)
 		free(rel->pages[f]);
 		rel->pages[f] = NULL;
 		rel->npages[f] = 0;
+		rel->cappages[f] = 0;
 	}
 }
 
@@ -244,7 +245,11 @@ Buffer ReadBufferExtended(Relation rel, ForkNumber fork, BlockNumber blk, ReadBu
 	if (blk == P_NEW)
 	{
 		blk = rel->npages[fork];
-		rel->pages[fork] = (char **) repalloc(rel->pages[fork], (Size) (blk + 1) * sizeof(char *));
+		if (blk == rel->cappages[fork])
+		{
+			rel->cappages[fork] = blk ? 2 * blk : 64;
+			rel->pages[fork] = (char **) repalloc(rel->pages[fork], (Size) rel->cappages[fork] * sizeof(char *));
+		}
 		rel->pages[fork][blk] = (char *) palloc0(BLCKSZ);
 		rel->npages[fork] = blk + 1;
 	}

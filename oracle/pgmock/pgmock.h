@@ -161,7 +161,7 @@ typedef struct RelationData
 	Oid    rd_id;
 	char   name[64];
 	char **pages[4];            /* per fork */
-	BlockNumber npages[4];
+	BlockNumber npages[4], cappages[4];
 	bool   needs_wal;
 	FmgrInfo distproc;          /* support procedure 1 of the operator class */
 	struct PgmockHeap *heap;    /* the indexed table (index relations) */

@@ -53,6 +53,7 @@ typedef struct
 	int32 next_id;
 	PgmockHeap heap;
 	bool *free_slot;                    /* vacuumed slots, reusable by later inserts */
+	size_t nfree;                       /* how many of them there are (0 = append without looking) */
 	struct { Relation rel; int op; } idx[MAX_INDEXES];
 	int nidx;
 } Table;
@@ -167,8 +168,8 @@ static void after_am_call(const char *what)
 static size_t heap_insert(Table *t, ArrayType *val)
 {
 	size_t slot = t->heap.n;
-	for (size_t i = 0; i < t->heap.n; i++)
-		if (t->free_slot[i]) { slot = i; break; }
+	for (size_t i = 0; t->nfree && i < t->heap.n; i++)
+		if (t->free_slot[i]) { slot = i; t->nfree--; break; }
 	if (slot == t->heap.n)
 	{
 		if (t->heap.n == t->heap.cap)
@@ -344,8 +345,9 @@ static void cmd_vacuum(Table *t)
 			t->heap.rows[r].val = NULL;
 			t->heap.rows[r].dead = false;
 			t->free_slot[r] = true;
+			t->nfree++;
 		}
-	while (t->heap.n > 0 && t->free_slot[t->heap.n - 1]) t->heap.n--;           /* truncate the empty tail */
+	while (t->heap.n > 0 && t->free_slot[t->heap.n - 1]) { t->heap.n--; t->nfree--; }   /* truncate the empty tail */
 }
 
 static void cmd_truncate(Table *t)
@@ -353,6 +355,7 @@ static void cmd_truncate(Table *t)
 	for (size_t r = 0; r < t->heap.n; r++)
 		if (t->heap.rows[r].val) pfree(t->heap.rows[r].val);
 	t->heap.n = 0;
+	t->nfree = 0;
 	for (int i = 0; i < t->nidx; i++)          /* new relfilenode + index_build on the empty table */
 	{
 		pgmock_truncate_relation(t->idx[i].rel);
@@ -419,13 +422,13 @@ static void run(char *line)
 		Table *t = table(tok[1]);
 		const long rows = atol(tok[2]), dim = atol(tok[3]);
 		unsigned long long lcg = strtoull(tok[4], NULL, 0) * 2862933555777941757ull + 3037000493ull;
-		float4 centre[64][256], v[256];
-		if (dim < 1 || dim > 256) pgmock_error("generate: 1..256 dimensions");
+		if (dim < 1 || dim > 4096) pgmock_error("generate: 1..4096 dimensions");
+		float4 *centre = (float4 *) palloc(64 * (Size) dim * sizeof(float4)), *v = (float4 *) palloc((Size) dim * sizeof(float4));
 		for (int c = 0; c < 64; c++)
 			for (long d = 0; d < dim; d++)
 			{
 				lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
-				centre[c][d] = (float4) ((lcg >> 40) % 40);
+				centre[c * dim + d] = (float4) ((lcg >> 40) % 40);
 			}
 		for (long r = 0; r < rows; r++)
 		{
@@ -434,7 +437,7 @@ static void run(char *line)
 			for (long d = 0; d < dim; d++)
 			{
 				lcg = lcg * 6364136223846793005ull + 1442695040888963407ull;
-				v[d] = (centre[c][d] + (float4) ((lcg >> 40) % 24)) / 8.0f;
+				v[d] = (centre[c * dim + d] + (float4) ((lcg >> 40) % 24)) / 8.0f;
 			}
 			ArrayType *val = pgmock_make_array(v, (int) dim);
 			const size_t row = heap_insert(t, val);
@@ -449,6 +452,8 @@ static void run(char *line)
 				pfree(ii);
 			}
 		}
+		pfree(centre);
+		pfree(v);
 		after_am_call("generate");
 	}
 	else if (strcmp(tok[0], "create_index") == 0 && n == 5) cmd_create_index(table(tok[1]), tok[2], tok[3], tok[4]);
