@@ -84,7 +84,7 @@ bool stage_reserve(size_t bytes)
 // not reached, among them the holes at the tail of a page (idx = blk*elems_per_page + off-1 with
 // un-aligned elems_per_page, embedding.c:229,693 / SURVEY.md §0.8), become zero-linked,
 // vacuum-flagged placeholders that nothing links to.
-extern "C" int hnsw_gpu_shim_snapshot(HnswMetadata *meta, hnsw_gpu_index **out)
+static int hnsw_gpu_shim_snapshot_impl(HnswMetadata *meta, hnsw_gpu_index **out)
 {
 	if (!meta || !out) return HNSW_GPU_ERR_ARG;
 	int dev = pick_device();
@@ -145,7 +145,7 @@ extern "C" dist_t hnsw_dist_func(dist_func_t dist, coord_t const *ax, coord_t co
 	return out;
 }
 
-extern "C" bool hnsw_search(HnswMetadata *meta, const coord_t *point, size_t *n_results, label_t **results)
+static bool hnsw_search_impl(HnswMetadata *meta, const coord_t *point, size_t *n_results, label_t **results)
 {
 	if (!meta || !point || !n_results || !results) return false;
 	const size_t ef = meta->efSearch;
@@ -199,7 +199,7 @@ extern "C" bool hnsw_search(HnswMetadata *meta, const coord_t *point, size_t *n_
 // to the host through hnsw_begin_write/hnsw_end_write (one write pin at a time,
 // embedding.c:780-781).  With an attached mirror that already holds elements [0, idx) only the
 // new element is uploaded; otherwise the index is mirrored first.
-extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t idx)
+static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t idx)
 {
 	if (!meta || !point) return false;
 	hnsw_gpu_index *ix = nullptr;
@@ -278,3 +278,12 @@ extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t 
 	if (own && ix) hnsw_gpu_index_destroy(ix);
 	return ok;
 }
+
+// ---------------------------------------------------------------------------------------
+// The C boundary.  Nothing may unwind through it (the callers are C: embedding.c): an allocation
+// failure inside the library (std::bad_alloc) becomes an ordinary failure, as the reference turns
+// every exception into `false` at the same place (hnswalg.cpp:258-276, 281-290).
+// ---------------------------------------------------------------------------------------
+extern "C" int hnsw_gpu_shim_snapshot(HnswMetadata *meta, hnsw_gpu_index **out) { try { return hnsw_gpu_shim_snapshot_impl(meta, out); } catch (...) { return HNSW_GPU_ERR_NOMEM; } }
+extern "C" bool hnsw_search(HnswMetadata *meta, const coord_t *point, size_t *n_results, label_t **results) { try { return hnsw_search_impl(meta, point, n_results, results); } catch (...) { return false; } }
+extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t idx) { try { return hnsw_bind_point_impl(meta, point, idx); } catch (...) { return false; } }

@@ -249,7 +249,7 @@ int simple(uint16_t op, uint64_t key, uint32_t aux, uint64_t a0, uint64_t a1, hg
 // ---------------------------------------------------------------------------------------
 extern "C" const char *hnsw_gpu_remote_last_error(void) { return t_err; }
 
-extern "C" int hnsw_gpu_remote_connect(const char *socket_path)
+static int hnsw_gpu_remote_connect_impl(const char *socket_path)
 {
 	if (!socket_path || !*socket_path) return fail(HGS_ERR_IO, "empty socket path");
 	{
@@ -262,7 +262,7 @@ extern "C" int hnsw_gpu_remote_connect(const char *socket_path)
 
 extern "C" void hnsw_gpu_remote_disconnect(void) { drop_connection(); }
 
-extern "C" int hnsw_gpu_remote_lookup(uint64_t key, uint64_t *generation, size_t *count, int *present)
+static int hnsw_gpu_remote_lookup_impl(uint64_t key, uint64_t *generation, size_t *count, int *present)
 {
 	hgs_hdr r;
 	int rc = simple(HGS_OP_LOOKUP, key, 0, 0, 0, &r);
@@ -273,7 +273,7 @@ extern "C" int hnsw_gpu_remote_lookup(uint64_t key, uint64_t *generation, size_t
 	return HGS_OK;
 }
 
-extern "C" int hnsw_gpu_remote_upload(const HnswMetadata *meta, uint64_t key, uint64_t generation,
+static int hnsw_gpu_remote_upload_impl(const HnswMetadata *meta, uint64_t key, uint64_t generation,
 									  const void *elements, size_t n)
 {
 	if (!meta || (n && !elements)) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
@@ -290,7 +290,7 @@ extern "C" int hnsw_gpu_remote_upload(const HnswMetadata *meta, uint64_t key, ui
 	return rpc(&h, meta, sizeof(*meta), nullptr, 0, n ? shm.fd : -1, &r);
 }
 
-extern "C" int hnsw_gpu_remote_update(uint64_t key, uint64_t expected_generation, uint64_t new_generation,
+static int hnsw_gpu_remote_update_impl(uint64_t key, uint64_t expected_generation, uint64_t new_generation,
 									  const HnswMetadata *meta, const void *elements, size_t first, size_t count)
 {
 	if (!meta || !elements || count == 0) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
@@ -304,7 +304,7 @@ extern "C" int hnsw_gpu_remote_update(uint64_t key, uint64_t expected_generation
 	return rpc(&h, &expected_generation, 8, nullptr, 0, shm.fd, &r);
 }
 
-extern "C" int hnsw_gpu_remote_search(uint64_t key, uint64_t generation, const coord_t *query, size_t dim, size_t ef,
+static int hnsw_gpu_remote_search_impl(uint64_t key, uint64_t generation, const coord_t *query, size_t dim, size_t ef,
 									  label_t *labels, dist_t *dists, size_t *count)
 {
 	if (!query || !labels || !count) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
@@ -322,13 +322,13 @@ extern "C" int hnsw_gpu_remote_search(uint64_t key, uint64_t generation, const c
 	return HGS_OK;
 }
 
-extern "C" int hnsw_gpu_remote_link(uint64_t key, size_t first, size_t count, size_t max_batch)
+static int hnsw_gpu_remote_link_impl(uint64_t key, size_t first, size_t count, size_t max_batch)
 {
 	hgs_hdr r;
 	return simple(HGS_OP_LINK, key, (uint32_t) max_batch, first, count, &r);
 }
 
-extern "C" int hnsw_gpu_remote_export(uint64_t key, void *elements, size_t bytes)
+static int hnsw_gpu_remote_export_impl(uint64_t key, void *elements, size_t bytes)
 {
 	if (!elements) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
 	Shm shm;
@@ -342,19 +342,19 @@ extern "C" int hnsw_gpu_remote_export(uint64_t key, void *elements, size_t bytes
 	return HGS_OK;
 }
 
-extern "C" int hnsw_gpu_remote_set_deleted(uint64_t key, idx_t idx, int deleted)
+static int hnsw_gpu_remote_set_deleted_impl(uint64_t key, idx_t idx, int deleted)
 {
 	hgs_hdr r;
 	return simple(HGS_OP_SET_DELETED, key, idx, deleted ? 1 : 0, 0, &r);
 }
 
-extern "C" int hnsw_gpu_remote_drop(uint64_t key)
+static int hnsw_gpu_remote_drop_impl(uint64_t key)
 {
 	hgs_hdr r;
 	return simple(HGS_OP_DROP, key, 0, 0, 0, &r);
 }
 
-extern "C" int hnsw_gpu_remote_stats(hgs_stats *out)
+static int hnsw_gpu_remote_stats_impl(hgs_stats *out)
 {
 	if (!out) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
 	hgs_hdr r;
@@ -365,7 +365,7 @@ extern "C" int hnsw_gpu_remote_stats(hgs_stats *out)
 	return HGS_OK;
 }
 
-extern "C" int hnsw_gpu_remote_attach(HnswMetadata *meta, uint64_t key, uint64_t generation)
+static int hnsw_gpu_remote_attach_impl(HnswMetadata *meta, uint64_t key, uint64_t generation)
 {
 	if (!meta) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
 	uint64_t have_gen = 0;
@@ -386,7 +386,7 @@ extern "C" int hnsw_gpu_remote_attach(HnswMetadata *meta, uint64_t key, uint64_t
 
 // CREATE INDEX offload.  Between begin_build and finish_build hnsw_bind_point(meta, ...) only reports
 // success: the host has stored the row zero-linked (embedding.c:619-621,670), nothing is linked yet.
-extern "C" int hnsw_gpu_remote_begin_build(HnswMetadata *meta)
+static int hnsw_gpu_remote_begin_build_impl(HnswMetadata *meta)
 {
 	if (!meta) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
 	std::lock_guard<std::mutex> lk(g_mu);
@@ -402,7 +402,7 @@ extern "C" int hnsw_gpu_remote_begin_build(HnswMetadata *meta)
 // fraction of the time), and write every element's link list back into the host's pages through
 // hnsw_begin_write/hnsw_end_write.  The caller holds the index-wide writer lock (embedding.c:624-629),
 // as for any hnsw_bind_point.  The mirror stays on the server as (key, generation).
-extern "C" int hnsw_gpu_remote_finish_build(HnswMetadata *meta, uint64_t key, uint64_t generation, size_t n_slots,
+static int hnsw_gpu_remote_finish_build_impl(HnswMetadata *meta, uint64_t key, uint64_t generation, size_t n_slots,
 											size_t max_batch)
 {
 	if (!meta) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
@@ -467,7 +467,7 @@ extern "C" int hnsw_gpu_remote_finish_build(HnswMetadata *meta, uint64_t key, ui
 	return rc;
 }
 
-extern "C" int hnsw_gpu_remote_advance(HnswMetadata *meta, uint64_t new_generation)
+static int hnsw_gpu_remote_advance_impl(HnswMetadata *meta, uint64_t new_generation)
 {
 	Attachment at;
 	if (!meta || !find_attached(meta, &at)) return fail(HNSW_GPU_ERR_ARG, "meta is not attached");
@@ -485,7 +485,7 @@ extern "C" int hnsw_gpu_remote_advance(HnswMetadata *meta, uint64_t new_generati
 	return HGS_OK;
 }
 
-extern "C" int hnsw_gpu_remote_detach(HnswMetadata *meta)
+static int hnsw_gpu_remote_detach_impl(HnswMetadata *meta)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
 	for (size_t i = 0; i < g_attached.size(); i++)
@@ -510,7 +510,7 @@ extern "C" void hnsw_init_dist_func(void)
 	if (g_path.empty() && env && *env) g_path = env;
 }
 
-extern "C" dist_t hnsw_dist_func(dist_func_t dist, coord_t const *ax, coord_t const *bx, size_t dim)
+static dist_t hnsw_dist_func_impl(dist_func_t dist, coord_t const *ax, coord_t const *bx, size_t dim)
 {
 	hgs_hdr h, r;
 	memset(&h, 0, sizeof(h));
@@ -525,7 +525,7 @@ extern "C" dist_t hnsw_dist_func(dist_func_t dist, coord_t const *ax, coord_t co
 	return out;
 }
 
-extern "C" bool hnsw_search(HnswMetadata *meta, const coord_t *point, size_t *n_results, label_t **results)
+static bool hnsw_search_impl(HnswMetadata *meta, const coord_t *point, size_t *n_results, label_t **results)
 {
 	if (!meta || !point || !n_results || !results) return false;
 	const size_t ef = meta->efSearch;
@@ -570,7 +570,7 @@ extern "C" bool hnsw_search(HnswMetadata *meta, const coord_t *point, size_t *n_
 // behind, runs the reference's insert in serial form and returns the changed link lists, which go
 // back to the host's pages through hnsw_begin_write/hnsw_end_write: the touched neighbours first,
 // then the new element (hnswalg.cpp:169-222), one write pin at a time (embedding.c:780-781).
-extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t idx)
+static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t idx)
 {
 	if (!meta || !point) return false;
 	{
@@ -626,3 +626,27 @@ extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t 
 	if (own) (void) hnsw_gpu_remote_drop(at.key);
 	return ok;
 }
+
+// ---------------------------------------------------------------------------------------
+// The C boundary.  Nothing may unwind through it (the callers are C: embedding.c): an allocation
+// failure inside the library (std::bad_alloc) becomes an ordinary failure, as the reference turns
+// every exception into `false` at the same place (hnswalg.cpp:258-276, 281-290).
+// ---------------------------------------------------------------------------------------
+extern "C" int hnsw_gpu_remote_connect(const char *socket_path) { try { return hnsw_gpu_remote_connect_impl(socket_path); } catch (...) { return fail(HNSW_GPU_ERR_NOMEM, "out of memory"); } }
+extern "C" int hnsw_gpu_remote_lookup(uint64_t key, uint64_t *generation, size_t *count, int *present) { try { return hnsw_gpu_remote_lookup_impl(key, generation, count, present); } catch (...) { return fail(HNSW_GPU_ERR_NOMEM, "out of memory"); } }
+extern "C" int hnsw_gpu_remote_upload(const HnswMetadata *meta, uint64_t key, uint64_t generation, const void *elements, size_t n) { try { return hnsw_gpu_remote_upload_impl(meta, key, generation, elements, n); } catch (...) { return fail(HNSW_GPU_ERR_NOMEM, "out of memory"); } }
+extern "C" int hnsw_gpu_remote_update(uint64_t key, uint64_t expected_generation, uint64_t new_generation, const HnswMetadata *meta, const void *elements, size_t first, size_t count) { try { return hnsw_gpu_remote_update_impl(key, expected_generation, new_generation, meta, elements, first, count); } catch (...) { return fail(HNSW_GPU_ERR_NOMEM, "out of memory"); } }
+extern "C" int hnsw_gpu_remote_search(uint64_t key, uint64_t generation, const coord_t *query, size_t dim, size_t ef, label_t *labels, dist_t *dists, size_t *count) { try { return hnsw_gpu_remote_search_impl(key, generation, query, dim, ef, labels, dists, count); } catch (...) { return fail(HNSW_GPU_ERR_NOMEM, "out of memory"); } }
+extern "C" int hnsw_gpu_remote_link(uint64_t key, size_t first, size_t count, size_t max_batch) { try { return hnsw_gpu_remote_link_impl(key, first, count, max_batch); } catch (...) { return fail(HNSW_GPU_ERR_NOMEM, "out of memory"); } }
+extern "C" int hnsw_gpu_remote_export(uint64_t key, void *elements, size_t bytes) { try { return hnsw_gpu_remote_export_impl(key, elements, bytes); } catch (...) { return fail(HNSW_GPU_ERR_NOMEM, "out of memory"); } }
+extern "C" int hnsw_gpu_remote_set_deleted(uint64_t key, idx_t idx, int deleted) { try { return hnsw_gpu_remote_set_deleted_impl(key, idx, deleted); } catch (...) { return fail(HNSW_GPU_ERR_NOMEM, "out of memory"); } }
+extern "C" int hnsw_gpu_remote_drop(uint64_t key) { try { return hnsw_gpu_remote_drop_impl(key); } catch (...) { return fail(HNSW_GPU_ERR_NOMEM, "out of memory"); } }
+extern "C" int hnsw_gpu_remote_stats(hgs_stats *out) { try { return hnsw_gpu_remote_stats_impl(out); } catch (...) { return fail(HNSW_GPU_ERR_NOMEM, "out of memory"); } }
+extern "C" int hnsw_gpu_remote_attach(HnswMetadata *meta, uint64_t key, uint64_t generation) { try { return hnsw_gpu_remote_attach_impl(meta, key, generation); } catch (...) { return fail(HNSW_GPU_ERR_NOMEM, "out of memory"); } }
+extern "C" int hnsw_gpu_remote_begin_build(HnswMetadata *meta) { try { return hnsw_gpu_remote_begin_build_impl(meta); } catch (...) { return fail(HNSW_GPU_ERR_NOMEM, "out of memory"); } }
+extern "C" int hnsw_gpu_remote_finish_build(HnswMetadata *meta, uint64_t key, uint64_t generation, size_t n_slots, size_t max_batch) { try { return hnsw_gpu_remote_finish_build_impl(meta, key, generation, n_slots, max_batch); } catch (...) { return fail(HNSW_GPU_ERR_NOMEM, "out of memory"); } }
+extern "C" int hnsw_gpu_remote_advance(HnswMetadata *meta, uint64_t new_generation) { try { return hnsw_gpu_remote_advance_impl(meta, new_generation); } catch (...) { return fail(HNSW_GPU_ERR_NOMEM, "out of memory"); } }
+extern "C" int hnsw_gpu_remote_detach(HnswMetadata *meta) { try { return hnsw_gpu_remote_detach_impl(meta); } catch (...) { return fail(HNSW_GPU_ERR_NOMEM, "out of memory"); } }
+extern "C" dist_t hnsw_dist_func(dist_func_t dist, coord_t const *ax, coord_t const *bx, size_t dim) { try { return hnsw_dist_func_impl(dist, ax, bx, dim); } catch (...) { return NAN; } }
+extern "C" bool hnsw_search(HnswMetadata *meta, const coord_t *point, size_t *n_results, label_t **results) { try { return hnsw_search_impl(meta, point, n_results, results); } catch (...) { return false; } }
+extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t idx) { try { return hnsw_bind_point_impl(meta, point, idx); } catch (...) { return false; } }
