@@ -27,7 +27,7 @@ import server_util as SU
 
 GOLD = os.path.join(SU.ROOT, "tests", "golden", "pg_regress")
 REF_EXPECTED = "/root/reference/test/expected"
-SCRIPTS = ["knn", "gh-2", "gh-3", "scenario", "exhaust"]
+SCRIPTS = ["knn", "gh-2", "gh-3", "scenario", "exhaust", "defaults"]
 
 needs_glue = pytest.mark.skipif(not SU.have_pg_glue(), reason="oracle/_ref/embedding.o is built only where /root/reference exists")
 
