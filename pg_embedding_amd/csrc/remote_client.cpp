@@ -59,6 +59,49 @@ void drop_connection()
 	t_fd = -1;
 }
 
+std::vector<std::string> split_paths(const std::string &list)
+{
+	std::vector<std::string> all;
+	size_t a = 0;
+	while (a <= list.size())
+	{
+		const size_t b = list.find(',', a);
+		const std::string one = list.substr(a, b == std::string::npos ? std::string::npos : b - a);
+		if (!one.empty()) all.push_back(one);
+		if (b == std::string::npos) break;
+		a = b + 1;
+	}
+	return all;
+}
+
+// One request on a connection of its own to the server at `path` (no payload either way).
+int one_shot(const std::string &path, uint16_t op, uint64_t key)
+{
+	struct sockaddr_un addr;
+	memset(&addr, 0, sizeof(addr));
+	addr.sun_family = AF_UNIX;
+	if (path.size() >= sizeof(addr.sun_path)) return HGS_ERR_IO;
+	strncpy(addr.sun_path, path.c_str(), sizeof(addr.sun_path) - 1);
+	int fd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+	if (fd < 0) return HGS_ERR_IO;
+	int rc = HGS_ERR_IO;
+	hgs_hdr h, r;
+	if (connect(fd, (struct sockaddr *) &addr, sizeof(addr)) == 0)
+	{
+		memset(&h, 0, sizeof(h));
+		h.magic = HGS_MAGIC; h.op = HGS_OP_HELLO; h.a0 = HGS_VERSION;
+		if (hgs::send_msg(fd, &h, nullptr, 0, nullptr, 0) == 0 && hgs::recv_exact(fd, &r, sizeof(r), nullptr) == 0 && r.status == HGS_OK)
+		{
+			memset(&h, 0, sizeof(h));
+			h.magic = HGS_MAGIC; h.op = op; h.key = key;
+			if (hgs::send_msg(fd, &h, nullptr, 0, nullptr, 0) == 0 && hgs::recv_exact(fd, &r, sizeof(r), nullptr) == 0 && r.len == 0)
+				rc = r.status;
+		}
+	}
+	close(fd);
+	return rc;
+}
+
 int ensure_connected()
 {
 	if (t_fd >= 0 && t_pid == getpid()) return HGS_OK;
@@ -78,19 +121,9 @@ int ensure_connected()
 	// Several GPUs = several servers (one process per GPU), sockets separated by ','.  A backend stays with
 	// one of them (by process id): every server mirrors the indexes its backends use — replicas, so
 	// read throughput scales with the GPUs; a mirror on another server that an insert here made stale is
-	// noticed by its generation at the next attach there and uploaded again.
-	if (path.find(',') != std::string::npos)
+	// noticed by its generation at the next attach there and uploaded again (a DROP goes to all of them).
 	{
-		std::vector<std::string> all;
-		size_t a = 0;
-		while (a <= path.size())
-		{
-			const size_t b = path.find(',', a);
-			const std::string one = path.substr(a, b == std::string::npos ? std::string::npos : b - a);
-			if (!one.empty()) all.push_back(one);
-			if (b == std::string::npos) break;
-			a = b + 1;
-		}
+		const std::vector<std::string> all = split_paths(path);
 		if (all.empty()) return fail(HGS_ERR_IO, "no server socket in \"%s\"", path.c_str());
 		path = all[(size_t) getpid() % all.size()];
 	}
@@ -351,7 +384,27 @@ static int hnsw_gpu_remote_set_deleted_impl(uint64_t key, idx_t idx, int deleted
 static int hnsw_gpu_remote_drop_impl(uint64_t key)
 {
 	hgs_hdr r;
-	return simple(HGS_OP_DROP, key, 0, 0, 0, &r);
+	int rc = simple(HGS_OP_DROP, key, 0, 0, 0, &r);
+	// With several servers every replica has to go: a mirror that outlives a VACUUM would keep answering
+	// with TIDs whose rows are gone — or, after TID reuse, are other rows.
+	std::string list;
+	{
+		std::lock_guard<std::mutex> lk(g_mu);
+		list = g_path;
+	}
+	const std::vector<std::string> all = split_paths(list);
+	if (all.size() > 1)
+	{
+		const std::string &mine = all[(size_t) getpid() % all.size()];
+		for (const std::string &p : all)
+			if (&p != &mine)
+			{
+				const int r2 = one_shot(p, HGS_OP_DROP, key);
+				if (r2 != HGS_OK && r2 != HGS_ERR_NOKEY)
+					rc = fail(HGS_ERR_IO, "could not drop mirror %llx on the server at %s (%d)", (unsigned long long) key, p.c_str(), r2);
+			}
+	}
+	return rc;
 }
 
 static int hnsw_gpu_remote_stats_impl(hgs_stats *out)

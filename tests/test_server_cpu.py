@@ -370,6 +370,14 @@ def test_several_servers_one_per_gpu_backends_spread_by_pid(double_bin, tmp_path
             served.append(c.stats()["searches"])
             c.close()
         assert sum(served) == len(Q) and min(served) > 0, served      # both took part
+        # a DROP (what VACUUM sends) must reach every replica, not only the server this process talks to
+        c = RemoteClient(both)
+        c.drop(5)
+        c.close()
+        for s in (a, b):
+            c = RemoteClient(s.socket_path)
+            assert c.lookup(5)[0] is False
+            c.close()
 
 
 def test_an_upload_that_does_not_fit_evicts_idle_mirrors_lru_first(double_bin):
