@@ -42,6 +42,7 @@
 #include <sys/epoll.h>
 #include <sys/eventfd.h>
 #include <sys/mman.h>
+#include <sys/resource.h>
 #include <sys/stat.h>
 #include <sys/un.h>
 
@@ -1055,6 +1056,15 @@ int main(int argc, char **argv)
 	}
 	g_t0 = std::chrono::steady_clock::now();
 
+	{
+		// one descriptor per backend: take what the hard limit allows
+		struct rlimit rl;
+		if (getrlimit(RLIMIT_NOFILE, &rl) == 0 && rl.rlim_cur < rl.rlim_max)
+		{
+			rl.rlim_cur = rl.rlim_max;
+			(void) setrlimit(RLIMIT_NOFILE, &rl);
+		}
+	}
 	signal(SIGPIPE, SIG_IGN);
 	struct sigaction sa;
 	memset(&sa, 0, sizeof(sa));
