@@ -13,7 +13,7 @@
 //                a walk is ~160 dependent hops and the slowest of a batch takes 2-3x the mean.
 //                Requests gather while the lanes are busy: no artificial delay unless --linger-us
 //                is given.  --lanes 0 = one blocking launch at a time per dispatcher.
-//   control      one thread: UPLOAD / UPDATE / BIND / LINK / EXPORT / DROP / SET_DELETED / DIST.
+//   control      one thread: UPLOAD / UPDATE / BIND / LINK / EXPORT / DROP / SET_DELETED / SETGEN / DIST.
 //                Mirror changes wait for the mirror's searches in flight and keep new ones out
 //                (counting gate, writer first).
 //
