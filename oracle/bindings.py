@@ -85,6 +85,14 @@ def _port():
         L.port_search_many.restype = C.c_double
         L.port_search_many.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_size_t, C.c_int,
                                        _u64p, _f32p, _u32p, _u32p, _u32p]
+        L.port_search_many_m.restype = C.c_double
+        L.port_search_many_m.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_size_t, C.c_int,
+                                         _u64p, _f32p, _u32p, _u32p, _u32p, _f32p,
+                                         C.POINTER(C.c_int32), _f32p]
+        L.port_set_dist_fn.restype = None
+        L.port_set_dist_fn.argtypes = [C.c_void_p, C.c_void_p]
+        L.port_set_dist2_fn.restype = None
+        L.port_set_dist2_fn.argtypes = [C.c_void_p, C.c_void_p]
         _port_lib = L
     return _port_lib
 
@@ -153,6 +161,21 @@ class PortIndex:
     def set_deleted(self, idx: int, deleted: bool = True) -> None:
         self.L.port_set_deleted(self.h, idx, int(deleted))
 
+    def use_reference_distances(self, on: bool = True) -> None:
+        """Score with the reference's own hnsw_dist_func (oracle/_ref) instead of the canonical-order
+        restatement: the traversal restated in hnsw_port.c must then reproduce the reference's results
+        exactly, which isolates the summation order as the only difference between device and reference."""
+        fn = C.cast(_ref().hnsw_dist_func, C.c_void_p) if on else None
+        self.L.port_set_dist_fn(self.h, fn)
+
+    def shadow_reference_distances(self, on: bool = True) -> None:
+        """Walk in the canonical arithmetic, but also score every evaluation with the reference's
+        hnsw_dist_func and record, per query, the first decision the reference's values would have taken
+        differently (search_many: 'div_kind', 'div_margin').  div_kind == 0 proves the reference returns the
+        same ids; a mismatching query has div_kind != 0 and div_margin says how close that call was."""
+        fn = C.cast(_ref().hnsw_dist_func, C.c_void_p) if on else None
+        self.L.port_set_dist2_fn(self.h, fn)
+
     def search(self, q, ef: Optional[int] = None):
         """hnsw_search semantics: (labels, dists, evals, hops), ascending by (dist, label)."""
         ef = ef or self.efs
@@ -185,10 +208,18 @@ class PortIndex:
         cnt = np.zeros(nq, np.uint32)
         ev = np.zeros(nq, np.uint32)
         hp = np.zeros(nq, np.uint32)
-        sec = self.L.port_search_many(self.h, _ptr(Q, _f32p), nq, ef, nthreads, _ptr(lab, _u64p),
-                                      _ptr(dst, _f32p), _ptr(cnt, _u32p), _ptr(ev, _u32p),
-                                      _ptr(hp, _u32p))
-        return dict(labels=lab, dists=dst, counts=cnt, evals=ev, hops=hp, seconds=sec)
+        mg = np.zeros(nq, np.float32)
+        dk = np.zeros(nq, np.int32)
+        dm = np.full(nq, np.inf, np.float32)
+        sec = self.L.port_search_many_m(self.h, _ptr(Q, _f32p), nq, ef, nthreads, _ptr(lab, _u64p),
+                                        _ptr(dst, _f32p), _ptr(cnt, _u32p), _ptr(ev, _u32p),
+                                        _ptr(hp, _u32p), _ptr(mg, _f32p), _ptr(dk, C.POINTER(C.c_int32)),
+                                        _ptr(dm, _f32p))
+        # margins[q]: smallest relative gap between two different elements' distances over every
+        # comparison that steered query q's walk or its output order (hnsw_port.c, PortStats)
+        # div_kind/div_margin: only meaningful after shadow_reference_distances() (0 / inf otherwise)
+        return dict(labels=lab, dists=dst, counts=cnt, evals=ev, hops=hp, margins=mg, div_kind=dk,
+                    div_margin=dm, seconds=sec)
 
 
 # ------------------------------------------------------------------- flat host family

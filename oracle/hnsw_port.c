@@ -11,7 +11,10 @@
  * reference's pg_regress expected files (tests/golden/knn_expected.json, restated
  * from test/expected/knn.out:16-19,39-42,56-59,97-122, gh-2.out:5-8, gh-3.out:9-14)
  * and (b) the UNMODIFIED reference sources compiled into oracle/_ref (see
- * oracle/Makefile) on seeded graphs: tests/test_oracle_pinning.py.
+ * oracle/Makefile) on seeded graphs: tests/test_oracle_golden.py; and, with the
+ * reference's own distance function plugged in (port_set_dist_fn), the traversal
+ * restated here returns the reference's result arrays EXACTLY, query for query
+ * (tests/test_oracle_golden.py::test_port_with_reference_distances_is_the_reference).
  *
  * ONE DELIBERATE, DOCUMENTED DIFFERENCE: summation order.  The reference is built
  * with -Ofast (Makefile:14), so its float summation order is whatever the
@@ -144,10 +147,14 @@ void port_dist_many(int func, const float *q, const float *rows, size_t nrows, s
 /* Index image: same bytes as the host's element array (embedding.c:222-228). */
 /* ------------------------------------------------------------------------- */
 
+typedef float (*port_dist_fn)(int func, const float *a, const float *b, size_t dim);
+
 typedef struct PortIndex
 {
 	size_t dim, M, maxM, efc, efs;
 	int    func;
+	port_dist_fn dist;        /* port_dist (canonical order) unless a test plugs in the reference's hnsw_dist_func */
+	port_dist_fn dist2;       /* NULL, or a second arithmetic that shadows every decision (see PortStats.div_*) */
 	size_t off_data, off_label, elem_size;
 	char  *data;
 	size_t n, cap;
@@ -166,6 +173,7 @@ PortIndex *port_create(size_t dim, size_t M, size_t efc, size_t efs, int func, s
 	if (!ix) return NULL;
 	ix->dim = dim; ix->M = M; ix->maxM = 2 * M;           /* embedding.c:224 */
 	ix->efc = efc; ix->efs = efs; ix->func = func;
+	ix->dist = port_dist;
 	ix->off_data = (ix->maxM + 1) * 4;                    /* embedding.c:226 */
 	ix->off_label = ix->off_data + dim * 4;               /* embedding.c:227 */
 	ix->elem_size = ix->off_label + 8;                    /* embedding.c:228 */
@@ -174,6 +182,13 @@ PortIndex *port_create(size_t dim, size_t M, size_t efc, size_t efs, int func, s
 	if (!ix->data) { free(ix); return NULL; }
 	return ix;
 }
+/* Swap the distance function: signature of hnsw_dist_func (embedding.h:55).  With the reference's own
+ * function (oracle/_ref) the restated traversal must reproduce the reference's results exactly, which
+ * separates "is the traversal restated faithfully" from "what does the summation order change". */
+void   port_set_dist_fn(PortIndex *ix, void *fn) { ix->dist = fn ? (port_dist_fn) fn : port_dist; }
+/* Shadow arithmetic: every evaluation is also scored with `fn`; the walk follows ix->dist, and the first
+ * decision that `fn`'s values would have taken differently is recorded per query (PortStats.div_*). */
+void   port_set_dist2_fn(PortIndex *ix, void *fn) { ix->dist2 = (port_dist_fn) fn; }
 void   port_destroy(PortIndex *ix) { if (ix) { free(ix->data); free(ix); } }
 size_t port_count(PortIndex *ix) { return ix->n; }
 void  *port_data(PortIndex *ix) { return ix->data; }
@@ -261,10 +276,44 @@ static void heap_pop(Heap *h)
 /* searchBaseLayer — hnswalg.cpp:42-114.                                     */
 /* ------------------------------------------------------------------------- */
 
-typedef struct { uint64_t evals, hops; } PortStats;
+/* min_margin: the smallest relative gap |a-b| / max(|a|,|b|,1e-6) over every comparison of two DIFFERENT
+ * elements' distances that steers the walk or the output — the decision-margin instrumentation the
+ * parity tests use to classify a mismatch against the reference binary: two implementations whose
+ * distances agree to delta (relative) can only take different decisions where a margin is <= 2*delta. */
+/* div_kind / div_margin (shadow arithmetic, port_set_dist2_fn): the FIRST decision of the walk that the second
+ * arithmetic would have taken differently — 0 none, 1 stop test (:70), 2 accept test (:99), 3 which candidate is
+ * popped (:69,73), 4 which result is evicted (:105), 5 output order (:236,246) — and the relative gap, in the
+ * walk's own arithmetic, between the two values that decision compared.  Up to that decision both arithmetics
+ * walk identically (same heaps, element for element), so: div_kind == 0  =>  the second arithmetic returns the
+ * same ids; and a query whose ids differ has div_kind != 0, with div_margin = how close the call was. */
+typedef struct { uint64_t evals, hops; float min_margin; int div_kind; float div_margin; } PortStats;
+#define PORT_STATS_INIT { 0, 0, INFINITY, 0, INFINITY }
 
-/* Leaves the <= ef nearest visited elements in `top` (max-heap on (dist, idx)). */
-static void port_search_base_layer(const PortIndex *ix, const float *q, size_t ef, Heap *top, PortStats *st)
+static inline float rel_gap(float a, float b)
+{
+	return fabsf(a - b) / fmaxf(fmaxf(fabsf(a), fabsf(b)), 1e-6f);
+}
+static inline void note_div(PortStats *st, int kind, float a, float b)
+{
+	if (st->div_kind == 0) { st->div_kind = kind; st->div_margin = rel_gap(a, b); }
+}
+
+static inline void note_margin(PortStats *st, float a, float b)
+{
+	float m = rel_gap(a, b);
+	if (m < st->min_margin) st->min_margin = m;
+}
+
+/* the runner-up of a heap (the larger child of the root under the pair order); h->n >= 2 */
+static inline HPair heap_second(const Heap *h)
+{
+	if (h->n >= 3 && pair_less(h->a[1], h->a[2])) return h->a[2];
+	return h->a[1];
+}
+
+/* Leaves the <= ef nearest visited elements in `top` (max-heap on (dist, idx)).
+ * d2: NULL, or an array of ix->n floats (contents irrelevant) for the shadow arithmetic's distances. */
+static void port_search_base_layer(const PortIndex *ix, const float *q, size_t ef, Heap *top, PortStats *st, float *d2)
 {
 	Heap cand;                          /* keys are (-dist, idx): hnswalg.cpp:53,63 */
 	uint32_t ep = 0;                    /* enterpoint_node, embedding.c:235 */
@@ -274,8 +323,10 @@ static void port_search_base_layer(const PortIndex *ix, const float *q, size_t e
 	heap_init(&cand);
 	size_t words = (ix->n + 31) / 32;
 	uint32_t *visited = (uint32_t *) calloc(words, 4);     /* hnswalg.cpp:45-50 */
+	if (!ix->dist2) d2 = NULL;
 
-	float dist = port_dist(ix->func, q, el_vec(ix, ep), ix->dim);   /* :59 */
+	float dist = ix->dist(ix->func, q, el_vec(ix, ep), ix->dim);    /* :59 */
+	if (d2) d2[ep] = ix->dist2(ix->func, q, el_vec(ix, ep), ix->dim);
 	st->evals++;
 	heap_push(top, dist, ep);                                       /* :62 */
 	heap_push(&cand, -dist, ep);                                    /* :63 */
@@ -285,8 +336,23 @@ static void port_search_base_layer(const PortIndex *ix, const float *q, size_t e
 	while (cand.n)                                                  /* :67 */
 	{
 		HPair cur = heap_top(&cand);
+		if (d2)                                                     /* would the shadow pop another candidate? */
+		{
+			HPair mine = { -d2[cur.k], cur.k };
+			for (size_t i = 1; i < cand.n; i++)
+			{
+				HPair o = { -d2[cand.a[i].k], cand.a[i].k };
+				if (pair_less(mine, o)) { note_div(st, 3, cur.d, cand.a[i].d); break; }
+			}
+			if ((-cur.d > lowerBound) != (d2[cur.k] > d2[heap_top(top).k]))
+				note_div(st, 1, -cur.d, lowerBound);
+		}
+		if (cur.k != heap_top(top).k)                               /* margin of the stop test */
+			note_margin(st, -cur.d, lowerBound);
 		if (-cur.d > lowerBound)                                    /* :70-71 */
 			break;
+		if (cand.n >= 2)                                            /* margin of "which candidate is next" */
+			note_margin(st, cur.d, heap_second(&cand).d);
 		heap_pop(&cand);                                            /* :73 */
 		const uint32_t *links = el_links(ix, (uint32_t) cur.k);     /* :76 */
 		size_t size = links[0];                                     /* :77 */
@@ -298,14 +364,34 @@ static void port_search_base_layer(const PortIndex *ix, const float *q, size_t e
 			if (visited[t >> 5] & (1u << (t & 31)))
 				continue;
 			visited[t >> 5] |= 1u << (t & 31);                      /* :93 */
-			dist = port_dist(ix->func, q, el_vec(ix, t), ix->dim);  /* :95-97 */
+			dist = ix->dist(ix->func, q, el_vec(ix, t), ix->dim);   /* :95-97 */
+			if (d2) d2[t] = ix->dist2(ix->func, q, el_vec(ix, t), ix->dim);
 			st->evals++;
+			if (top->n >= ef)                                       /* margin of the accept test */
+			{
+				note_margin(st, heap_top(top).d, dist);
+				if (d2 && (heap_top(top).d > dist) != (d2[heap_top(top).k] > d2[t]))
+					note_div(st, 2, heap_top(top).d, dist);
+			}
 			if (heap_top(top).d > dist || top->n < ef)              /* :99 */
 			{
 				heap_push(&cand, -dist, t);                         /* :100 */
 				heap_push(top, dist, t);                            /* :102 */
 				if (top->n > ef)                                    /* :104-105 */
+				{
+					if (top->n >= 2)                                /* margin of "which result is evicted" */
+						note_margin(st, heap_top(top).d, heap_second(top).d);
+					if (d2)                                         /* would the shadow evict another result? */
+					{
+						HPair w = heap_top(top), mine = { d2[w.k], w.k };
+						for (size_t i = 1; i < top->n; i++)
+						{
+							HPair o = { d2[top->a[i].k], top->a[i].k };
+							if (pair_less(mine, o)) { note_div(st, 4, w.d, top->a[i].d); break; }
+						}
+					}
 					heap_pop(top);
+				}
 				lowerBound = heap_top(top).d;                       /* :107 */
 			}
 		}
@@ -319,8 +405,8 @@ int port_search_base(PortIndex *ix, const float *q, size_t ef, uint32_t *idx_out
 					 size_t *n_out, uint32_t *evals, uint32_t *hops)
 {
 	Heap top;
-	PortStats st = { 0, 0 };
-	port_search_base_layer(ix, q, ef, &top, &st);
+	PortStats st = PORT_STATS_INIT;
+	port_search_base_layer(ix, q, ef, &top, &st, NULL);
 	size_t n = top.n;
 	for (size_t i = n; i-- != 0;)
 	{
@@ -343,36 +429,63 @@ int port_search_base(PortIndex *ix, const float *q, size_t ef, uint32_t *idx_out
 /* out arrays must hold ef entries.  Result ascending by (dist, label), vacuumed
  * labels dropped (hnswalg.cpp:245).  dist_out may be NULL (the reference does
  * not return distances; the device batch API does). */
-int port_search(PortIndex *ix, const float *q, size_t ef, uint64_t *label_out, float *dist_out,
-				size_t *n_out, uint32_t *evals, uint32_t *hops)
+static int port_search_m(PortIndex *ix, const float *q, size_t ef, uint64_t *label_out, float *dist_out,
+						 size_t *n_out, uint32_t *evals, uint32_t *hops, PortStats *st_out, float *d2)
 {
 	Heap top, res;
-	PortStats st = { 0, 0 };
-	port_search_base_layer(ix, q, ef, &top, &st);            /* :237 */
+	PortStats st = PORT_STATS_INIT;
+	if (!ix->dist2) d2 = NULL;
+	port_search_base_layer(ix, q, ef, &top, &st, d2);        /* :237 */
 	while (top.n > ef) heap_pop(&top);                       /* :238-240 */
 	heap_init(&res);
+	/* shadow distance of each returned label (labels of live elements are unique) */
+	size_t nsh = 0;
+	uint64_t *sh_label = d2 ? (uint64_t *) malloc((top.n ? top.n : 1) * 8) : NULL;
+	float    *sh_d2    = d2 ? (float *) malloc((top.n ? top.n : 1) * 4) : NULL;
 	while (top.n)                                            /* :241-249 */
 	{
 		HPair r = heap_top(&top);
 		uint64_t label = el_label(ix, (uint32_t) r.k);
 		if (!((label >> 48) & 1))                            /* hnsw_is_deleted, embedding.c:948-953 */
+		{
 			heap_push(&res, r.d, label);
+			if (d2) { sh_label[nsh] = label; sh_d2[nsh] = d2[r.k]; nsh++; }
+		}
 		heap_pop(&top);
 	}
 	size_t n = res.n;
+	HPair prev = { 0.f, 0 }, prev2 = { 0.f, 0 };
 	for (size_t i = n; i-- != 0;)                            /* back-to-front fill, :265-269 */
 	{
 		HPair p = heap_top(&res);
 		label_out[i] = p.k;
 		if (dist_out) dist_out[i] = p.d;
+		HPair p2 = { 0.f, p.k };
+		if (d2)
+			for (size_t j = 0; j < nsh; j++)
+				if (sh_label[j] == p.k) { p2.d = sh_d2[j]; break; }
+		if (i + 1 < n)
+		{
+			note_margin(&st, p.d, prev.d);                   /* margin of the output order */
+			if (d2 && pair_less(prev2, p2)) note_div(&st, 5, p.d, prev.d);
+		}
+		prev = p; prev2 = p2;
 		heap_pop(&res);
 	}
+	free(sh_label); free(sh_d2);
 	heap_free(&top);
 	heap_free(&res);
 	*n_out = n;
 	if (evals) *evals = (uint32_t) st.evals;
 	if (hops)  *hops = (uint32_t) st.hops;
+	if (st_out) *st_out = st;
 	return 0;
+}
+
+int port_search(PortIndex *ix, const float *q, size_t ef, uint64_t *label_out, float *dist_out,
+				size_t *n_out, uint32_t *evals, uint32_t *hops)
+{
+	return port_search_m(ix, q, ef, label_out, dist_out, n_out, evals, hops, NULL, NULL);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -405,7 +518,7 @@ static void port_neighbors_by_heuristic(const PortIndex *ix, Heap *top, size_t N
 		bool good = true;
 		for (size_t i = 0; i < nret; i++)                    /* :137-148 */
 		{
-			float curdist = port_dist(ix->func, el_vec(ix, (uint32_t) ret[i].k),
+			float curdist = ix->dist(ix->func, el_vec(ix, (uint32_t) ret[i].k),
 									  el_vec(ix, (uint32_t) cur.k), ix->dim);
 			st->evals++;
 			if (curdist < dist_to_query) { good = false; break; }
@@ -451,13 +564,13 @@ static int port_mutually_connect(PortIndex *ix, uint32_t cur_c, Heap *top, PortS
 			const float *pc = el_vec(ix, res[i]);
 			Heap cands;
 			heap_init(&cands);
-			float d_max = port_dist(ix->func, el_vec(ix, cur_c), pc, ix->dim);    /* :200 */
+			float d_max = ix->dist(ix->func, el_vec(ix, cur_c), pc, ix->dim);    /* :200 */
 			st->evals++;
 			heap_push(&cands, d_max, cur_c);                                      /* :204 */
 			for (uint32_t j = 0; j < sz; j++)                                     /* :206-211 */
 			{
 				uint32_t o = other[1 + j];
-				heap_push(&cands, port_dist(ix->func, el_vec(ix, o), pc, ix->dim), o);
+				heap_push(&cands, ix->dist(ix->func, el_vec(ix, o), pc, ix->dim), o);
 				st->evals++;
 			}
 			port_neighbors_by_heuristic(ix, &cands, ix->maxM, st);                /* :212 */
@@ -482,8 +595,8 @@ int port_bind_point(PortIndex *ix, const float *point, uint32_t cur_c)
 	if (cur_c == 0)                                           /* :228 */
 		return 0;
 	Heap top;
-	PortStats st = { 0, 0 };
-	port_search_base_layer(ix, point, ix->efc, &top, &st);    /* :229 */
+	PortStats st = PORT_STATS_INIT;
+	port_search_base_layer(ix, point, ix->efc, &top, &st, NULL);    /* :229 */
 	int rc = port_mutually_connect(ix, cur_c, &top, &st);     /* :230 */
 	heap_free(&top);
 	return rc;
@@ -520,7 +633,8 @@ long port_add_many(PortIndex *ix, const float *vecs, const uint64_t *labels, siz
 typedef struct
 {
 	PortIndex *ix; const float *Q; size_t q0, q1, ef;
-	uint64_t *labels; float *dists; uint32_t *counts, *evals, *hops;
+	uint64_t *labels; float *dists; uint32_t *counts, *evals, *hops; float *margins;
+	int32_t *div_kind; float *div_margin;
 } PortJob;
 
 static void *port_worker(void *arg)
@@ -528,22 +642,39 @@ static void *port_worker(void *arg)
 	PortJob *j = (PortJob *) arg;
 	uint64_t *lab = (uint64_t *) malloc(j->ef * 8);
 	float *dst = (float *) malloc(j->ef * 4);
+	float *d2 = j->ix->dist2 ? (float *) malloc((j->ix->n ? j->ix->n : 1) * 4) : NULL;
 	for (size_t q = j->q0; q < j->q1; q++)
 	{
-		size_t n; uint32_t ev, hp;
-		port_search(j->ix, j->Q + q * j->ix->dim, j->ef, lab, dst, &n, &ev, &hp);
+		size_t n; uint32_t ev, hp; PortStats st;
+		port_search_m(j->ix, j->Q + q * j->ix->dim, j->ef, lab, dst, &n, &ev, &hp, &st, d2);
+		if (j->margins) j->margins[q] = st.min_margin;
+		if (j->div_kind) j->div_kind[q] = st.div_kind;
+		if (j->div_margin) j->div_margin[q] = st.div_margin;
 		if (j->labels) memcpy(j->labels + q * j->ef, lab, n * 8);
 		if (j->dists)  memcpy(j->dists + q * j->ef, dst, n * 4);
 		if (j->counts) j->counts[q] = (uint32_t) n;
 		if (j->evals)  j->evals[q] = ev;
 		if (j->hops)   j->hops[q] = hp;
 	}
-	free(lab); free(dst);
+	free(lab); free(dst); free(d2);
 	return NULL;
 }
 
+/* margins: NULL, or per query the smallest decision margin of its walk (PortStats.min_margin);
+ * div_kind / div_margin: NULL, or per query the first decision the shadow arithmetic takes differently. */
+double port_search_many_m(PortIndex *ix, const float *Q, size_t nq, size_t ef, int nthreads,
+						  uint64_t *labels, float *dists, uint32_t *counts, uint32_t *evals, uint32_t *hops,
+						  float *margins, int32_t *div_kind, float *div_margin);
+
 double port_search_many(PortIndex *ix, const float *Q, size_t nq, size_t ef, int nthreads,
 						uint64_t *labels, float *dists, uint32_t *counts, uint32_t *evals, uint32_t *hops)
+{
+	return port_search_many_m(ix, Q, nq, ef, nthreads, labels, dists, counts, evals, hops, NULL, NULL, NULL);
+}
+
+double port_search_many_m(PortIndex *ix, const float *Q, size_t nq, size_t ef, int nthreads,
+						  uint64_t *labels, float *dists, uint32_t *counts, uint32_t *evals, uint32_t *hops,
+						  float *margins, int32_t *div_kind, float *div_margin)
 {
 	if (nthreads < 1) nthreads = 1;
 	if ((size_t) nthreads > nq && nq > 0) nthreads = (int) nq;
@@ -557,7 +688,7 @@ double port_search_many(PortIndex *ix, const float *Q, size_t nq, size_t ef, int
 		j->ix = ix; j->Q = Q; j->ef = ef;
 		j->q0 = nq * (size_t) t / (size_t) nthreads;
 		j->q1 = nq * (size_t) (t + 1) / (size_t) nthreads;
-		j->labels = labels; j->dists = dists; j->counts = counts; j->evals = evals; j->hops = hops;
+		j->labels = labels; j->dists = dists; j->counts = counts; j->evals = evals; j->hops = hops; j->margins = margins; j->div_kind = div_kind; j->div_margin = div_margin;
 		if (nthreads == 1) port_worker(j); else pthread_create(&th[t], NULL, port_worker, j);
 	}
 	for (int t = 0; t < nthreads && nthreads > 1; t++) pthread_join(th[t], NULL);

@@ -40,3 +40,40 @@ def near_tie_mask(dists, rel=REL_TOL):
         m[1:] |= close
         m[:-1] |= close
     return m
+
+
+def classify_against_reference(port, Q, ef, ref_labels, nthreads=8):
+    """The north-star id contract, proven query by query (oracle/hnsw_port.c, PortStats.div_*).
+
+    `port` walks in the canonical (device) arithmetic and shadows every decision of the walk — stop test
+    (hnswalg.cpp:70), accept test (:99), which candidate is popped, which result is evicted, output order —
+    with the reference's own hnsw_dist_func.  Asserts
+      * a query with no diverging decision has the reference's id array (a theorem: both arithmetics then
+        walk identically element for element — so this checks the restatement and the harness);
+      * a query whose ids differ has a diverging decision, and the two values that decision compared are
+        within REL_TOL (1e-5 relative, the north-star tolerance — not a multiple of it) in the walk's own
+        arithmetic, i.e. the mismatch is a near-tie flipped by float summation order and nothing else.
+    Returns the port's result dict plus the classification counts (what bench.py reports)."""
+    port.shadow_reference_distances(True)
+    try:
+        got = port.search_many(Q, ef, nthreads=nthreads)
+    finally:
+        port.shadow_reference_distances(False)
+    same = (got["labels"] == ref_labels).all(axis=1)
+    dk, dm = got["div_kind"], got["div_margin"]
+    unexplained = (~same) & (dk == 0)
+    assert not unexplained.any(), f"queries {np.flatnonzero(unexplained)[:8]}: ids differ from the reference without any diverging decision"
+    worst = float(dm[~same].max()) if (~same).any() else 0.0
+    assert worst <= REL_TOL, f"a mismatching query diverged at a decision with relative gap {worst:.3g} > {REL_TOL}"
+    got["classification"] = {
+        "queries": int(Q.shape[0]),
+        "identical_ids": int(same.sum()),
+        "mismatch_count": int((~same).sum()),
+        "mismatch_explained_by_near_tie": int(((~same) & (dk != 0)).sum()),
+        "mismatch_unexplained": int(unexplained.sum()),
+        "largest_gap_at_a_mismatching_decision": worst,
+        "queries_with_a_diverging_decision": int((dk != 0).sum()),
+        "diverging_decision_kinds": {k: int((dk == i).sum()) for i, k in
+                                     ((1, "stop"), (2, "accept"), (3, "pop_order"), (4, "evict"), (5, "output_order"))},
+    }
+    return got
