@@ -2,14 +2,17 @@
 // (embedding.h:46-47,55-56), implemented on the MI355X library (libhnsw_gpu.so).
 //
 //   hnsw_search          hnswalg.cpp:256-277  -> one-query launch of the fused search kernel
-//   hnsw_dist_func       distfunc.c:171-174   -> one-row launch of the distance kernel
+//   hnsw_dist_func       distfunc.c:171-174   -> one pair, computed on the calling core in the device's
+//                                                canonical summation order (host_dist.h): bit-identical to
+//                                                hnsw_gpu_dist_batch at ~0.1 us instead of a 16-28 us launch
 //   hnsw_init_dist_func  distfunc.c:159-169   -> device selection / runtime warm-up
 //   hnsw_bind_point      hnswalg.cpp:279-291  -> serial device insert + write-back of the changed
 //                                                link lists through hnsw_begin_write
 //
 // It imports the host's storage callbacks (embedding.h:44,48-53) exactly like hnswalg.cpp does.
-// There is no CPU implementation behind any of these: without a gfx950 device every call fails
-// (false / NaN) and says why on stderr.
+// There is no CPU implementation of the search or the insert: without a gfx950 device hnsw_search and
+// hnsw_bind_point fail (false) and say why on stderr.  hnsw_dist_func is host code by design (its only
+// caller left is the SQL operator, one pair per call, embedding.c:1037), not a fallback.
 //
 // Where does the index come from?  HnswMetadata carries no relation identity and Postgres
 // rebuilds it for every scan (embedding.c:254), so by default each hnsw_search() call walks the
@@ -27,6 +30,7 @@
 #include "hnsw_gpu.h"
 #include "hnsw_gpu_shim.h"
 #include "host_walk.h"
+#include "host_dist.h"
 
 namespace {
 
@@ -136,13 +140,8 @@ extern "C" void hnsw_init_dist_func(void)
 
 extern "C" dist_t hnsw_dist_func(dist_func_t dist, coord_t const *ax, coord_t const *bx, size_t dim)
 {
-	dist_t out = NAN;
-	if (pick_device() < 0 || hnsw_gpu_dist_batch(dist, ax, bx, 1, dim, &out) != HNSW_GPU_OK)
-	{
-		fprintf(stderr, "pg_embedding_amd: hnsw_dist_func failed: %s\n", hnsw_gpu_last_error());
-		return NAN;
-	}
-	return out;
+	if (!ax || !bx) return NAN;
+	return hostdist::dist((int) dist, ax, bx, dim);
 }
 
 static bool hnsw_search_impl(HnswMetadata *meta, const coord_t *point, size_t *n_results, label_t **results)

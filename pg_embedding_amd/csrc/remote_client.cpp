@@ -4,11 +4,12 @@
 //   hnsw_search          hnswalg.cpp:256-277  -> SEARCH  (batched with the other backends' scans)
 //   hnsw_bind_point      hnswalg.cpp:279-291  -> BIND    (serial device insert on the server's mirror)
 //                                                + write-back of the changed lists via hnsw_begin_write
-//   hnsw_dist_func       distfunc.c:171-174   -> DIST
+//   hnsw_dist_func       distfunc.c:171-174   -> one pair on the calling core, canonical order (host_dist.h);
+//                                                PG_EMBEDDING_GPU_REMOTE_DIST=1 sends it to the server (DIST) instead
 //   hnsw_init_dist_func  distfunc.c:159-169   -> reads PG_EMBEDDING_GPU_SERVER
 //
-// No HIP is linked and nothing is computed here: when the server cannot be reached every call
-// fails (false / NaN) with a message on stderr.  It imports the host's storage callbacks
+// No HIP is linked and no search or insert is computed here: when the server cannot be reached those
+// calls fail (false) with a message on stderr.  It imports the host's storage callbacks
 // (embedding.h:44,48-53) like hnswalg.cpp does, for the index walk of an upload and the write-back
 // of an insert.
 #include <atomic>
@@ -27,6 +28,7 @@
 
 #include "hgs_io.h"
 #include "host_walk.h"
+#include "host_dist.h"
 #include "hnsw_gpu.h"      // error codes only: nothing of libhnsw_gpu.so is linked
 
 namespace {
@@ -565,6 +567,10 @@ extern "C" void hnsw_init_dist_func(void)
 
 static dist_t hnsw_dist_func_impl(dist_func_t dist, coord_t const *ax, coord_t const *bx, size_t dim)
 {
+	// One pair per call (embedding.c:1037): computed here, bit-identical to the device kernels.  The DIST
+	// request stays for hosts that want the device's answer itself (the tests compare the two).
+	static const bool remote = getenv("PG_EMBEDDING_GPU_REMOTE_DIST") && atoi(getenv("PG_EMBEDDING_GPU_REMOTE_DIST")) > 0;
+	if (!remote) return (ax && bx) ? hostdist::dist((int) dist, ax, bx, dim) : NAN;
 	hgs_hdr h, r;
 	memset(&h, 0, sizeof(h));
 	h.op = HGS_OP_DIST; h.aux = (uint32_t) dist; h.a0 = dim;

@@ -126,6 +126,56 @@ def test_libraries_export_every_declared_symbol():
     assert {"hnsw_gpu_search_batch_ctx_flags", "hnsw_gpu_index_create_from_flat", "hnsw_gpu_index_link"} <= srv
 
 
+DIST_DIMS = [1, 3, 4, 5, 63, 64, 65, 100, 128, 255, 256, 257, 768, 1000, 1536, 2000]
+
+
+@pytest.mark.parametrize("lib", ["shim", "client"])
+def test_hnsw_dist_func_is_host_code_in_the_canonical_order(lib):
+    """hnsw_dist_func (distfunc.c:171-174; one pair per SQL operator call, embedding.c:1037) is computed
+    on the calling core in the summation order of the device kernels (csrc/host_dist.h): bit-identical to
+    the oracle's canonical restatement here — and so to hnsw_gpu_dist_batch, which tests/test_gpu_dist.py
+    and tests/test_gpu_dropin.py pin to the same oracle on the device — and within 1e-5 of the reference."""
+    import ctypes as C
+    import oracle
+    from util import REL_TOL, bits, rel_err
+    L = C.CDLL(B.SHIM_LIB if lib == "shim" else B.CLIENT_LIB, mode=os.RTLD_LAZY)
+    L.hnsw_dist_func.restype = C.c_float
+    L.hnsw_dist_func.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_size_t]
+    L.hnsw_init_dist_func()
+    for func in (0, 1, 2):
+        for dim in DIST_DIMS:
+            rng = np.random.default_rng(dim * 7 + func)
+            q = rng.standard_normal(dim).astype(np.float32)
+            rows = rng.standard_normal((40, dim)).astype(np.float32)
+            rows[0] = q
+            rows[1] = -q
+            rows[2] = q * np.float32(1e-3)
+            rows[3] *= np.float32(1e4)
+            got = np.array([L.hnsw_dist_func(func, q.ctypes.data, rows[i].ctypes.data, dim) for i in range(40)], np.float32)
+            want = oracle.port_dist_many(func, q, rows)
+            assert (bits(got) == bits(want)).all(), (func, dim)
+            if oracle.have_ref() and dim >= 3:
+                ref = oracle.ref_dist_many(func, q, rows[4:])
+                assert rel_err(got[4:], ref).max() <= REL_TOL
+    a = np.array([1, 2, 3], np.float32)
+    b = np.array([3, 3, 3], np.float32)
+    f = lambda func: L.hnsw_dist_func(func, a.ctypes.data, b.ctypes.data, 3)
+    assert abs(f(0) - 2.236068) < 1e-6 and abs(f(1) - 0.0741799) < 1e-6 and f(2) == 3.0       # knn.out toy rows
+
+
+def test_one_pair_costs_less_than_a_microsecond(tmp_path):
+    """`<->` in a sequential scan must not pay a kernel launch per pair (16-28 us in round 1;
+    the reference needs ~0.1 us).  Timed from C the way calc_distance calls it."""
+    import subprocess
+    exe = str(tmp_path / "dist_bench")
+    subprocess.run(["gcc", "-O2", "-std=gnu11", os.path.join(ROOT, "tests", "dropin_c", "dist_bench.c"), "-o", exe, "-ldl"],
+                   check=True)
+    out = subprocess.run([exe, B.SHIM_LIB, "768", "200000"], check=True, capture_output=True, text=True).stdout
+    ns = [float(l.split()[1]) for l in out.strip().splitlines()]
+    print("ns per hnsw_dist_func call at 768 dims (l2, cosine, manhattan):", ns)
+    assert max(ns) < 1000.0, out
+
+
 def test_no_cpu_fallback_product_never_links_the_oracle():
     for lib in (B.GPU_LIB, B.SHIM_LIB, B.CLIENT_LIB, B.SERVER_BIN):
         und = undefined(lib) | exported(lib)
