@@ -128,6 +128,11 @@ int hnsw_gpu_last_search_ms(hnsw_gpu_index *ix, float *ms);
 /* Same for the launch `back` launches ago (0 = most recent; the last 64 are kept). */
 int hnsw_gpu_search_ms(hnsw_gpu_index *ix, unsigned back, float *ms);
 
+/* Symbol of the kernel the mirror's last search launch ran, spelled as rocprofv3 prints it
+ * (e.g. "pgemb::hnsw_search_kernel_beam<0, pgemb::Shape12x2, 4>"), so a bench line and a kernel trace
+ * can be matched by name. */
+int hnsw_gpu_last_search_kernel(hnsw_gpu_index *ix, char *buf, size_t len);
+
 /* Resident query slots (waves) the last search launch used — occupancy figure. */
 int hnsw_gpu_last_search_slots(hnsw_gpu_index *ix, uint32_t *slots);
 
@@ -203,6 +208,40 @@ int hnsw_gpu_merge_topk_dev(int device, const label_t *d_in_labels, const dist_t
 							size_t nlists, size_t nq, size_t ef,
 							label_t *d_out_labels, dist_t *d_out_dists, uint32_t *d_out_counts,
 							void *stream);
+
+/* Same with the per-list arrays anywhere in memory: list l's labels start at d_in_labels +
+ * l*label_list_stride (in label_t), its distances at d_in_dists + l*dist_list_stride (in dist_t).  Lets ONE
+ * gathered buffer of per-rank blocks [labels | dists] be merged in place (one all-gather per search). */
+int hnsw_gpu_merge_topk_strided_dev(int device, const label_t *d_in_labels, size_t label_list_stride,
+									const dist_t *d_in_dists, size_t dist_list_stride, size_t nlists,
+									size_t nq, size_t ef, label_t *d_out_labels, dist_t *d_out_dists,
+									uint32_t *d_out_counts, void *stream);
+
+/* A row-sharded index inside ONE process (an index larger than one GPU behind a C host; the reference has no
+ * counterpart: embedding.c:982 amcanparallel = false).  `shards` are mirrors the caller built — one graph per
+ * contiguous row range, labels globally unique (SURVEY.md §8e mode 2) — on one or several devices; they are
+ * borrowed, not owned.  A search runs hnsw_search() semantics (hnswalg.cpp:256-277) for every query on every
+ * shard concurrently (one stream per shard; a shard on another device gets its own copy of the queries and,
+ * with peer access, stores its result lists straight into the merge device's memory over xGMI), then one
+ * merge kernel keeps the ef best by (distance, label).  Result = "per-shard search + merge" exactly; parity
+ * is defined against the oracle per shard + a CPU merge.  Queries arrive and results leave on the device of
+ * shard 0; the *_dev form is enqueued on `stream` of that device and not synchronised. */
+typedef struct hnsw_gpu_sharded hnsw_gpu_sharded;
+int    hnsw_gpu_sharded_create(hnsw_gpu_index *const *shards, size_t nshards, hnsw_gpu_sharded **out);
+void   hnsw_gpu_sharded_destroy(hnsw_gpu_sharded *s);
+size_t hnsw_gpu_sharded_nshards(const hnsw_gpu_sharded *s);
+int    hnsw_gpu_sharded_search_dev(hnsw_gpu_sharded *s, const coord_t *d_queries, size_t nq, size_t ef,
+								   label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, void *stream);
+int    hnsw_gpu_sharded_search(hnsw_gpu_sharded *s, const coord_t *queries, size_t nq, size_t ef,
+							   label_t *labels, dist_t *dists, uint32_t *counts);
+
+/* ------------------------------------------------------------------ measurement */
+
+/* Practical roof of the search kernel's memory access pattern on THIS mirror's row table: independent
+ * waves gathering random whole rows with 16-byte loads, `loads_per_lane` (4/8/12/16/24) in flight per lane,
+ * `waves_per_cu` resident waves per CU, `iters` gathers per wave; best of three timed repetitions in GB/s.
+ * No query of the fused kernel can read rows faster from HBM than this dependency-free gather. */
+int hnsw_gpu_gather_roof(hnsw_gpu_index *ix, int loads_per_lane, int waves_per_cu, unsigned iters, float *gbps);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ from .index import (  # noqa: F401
     DIST_L2, DIST_COSINE, DIST_MANHATTAN, OPCLASS, LABEL_DELETED, NO_LABEL,
     DEFAULT_M, DEFAULT_EF_CONSTRUCTION, DEFAULT_EF_SEARCH,
     GpuIndex, SearchContext, make_meta, dist_batch, l2_distance, cosine_distance, manhattan_distance,
-    merge_topk_torch,
+    merge_topk_torch, merge_packed_torch, LocalShardedIndex,
 )
 from ._lib import HnswMetadata, LibraryMissing  # noqa: F401
 

@@ -112,6 +112,16 @@ def gpu_lib():
     L.hnsw_gpu_bruteforce_mfma_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp]
     L.hnsw_gpu_last_bruteforce_gemm_ms.restype = C.c_float
     L.hnsw_gpu_merge_topk_dev.argtypes = [i32, vp, vp, sz, sz, sz, vp, vp, vp, vp]
+    L.hnsw_gpu_merge_topk_strided_dev.argtypes = [i32, vp, sz, vp, sz, sz, sz, sz, vp, vp, vp, vp]
+    L.hnsw_gpu_last_search_kernel.argtypes = [vp, C.c_char_p, sz]
+    L.hnsw_gpu_gather_roof.argtypes = [vp, i32, i32, C.c_uint, _f32p]
+    L.hnsw_gpu_sharded_create.argtypes = [C.POINTER(vp), sz, C.POINTER(vp)]
+    L.hnsw_gpu_sharded_destroy.restype = None
+    L.hnsw_gpu_sharded_destroy.argtypes = [vp]
+    L.hnsw_gpu_sharded_nshards.restype = sz
+    L.hnsw_gpu_sharded_nshards.argtypes = [vp]
+    L.hnsw_gpu_sharded_search_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp]
+    L.hnsw_gpu_sharded_search.argtypes = [vp, vp, sz, sz, vp, vp, vp]
     _gpu = L
     return L
 

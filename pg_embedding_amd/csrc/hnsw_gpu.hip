@@ -10,12 +10,14 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <vector>
 
 #include "hnsw_gpu.h"
 #include "device_dist.h"
 #include "device_search.h"
 #include "device_build.h"
 #include "device_bf_mfma.h"
+#include "device_roof.h"
 
 using namespace pgemb;
 
@@ -70,6 +72,7 @@ struct SearchWs
 	uint64_t launches = 0;
 	uint32_t last_slots = 0;
 	uint32_t *done_next = nullptr;                       // completion flags for the next launch only
+	char kname[96] = "";                                 // symbol of the kernel the last launch used (as rocprofv3 prints it)
 };
 
 static int ws_init(SearchWs *w)
@@ -623,6 +626,13 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	while (wpb > 1 && (size_t) wpb * a.wave_bytes > 64 * 1024) wpb >>= 1;
 	const size_t lds = (size_t) wpb * a.wave_bytes;
 	search_kernel_t kern = pick_search_kernel((int) ix->meta.dist_func, a.kiters, rreg);
+	{
+		static const char *const shapes[4] = { "Shape2x4", "Shape4x2", "Shape8x2", "Shape12x2" };
+		const char *shp = (shape_index(a.kiters) == 3 && getenv("HNSW_GPU_SHAPE_12X1")) ? "Shape12x1" : shapes[shape_index(a.kiters)];
+		if (rreg < 0) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_beam<%d, pgemb::%s, %d>", (int) ix->meta.dist_func, shp, -rreg);
+		else if (rreg >= 2) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_reg<%d, pgemb::%s, %d>", (int) ix->meta.dist_func, shp, rreg);
+		else snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_lds<%d, pgemb::%s, %s>", (int) ix->meta.dist_func, shp, rreg == 1 ? "true" : "false");
+	}
 	if (lds > 48 * 1024)
 		HIPCHK(hipFuncSetAttribute((const void *) kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds));
 	int per_cu = 0;
@@ -744,6 +754,13 @@ extern "C" int hnsw_gpu_search_ms(hnsw_gpu_index *ix, unsigned back, float *ms)
 }
 
 extern "C" int hnsw_gpu_last_search_ms(hnsw_gpu_index *ix, float *ms) { return hnsw_gpu_search_ms(ix, 0, ms); }
+
+extern "C" int hnsw_gpu_last_search_kernel(hnsw_gpu_index *ix, char *buf, size_t len)
+{
+	if (!ix || !buf || len == 0) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	snprintf(buf, len, "%s", ix->ws.kname);
+	return HNSW_GPU_OK;
+}
 
 extern "C" int hnsw_gpu_last_search_slots(hnsw_gpu_index *ix, uint32_t *slots)
 {
@@ -1143,6 +1160,7 @@ __device__ __forceinline__ bool dl_less(uint32_t da, uint64_t la, uint32_t db, u
 }
 
 __global__ __launch_bounds__(64) void topk_merge_kernel(const uint64_t *__restrict__ in_labels, const float *__restrict__ in_dists,
+														size_t lstep, size_t dstep,       /* list-to-list strides, in elements */
 														uint32_t nlists, uint32_t nq, uint32_t ef,
 														uint64_t *__restrict__ out_labels, float *__restrict__ out_dists,
 														uint32_t *__restrict__ out_counts)
@@ -1158,22 +1176,22 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const uint64_t *__restri
 		if (x < total)
 		{
 			const uint32_t l = x / ef, i = x - l * ef;
-			const size_t at = ((size_t) l * nq + qi) * ef + i;
-			const uint64_t lab = in_labels[at];
-			const uint32_t d = ord_f32(in_dists[at]);
+			const size_t at = (size_t) qi * ef + i;
+			const uint64_t lab = in_labels[l * lstep + at];
+			const uint32_t d = ord_f32(in_dists[l * dstep + at]);
 			if (lab != ~0ull)
 			{
 				uint32_t rank = i;
 				for (uint32_t m = 0; m < nlists && rank < ef; m++)
 				{
 					if (m == l) continue;
-					const size_t ob = ((size_t) m * nq + qi) * ef;
+					const size_t ob = (size_t) qi * ef;
 					uint32_t lo = 0, hi = ef;
 					while (lo < hi)
 					{
 						const uint32_t mid = (lo + hi) >> 1;
-						const uint64_t ol = in_labels[ob + mid];
-						const uint32_t od = ord_f32(in_dists[ob + mid]);
+						const uint64_t ol = in_labels[m * lstep + ob + mid];
+						const uint32_t od = ord_f32(in_dists[m * dstep + ob + mid]);
 						// equal keys (cannot happen for disjoint shards) go to the lower list number
 						const bool below = (ol != ~0ull) && (dl_less(od, ol, d, lab) || (od == d && ol == lab && m < l));
 						if (below) lo = mid + 1; else hi = mid;
@@ -1198,19 +1216,30 @@ __global__ __launch_bounds__(64) void topk_merge_kernel(const uint64_t *__restri
 	if (lane == 0) out_counts[qi] = kept;
 }
 
-extern "C" int hnsw_gpu_merge_topk_dev(int device, const label_t *d_in_labels, const dist_t *d_in_dists, size_t nlists,
-									   size_t nq, size_t ef, label_t *d_out_labels, dist_t *d_out_dists,
-									   uint32_t *d_out_counts, void *stream)
+extern "C" int hnsw_gpu_merge_topk_strided_dev(int device, const label_t *d_in_labels, size_t label_list_stride,
+											   const dist_t *d_in_dists, size_t dist_list_stride, size_t nlists,
+											   size_t nq, size_t ef, label_t *d_out_labels, dist_t *d_out_dists,
+											   uint32_t *d_out_counts, void *stream)
 {
 	if (nq == 0) return HNSW_GPU_OK;
 	if (!d_in_labels || !d_in_dists || !d_out_labels || !d_out_counts) return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
 	if (nlists == 0 || ef == 0) return fail(HNSW_GPU_ERR_ARG, "nlists and ef must be positive");
 	if (nlists * ef >= 0xFFFFFFFFull || nq >= 0x7FFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "merge too large");
+	if (label_list_stride < nq * ef || dist_list_stride < nq * ef) return fail(HNSW_GPU_ERR_ARG, "list stride smaller than one list");
 	HIPCHK(hipSetDevice(device));
 	hipLaunchKernelGGL(topk_merge_kernel, dim3((uint32_t) nq), dim3(64), 0, (hipStream_t) stream, d_in_labels, d_in_dists,
-					   (uint32_t) nlists, (uint32_t) nq, (uint32_t) ef, d_out_labels, d_out_dists, d_out_counts);
+					   label_list_stride, dist_list_stride, (uint32_t) nlists, (uint32_t) nq, (uint32_t) ef, d_out_labels, d_out_dists,
+					   d_out_counts);
 	HIPCHK(hipGetLastError());
 	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_merge_topk_dev(int device, const label_t *d_in_labels, const dist_t *d_in_dists, size_t nlists,
+									   size_t nq, size_t ef, label_t *d_out_labels, dist_t *d_out_dists,
+									   uint32_t *d_out_counts, void *stream)
+{
+	return hnsw_gpu_merge_topk_strided_dev(device, d_in_labels, nq * ef, d_in_dists, nq * ef, nlists, nq, ef, d_out_labels,
+										   d_out_dists, d_out_counts, stream);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1533,4 +1562,228 @@ extern "C" void *hnsw_gpu_host_alloc(size_t bytes)
 extern "C" void hnsw_gpu_host_free(void *p)
 {
 	if (p) (void) hipHostFree(p);
+}
+
+// ------------------------------------------------------------------------------------
+// measured roof of the access pattern (device_roof.h)
+// ------------------------------------------------------------------------------------
+extern "C" int hnsw_gpu_gather_roof(hnsw_gpu_index *ix, int loads_per_lane, int waves_per_cu, unsigned iters, float *gbps)
+{
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
+	if (!ix || !gbps) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	if (ix->n == 0 || iters == 0 || waves_per_cu <= 0 || (waves_per_cu & 3)) return fail(HNSW_GPU_ERR_ARG, "need rows, iters > 0 and waves_per_cu %% 4 == 0");
+	HIPCHK(hipSetDevice(ix->device));
+	const uint32_t row_f4 = ix->stride / 4;
+	const uint32_t blocks = (uint32_t) (ix->num_cu * waves_per_cu / 4);
+	float *out = (float *) ix->misc + 8;
+	hipEvent_t e0, e1;
+	HIPCHK(hipEventCreate(&e0));
+	HIPCHK(hipEventCreate(&e1));
+	float best = 1e30f;
+	int rc = HNSW_GPU_OK;
+	for (int rep = 0; rep < 4 && rc == HNSW_GPU_OK; rep++)
+	{
+		(void) hipEventRecord(e0, nullptr);
+		const float4 *base = (const float4 *) ix->vec;
+		switch (loads_per_lane)
+		{
+#define ROOF(T) case T: hipLaunchKernelGGL(gather_roof_kernel<T>, dim3(blocks), dim3(256), 0, nullptr, base, (uint32_t) ix->n, row_f4, iters, out); break
+			ROOF(4); ROOF(8); ROOF(12); ROOF(16); ROOF(24);
+#undef ROOF
+			default: rc = fail(HNSW_GPU_ERR_ARG, "loads_per_lane must be 4, 8, 12, 16 or 24");
+		}
+		if (rc) break;
+		(void) hipEventRecord(e1, nullptr);
+		if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(HNSW_GPU_ERR_HIP, "gather roof kernel failed"); break; }
+		float ms = 0.f;
+		(void) hipEventElapsedTime(&ms, e0, e1);
+		if (rep > 0 && ms < best) best = ms;          // first repetition warms up
+	}
+	(void) hipEventDestroy(e0);
+	(void) hipEventDestroy(e1);
+	if (rc) return rc;
+	const double bytes = (double) blocks * 4.0 * iters * loads_per_lane * 64.0 * 16.0;
+	*gbps = (float) (bytes / best / 1e6);
+	return HNSW_GPU_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// row-sharded index inside ONE process: shards on one or several devices, per-shard searchKnn,
+// results written straight into the merge device's memory (peer access over xGMI), one merge kernel
+// ------------------------------------------------------------------------------------
+struct hnsw_gpu_sharded
+{
+	std::mutex mu;
+	std::vector<hnsw_gpu_index *> shards;
+	int home = 0;                                   // device of shard 0: queries arrive and results leave there
+	std::vector<hipStream_t> streams;               // one per shard, on the shard's device
+	std::vector<hipEvent_t> done;
+	std::vector<bool> direct;                       // the shard's device writes home memory directly
+	std::vector<float *> q_local; std::vector<size_t> q_cap;          // query copy on a remote shard's device
+	std::vector<char *> out_local; std::vector<size_t> out_cap;       // result block when not `direct`
+	hipEvent_t ready = nullptr;
+	char *gather = nullptr; size_t gather_bytes = 0;                  // home: nshards result blocks
+	char *io = nullptr; size_t io_bytes = 0;                          // home: staging of the host-pointer form
+	hipStream_t home_stream = nullptr;
+};
+
+extern "C" void hnsw_gpu_sharded_destroy(hnsw_gpu_sharded *s)
+{
+	if (!s) return;
+	for (size_t i = 0; i < s->shards.size(); i++)
+	{
+		(void) hipSetDevice(s->shards[i]->device);
+		if (i < s->streams.size() && s->streams[i]) (void) hipStreamDestroy(s->streams[i]);
+		if (i < s->done.size() && s->done[i]) (void) hipEventDestroy(s->done[i]);
+		if (i < s->q_local.size() && s->q_local[i]) (void) hipFree(s->q_local[i]);
+		if (i < s->out_local.size() && s->out_local[i]) (void) hipFree(s->out_local[i]);
+	}
+	(void) hipSetDevice(s->home);
+	if (s->ready) (void) hipEventDestroy(s->ready);
+	if (s->gather) (void) hipFree(s->gather);
+	if (s->io) (void) hipFree(s->io);
+	if (s->home_stream) (void) hipStreamDestroy(s->home_stream);
+	delete s;
+}
+
+extern "C" int hnsw_gpu_sharded_create(hnsw_gpu_index *const *shards, size_t nshards, hnsw_gpu_sharded **out)
+{
+	if (!shards || !out || nshards == 0) return fail(HNSW_GPU_ERR_ARG, "need at least one shard");
+	for (size_t i = 0; i < nshards; i++)
+	{
+		if (!shards[i]) return fail(HNSW_GPU_ERR_ARG, "shard %zu is NULL", i);
+		if (shards[i]->meta.dim != shards[0]->meta.dim || shards[i]->meta.dist_func != shards[0]->meta.dist_func)
+			return fail(HNSW_GPU_ERR_ARG, "shard %zu differs in dims / metric from shard 0", i);
+	}
+	hnsw_gpu_sharded *s = new (std::nothrow) hnsw_gpu_sharded();
+	if (!s) return fail(HNSW_GPU_ERR_NOMEM, "out of host memory");
+	s->shards.assign(shards, shards + nshards);
+	s->home = shards[0]->device;
+	s->streams.assign(nshards, nullptr); s->done.assign(nshards, nullptr); s->direct.assign(nshards, false);
+	s->q_local.assign(nshards, nullptr); s->q_cap.assign(nshards, 0);
+	s->out_local.assign(nshards, nullptr); s->out_cap.assign(nshards, 0);
+	hipError_t e = hipSuccess;
+	for (size_t i = 0; i < nshards && e == hipSuccess; i++)
+	{
+		const int dev = shards[i]->device;
+		if ((e = hipSetDevice(dev)) != hipSuccess) break;
+		if ((e = hipStreamCreateWithFlags(&s->streams[i], hipStreamNonBlocking)) != hipSuccess) break;
+		if ((e = hipEventCreateWithFlags(&s->done[i], hipEventDisableTiming)) != hipSuccess) break;
+		if (dev == s->home) s->direct[i] = true;
+		else
+		{
+			int can = 0;
+			if (hipDeviceCanAccessPeer(&can, dev, s->home) == hipSuccess && can && !getenv("HNSW_GPU_SHARDED_NO_PEER"))
+			{
+				const hipError_t pe = hipDeviceEnablePeerAccess(s->home, 0);
+				if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) s->direct[i] = true;
+				(void) hipGetLastError();
+			}
+		}
+	}
+	if (e == hipSuccess) e = hipSetDevice(s->home);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ready, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->home_stream, hipStreamNonBlocking);
+	if (e != hipSuccess)
+	{
+		hnsw_gpu_sharded_destroy(s);
+		return fail(HNSW_GPU_ERR_HIP, "sharded index set-up failed: %s", hipGetErrorString(e));
+	}
+	*out = s;
+	return HNSW_GPU_OK;
+}
+
+extern "C" size_t hnsw_gpu_sharded_nshards(const hnsw_gpu_sharded *s) { return s ? s->shards.size() : 0; }
+
+static int grow(char **p, size_t *have, size_t want)
+{
+	if (want <= *have) return HNSW_GPU_OK;
+	if (*p) (void) hipFree(*p);
+	*p = nullptr; *have = 0;
+	HIPCHK(hipMalloc((void **) p, want));
+	*have = want;
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_sharded_search_dev(hnsw_gpu_sharded *s, const coord_t *d_queries, size_t nq, size_t ef,
+										   label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, void *stream_)
+{
+	if (!s) return fail(HNSW_GPU_ERR_ARG, "sharded index is NULL");
+	if (nq == 0) return HNSW_GPU_OK;
+	if (!d_queries || !d_labels || !d_counts) return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
+	if (ef == 0 || ef >= 0xFFFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "ef %zu out of range", ef);
+	std::lock_guard<std::mutex> lk(s->mu);
+	hipStream_t stream = (hipStream_t) stream_;
+	const size_t ns = s->shards.size(), dim = s->shards[0]->meta.dim;
+	// one result block per shard on the home device: [labels nq*ef | dists nq*ef | counts nq]
+	const size_t o_d = round_up(nq * ef * 8, 256), o_c = o_d + round_up(nq * ef * 4, 256), block = o_c + round_up(nq * 4, 256);
+	HIPCHK(hipSetDevice(s->home));
+	int rc = grow(&s->gather, &s->gather_bytes, ns * block);
+	if (rc) return rc;
+	HIPCHK(hipEventRecord(s->ready, stream));
+	for (size_t i = 0; i < ns; i++)
+	{
+		hnsw_gpu_index *ix = s->shards[i];
+		HIPCHK(hipSetDevice(ix->device));
+		HIPCHK(hipStreamWaitEvent(s->streams[i], s->ready, 0));
+		const float *q = d_queries;
+		if (ix->device != s->home)                  // the shard reads its queries from its own HBM
+		{
+			rc = grow((char **) &s->q_local[i], &s->q_cap[i], nq * dim * 4);
+			if (rc) return rc;
+			HIPCHK(hipMemcpyPeerAsync(s->q_local[i], ix->device, d_queries, s->home, nq * dim * 4, s->streams[i]));
+			q = s->q_local[i];
+		}
+		char *blk = s->gather + i * block;
+		if (!s->direct[i])
+		{
+			rc = grow(&s->out_local[i], &s->out_cap[i], block);
+			if (rc) return rc;
+			blk = s->out_local[i];
+		}
+		// per-shard searchKnn (hnswalg.cpp:234-252); with peer access the kernel's result stores land in the
+		// home device's memory directly — no copy step, no collective
+		rc = launch_search(ix, &ix->ws, q, dim, nq, ef, 0, (uint64_t *) blk, nullptr, (float *) (blk + o_d), (uint32_t *) (blk + o_c),
+						   nullptr, s->streams[i]);
+		if (rc) return rc;
+		if (!s->direct[i])
+			HIPCHK(hipMemcpyPeerAsync(s->gather + i * block, s->home, blk, ix->device, block, s->streams[i]));
+		HIPCHK(hipEventRecord(s->done[i], s->streams[i]));
+	}
+	HIPCHK(hipSetDevice(s->home));
+	for (size_t i = 0; i < ns; i++) HIPCHK(hipStreamWaitEvent(stream, s->done[i], 0));
+	return hnsw_gpu_merge_topk_strided_dev(s->home, (const label_t *) s->gather, block / 8, (const dist_t *) (s->gather + o_d), block / 4,
+										   ns, nq, ef, d_labels, d_dists, d_counts, stream);
+}
+
+extern "C" int hnsw_gpu_sharded_search(hnsw_gpu_sharded *s, const coord_t *queries, size_t nq, size_t ef,
+									   label_t *labels, dist_t *dists, uint32_t *counts)
+{
+	if (!s) return fail(HNSW_GPU_ERR_ARG, "sharded index is NULL");
+	if (nq == 0) return HNSW_GPU_OK;
+	if (!queries || !labels || !counts) return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
+	if (ef == 0 || ef >= 0xFFFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "ef %zu out of range", ef);
+	const size_t dim = s->shards[0]->meta.dim;
+	const size_t qb = round_up(nq * dim * 4, 256), lb = round_up(nq * ef * 8, 256), db = round_up(nq * ef * 4, 256),
+				 cb = round_up(nq * 4, 256);
+	char *p;
+	{
+		std::lock_guard<std::mutex> lk(s->mu);
+		HIPCHK(hipSetDevice(s->home));
+		int rc = grow(&s->io, &s->io_bytes, qb + lb + db + cb);
+		if (rc) return rc;
+		p = s->io;
+	}
+	float *dq = (float *) p; uint64_t *dl = (uint64_t *) (p + qb); float *dd = (float *) (p + qb + lb);
+	uint32_t *dc = (uint32_t *) (p + qb + lb + db);
+	HIPCHK(hipMemcpyAsync(dq, queries, nq * dim * 4, hipMemcpyHostToDevice, s->home_stream));
+	int rc = hnsw_gpu_sharded_search_dev(s, dq, nq, ef, dl, dd, dc, s->home_stream);
+	if (rc) return rc;
+	HIPCHK(hipSetDevice(s->home));
+	HIPCHK(hipMemcpyAsync(labels, dl, nq * ef * 8, hipMemcpyDeviceToHost, s->home_stream));
+	if (dists) HIPCHK(hipMemcpyAsync(dists, dd, nq * ef * 4, hipMemcpyDeviceToHost, s->home_stream));
+	HIPCHK(hipMemcpyAsync(counts, dc, nq * 4, hipMemcpyDeviceToHost, s->home_stream));
+	HIPCHK(hipStreamSynchronize(s->home_stream));
+	return HNSW_GPU_OK;
 }

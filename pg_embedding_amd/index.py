@@ -190,6 +190,19 @@ class GpuIndex:
         check(self.L.hnsw_gpu_search_ms(self._h, back, C.byref(ms)), "hnsw_gpu_search_ms")
         return float(ms.value)
 
+    def last_search_kernel(self) -> str:
+        """Symbol of the kernel the last search launch ran, as rocprofv3 prints it."""
+        buf = C.create_string_buffer(128)
+        check(self.L.hnsw_gpu_last_search_kernel(self._h, buf, 128), "hnsw_gpu_last_search_kernel")
+        return buf.value.decode()
+
+    def gather_roof(self, loads_per_lane: int = 12, waves_per_cu: int = 16, iters: int = 200) -> float:
+        """GB/s of a dependency-free random gather of whole rows of THIS mirror's row table — the practical
+        roof of the search kernel's access pattern (csrc/device_roof.h)."""
+        v = C.c_float(0)
+        check(self.L.hnsw_gpu_gather_roof(self._h, loads_per_lane, waves_per_cu, iters, C.byref(v)), "hnsw_gpu_gather_roof")
+        return float(v.value)
+
     def last_search_slots(self) -> int:
         v = C.c_uint32(0)
         check(self.L.hnsw_gpu_last_search_slots(self._h, C.byref(v)), "hnsw_gpu_last_search_slots")
@@ -327,6 +340,93 @@ def cosine_distance(a, b) -> float:
 def manhattan_distance(a, b) -> float:
     """SQL manhattan_distance / operator <~> (embedding--0.3.6.sql:26-27,41-44)."""
     return _scalar(DIST_MANHATTAN, a, b)
+
+
+class LocalShardedIndex:
+    """A row-sharded index inside one process (include/hnsw_gpu.h, hnsw_gpu_sharded_*): shards on one or
+    several devices, per-shard search + one device merge, no torch.distributed involved.  The shards are
+    GpuIndex objects the caller built (labels globally unique) and stay owned by the caller."""
+
+    def __init__(self, shards):
+        self.shards = list(shards)
+        self.L = gpu_lib()
+        arr = (C.c_void_p * len(self.shards))(*[sh.handle for sh in self.shards])
+        h = C.c_void_p()
+        check(self.L.hnsw_gpu_sharded_create(arr, len(self.shards), C.byref(h)), "hnsw_gpu_sharded_create")
+        self._h = h
+
+    @classmethod
+    def build(cls, rows, meta, nshards: int, devices=None, max_batch: int = 0, ratio: int = 0):
+        """Split host rows [n, dim] into `nshards` contiguous ranges, one graph per range on
+        devices[i % len(devices)]; label = global row number."""
+        rows = np.ascontiguousarray(rows, dtype=np.float32)
+        n = rows.shape[0]
+        ndev = gpu_lib().hnsw_gpu_device_count()
+        devices = list(devices) if devices else list(range(max(1, min(ndev, nshards))))
+        shards = []
+        for i in range(nshards):
+            lo, hi = n * i // nshards, n * (i + 1) // nshards
+            ix = GpuIndex.empty(meta, max(hi - lo, 1), device=devices[i % len(devices)])
+            ix.append(rows[lo:hi], np.arange(lo, hi, dtype=np.uint64))
+            ix.link(0, hi - lo, max_batch, ratio)
+            shards.append(ix)
+        return cls(shards)
+
+    def close(self) -> None:
+        if self._h:
+            self.L.hnsw_gpu_sharded_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def search(self, queries: np.ndarray, ef: int):
+        """Host arrays: (labels[nq, ef] u64, dists[nq, ef] f32, counts[nq] u32) of the merged result."""
+        dim = int(self.shards[0].meta.dim)
+        queries = np.ascontiguousarray(queries, dtype=np.float32).reshape(-1, dim)
+        nq = queries.shape[0]
+        labels = np.empty((nq, ef), np.uint64)
+        dists = np.empty((nq, ef), np.float32)
+        counts = np.empty(nq, np.uint32)
+        check(self.L.hnsw_gpu_sharded_search(self._h, queries.ctypes.data, nq, ef, labels.ctypes.data,
+                                             dists.ctypes.data, counts.ctypes.data), "hnsw_gpu_sharded_search")
+        return labels, dists, counts
+
+    def search_torch(self, queries, ef: int):
+        """Device tensors on the device of shard 0; enqueued on the current torch stream."""
+        torch = _torch()
+        assert queries.is_cuda and queries.dtype == torch.float32 and queries.is_contiguous()
+        nq, dev = queries.shape[0], queries.device
+        ol = torch.empty((nq, ef), dtype=torch.int64, device=dev)
+        od = torch.empty((nq, ef), dtype=torch.float32, device=dev)
+        oc = torch.empty(nq, dtype=torch.int32, device=dev)
+        s = torch.cuda.current_stream(dev).cuda_stream
+        check(self.L.hnsw_gpu_sharded_search_dev(self._h, queries.data_ptr(), nq, ef, ol.data_ptr(), od.data_ptr(),
+                                                 oc.data_ptr(), s), "hnsw_gpu_sharded_search_dev")
+        return ol, od, oc
+
+
+def merge_packed_torch(blocks, nq: int, ef: int):
+    """Merge the gathered per-rank blocks of ShardedIndex ([world, block_bytes] uint8, block =
+    [labels nq*ef*8 | dists nq*ef*4 | pad]) in place: the strided merge entry reads every list where the
+    all-gather put it."""
+    torch = _torch()
+    L = gpu_lib()
+    assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous()
+    world, block = blocks.shape
+    assert block % 8 == 0 and block >= nq * ef * 12
+    dev = blocks.device
+    ol = torch.empty((nq, ef), dtype=torch.int64, device=dev)
+    od = torch.empty((nq, ef), dtype=torch.float32, device=dev)
+    oc = torch.empty(nq, dtype=torch.int32, device=dev)
+    s = torch.cuda.current_stream(dev).cuda_stream
+    base = blocks.data_ptr()
+    check(L.hnsw_gpu_merge_topk_strided_dev(dev.index or 0, base, block // 8, base + nq * ef * 8, block // 4, world, nq, ef,
+                                            ol.data_ptr(), od.data_ptr(), oc.data_ptr(), s), "hnsw_gpu_merge_topk_strided_dev")
+    return ol, od, oc
 
 
 def merge_topk_torch(labels, dists, ef: int):

@@ -6,9 +6,13 @@
   contiguous row ranges, an independent graph per shard (entry = shard-local element 0), every
   rank searches every query on its shard, then ONE exchange: an all-gather of the per-shard
   (dist, label) lists over RCCL (``torch.distributed`` backend "nccl") followed by the device
-  merge kernel (``hnsw_gpu_merge_topk_dev``).  Labels carry the global row number, so they are
-  unique across shards.  The exchange is latency-bound (nq*ef*12 bytes per rank), hence a single
-  all-gather and no chunking.
+  merge kernel.  Labels carry the global row number, so they are unique across shards.  The exchange is
+  latency-bound (nq*ef*12 bytes per rank), hence ONE all-gather of one packed block per rank
+  ([labels | dists], :func:`pack_block`) and no chunking; the device merge
+  (``hnsw_gpu_merge_topk_strided_dev``) reads the lists where the all-gather put them.
+
+The same layout inside one process (several devices, no torch.distributed) is native:
+``hnsw_gpu_sharded_*`` in include/hnsw_gpu.h / :class:`pg_embedding_amd.LocalShardedIndex`.
 
 The collective and the control flow are device-agnostic torch code, so the N>1 path is covered on
 CPU by world-size-2 gloo tests with the local search / merge steps injected by the test.
@@ -23,6 +27,30 @@ def shard_range(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
     return n_rows * rank // world, n_rows * (rank + 1) // world
 
 
+def block_bytes(nq: int, ef: int) -> int:
+    """Bytes of one rank's packed result block: nq*ef labels (8 B) then nq*ef distances (4 B), padded to 16."""
+    return (nq * ef * 12 + 15) // 16 * 16
+
+
+def pack_block(labels, dists):
+    """[nq, ef] int64 labels + [nq, ef] float32 dists -> one uint8 block (what ONE all-gather moves)."""
+    import torch
+    nq, ef = labels.shape
+    blk = torch.zeros(block_bytes(nq, ef), dtype=torch.uint8, device=labels.device)
+    blk[:nq * ef * 8] = labels.contiguous().view(torch.uint8).reshape(-1)
+    blk[nq * ef * 8:nq * ef * 12] = dists.contiguous().view(torch.uint8).reshape(-1)
+    return blk
+
+
+def unpack_blocks(blocks, nq: int, ef: int):
+    """[world, block] uint8 -> (labels[world, nq, ef] int64, dists[world, nq, ef] float32) (copies)."""
+    import torch
+    world = blocks.shape[0]
+    lab = blocks[:, :nq * ef * 8].contiguous().view(torch.int64).reshape(world, nq, ef)
+    dst = blocks[:, nq * ef * 8:nq * ef * 12].contiguous().view(torch.float32).reshape(world, nq, ef)
+    return lab, dst
+
+
 def query_slice(n_queries: int, world: int, rank: int) -> Tuple[int, int]:
     """Query range of `rank` when the index is replicated."""
     return n_queries * rank // world, n_queries * (rank + 1) // world
@@ -34,7 +62,8 @@ class ShardedIndex:
     local_search(queries, ef) -> (labels[nq, ef] int64, dists[nq, ef] float32) ascending by
         (dist, label), unused tail = (-1 / all-ones, +inf)   [default: the device search]
     merge(labels[world, nq, ef], dists[world, nq, ef], ef) -> (labels[nq, ef], dists[nq, ef],
-        counts[nq])                                          [default: the device merge kernel]
+        counts[nq])                      [injected by the CPU tests; default: the device merge kernel
+                                          reading the gathered blocks in place, merge_packed_torch]
     """
 
     def __init__(self, index=None, local_search: Optional[Callable] = None,
@@ -52,11 +81,13 @@ class ShardedIndex:
             def local_search(q, ef):
                 out = index.search_torch(q, ef)
                 return out["labels"], out["dists"]
+        self.merge_packed = None
         if merge is None:
-            from .index import merge_topk_torch
-            merge = merge_topk_torch
+            from .index import merge_packed_torch
+            self.merge_packed = merge_packed_torch
         self.local_search = local_search
         self.merge = merge
+        self.exchanges = 0                     # collectives issued so far (one per search)
 
     @classmethod
     def build(cls, rows, global_first: int, meta, device: int = 0, max_batch: int = 0, ratio: int = 0):
@@ -74,12 +105,21 @@ class ShardedIndex:
         """Every rank passes the SAME queries; every rank returns the merged result."""
         import torch
         labels, dists = self.local_search(queries, ef)
+        nq = labels.shape[0]
+        mine = pack_block(labels, dists)
         if self.world == 1:
-            all_l, all_d = labels.unsqueeze(0), dists.unsqueeze(0)
+            blocks = mine.unsqueeze(0)
         else:
-            all_l = torch.empty((self.world,) + tuple(labels.shape), dtype=labels.dtype, device=labels.device)
-            all_d = torch.empty((self.world,) + tuple(dists.shape), dtype=dists.dtype, device=dists.device)
-            # one all-gather per array into views of the [world, nq, ef] buffers
-            self.dist.all_gather(list(all_l.unbind(0)), labels.contiguous(), group=self.group)
-            self.dist.all_gather(list(all_d.unbind(0)), dists.contiguous(), group=self.group)
-        return self.merge(all_l.contiguous(), all_d.contiguous(), ef)
+            flat = torch.empty(self.world * mine.numel(), dtype=torch.uint8, device=mine.device)
+            blocks = flat.view(self.world, mine.numel())
+            # THE exchange step: one all-gather.  (gloo with device tensors — the 2-process test on a
+            # 1-GPU box — only has the list form; over RCCL and for CPU tensors the flat form is used.)
+            if mine.is_cuda and self.dist.get_backend(self.group) != "nccl":
+                self.dist.all_gather(list(blocks.unbind(0)), mine, group=self.group)
+            else:
+                self.dist.all_gather_into_tensor(flat, mine, group=self.group)
+            self.exchanges += 1
+        if self.merge_packed is not None:
+            return self.merge_packed(blocks, nq, ef)
+        lab, dst = unpack_blocks(blocks, nq, ef)
+        return self.merge(lab, dst, ef)

@@ -44,6 +44,65 @@ def test_two_shards_on_one_gpu_match_oracle_merge(nshards):
         assert (md[q, :order.size].view(np.uint32) == d[order].view(np.uint32)).all()
 
 
+@pytest.mark.parametrize("nshards", [1, 2, 5])
+def test_native_sharded_search_in_one_process(nshards, gpu_count):
+    """hnsw_gpu_sharded_* (C-ABI, no torch.distributed): shards spread round-robin over the visible devices
+    (all on device 0 on a 1-GPU box), per-shard search on its own stream writing into the merge device's
+    memory, one merge kernel == oracle per shard + CPU merge.  Host-pointer and device-pointer forms."""
+    import torch
+    n, dim, m, efc, ef, nq = 9000, 96, 8, 48, 40, 300
+    X = gmm(n, dim, k=40, seed=41)
+    Q = gmm(nq, dim, k=40, seed=41, stream=1)
+    X[n - 5] = X[7]                        # identical rows in different shards: equal distances, label order decides
+    meta = pg.make_meta(dim, m, efc, ef, pg.DIST_L2)
+    shards, per = [], []
+    for r in range(nshards):
+        lo, hi = shard_range(n, nshards, r)
+        port = oracle.PortIndex(dim, m, efc, ef, pg.DIST_L2)
+        port.add(X[lo:hi], np.arange(lo, hi, dtype=np.uint64))
+        port.set_deleted(1)                                     # a vacuumed row per shard is filtered before the merge
+        per.append(port.search_many(Q, ef))
+        shards.append(pg.GpuIndex.from_flat(meta, port.raw(), hi - lo, device=r % max(gpu_count, 1)))
+    sh = pg.LocalShardedIndex(shards)
+    ml, md, mc = sh.search(Q, ef)
+    tl, td, tc = sh.search_torch(torch.from_numpy(Q).cuda(shards[0].device), ef)
+    torch.cuda.synchronize()
+    assert (tl.cpu().numpy().view(np.uint64) == ml).all() and (tc.cpu().numpy().view(np.uint32) == mc).all()
+    assert (td.cpu().numpy().view(np.uint32) == md.view(np.uint32)).all()
+    for q in range(nq):
+        l = np.concatenate([p["labels"][q, :p["counts"][q]] for p in per])
+        d = np.concatenate([p["dists"][q, :p["counts"][q]] for p in per])
+        order = np.lexsort((l, d))[:ef]
+        assert mc[q] == order.size
+        assert (ml[q, :order.size] == l[order]).all()
+        assert (md[q, :order.size].view(np.uint32) == d[order].view(np.uint32)).all()
+        assert (ml[q, order.size:] == pg.NO_LABEL).all()
+    sh.close()
+    for s in shards:
+        s.close()
+
+
+def test_native_sharded_build_recall():
+    """LocalShardedIndex.build (device insert path per shard): a sharded index is a different graph from the
+    monolithic one, so quality is checked by recall@10 against exhaustive search."""
+    n, dim, ef = 40000, 64, 64
+    X = gmm(n, dim, k=100, seed=9)
+    Q = gmm(200, dim, k=100, seed=9, stream=1)
+    meta = pg.make_meta(dim, 12, 100, ef, pg.DIST_L2)
+    sh = pg.LocalShardedIndex.build(X, meta, 4)
+    labels, dists, counts = sh.search(Q, ef)
+    assert (counts == ef).all() and (np.diff(dists, axis=1) >= 0).all()
+    Qd, Xd = Q.astype(np.float64), X.astype(np.float64)
+    d2 = (Qd ** 2).sum(1)[:, None] - 2.0 * Qd @ Xd.T + (Xd ** 2).sum(1)[None, :]
+    truth = np.argsort(d2, axis=1)[:, :10]
+    from pg_embedding_amd.datasets import recall_at_k
+    assert recall_at_k(labels.astype(np.int64), truth, 10) >= 0.95
+    shards = sh.shards
+    sh.close()
+    for s in shards:
+        s.close()
+
+
 def test_sharded_index_world1_builds_and_searches():
     import torch
     n, dim, ef = 20000, 48, 64
