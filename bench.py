@@ -7,19 +7,28 @@ A "step" is one pass of the hot path over one batch of `--nq` (default 40 000) s
 (already resident in HBM): the fused searchBaseLayer/searchKnn kernel over an HBM-resident index.
 Workload at N=1 = the configuration the metric is quoted on: 1M x 768 fp32, L2,
 efsearch=128 (graph built in HBM by the device insert path before the timed region).
-N>1: one process per GPU, every rank holds a replica of the index and its own query
-batch (queries are the independent units; no data-path collective) -> weak scaling.
+
+N>1: one process per GPU over RCCL (torch.distributed backend "nccl").  Started by the driver under
+`python -m torch.distributed.run ...` it reads RANK/LOCAL_RANK/WORLD_SIZE; started plainly as
+`python bench.py --gpus N` it launches those N ranks ITSELF (re-exec under torch.distributed.run,
+rendezvous on 127.0.0.1).  --mode replicas (default, the headline metric): every rank holds a replica of
+the index and its own query batch (queries are the independent units; no data-path collective) -> weak
+scaling.  --mode sharded (BASELINE config C4): the rows are partitioned over the ranks, every rank
+searches every query on its shard, ONE packed all-gather + the device merge kernel -> strong scaling.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description) with two extra
-objects: "roofline" (dominant kernel vs the HBM roof, from HIP events on the kernel's own
-stream) and "cpu_baseline" (the reference's CPU path on the same graph bytes, bounded
-sample, host cores of this box).
+objects: "roofline" (dominant kernel vs the HBM roof — nominal peak AND the measured dependency-free gather
+roof of the same row table — from HIP events on the kernel's own stream, for the headline dataset and for
+a cache-hostile one) and "cpu_baseline" (the reference's CPU path on the same graph bytes, bounded sample,
+host cores of this box, with every id mismatch against the reference classified).
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,6 +37,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+REL_TOL = 1e-5            # north-star tolerance (BASELINE.json)
 
 
 def parse():
@@ -35,12 +45,12 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--rows", dest="n", type=int, default=1_000_000, help="index rows")
+    ap.add_argument("--rows", dest="n", type=int, default=0, help="index rows (default 1M; 10M in --mode sharded)")
     ap.add_argument("--dim", type=int, default=768)
     ap.add_argument("--hnsw-m", dest="m", type=int, default=16, help="m reloption (maxM = 2m)")
     ap.add_argument("--efc", type=int, default=200, help="efconstruction for the device build")
     ap.add_argument("--ef", type=int, default=128, help="efsearch")
-    ap.add_argument("--nq", type=int, default=40_000, help="queries per step per GPU")
+    ap.add_argument("--nq", type=int, default=0, help="queries per step per GPU (default 40000; 1024 in --mode sharded)")
     ap.add_argument("--nq-small", type=int, default=10_000, help="also report a smaller launch (0 = skip)")
     ap.add_argument("--metric", default="l2", choices=["l2", "cosine", "manhattan"])
     ap.add_argument("--clusters", type=int, default=1000)
@@ -49,14 +59,146 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--recall-queries", type=int, default=1000)
+    ap.add_argument("--hostile-rows", type=int, default=8_000_000,
+                    help="second timed dataset whose rows do not repeat inside a launch (rows; clusters scale with it so "
+                         "cluster size stays 1000); 0 = skip; skipped for N>1")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
                     help="replicas: index mirrored on every GPU, queries sharded (headline metric). sharded: rows partitioned "
-                         "across GPUs (config C4), every GPU searches every query, RCCL all-gather + merge kernel")
-    return ap.parse_args()
+                         "across GPUs (config C4), every GPU searches every query, one packed RCCL all-gather + merge kernel")
+    a = ap.parse_args()
+    if a.n == 0:
+        a.n = 10_000_000 if a.mode == "sharded" else 1_000_000
+    if a.nq == 0:
+        a.nq = 1024 if a.mode == "sharded" else 40_000
+    return a
 
 
+# ------------------------------------------------------------------------------------------ launcher
+def _free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` with no rendezvous in the environment: start the N ranks here, one per GPU,
+    exactly as the driver would (torch.distributed.run, 127.0.0.1)."""
+    selftest = os.environ.get("PGEMB_BENCH_SELFTEST") == "1"
+    if not selftest:
+        import torch
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} device(s) visible", file=sys.stderr)
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this driver (RCCL needs it)
+    env["PGEMB_BENCH_SELF_LAUNCHED"] = "1"
+    return subprocess.run(cmd, env=env).returncode
+
+
+def init_ranks(args):
+    """(world, rank, local, use_dist, backend) after joining the process group when there is one."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ       # launched by torch.distributed.run
+    backend = None
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if os.environ.get("PGEMB_BENCH_SELFTEST") == "1":
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = dist.get_backend()
+        world = dist.get_world_size()                                   # what the collective library reports
+    if args.gpus != world and rank == 0:
+        print(f"warning: --gpus {args.gpus} but {world} rank(s) joined", file=sys.stderr)
+    return world, rank, local, use_dist, backend
+
+
+def selftest_main(args):
+    """CPU check of the launch path (tests/test_bench_launch.py): ranks rendezvous over gloo, agree on the
+    world size through a collective, rank 0 prints one line.  No device work."""
+    import torch
+    import torch.distributed as dist
+    world, rank, local, use_dist, backend = init_ranks(args)
+    t = torch.ones(1)
+    if use_dist:
+        dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"selftest": True, "n_gpus": world, "ranks_joined": int(t.item()), "backend": backend,
+                          "mode": args.mode, "self_launched": os.environ.get("PGEMB_BENCH_SELF_LAUNCHED") == "1"}))
+    if use_dist:
+        dist.destroy_process_group()
+
+
+# ------------------------------------------------------------------------------------------ helpers
+def alg_bytes(stats, counts, dim, m):
+    """algorithmic bytes per query, SURVEY.md §8(d): B_q = E_q*dim*4 + H_q*(maxM+1)*4 + dim*4 + R_q*8"""
+    E, H = stats[:, 0], stats[:, 1]
+    return E * dim * 4 + H * (2 * m + 1) * 4 + dim * 4 + counts * 8
+
+
+def gather_roof(ix):
+    """best dependency-free random-row gather rate on this mirror's own row table (csrc/device_roof.h)"""
+    best, cfg = 0.0, None
+    for wpc in (8, 16):
+        for t in (8, 12, 16, 24):
+            g = ix.gather_roof(t, wpc, 200)
+            if g > best:
+                best, cfg = g, {"loads_per_lane": t, "waves_per_cu": wpc}
+    return best, cfg
+
+
+def copy_roof(dev):
+    import torch
+    cp_src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
+    cp_dst = torch.empty_like(cp_src)
+    cp_dst.copy_(cp_src)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(5):
+        cp_dst.copy_(cp_src)
+    e1.record()
+    torch.cuda.synchronize()
+    return 5 * 2 * cp_src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+
+
+def build_index(args, n, clusters, dev, local, func):
+    import torch
+    import pg_embedding_amd as pg
+    from pg_embedding_amd.datasets import gmm_torch
+    t0 = time.time()
+    X = gmm_torch(n, args.dim, k=clusters, sigma=0.3, seed=42, device=dev)
+    meta = pg.make_meta(args.dim, args.m, args.efc, args.ef, func)
+    ix = pg.GpuIndex.empty(meta, n, device=local)
+    ix.append_torch(X)
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+    t0 = time.time()
+    ix.link(0, n, args.max_batch, args.ratio, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    t_build = time.time() - t0
+    del X
+    return ix, t_gen, t_build
+
+
+# ------------------------------------------------------------------------------------------ replicas
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
+    if os.environ.get("PGEMB_BENCH_SELFTEST") == "1":
+        return selftest_main(args)
     if args.mode == "sharded":
         return main_sharded(args)
     import numpy as np
@@ -66,17 +208,7 @@ def main():
     import pg_embedding_amd as pg
     from pg_embedding_amd.datasets import gmm_torch, recall_at_k
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ       # launched by torch.distributed.run
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
-    if args.gpus != world and rank == 0 and world > 1:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
+    world, rank, local, use_dist, backend = init_ranks(args)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     func = {"l2": pg.DIST_L2, "cosine": pg.DIST_COSINE, "manhattan": pg.DIST_MANHATTAN}[args.metric]
@@ -88,36 +220,22 @@ def main():
         torch.cuda.synchronize()
 
     # ---- index: synthetic rows generated in HBM, graph built by the device insert path ----
-    t0 = time.time()
-    X = gmm_torch(args.n, args.dim, k=args.clusters, sigma=0.3, seed=42, device=dev)
-    meta = pg.make_meta(args.dim, args.m, args.efc, args.ef, func)
-    ix = pg.GpuIndex.empty(meta, args.n, device=local)
-    ix.append_torch(X)
-    torch.cuda.synchronize()
-    t_gen = time.time() - t0
-    t0 = time.time()
-    ix.link(0, args.n, args.max_batch, args.ratio, torch.cuda.current_stream(dev).cuda_stream)
-    torch.cuda.synchronize()
-    t_build = time.time() - t0
-    del X
+    ix, t_gen, t_build = build_index(args, args.n, args.clusters, dev, local, func)
 
     # every rank searches its own query stream (weak scaling)
     Q = gmm_torch(args.nq, args.dim, k=args.clusters, sigma=0.3, seed=42, stream=1 + rank, device=dev)
 
     # ---- recall@10 against exhaustive search with the same metric ---------------------
     nrec = min(args.recall_queries, args.nq)
-    truth, _ = ix.bruteforce_torch(Q[:nrec].contiguous(), 10)
+    truth, _ = ix.bruteforce_torch(Q[:nrec].contiguous(), 10, mfma=True)
     out = ix.search_torch(Q, args.ef, stats=True)
     torch.cuda.synchronize()
     labels0 = out["labels"].clone()
     recall = recall_at_k(labels0[:nrec].cpu().numpy(), truth.cpu().numpy(), 10)
     stats = out["stats"].cpu().numpy().astype(np.int64)
     counts = out["counts"].cpu().numpy().astype(np.int64)
-    E, H, R = stats[:, 0], stats[:, 1], counts
-    maxM = 2 * args.m
-    # algorithmic bytes per query, SURVEY.md §8(d):
-    #   B_q = E_q*dim*4 + H_q*(maxM+1)*4 + dim*4 + R_q*8
-    bytes_q = E * args.dim * 4 + H * (maxM + 1) * 4 + args.dim * 4 + R * 8
+    E, H = stats[:, 0], stats[:, 1]
+    bytes_q = alg_bytes(stats, counts, args.dim, args.m)
     bytes_launch = float(bytes_q.sum())
 
     # ---- the same hot path at a smaller launch (the fixed ramp-up/drain cost of a launch is
@@ -134,7 +252,6 @@ def main():
         small = {"queries_per_launch": args.nq_small, "kernel_ms": float(np.median(ms_small)),
                  "queries_per_s": args.nq_small / float(np.median(ms_small)) * 1e3,
                  "achieved_GBps": float(bytes_q[:args.nq_small].sum()) / float(np.median(ms_small)) / 1e6}
-
 
     # ---- two search contexts on two streams: consecutive small launches overlap (the next one
     # fills the CUs the previous one frees while it drains).  Extra figure, not `value`.
@@ -161,6 +278,22 @@ def main():
         for c in ctxs:
             c.close()
 
+    # ---- single query per launch: the reference's own call shape (embedding.c:317), device time only
+    single = None
+    if rank == 0:
+        q1 = Q[:1].contiguous()
+        b1 = ix.search_torch(q1, args.ef)
+        ms1 = []
+        for i in range(48):
+            ix.search_torch(Q[i:i + 1].contiguous(), args.ef, out=b1)
+            ms1.append(ix.last_search_ms())
+        single = {"kernel_ms_median": float(np.median(ms1[8:])), "kernel_ms_mean": float(np.mean(ms1[8:])),
+                  "kernel": ix.last_search_kernel()}
+
+    # ---- roofs measured on this device: dependency-free gather of this table's rows, plain copy
+    g_roof, g_cfg = gather_roof(ix)
+    copy_gbps = copy_roof(dev)
+
     # ---- timed region -----------------------------------------------------------------
     bufs = ix.search_torch(Q, args.ef)           # allocate outputs once
     for _ in range(args.warmup):
@@ -172,6 +305,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     same = bool((bufs["labels"] == labels0).all().item())
+    kernel_name = ix.last_search_kernel()
     # per-launch kernel time of exactly the K timed launches, from the HIP events the library
     # recorded on the launch stream around each kernel
     kernel_ms = [ix.last_search_ms(back) for back in range(min(args.steps, 64))]
@@ -179,7 +313,12 @@ def main():
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     rec_t = torch.tensor([recall], dtype=torch.float64, device=dev)
+    per_rank = [elapsed]
     if use_dist:
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        per_rank = [float(t.item()) for t in every]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(rec_t, op=dist.ReduceOp.MIN)
     elapsed = float(tmax.item())
@@ -187,19 +326,7 @@ def main():
     qps = total_queries / elapsed
 
     achieved = bytes_launch / (kms * 1e-3) / 1e9
-    # context for the roof: what a plain device-to-device copy reaches on this GPU (read + write bytes)
-    cp_src = torch.empty(1 << 28, dtype=torch.float32, device=dev)
-    cp_dst = torch.empty_like(cp_src)
-    cp_dst.copy_(cp_src)
-    torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(5):
-        cp_dst.copy_(cp_src)
-    e1.record()
-    torch.cuda.synchronize()
-    copy_gbps = 5 * 2 * cp_src.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
-    del cp_src, cp_dst
+    traffic, traffic_src = pmc_traffic(args)
     result = {
         "metric": "queries/sec at recall@10>=0.95, 1Mx768 L2 efsearch=128",
         "value": qps,
@@ -221,6 +348,9 @@ def main():
             "queries_per_step_per_gpu": args.nq,
             "parallelism": "replica per GPU, queries sharded" if world > 1 else "single GPU",
         },
+        "ranks": {"world_size_reported_by_backend": world, "backend": backend or "none (single process)",
+                  "self_launched": os.environ.get("PGEMB_BENCH_SELF_LAUNCHED") == "1",
+                  "queries_per_s_per_rank": [args.nq * args.steps / t for t in per_rank]},
         "recall_at_10": float(rec_t.item()),
         "results_stable_across_steps": same,
         "evals_per_query": float(E.mean()),
@@ -231,62 +361,110 @@ def main():
         "resident_query_slots": ix.last_search_slots(),
         "roofline": {
             "bound": "hbm",
-            "kernel": "hnsw_search_kernel",
+            "kernel": kernel_name,
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": pmc_traffic(args),
+            "traffic": traffic,
+            "traffic_source": traffic_src,
             "alg_bytes_per_launch": bytes_launch,
             "kernel_ms_per_launch": kms,
+            # what the memory system gives this access pattern with nothing depending on anything, on the same
+            # row table (csrc/device_roof.h), and a plain copy: `achieved` above the gather roof is Infinity
+            # Cache / L2 service of rows that queries of one launch share (this dataset: ~58 reads per row per launch)
+            "measured_gather_GBps": g_roof,
+            "measured_gather_config": g_cfg,
+            "frac_of_measured_gather": achieved / g_roof if g_roof else None,
             "measured_copy_GBps": copy_gbps,
         },
         "smaller_launch": small,
         "smaller_launch_two_streams": pipelined,
+        "single_query_launch": single,
     }
 
     # ---- CPU baseline: the reference's own code on the same graph bytes, rank 0, N=1 only --
     if rank == 0 and world == 1 and not args.no_cpu:
-        result["cpu_baseline"] = cpu_baseline(args, ix, Q, labels0, func)
+        result["cpu_baseline"] = cpu_baseline(args, ix, Q, labels0, out["dists"], func)
+    ix.close()
+    del ix, out, bufs, labels0
+
+    # ---- a dataset whose rows do not repeat inside a launch (N=1 only): the Infinity-Cache share made visible
+    if rank == 0 and world == 1 and args.hostile_rows > 0:
+        result["roofline"]["cache_hostile"] = hostile(args, dev, local, func)
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
 
 
+def hostile(args, dev, local, func):
+    """Same kernel, same row width, but a table 8x larger with 8x more clusters (cluster size unchanged):
+    a launch's queries land in mostly different clusters and the ~24 GB working set dwarfs the 256 MB
+    Infinity Cache, so (almost) every row read comes from HBM."""
+    import numpy as np
+    import torch
+    from pg_embedding_amd.datasets import gmm_torch, recall_at_k
+    n = args.hostile_rows
+    clusters = max(1, n // 1000)
+    ix, t_gen, t_build = build_index(args, n, clusters, dev, local, func)
+    Q = gmm_torch(args.nq, args.dim, k=clusters, sigma=0.3, seed=42, stream=1, device=dev)
+    out = ix.search_torch(Q, args.ef, stats=True)
+    torch.cuda.synchronize()
+    stats = out["stats"].cpu().numpy().astype(np.int64)
+    counts = out["counts"].cpu().numpy().astype(np.int64)
+    bq = alg_bytes(stats, counts, args.dim, args.m)
+    nrec = min(500, args.nq)
+    truth, _ = ix.bruteforce_torch(Q[:nrec].contiguous(), 10, mfma=True)
+    rec = recall_at_k(out["labels"][:nrec].cpu().numpy(), truth.cpu().numpy(), 10)
+    g_roof, g_cfg = gather_roof(ix)
+    ms = []
+    for _ in range(max(3, args.steps)):
+        ix.search_torch(Q, args.ef, out=out)
+        ms.append(ix.last_search_ms())
+    kms = float(np.mean(ms[1:]))
+    ach = float(bq.sum()) / (kms * 1e-3) / 1e9
+    res = {"workload": f"{n}x{args.dim} fp32 GMM({clusters}, sigma 0.3), {args.metric}, m={args.m}, efsearch={args.ef}, "
+                       f"{args.nq} queries/launch",
+           "kernel": ix.last_search_kernel(), "achieved": ach, "frac": ach / HBM_PEAK_GBS,
+           "measured_gather_GBps": g_roof, "measured_gather_config": g_cfg,
+           "frac_of_measured_gather": ach / g_roof if g_roof else None,
+           "kernel_ms_per_launch": kms, "queries_per_s": args.nq / kms * 1e3,
+           "alg_bytes_per_launch": float(bq.sum()), "evals_per_query": float(stats[:, 0].mean()),
+           "hops_per_query": float(stats[:, 1].mean()), "recall_at_10": rec,
+           "build_seconds": t_build, "datagen_seconds": t_gen}
+    ix.close()
+    return res
+
+
+# ------------------------------------------------------------------------------------------ sharded
 def main_sharded(args):
     """Row-sharded index (SURVEY.md §8e mode 2, BASELINE config C4): contiguous row ranges, one
     graph per shard, every rank searches the same query batch on its shard, ONE exchange
-    (all-gather of (dist,label) lists over RCCL) and the device merge kernel."""
+    (a packed all-gather of the (dist,label) lists over RCCL) and the device merge kernel."""
     import numpy as np
     import torch
     import torch.distributed as dist
 
     import pg_embedding_amd as pg
-    from pg_embedding_amd.datasets import gmm_torch
-    from pg_embedding_amd.sharded import ShardedIndex, shard_range
+    from pg_embedding_amd.datasets import gmm_torch, recall_at_k
+    from pg_embedding_amd.sharded import ShardedIndex, block_bytes, shard_range
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    use_dist = world > 1 or "TORCHELASTIC_RUN_ID" in os.environ
+    world, rank, local, use_dist, backend = init_ranks(args)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29500")
-        dist.init_process_group("nccl", device_id=dev)
     func = {"l2": pg.DIST_L2, "cosine": pg.DIST_COSINE, "manhattan": pg.DIST_MANHATTAN}[args.metric]
     lo, hi = shard_range(args.n, world, rank)
+    clusters = max(args.clusters, args.n // 1000)
     t0 = time.time()
-    rows = gmm_torch(hi - lo, args.dim, k=args.clusters, sigma=0.3, seed=42, stream=100 + rank, device=dev)
+    # every rank generates ITS rows of one global mixture: same centres everywhere (seed), own stream
+    rows = gmm_torch(hi - lo, args.dim, k=clusters, sigma=0.3, seed=42, stream=100 + rank, device=dev)
     meta = pg.make_meta(args.dim, args.m, args.efc, args.ef, func)
     sh = ShardedIndex.build(rows, lo, meta, device=local, max_batch=args.max_batch, ratio=args.ratio)
     torch.cuda.synchronize()
     t_build = time.time() - t0
-    del rows
     nq = args.nq
-    Q = gmm_torch(nq, args.dim, k=args.clusters, sigma=0.3, seed=42, stream=1, device=dev)   # same on every rank
+    Q = gmm_torch(nq, args.dim, k=clusters, sigma=0.3, seed=42, stream=1, device=dev)   # same on every rank
 
     def barrier():
         torch.cuda.synchronize()
@@ -294,19 +472,31 @@ def main_sharded(args):
             dist.barrier()
         torch.cuda.synchronize()
 
+    # recall@10 of the merged answer against exhaustive search over ALL shards (exact per shard + same merge)
+    nrec = min(200, nq)
+    tl, td = sh.index.bruteforce_torch(Q[:nrec].contiguous(), 10, mfma=True)
+    tlab = (tl.to(torch.int64) + lo)
+    tsh = ShardedIndex(index=sh.index, local_search=lambda q, ef: (tlab, td))
+    truth, _, _ = tsh.search(Q[:nrec].contiguous(), 10)
+    del rows
+
     for _ in range(args.warmup):
         sh.search(Q, args.ef)
     barrier()
+    ex0 = sh.exchanges
     t0 = time.perf_counter()
     for _ in range(args.steps):
         labels, dists, counts = sh.search(Q, args.ef)
     barrier()
     elapsed = time.perf_counter() - t0
+    exchanges = sh.exchanges - ex0
+    local_ms = sh.index.last_search_ms()
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     elapsed = float(tmax.item())
     ok = bool((counts == args.ef).all().item()) and bool((dists[:, 1:] >= dists[:, :-1]).all().item())
+    rec = recall_at_k(labels[:nrec].cpu().numpy(), truth.cpu().numpy(), 10)
     if rank == 0:
         print(json.dumps({
             "metric": "queries/sec, row-sharded index, per-shard searchKnn + RCCL top-k merge",
@@ -316,7 +506,12 @@ def main_sharded(args):
             "config": {"workload": f"HNSW search, index of {args.n}x{args.dim} rows sharded over {world} GPU(s) "
                                    f"({hi - lo} rows/shard), {args.metric}, m={args.m}, efsearch={args.ef}, "
                                    f"{nq} queries/step (every GPU searches all of them)",
-                       "parallelism": f"row-sharded x{world}, all-gather + merge"},
+                       "parallelism": f"row-sharded x{world}, one packed all-gather + merge"},
+            "ranks": {"world_size_reported_by_backend": world, "backend": backend or "none (single process)",
+                      "self_launched": os.environ.get("PGEMB_BENCH_SELF_LAUNCHED") == "1"},
+            "exchange": {"collectives_per_step": exchanges / max(args.steps, 1), "bytes_per_rank": block_bytes(nq, args.ef)},
+            "local_search_kernel_ms": local_ms,
+            "recall_at_10": rec,
             "build_seconds": t_build, "merged_results_sorted_and_full": ok}))
     if use_dist:
         dist.destroy_process_group()
@@ -326,22 +521,26 @@ def pmc_traffic(args):
     """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of THIS command
     ((2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 FETCH_SIZE correction of the micro-arch guide).  The
     counters cannot be collected from inside the timed process, so the value measured by
-    scripts/profile_bench.sh is committed as profiles/traffic.json and reported here only when it
-    was taken for the same workload; otherwise null."""
+    scripts/profile_bench.sh is committed as profiles/traffic.json and reported here — with its source
+    named — only when it was taken for the same workload; otherwise null."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
         same = all(t["workload"].get(k) == getattr(args, k) for k in ("n", "dim", "m", "efc", "ef", "nq", "metric"))
-        return float(t["hbm_bytes_per_launch"]) if same else None
+        if not same:
+            return None, None
+        return float(t["hbm_bytes_per_launch"]), f"profiles/traffic.json ({t.get('run', 'scripts/profile_bench.sh')}): " + t["source"]
     except Exception:
-        return None
+        return None, None
 
 
-def cpu_baseline(args, ix, Q, gpu_labels, func):
+def cpu_baseline(args, ix, Q, gpu_labels, gpu_dists, func):
     """oracle/_ref (the unmodified reference distfunc.c + hnswalg.cpp) or, where that was
     not shipped, the C restatement, timed on this box's host cores over a bounded sample of
-    the same queries on the identical graph bytes.  Checker/baseline only."""
+    the same queries on the identical graph bytes — and the id parity of the device against the reference
+    itself on that sample, every mismatch classified (oracle/hnsw_port.c, PortStats.div_*).
+    Checker/baseline only."""
     import numpy as np
     import oracle
 
@@ -350,7 +549,6 @@ def cpu_baseline(args, ix, Q, gpu_labels, func):
     Cls = oracle.RefIndex if kind == "reference" else oracle.PortIndex
     cpu = Cls(args.dim, args.m, args.efc, args.ef, func, capacity=args.n)
     cpu.load_raw(raw, args.n)
-    del raw
     Qh = Q.cpu().numpy()
     ncores = os.cpu_count() or 1
     threads = min(ncores, 64)
@@ -367,17 +565,43 @@ def cpu_baseline(args, ix, Q, gpu_labels, func):
     n8 = int(max(64, min(args.nq, qps1 * 8 * args.cpu_seconds * 0.25)))
     r8 = cpu.search_many(Qh[:n8], args.ef, nthreads=min(8, ncores))
     qps8 = n8 / r8["seconds"]
-    glab = gpu_labels[:n1].cpu().numpy().view(np.uint64)
-    agree = float((r1["labels"] == glab).all(axis=1).mean())
-    return {
+    res = {
         "value": qpst, "unit": "queries/s", "cores": threads, "kind": kind,
         "sample": f"{nt} of the {args.nq} queries on {threads} host threads (one query per thread, "
                   f"shared read-only index); single thread: {n1} queries",
         "single_thread_qps": qps1,
         "eight_thread_qps": qps8,
         "host_cpus": ncores,
-        "fraction_of_queries_with_identical_ids": agree,
     }
+    glab = gpu_labels[:nt].cpu().numpy().view(np.uint64)
+    same = (rt["labels"] == glab).all(axis=1)
+    res["fraction_of_queries_with_identical_ids"] = float(same.mean())
+    if kind == "reference":
+        # device == canonical-order oracle bit for bit; the oracle shadows every decision of its walk with the
+        # reference's own hnsw_dist_func: a query with no diverging decision provably has the reference's ids,
+        # a mismatching query has one, and `gap` is how close the two compared distances were (relative)
+        del cpu
+        port = oracle.PortIndex(args.dim, args.m, args.efc, args.ef, func, capacity=args.n)
+        port.load_raw(raw, args.n)
+        port.shadow_reference_distances(True)
+        p = port.search_many(Qh[:nt], args.ef, nthreads=threads)
+        dk, dm = p["div_kind"], p["div_margin"]
+        gd = gpu_dists[:nt].cpu().numpy()
+        unexplained = (~same) & (dk == 0)
+        res["parity_vs_reference"] = {
+            "queries": nt,
+            "device_equals_oracle_bit_exact": bool((p["labels"] == glab).all() and
+                                                   (p["dists"].view(np.uint32) == gd.view(np.uint32)).all()),
+            "mismatch_count": int((~same).sum()),
+            "mismatch_explained_by_near_tie": int(((~same) & (dk != 0)).sum()),
+            "mismatch_unexplained": int(unexplained.sum()),
+            "largest_unexplained_margin": float(p["margins"][unexplained].max()) if unexplained.any() else None,
+            "largest_gap_at_a_mismatching_decision": float(dm[~same].max()) if (~same).any() else 0.0,
+            "tolerance": REL_TOL,
+            "queries_with_a_diverging_decision": int((dk != 0).sum()),
+            "queries_without_one_all_identical": bool(same[dk == 0].all()),
+        }
+    return res
 
 
 if __name__ == "__main__":
