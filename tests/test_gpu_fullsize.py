@@ -124,7 +124,11 @@ def test_device_equals_oracle_and_every_reference_mismatch_is_a_flipped_near_tie
         c = want["classification"]
         print(f"\n[{cfg['name']}] vs reference binary: {c}")
         assert c["mismatch_unexplained"] == 0
-        assert c["identical_ids"] >= 0.9 * nq
+        # How many queries contain a flipped near-tie is a property of the metric, not of the kernel: the float
+        # result of 1 - dot/sqrt(na*nb) (distfunc.c:144) near 0.08 carries ~1e-6 of relative round-off, ten times
+        # that of an L2 distance, so cosine walks (~1400 scored rows, ~130 evictions each) hit a tie inside the
+        # noise far more often (measured at 1M x 768: L2 1.4 % of queries, cosine 25 %; every one classified).
+        assert c["identical_ids"] >= (0.5 if func == pg.DIST_COSINE else 0.9) * nq
         if cfg["sift"]:
             # integer coordinates: every sum is exact in any order, so there is nothing to flip
             assert c["mismatch_count"] == 0 and c["queries_with_a_diverging_decision"] == 0
