@@ -85,6 +85,10 @@ struct SearchArgs
 	uint32_t out_stride;        // result slots per query in the output arrays (the caller's ef; a.ef may be clamped to n)
 	size_t set_stride;
 	int mode;                   // 0 = hnsw_search semantics, 1 = searchBaseLayer only
+	// team form (beam kernel, TEAM = true; banner "Team form" further down)
+	uint32_t team_mains;        // waves of a block that take queries (wib < team_mains); the others start as helpers
+	uint32_t off_ctl;           // byte offset of the block's TeamCtl array in dynamic LDS (behind the wave regions)
+	uint32_t tm_off_ex, tm_off_miss, tm_off_lctag, tm_off_lcstate, tm_off_lclinks, tm_lcslots, tm_off_dc, tm_dccap;
 };
 
 // Streamed completion: everything this wave wrote for the query becomes visible system-wide, then
@@ -1074,8 +1078,292 @@ __device__ __forceinline__ void beam_set(uint64_t (&uk)[U], uint32_t slot, uint6
 	}
 }
 
+
+// =====================================================================================
+// Team form (TEAM = true): waves of a block that have no query left help a sibling's walk.
+//
+// One query is a chain of ~ef dependent hops, each two memory round trips (link list, then rows) plus the
+// set upkeep: 0.6-0.7 ms at 768 dims however idle the chip is — the shape of the reference's own call
+// (one query per hnsw_search, embedding.c:317) and of the tail of every batch (its last, longest walks run
+// on an empty chip).  The walk cannot be reordered without changing results, but its INPUTS can be fetched
+// ahead: a distance is a pure function of (query, row), a link list a pure function of the element.
+//   * The walking wave ("main") publishes its accepted set (keys + expanded bits) once per hop.
+//   * A helper picks the r-th best unexpanded element of that snapshot (r = its rank among the helpers; r = 0
+//     is the predicted next pop: right in 83-85 % of the hops), loads its link list into a small link cache,
+//     scores the neighbours that are not yet visited with the SAME canonical code and puts (id -> ord(dist))
+//     into a distance cache.  Both caches live in the helper's own LDS region (it has no query of its own),
+//     so helpers cost no extra LDS and write only their own region.
+//   * The main walks exactly as before — pops, marks visited and accepts in the reference's order — but
+//     takes a link list or a distance from a cache when it is there and fetches/scores only what is not.
+// Exactness: every cached value is identical, bit for bit, to what the main would compute (same code, same
+// summation order; entries carry their id, a link-list copy is validated by re-reading its tag after the
+// copy), and nothing a helper does can change WHICH values the walk consumes or in what order.  A stale or
+// torn snapshot only makes a helper fetch something useless.  Outputs, E_q and H_q equal the one-wave form
+// (tests/test_gpu_search.py::test_every_kernel_variant_is_exact).
+// =====================================================================================
+struct TeamCtl
+{
+	uint32_t state;        // 0 = has or may get a query but is not walking, 1 = walking, 2 = will never walk again
+	uint32_t helpers;      // main: bit h set = wave h of this block is helping me
+	uint32_t pad0, pad1;
+};
+constexpr uint64_t DC_EMPTY = ~0ull;
+enum : uint32_t { LC_CLAIMED = 1u, LC_LINKS = 2u };
+
+struct TeamView            // the cache carve of one (helper's) LDS region
+{
+	uint64_t *pub;         // 64*UREG keys: the main's accepted set (only in the region of its lowest helper)
+	uint32_t *ex;          // 64 words: expanded bits per lane
+	uint32_t *miss;        // 64 ids: the main's compaction scratch for cache misses
+	uint32_t *lctag, *lcstate, *lclinks;   // link cache: tm_lcslots direct-mapped slots of lstride ids
+	uint64_t *dc;          // distance cache: open addressing, entry = id << 32 | ord(dist)
+};
+
+__device__ __forceinline__ TeamView team_view(unsigned char *smem, const SearchArgs &a, uint32_t w)
+{
+	unsigned char *r = smem + (size_t) w * a.wave_bytes;
+	TeamView v;
+	v.pub     = reinterpret_cast<uint64_t *>(r);
+	v.ex      = reinterpret_cast<uint32_t *>(r + a.tm_off_ex);
+	v.miss    = reinterpret_cast<uint32_t *>(r + a.tm_off_miss);
+	v.lctag   = reinterpret_cast<uint32_t *>(r + a.tm_off_lctag);
+	v.lcstate = reinterpret_cast<uint32_t *>(r + a.tm_off_lcstate);
+	v.lclinks = reinterpret_cast<uint32_t *>(r + a.tm_off_lclinks);
+	v.dc      = reinterpret_cast<uint64_t *>(r + a.tm_off_dc);
+	return v;
+}
+
+__device__ __forceinline__ uint32_t lc_slot(uint32_t id, uint32_t slots)
+{
+	return ((id * 0x9E3779B1u) >> 11) & (slots - 1);
+}
+
+// main: the link list of `c` from a helper's link cache.  Wave-uniform result; lane j gets link j.
+__device__ __forceinline__ bool team_links(unsigned char *smem, const SearchArgs &a, uint32_t hmask, uint32_t c, uint32_t j, uint32_t &t)
+{
+	for (uint32_t m = hmask; m; m &= m - 1)
+	{
+		const TeamView v = team_view(smem, a, (uint32_t) __builtin_ctz(m));
+		const uint32_t s = lc_slot(c, a.tm_lcslots);
+		uint32_t tag = __builtin_amdgcn_readfirstlane(v.lctag[s]), st = __builtin_amdgcn_readfirstlane(v.lcstate[s]);
+		if (tag != c || st < LC_LINKS) continue;
+		const uint32_t val = v.lclinks[s * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
+		wave_sync();                                  // the copy is read before the tag is checked again
+		tag = __builtin_amdgcn_readfirstlane(v.lctag[s]);
+		st = __builtin_amdgcn_readfirstlane(v.lcstate[s]);
+		if (tag == c && st >= LC_LINKS) { t = val; return true; }      // not re-claimed meanwhile: the copy is whole
+	}
+	return false;
+}
+
+// main: ord(dist) of element `id` from the helpers' distance caches (per lane)
+__device__ __forceinline__ bool team_dist(unsigned char *smem, const SearchArgs &a, uint32_t hmask, uint32_t id, uint32_t &od)
+{
+	const uint32_t cmask = a.tm_dccap - 1;
+	for (uint32_t m = hmask; m; m &= m - 1)
+	{
+		const uint64_t *dc = team_view(smem, a, (uint32_t) __builtin_ctz(m)).dc;
+		uint32_t s = hash_slot(id, cmask);
+		for (uint32_t probe = 0; probe < 24; probe++)
+		{
+			const uint64_t e = dc[s];
+			if ((uint32_t) (e >> 32) == id) { od = (uint32_t) e; return true; }
+			if (e == DC_EMPTY) break;
+			s = (s + 1) & cmask;
+		}
+	}
+	return false;
+}
+
+// helper's look at the main's visited set: bounded, because the main may be past its walk and have reused the area
+__device__ __forceinline__ bool hash_contains_bounded(const uint32_t *tab, uint32_t mask, uint32_t id)
+{
+	uint32_t s = hash_slot(id, mask);
+	for (uint32_t probe = 0; probe < 48; probe++)
+	{
+		const uint32_t v = tab[s];
+		if (v == id) return true;
+		if (v == HASH_EMPTY) return false;
+		s = (s + 1) & mask;
+	}
+	return false;
+}
+
+__device__ __forceinline__ bool dc_contains(const uint64_t *dc, uint32_t cmask, uint32_t id)
+{
+	uint32_t s = hash_slot(id, cmask);
+	for (uint32_t probe = 0; probe < 24; probe++)
+	{
+		const uint64_t e = dc[s];
+		if ((uint32_t) (e >> 32) == id) return true;
+		if (e == DC_EMPTY) return false;
+		s = (s + 1) & cmask;
+	}
+	return false;
+}
+
+// helper: insert (id -> od); lanes of the wave may collide on a slot, other waves only read
+__device__ __forceinline__ void dc_insert(uint64_t *dc, uint32_t cmask, uint32_t id, uint32_t od)
+{
+	const uint64_t e = ((uint64_t) id << 32) | od;
+	uint32_t s = hash_slot(id, cmask);
+	for (uint32_t probe = 0; probe < 64; probe++)
+	{
+		const uint64_t old = atomicCAS(reinterpret_cast<unsigned long long *>(&dc[s]), (unsigned long long) DC_EMPTY, (unsigned long long) e);
+		if (old == DC_EMPTY || (uint32_t) (old >> 32) == id) return;
+		s = (s + 1) & cmask;
+	}
+}
+
+// smallest 64-bit value over the wavefront (uniform); ~0 when every lane passes ~0
+__device__ __forceinline__ uint64_t wave_min_u64(uint64_t v)
+{
+	const uint32_t h = (uint32_t) (v >> 32);
+	const uint32_t hmin = wave_min_u32(h);
+	const uint32_t lo = (h == hmin) ? (uint32_t) v : 0xFFFFFFFFu;
+	const uint32_t lomin = wave_min_u32(lo);
+	return ((uint64_t) hmin << 32) | lomin;
+}
+
+// The life of a wave that has no query: help walking siblings until none is left.
 template <int FUNC, typename SH, int UREG>
-__global__ __launch_bounds__(256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MIN_WAVES) void hnsw_search_kernel_beam(const SearchArgs a)
+__device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *smem, TeamCtl *ctl, uint32_t wib, uint32_t wpb, int lane)
+{
+	const TeamView mine = team_view(smem, a, wib);
+	unsigned char *my = smem + (size_t) wib * a.wave_bytes;
+	uint32_t *newid   = reinterpret_cast<uint32_t *>(my + a.off_newid);
+	float    *newdist = reinterpret_cast<float *>(my + a.off_newdist);
+	const uint32_t cmask = a.tm_dccap - 1;
+	for (;;)
+	{
+		// ---- pick the walking sibling with the fewest helpers -------------------------------
+		uint32_t target = 0xFFFFFFFFu, best = 0xFFFFFFFFu;
+		bool pending = false;
+		for (uint32_t m = 0; m < wpb; m++)
+		{
+			if (m == wib) continue;
+			const uint32_t st = __builtin_amdgcn_readfirstlane(ctl[m].state);
+			if (st == 0) pending = true;
+			if (st != 1) continue;
+			const uint32_t cnt = (uint32_t) __builtin_popcount(__builtin_amdgcn_readfirstlane(ctl[m].helpers));
+			if (cnt < best) { best = cnt; target = m; }
+		}
+		if (target == 0xFFFFFFFFu)
+		{
+			if (!pending) return;                      // nobody will walk again
+			__builtin_amdgcn_s_sleep(8);
+			continue;
+		}
+		// ---- my region becomes that walk's cache ---------------------------------------------
+		for (uint32_t i = lane; i < a.tm_dccap; i += 64) mine.dc[i] = DC_EMPTY;
+		for (uint32_t i = lane; i < a.tm_lcslots; i += 64) { mine.lctag[i] = LINK_NONE; mine.lcstate[i] = 0; }
+		for (uint32_t i = lane; i < 64u * UREG; i += 64) mine.pub[i] = ~0ull;
+		mine.ex[lane] = 0;
+		wave_sync();
+		if (lane == 0) atomicOr(&ctl[target].helpers, 1u << wib);
+		unsigned char *mreg = smem + (size_t) target * a.wave_bytes;
+		const float4 *q4 = reinterpret_cast<const float4 *>(mreg);
+		const uint32_t *mhtab = reinterpret_cast<const uint32_t *>(mreg + a.off_hash);
+		const uint32_t mhmask = a.hcap - 1;
+		float qnorm = 0.f;
+		if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
+		uint32_t dcount = 0;
+		uint64_t last_done = ~0ull;                    // the last element I finished, as a candidate key
+
+		while (__builtin_amdgcn_readfirstlane(ctl[target].state) == 1)
+		{
+			const uint32_t hm = __builtin_amdgcn_readfirstlane(ctl[target].helpers);
+			if (!(hm & (1u << wib))) break;
+			const TeamView pubv = team_view(smem, a, (uint32_t) __builtin_ctz(hm));
+			uint32_t myrank = (uint32_t) __builtin_popcount(hm & ((1u << wib) - 1u));
+			// snapshot of the main's accepted set: candidate keys (dist, ~idx) of the unexpanded elements
+			uint64_t ck[UREG];
+			const uint32_t ex = pubv.ex[lane];
+#pragma unroll
+			for (int k = 0; k < UREG; k++)
+			{
+				const uint64_t key = pubv.pub[k * 64 + lane];
+				const bool open = !((ex >> k) & 1u) && (uint32_t) (key >> 32) != 0xFFFFFFFFu && (uint32_t) key < a.n;
+				ck[k] = open ? (key ^ 0xFFFFFFFFull) : ~0ull;
+			}
+			// the myrank-th smallest that nobody has cached yet (at most myrank + 4 steps down the order)
+			uint64_t prev = 0, pick = ~0ull;
+			bool first = true;
+			for (uint32_t step = 0; step < myrank + 5; step++)
+			{
+				uint64_t m = ~0ull;
+#pragma unroll
+				for (int k = 0; k < UREG; k++)
+				{
+					const bool ok = first || ck[k] > prev;
+					m = (ok && ck[k] < m) ? ck[k] : m;
+				}
+				m = wave_min_u64(m);
+				if (m == ~0ull) break;
+				prev = m; first = false;
+				if (step < myrank) continue;
+				const uint32_t c = ~(uint32_t) m;
+				bool cached = (m == last_done);
+				for (uint32_t mm = hm; mm && !cached; mm &= mm - 1)
+				{
+					const TeamView v = team_view(smem, a, (uint32_t) __builtin_ctz(mm));
+					const uint32_t s = lc_slot(c, a.tm_lcslots);
+					cached = __builtin_amdgcn_readfirstlane(v.lctag[s]) == c && __builtin_amdgcn_readfirstlane(v.lcstate[s]) >= LC_CLAIMED;
+				}
+				if (!cached) { pick = m; break; }
+			}
+			if (pick == ~0ull) { __builtin_amdgcn_s_sleep(4); continue; }
+			const uint32_t cand = ~(uint32_t) pick;
+
+			if (dcount + 2 * a.lstride > a.tm_dccap - a.tm_dccap / 4)       // cache nearly full: start over
+			{
+				for (uint32_t i = lane; i < a.tm_dccap; i += 64) mine.dc[i] = DC_EMPTY;
+				dcount = 0;
+				wave_sync();
+			}
+			const uint32_t slot = lc_slot(cand, a.tm_lcslots);
+			if (lane == 0) { mine.lcstate[slot] = LC_CLAIMED; mine.lctag[slot] = cand; }
+			wave_sync();
+			for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)                    // hnswalg.cpp:76-77, ahead of time
+			{
+				const uint32_t j = j0 + lane;
+				const uint32_t t = a.links[(size_t) cand * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
+				if (j < a.lstride) mine.lclinks[slot * a.lstride + j] = t;
+			}
+			wave_sync();
+			if (lane == 0) mine.lcstate[slot] = LC_LINKS;
+			wave_sync();
+			for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)
+			{
+				const uint32_t j = j0 + lane;
+				const uint32_t t = (j < a.lstride) ? mine.lclinks[slot * a.lstride + j] : LINK_NONE;
+				bool need = j < a.lstride && t != LINK_NONE && t < a.n;
+				if (need && a.hcap) need = !hash_contains_bounded(mhtab, mhmask, t);  // a stale view only costs work
+				if (need) need = !dc_contains(mine.dc, cmask, t);
+				const uint64_t nm = __ballot(need);
+				const uint32_t nn = (uint32_t) __builtin_popcountll(nm);
+				if (nn == 0) continue;
+				if (need) newid[lane_rank(nm)] = t;
+				wave_sync();
+				{
+					const uint32_t *ids = newid;
+					auto by_id = [ids](uint32_t r) { return ids[r]; };
+					score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nn, newdist, lane);
+				}
+				wave_sync();
+				const uint32_t od = ord_f32(finish_dist<FUNC>(newdist[lane], newdist[OUT2 + lane], qnorm));
+				if ((uint32_t) lane < nn) dc_insert(mine.dc, cmask, newid[lane], od);
+				dcount += nn;
+				wave_sync();
+			}
+			last_done = pick;
+		}
+		if (lane == 0) atomicAnd(&ctl[target].helpers, ~(1u << wib));
+	}
+}
+
+template <int FUNC, typename SH, int UREG, bool TEAM = false>
+__global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MIN_WAVES) void hnsw_search_kernel_beam(const SearchArgs a)
 {
 	constexpr uint32_t UCAP = 64u * UREG;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1096,9 +1384,17 @@ __global__ __launch_bounds__(256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MI
 	uint32_t *vlog = a.vlog + (size_t) slot * a.logcap;
 	uint64_t *scratch = a.beam_scratch + (size_t) slot * UCAP;
 	const uint32_t ef = a.ef;
+	TeamCtl *ctl = reinterpret_cast<TeamCtl *>(smem + a.off_ctl);
+	const uint32_t wpb = blockDim.x >> 6;
+	if (TEAM)
+	{
+		if (lane == 0) { ctl[wib].state = wib < a.team_mains ? 0u : 2u; ctl[wib].helpers = 0u; }
+		__syncthreads();
+	}
 
 	for (;;)
 	{
+		if (TEAM && wib >= a.team_mains) break;                       // this wave only ever helps
 		uint32_t qi = 0;
 		if (lane == 0) qi = atomicAdd(a.ticket, 1u);
 		qi = __builtin_amdgcn_readfirstlane(qi);
@@ -1148,9 +1444,13 @@ __global__ __launch_bounds__(256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MI
 			logn = spill ? 1 : 0;
 			hcount = 1;
 			wave_sync();
+			if (TEAM && lane == 0) ctl[wib].state = 1u;                     // helpers may attach from here on
 
 			for (;;)                                                        // hnswalg.cpp:67-112
 			{
+				// helpers attached to this walk (wave-uniform; read early, used after the pop)
+				uint32_t hm = 0;
+				if (TEAM) hm = __builtin_amdgcn_readfirstlane(ctl[wib].helpers);
 				uint32_t cslot;
 				uint64_t ckey;
 				if (!beam_next<UREG>(uk, ex, cslot, ckey)) break;          // candidateSet empty
@@ -1159,11 +1459,21 @@ __global__ __launch_bounds__(256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MI
 				const uint32_t cur = ~(uint32_t) ckey;
 				ex |= ((uint32_t) lane == (cslot & 63)) ? (1u << (cslot >> 6)) : 0u;   // :73 pop
 				hops++;
+				TeamView h0v = {};
+				if (TEAM && hm)                                             // publish the accepted set for the helpers
+				{
+					h0v = team_view(smem, a, (uint32_t) __builtin_ctz(hm));
+#pragma unroll
+					for (int k = 0; k < UREG; k++) h0v.pub[k * 64 + lane] = uk[k];
+					h0v.ex[lane] = ex;
+				}
 
 				for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)               // :76-77
 				{
 					const uint32_t j = j0 + lane;
-					const uint32_t t = a.links[(size_t) cur * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
+					uint32_t t = 0;
+					if (!(TEAM && hm && team_links(smem, a, hm, cur, j, t)))
+						t = a.links[(size_t) cur * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
 					bool isnew = false;
 					if (j < a.lstride && t != LINK_NONE)                    // :91-93
 					{
@@ -1215,14 +1525,39 @@ __global__ __launch_bounds__(256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MI
 						}
 					}
 					wave_sync();
+					uint32_t od_mine;
+					if (TEAM && hm)
+					{
+						// distances a helper has already computed come from its cache; only the misses are scored here
+						uint32_t od_c = 0;
+						const uint32_t myid = newid[lane];
+						bool hit = false;
+						if ((uint32_t) lane < nnew) hit = team_dist(smem, a, hm, myid, od_c);
+						const uint64_t all = nnew >= 64 ? ~0ull : ((1ull << nnew) - 1ull);
+						const uint64_t missm = ~__ballot(hit) & all;
+						const uint32_t nmiss = (uint32_t) __builtin_popcountll(missm);
+						const uint32_t krank = lane_rank(missm);
+						if (nmiss)
+						{
+							if (!hit && (uint32_t) lane < nnew) h0v.miss[krank] = myid;
+							wave_sync();
+							const uint32_t *ids = h0v.miss;
+							auto by_id = [ids](uint32_t r) { return ids[r]; };
+							score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nmiss, newdist, lane);
+							wave_sync();
+						}
+						const uint32_t od_m = ord_f32(finish_dist<FUNC>(newdist[krank & 63], newdist[OUT2 + (krank & 63)], qnorm));
+						od_mine = hit ? od_c : od_m;
+					}
+					else
 					{
 						const uint32_t *ids = newid;
 						auto by_id = [ids](uint32_t r) { return ids[r]; };
 						score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nnew, newdist, lane);
+						wave_sync();
+						od_mine = ord_f32(finish_dist<FUNC>(newdist[lane], newdist[OUT2 + lane], qnorm));
 					}
 					evals += nnew;
-					wave_sync();
-					const uint32_t od_mine = ord_f32(finish_dist<FUNC>(newdist[lane], newdist[OUT2 + lane], qnorm));
 					const uint32_t t_mine = newid[lane];
 					// rows at or above a valid upper bound of lowerBound cannot be accepted (:99)
 					uint64_t todo = __ballot((uint32_t) lane < nnew && od_mine < bstale);
@@ -1252,6 +1587,7 @@ __global__ __launch_bounds__(256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MI
 			}
 		}
 
+		if (TEAM && lane == 0) ctl[wib].state = 0u;                       // walk over: helpers let go
 		// ---- emit: the ef smallest (dist, idx) keys of the set, then the reference's output order ----
 		uint32_t rsize = usize;
 		if (usize > ef)
@@ -1375,6 +1711,12 @@ __global__ __launch_bounds__(256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MI
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_s_waitcnt(0);
 		wave_sync();
+	}
+	if (TEAM)
+	{
+		if (lane == 0) ctl[wib].state = 2u;
+		wave_sync();
+		team_help<FUNC, SH, UREG>(a, smem, ctl, wib, wpb, lane);
 	}
 }
 

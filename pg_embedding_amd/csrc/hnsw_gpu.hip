@@ -446,16 +446,23 @@ typedef void (*search_kernel_t)(const SearchArgs);
 // rreg: 0 = generic form, sets in LDS; 1 = generic form, sets in HBM (any ef); 2 / 4 = register form for ef <= 128 / 256,
 //       -2 / -4 / -8 / -16 = beam form (counting acceptance) with that many set registers, ef <= 64 / 128 / 256 / 512
 template <typename SH, int RREG>
-static search_kernel_t pick_search_kernel_f(int func)
+static search_kernel_t pick_search_kernel_f(int func, bool team)
 {
 	if (RREG < 0)
 	{
 		constexpr int U = RREG < 0 ? -RREG : 2;
+		if (team)
+			switch (func)
+			{
+				case F_L2:     return hnsw_search_kernel_beam<F_L2, SH, U, true>;
+				case F_COSINE: return hnsw_search_kernel_beam<F_COSINE, SH, U, true>;
+				default:       return hnsw_search_kernel_beam<F_MANHATTAN, SH, U, true>;
+			}
 		switch (func)
 		{
-			case F_L2:     return hnsw_search_kernel_beam<F_L2, SH, U>;
-			case F_COSINE: return hnsw_search_kernel_beam<F_COSINE, SH, U>;
-			default:       return hnsw_search_kernel_beam<F_MANHATTAN, SH, U>;
+			case F_L2:     return hnsw_search_kernel_beam<F_L2, SH, U, false>;
+			case F_COSINE: return hnsw_search_kernel_beam<F_COSINE, SH, U, false>;
+			default:       return hnsw_search_kernel_beam<F_MANHATTAN, SH, U, false>;
 		}
 	}
 	if (RREG == 1)          // generic form, sets in HBM
@@ -482,31 +489,31 @@ static search_kernel_t pick_search_kernel_f(int func)
 }
 
 template <typename SH>
-static search_kernel_t pick_search_kernel_s(int func, int rreg)
+static search_kernel_t pick_search_kernel_s(int func, int rreg, bool team)
 {
 	switch (rreg)
 	{
-		case 2:  return pick_search_kernel_f<SH, 2>(func);
-		case 4:  return pick_search_kernel_f<SH, 4>(func);
-		case -2: return pick_search_kernel_f<SH, -2>(func);
-		case -4: return pick_search_kernel_f<SH, -4>(func);
-		case -8: return pick_search_kernel_f<SH, -8>(func);
-		case -16: return pick_search_kernel_f<SH, -16>(func);
-		case 1:  return pick_search_kernel_f<SH, 1>(func);
-		default: return pick_search_kernel_f<SH, 0>(func);
+		case 2:  return pick_search_kernel_f<SH, 2>(func, false);
+		case 4:  return pick_search_kernel_f<SH, 4>(func, false);
+		case -2: return pick_search_kernel_f<SH, -2>(func, team);
+		case -4: return pick_search_kernel_f<SH, -4>(func, team);
+		case -8: return pick_search_kernel_f<SH, -8>(func, team);
+		case -16: return pick_search_kernel_f<SH, -16>(func, team);
+		case 1:  return pick_search_kernel_f<SH, 1>(func, false);
+		default: return pick_search_kernel_f<SH, 0>(func, false);
 	}
 }
 
-static search_kernel_t pick_search_kernel(int func, uint32_t kiters, int rreg)
+static search_kernel_t pick_search_kernel(int func, uint32_t kiters, int rreg, bool team)
 {
 	switch (shape_index(kiters))
 	{
-		case 0:  return pick_search_kernel_s<Shape2x4>(func, rreg);
-		case 1:  return pick_search_kernel_s<Shape4x2>(func, rreg);
-		case 2:  return pick_search_kernel_s<Shape8x2>(func, rreg);
+		case 0:  return pick_search_kernel_s<Shape2x4>(func, rreg, team);
+		case 1:  return pick_search_kernel_s<Shape4x2>(func, rreg, team);
+		case 2:  return pick_search_kernel_s<Shape8x2>(func, rreg, team);
 		default:
-			if (getenv("HNSW_GPU_SHAPE_12X1")) return pick_search_kernel_s<Shape12x1>(func, rreg);
-			return pick_search_kernel_s<Shape12x2>(func, rreg);
+			if (getenv("HNSW_GPU_SHAPE_12X1")) return pick_search_kernel_s<Shape12x1>(func, rreg, team);
+			return pick_search_kernel_s<Shape12x2>(func, rreg, team);
 	}
 }
 
@@ -624,12 +631,57 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 					a.wave_bytes, LDS_PER_CU);
 	uint32_t wpb = 4;
 	while (wpb > 1 && (size_t) wpb * a.wave_bytes > 64 * 1024) wpb >>= 1;
-	const size_t lds = (size_t) wpb * a.wave_bytes;
-	search_kernel_t kern = pick_search_kernel((int) ix->meta.dist_func, a.kiters, rreg);
+	// Team form of the beam kernel (device_search.h, "Team form"): waves of a block that have no query help a
+	// sibling's walk through LDS caches carved out of their own (otherwise idle) regions.  Used when the launch
+	// cannot fill the chip anyway — fewer queries than resident waves — where a query's latency is what matters:
+	// the one-query call of the drop-in boundary (embedding.c:317) above all.  HNSW_GPU_TEAM=0/1 forces it off/on,
+	// HNSW_GPU_TEAM_MAX_NQ moves the automatic threshold, HNSW_GPU_TEAM_WPB the waves per block (default: 8 if the
+	// LDS of a block allows).
+	bool team = false;
+	if (rreg < 0)
+	{
+		const char *tenv = getenv("HNSW_GPU_TEAM");
+		const int treq = tenv ? atoi(tenv) : -1;
+		const char *tmax = getenv("HNSW_GPU_TEAM_MAX_NQ");
+		const size_t auto_nq = tmax ? (size_t) atoll(tmax) : (size_t) ix->num_cu;
+		const size_t pub = (size_t) 64 * ucap / 64 * 8;                 // 64*UREG keys
+		uint32_t lcs = 8;
+		size_t o_ex = pub, o_miss = o_ex + 256, o_tag = o_miss + 256, o_state = 0, o_links = 0, o_dc = 0, dccap = 0;
+		for (; lcs >= 4; lcs >>= 1)
+		{
+			o_state = o_tag + lcs * 4; o_links = o_state + lcs * 4;
+			o_dc = round_up(o_links + (size_t) lcs * a.lstride * 4, 16);
+			dccap = 0;
+			if (o_dc + 256 * 8 <= a.off_newid)
+			{
+				dccap = 256;
+				while (o_dc + dccap * 2 * 8 <= a.off_newid && dccap < 4096) dccap *= 2;
+				break;
+			}
+		}
+		if (dccap >= 256 && treq != 0 && (treq > 0 || nq <= auto_nq))
+		{
+			team = true;
+			a.tm_off_ex = (uint32_t) o_ex; a.tm_off_miss = (uint32_t) o_miss; a.tm_off_lctag = (uint32_t) o_tag;
+			a.tm_off_lcstate = (uint32_t) o_state; a.tm_off_lclinks = (uint32_t) o_links; a.tm_lcslots = lcs;
+			a.tm_off_dc = (uint32_t) o_dc; a.tm_dccap = (uint32_t) dccap;
+			int maxlds = 64 * 1024;
+			(void) hipDeviceGetAttribute(&maxlds, hipDeviceAttributeMaxSharedMemoryPerBlock, ix->device);
+			const char *wenv = getenv("HNSW_GPU_TEAM_WPB");
+			uint32_t want = wenv && atoi(wenv) > 0 ? (uint32_t) atoi(wenv) : 8u;
+			want = std::min(want, 8u);
+			wpb = std::max<uint32_t>(1, (uint32_t) std::min<size_t>(want, ((size_t) maxlds - 8 * sizeof(TeamCtl)) / a.wave_bytes));
+			if (wpb < 2) team = false;
+		}
+	}
+	if (!team) { wpb = 4; while (wpb > 1 && (size_t) wpb * a.wave_bytes > 64 * 1024) wpb >>= 1; }
+	a.off_ctl = (uint32_t) ((size_t) wpb * a.wave_bytes);
+	const size_t lds = (size_t) wpb * a.wave_bytes + (team ? wpb * sizeof(TeamCtl) : 0);
+	search_kernel_t kern = pick_search_kernel((int) ix->meta.dist_func, a.kiters, rreg, team);
 	{
 		static const char *const shapes[4] = { "Shape2x4", "Shape4x2", "Shape8x2", "Shape12x2" };
 		const char *shp = (shape_index(a.kiters) == 3 && getenv("HNSW_GPU_SHAPE_12X1")) ? "Shape12x1" : shapes[shape_index(a.kiters)];
-		if (rreg < 0) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_beam<%d, pgemb::%s, %d>", (int) ix->meta.dist_func, shp, -rreg);
+		if (rreg < 0) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_beam<%d, pgemb::%s, %d, %s>", (int) ix->meta.dist_func, shp, -rreg, team ? "true" : "false");
 		else if (rreg >= 2) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_reg<%d, pgemb::%s, %d>", (int) ix->meta.dist_func, shp, rreg);
 		else snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_lds<%d, pgemb::%s, %s>", (int) ix->meta.dist_func, shp, rreg == 1 ? "true" : "false");
 	}
@@ -641,6 +693,13 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	const char *env = getenv("HNSW_GPU_BLOCKS_PER_CU");
 	if (env && atoi(env) > 0) per_cu = std::min(per_cu, atoi(env));
 	size_t blocks = std::min<size_t>((nq + wpb - 1) / wpb, (size_t) per_cu * ix->num_cu);
+	a.team_mains = wpb;
+	if (team && nq < (size_t) per_cu * ix->num_cu * wpb)
+	{
+		// fewer queries than resident waves: spread them over the blocks, the other waves of a block start as helpers
+		blocks = std::min<size_t>(nq, (size_t) per_cu * ix->num_cu);
+		a.team_mains = (uint32_t) std::min<size_t>(wpb, (nq + blocks - 1) / blocks);
+	}
 
 	// workspace: one bitmap + log per resident wave
 	const size_t words = std::max<size_t>(1, (ix->cap + 31) / 32);   // by capacity: stable while the index grows

@@ -275,6 +275,10 @@ def test_many_queries_reuse_slots():
     {"HNSW_GPU_BEAM": "0"},                  # two-set register form instead of the beam form
     {"HNSW_GPU_BEAM": "0", "HNSW_GPU_HASH_ENTRIES": "512"},
     {"HNSW_GPU_BEAM16": "0"},                # ef in (256, 512]: LDS form instead of 16 set registers
+    {"HNSW_GPU_TEAM": "1"},                  # team form: idle waves of a block feed a sibling's walk from LDS caches
+    {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "4"},
+    {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "2", "HNSW_GPU_HASH_ENTRIES": "512"},
+    {"HNSW_GPU_TEAM": "0"},
     {},
 ])
 def test_every_kernel_variant_is_exact(env, monkeypatch):
@@ -300,6 +304,33 @@ def test_every_kernel_variant_is_exact(env, monkeypatch):
     # a second launch on the same slots: bitmap bits set by the spill path were undone
     labels2, _, _ = ix.search(Q, 100)
     assert (labels2 == port.search_many(Q, 100)["labels"]).all()
+    ix.close()
+
+
+@pytest.mark.parametrize("func", FUNCS)
+@pytest.mark.parametrize("dim,m", [(128, 16), (768, 16), (1536, 32), (100, 40)])
+def test_team_form_is_exact_at_every_launch_size(func, dim, m, monkeypatch):
+    """Team form (device_search.h): from one query per launch (1 walking wave + 7 helpers per block) through
+    launches where most waves walk and helpers only appear in the tail — ids, distance bits, E_q and H_q must
+    equal the oracle's, i.e. the one-wave form's.  m=40 exercises link lists longer than one wave (maxM=80)."""
+    import torch
+    monkeypatch.setenv("HNSW_GPU_TEAM", "1")
+    n = 6000
+    port, X = build_port(n, dim, m, 48, func, seed=3 * dim + func)
+    Q = gmm(700, dim, k=50, seed=3 * dim + func, stream=1)
+    ix = mirror(port, func)
+    ef = 96
+    want = port.search_many(Q, ef, nthreads=8)
+    dQ = torch.from_numpy(Q).cuda()
+    for nq in (1, 3, 64, 700):
+        for rep in range(2):               # second launch: caches and control words start from a used LDS
+            out = ix.search_torch(dQ[:nq].contiguous(), ef, stats=True)
+            torch.cuda.synchronize()
+            assert "true>" in ix.last_search_kernel()
+            assert (out["labels"].cpu().numpy().view(np.uint64) == want["labels"][:nq]).all(), (nq, rep)
+            assert (bits(out["dists"].cpu().numpy()) == bits(want["dists"][:nq])).all()
+            st = out["stats"].cpu().numpy().astype(np.uint32)
+            assert (st[:, 0] == want["evals"][:nq]).all() and (st[:, 1] == want["hops"][:nq]).all()
     ix.close()
 
 
