@@ -133,6 +133,16 @@ int hnsw_gpu_search_ms(hnsw_gpu_index *ix, unsigned back, float *ms);
  * can be matched by name. */
 int hnsw_gpu_last_search_kernel(hnsw_gpu_index *ix, char *buf, size_t len);
 
+/* Diagnostics of the team form of the search kernel (launches with fewer queries than resident waves: idle
+ * waves of a block pre-fetch link lists and distances for a sibling's walk).  With HNSW_GPU_TEAM_COUNTERS=1 in
+ * the environment the last launch of the mirror's default workspace counted, over all its queries:
+ * out[0] hops that had helpers, [1] link lists served from a helper's cache, [2] neighbour ids looked up,
+ * [3] distances served from a cache, [4] hops that still scored rows themselves, [5] all hops, [6] polls spent
+ * waiting for a helper that had the element in flight, [10] hops that waited, [7]/[8]/[9] shader cycles of the
+ * walking waves in: pop + stop test + link list / visited test + distances / accept loop, [11] elements the
+ * helpers finished, [12] helper cycles spent on them.  `out` holds 16 values. */
+int hnsw_gpu_team_counters(hnsw_gpu_index *ix, uint32_t *out16);
+
 /* Resident query slots (waves) the last search launch used — occupancy figure. */
 int hnsw_gpu_last_search_slots(hnsw_gpu_index *ix, uint32_t *slots);
 

@@ -89,6 +89,8 @@ struct SearchArgs
 	uint32_t team_mains;        // waves of a block that take queries (wib < team_mains); the others start as helpers
 	uint32_t off_ctl;           // byte offset of the block's TeamCtl array in dynamic LDS (behind the wave regions)
 	uint32_t tm_off_ex, tm_off_miss, tm_off_lctag, tm_off_lcstate, tm_off_lclinks, tm_lcslots, tm_off_dc, tm_dccap;
+	uint32_t *team_dbg;         // null, or 16 counters for the whole launch (hnsw_gpu_team_counters): hops with helpers,
+	                            // link-list hits, ids looked up, distance hits, hops that still scored rows, all hops
 };
 
 // Streamed completion: everything this wave wrote for the query becomes visible system-wide, then
@@ -1089,17 +1091,20 @@ __device__ __forceinline__ void beam_set(uint64_t (&uk)[U], uint32_t slot, uint6
 // ahead: a distance is a pure function of (query, row), a link list a pure function of the element.
 //   * The walking wave ("main") publishes its accepted set (keys + expanded bits) once per hop.
 //   * A helper picks the r-th best unexpanded element of that snapshot (r = its rank among the helpers; r = 0
-//     is the predicted next pop: right in 83-85 % of the hops), loads its link list into a small link cache,
-//     scores the neighbours that are not yet visited with the SAME canonical code and puts (id -> ord(dist))
-//     into a distance cache.  Both caches live in the helper's own LDS region (it has no query of its own),
-//     so helpers cost no extra LDS and write only their own region.
-//   * The main walks exactly as before — pops, marks visited and accepts in the reference's order — but
-//     takes a link list or a distance from a cache when it is there and fetches/scores only what is not.
-// Exactness: every cached value is identical, bit for bit, to what the main would compute (same code, same
-// summation order; entries carry their id, a link-list copy is validated by re-reading its tag after the
-// copy), and nothing a helper does can change WHICH values the walk consumes or in what order.  A stale or
-// torn snapshot only makes a helper fetch something useless.  Outputs, E_q and H_q equal the one-wave form
-// (tests/test_gpu_search.py::test_every_kernel_variant_is_exact).
+//     is the predicted next pop: right in 83-85 % of the hops), loads its link list, scores the neighbours the
+//     main has not visited yet with the SAME canonical code, and leaves a "package" for that element in a slot of
+//     its own LDS region (it has no query of its own, so helpers cost no extra LDS and write only their own
+//     region): per link position (neighbour id, ord(dist)).
+//   * The main walks exactly as before — pops, marks visited and accepts in the reference's order — but when a
+//     package for the popped element exists it takes link list and distances from it (waiting for a helper that
+//     has the element in flight: that helper is further along than a fresh fetch would be and depends on
+//     nothing the main does) and fetches/scores only what a package does not hold.
+// Exactness: a packaged value is identical, bit for bit, to what the main would compute (same code, same
+// summation order); a package is validated by re-reading its header (element, state) after the copy; a
+// neighbour a helper skipped as visited IS visited (the main's visited set only grows during a walk), and
+// nothing a helper does can change WHICH values the walk consumes or in what order.  A stale or torn snapshot
+// only makes a helper fetch something useless.  Outputs, E_q and H_q equal the one-wave form
+// (tests/test_gpu_search.py::test_every_kernel_variant_is_exact, ::test_team_form_is_exact_at_every_launch_size).
 // =====================================================================================
 struct TeamCtl
 {
@@ -1108,28 +1113,31 @@ struct TeamCtl
 	uint32_t pad0, pad1;
 };
 constexpr uint64_t DC_EMPTY = ~0ull;
-enum : uint32_t { LC_CLAIMED = 1u, LC_LINKS = 2u };
+constexpr uint32_t OD_MISSING = 0xFFFFFFFFu;      // package entry without a distance (ord() of a real distance is never all ones: that is a NaN payload no sum produces... guarded anyway: such an entry is simply re-scored)
+constexpr uint32_t PK_VISITED = 0x80000000u;
+constexpr int TEAM_MAX_WPB = 8;
+enum : uint32_t { LC_CLAIMED = 1u, LC_DONE = 2u };   // package slot: claimed (in flight) -> complete
 
-struct TeamView            // the cache carve of one (helper's) LDS region
+struct TeamView            // the carve of one (helper's) LDS region
 {
 	uint64_t *pub;         // 64*UREG keys: the main's accepted set (only in the region of its lowest helper)
 	uint32_t *ex;          // 64 words: expanded bits per lane
-	uint32_t *miss;        // 64 ids: the main's compaction scratch for cache misses
-	uint32_t *lctag, *lcstate, *lclinks;   // link cache: tm_lcslots direct-mapped slots of lstride ids
-	uint64_t *dc;          // distance cache: open addressing, entry = id << 32 | ord(dist)
+	uint32_t *miss;        // 64 ids: the main's compaction scratch for neighbours a package has no distance for
+	uint64_t *hdr;         // tm_lcslots direct-mapped package slots: element | state << 32 ...
+	uint64_t *pk;          // ... and lstride entries each: neighbour id | ord(dist) << 32
+	uint64_t *dc;          // the helper's own memo of distances it has computed for this walk: id << 32 | ord(dist)
 };
 
 __device__ __forceinline__ TeamView team_view(unsigned char *smem, const SearchArgs &a, uint32_t w)
 {
 	unsigned char *r = smem + (size_t) w * a.wave_bytes;
 	TeamView v;
-	v.pub     = reinterpret_cast<uint64_t *>(r);
-	v.ex      = reinterpret_cast<uint32_t *>(r + a.tm_off_ex);
-	v.miss    = reinterpret_cast<uint32_t *>(r + a.tm_off_miss);
-	v.lctag   = reinterpret_cast<uint32_t *>(r + a.tm_off_lctag);
-	v.lcstate = reinterpret_cast<uint32_t *>(r + a.tm_off_lcstate);
-	v.lclinks = reinterpret_cast<uint32_t *>(r + a.tm_off_lclinks);
-	v.dc      = reinterpret_cast<uint64_t *>(r + a.tm_off_dc);
+	v.pub  = reinterpret_cast<uint64_t *>(r);
+	v.ex   = reinterpret_cast<uint32_t *>(r + a.tm_off_ex);
+	v.miss = reinterpret_cast<uint32_t *>(r + a.tm_off_miss);
+	v.hdr  = reinterpret_cast<uint64_t *>(r + a.tm_off_lctag);
+	v.pk   = reinterpret_cast<uint64_t *>(r + a.tm_off_lclinks);
+	v.dc   = reinterpret_cast<uint64_t *>(r + a.tm_off_dc);
 	return v;
 }
 
@@ -1138,41 +1146,20 @@ __device__ __forceinline__ uint32_t lc_slot(uint32_t id, uint32_t slots)
 	return ((id * 0x9E3779B1u) >> 11) & (slots - 1);
 }
 
-// main: the link list of `c` from a helper's link cache.  Wave-uniform result; lane j gets link j.
-__device__ __forceinline__ bool team_links(unsigned char *smem, const SearchArgs &a, uint32_t hmask, uint32_t c, uint32_t j, uint32_t &t)
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v)
 {
-	for (uint32_t m = hmask; m; m &= m - 1)
-	{
-		const TeamView v = team_view(smem, a, (uint32_t) __builtin_ctz(m));
-		const uint32_t s = lc_slot(c, a.tm_lcslots);
-		uint32_t tag = __builtin_amdgcn_readfirstlane(v.lctag[s]), st = __builtin_amdgcn_readfirstlane(v.lcstate[s]);
-		if (tag != c || st < LC_LINKS) continue;
-		const uint32_t val = v.lclinks[s * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
-		wave_sync();                                  // the copy is read before the tag is checked again
-		tag = __builtin_amdgcn_readfirstlane(v.lctag[s]);
-		st = __builtin_amdgcn_readfirstlane(v.lcstate[s]);
-		if (tag == c && st >= LC_LINKS) { t = val; return true; }      // not re-claimed meanwhile: the copy is whole
-	}
-	return false;
+	const uint32_t lo = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) v);
+	const uint32_t hi = (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) (v >> 32));
+	return ((uint64_t) hi << 32) | lo;
 }
 
-// main: ord(dist) of element `id` from the helpers' distance caches (per lane)
-__device__ __forceinline__ bool team_dist(unsigned char *smem, const SearchArgs &a, uint32_t hmask, uint32_t id, uint32_t &od)
+// Which helper (bit in hmask) holds a package slot for element `c`?  Lane w looks at helper w's slot: one LDS
+// access for the whole team.  Returns a lane mask over helper numbers.
+__device__ __forceinline__ uint64_t team_find(unsigned char *smem, const SearchArgs &a, uint32_t hmask, uint32_t c, int lane)
 {
-	const uint32_t cmask = a.tm_dccap - 1;
-	for (uint32_t m = hmask; m; m &= m - 1)
-	{
-		const uint64_t *dc = team_view(smem, a, (uint32_t) __builtin_ctz(m)).dc;
-		uint32_t s = hash_slot(id, cmask);
-		for (uint32_t probe = 0; probe < 24; probe++)
-		{
-			const uint64_t e = dc[s];
-			if ((uint32_t) (e >> 32) == id) { od = (uint32_t) e; return true; }
-			if (e == DC_EMPTY) break;
-			s = (s + 1) & cmask;
-		}
-	}
-	return false;
+	uint64_t u = 0;
+	if (lane < TEAM_MAX_WPB && ((hmask >> lane) & 1u)) u = team_view(smem, a, (uint32_t) lane).hdr[lc_slot(c, a.tm_lcslots)];
+	return __ballot((uint32_t) u == c && (uint32_t) (u >> 32) >= LC_CLAIMED);
 }
 
 // helper's look at the main's visited set: bounded, because the main may be past its walk and have reused the area
@@ -1189,20 +1176,20 @@ __device__ __forceinline__ bool hash_contains_bounded(const uint32_t *tab, uint3
 	return false;
 }
 
-__device__ __forceinline__ bool dc_contains(const uint64_t *dc, uint32_t cmask, uint32_t id)
+__device__ __forceinline__ bool dc_lookup(const uint64_t *dc, uint32_t cmask, uint32_t id, uint32_t &od)
 {
 	uint32_t s = hash_slot(id, cmask);
 	for (uint32_t probe = 0; probe < 24; probe++)
 	{
 		const uint64_t e = dc[s];
-		if ((uint32_t) (e >> 32) == id) return true;
+		if ((uint32_t) (e >> 32) == id) { od = (uint32_t) e; return true; }
 		if (e == DC_EMPTY) return false;
 		s = (s + 1) & cmask;
 	}
 	return false;
 }
 
-// helper: insert (id -> od); lanes of the wave may collide on a slot, other waves only read
+// insert (id -> od); lanes of the wave may collide on a slot, nobody else touches the table
 __device__ __forceinline__ void dc_insert(uint64_t *dc, uint32_t cmask, uint32_t id, uint32_t od)
 {
 	const uint64_t e = ((uint64_t) id << 32) | od;
@@ -1254,9 +1241,9 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 			__builtin_amdgcn_s_sleep(8);
 			continue;
 		}
-		// ---- my region becomes that walk's cache ---------------------------------------------
+		// ---- my region becomes that walk's package store ---------------------------------------
 		for (uint32_t i = lane; i < a.tm_dccap; i += 64) mine.dc[i] = DC_EMPTY;
-		for (uint32_t i = lane; i < a.tm_lcslots; i += 64) { mine.lctag[i] = LINK_NONE; mine.lcstate[i] = 0; }
+		for (uint32_t i = lane; i < a.tm_lcslots; i += 64) mine.hdr[i] = (uint64_t) LINK_NONE;
 		for (uint32_t i = lane; i < 64u * UREG; i += 64) mine.pub[i] = ~0ull;
 		mine.ex[lane] = 0;
 		wave_sync();
@@ -1275,7 +1262,7 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 			const uint32_t hm = __builtin_amdgcn_readfirstlane(ctl[target].helpers);
 			if (!(hm & (1u << wib))) break;
 			const TeamView pubv = team_view(smem, a, (uint32_t) __builtin_ctz(hm));
-			uint32_t myrank = (uint32_t) __builtin_popcount(hm & ((1u << wib) - 1u));
+			const uint32_t myrank = (uint32_t) __builtin_popcount(hm & ((1u << wib) - 1u));
 			// snapshot of the main's accepted set: candidate keys (dist, ~idx) of the unexpanded elements
 			uint64_t ck[UREG];
 			const uint32_t ex = pubv.ex[lane];
@@ -1286,7 +1273,7 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 				const bool open = !((ex >> k) & 1u) && (uint32_t) (key >> 32) != 0xFFFFFFFFu && (uint32_t) key < a.n;
 				ck[k] = open ? (key ^ 0xFFFFFFFFull) : ~0ull;
 			}
-			// the myrank-th smallest that nobody has cached yet (at most myrank + 4 steps down the order)
+			// the myrank-th smallest that nobody has packaged or claimed yet (at most myrank + 4 steps down the order)
 			uint64_t prev = 0, pick = ~0ull;
 			bool first = true;
 			for (uint32_t step = 0; step < myrank + 5; step++)
@@ -1302,59 +1289,76 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 				if (m == ~0ull) break;
 				prev = m; first = false;
 				if (step < myrank) continue;
-				const uint32_t c = ~(uint32_t) m;
-				bool cached = (m == last_done);
-				for (uint32_t mm = hm; mm && !cached; mm &= mm - 1)
+				if (m != last_done && team_find(smem, a, hm, ~(uint32_t) m, lane) == 0) { pick = m; break; }
+			}
+			if (pick == ~0ull) { __builtin_amdgcn_s_sleep(2); continue; }
+			uint32_t cand = ~(uint32_t) pick;
+			// Two elements per pick: the chosen one, then — if it beats every other open candidate — its best
+			// neighbour: when the main expands `cand` that neighbour is accepted and popped at once (the case no
+			// snapshot can predict: 15-17 % of the hops), so its package is prepared right behind cand's.
+			uint64_t other = ~0ull;                                        // best open candidate besides the pick
+#pragma unroll
+			for (int k = 0; k < UREG; k++) other = (ck[k] != pick && ck[k] < other) ? ck[k] : other;
+			other = wave_min_u64(other);
+			for (int depth = 0; depth < 2; depth++)
+			{
+				uint64_t hc0 = 0;
+				if (a.team_dbg) hc0 = __builtin_amdgcn_s_memtime();
+				if (dcount + 2 * a.lstride > a.tm_dccap - a.tm_dccap / 4)   // memo nearly full: start over
 				{
-					const TeamView v = team_view(smem, a, (uint32_t) __builtin_ctz(mm));
-					const uint32_t s = lc_slot(c, a.tm_lcslots);
-					cached = __builtin_amdgcn_readfirstlane(v.lctag[s]) == c && __builtin_amdgcn_readfirstlane(v.lcstate[s]) >= LC_CLAIMED;
+					for (uint32_t i = lane; i < a.tm_dccap; i += 64) mine.dc[i] = DC_EMPTY;
+					dcount = 0;
+					wave_sync();
 				}
-				if (!cached) { pick = m; break; }
-			}
-			if (pick == ~0ull) { __builtin_amdgcn_s_sleep(4); continue; }
-			const uint32_t cand = ~(uint32_t) pick;
-
-			if (dcount + 2 * a.lstride > a.tm_dccap - a.tm_dccap / 4)       // cache nearly full: start over
-			{
-				for (uint32_t i = lane; i < a.tm_dccap; i += 64) mine.dc[i] = DC_EMPTY;
-				dcount = 0;
+				const uint32_t slot = lc_slot(cand, a.tm_lcslots);
+				if (lane == 0) mine.hdr[slot] = (uint64_t) cand | ((uint64_t) LC_CLAIMED << 32);
 				wave_sync();
-			}
-			const uint32_t slot = lc_slot(cand, a.tm_lcslots);
-			if (lane == 0) { mine.lcstate[slot] = LC_CLAIMED; mine.lctag[slot] = cand; }
-			wave_sync();
-			for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)                    // hnswalg.cpp:76-77, ahead of time
-			{
-				const uint32_t j = j0 + lane;
-				const uint32_t t = a.links[(size_t) cand * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
-				if (j < a.lstride) mine.lclinks[slot * a.lstride + j] = t;
-			}
-			wave_sync();
-			if (lane == 0) mine.lcstate[slot] = LC_LINKS;
-			wave_sync();
-			for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)
-			{
-				const uint32_t j = j0 + lane;
-				const uint32_t t = (j < a.lstride) ? mine.lclinks[slot * a.lstride + j] : LINK_NONE;
-				bool need = j < a.lstride && t != LINK_NONE && t < a.n;
-				if (need && a.hcap) need = !hash_contains_bounded(mhtab, mhmask, t);  // a stale view only costs work
-				if (need) need = !dc_contains(mine.dc, cmask, t);
-				const uint64_t nm = __ballot(need);
-				const uint32_t nn = (uint32_t) __builtin_popcountll(nm);
-				if (nn == 0) continue;
-				if (need) newid[lane_rank(nm)] = t;
-				wave_sync();
+				uint64_t bestnb = ~0ull;                                    // best scored neighbour, as a candidate key
+				for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)                // hnswalg.cpp:76-77 + :95-97, ahead of time
 				{
-					const uint32_t *ids = newid;
-					auto by_id = [ids](uint32_t r) { return ids[r]; };
-					score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nn, newdist, lane);
+					const uint32_t j = j0 + lane;
+					const uint32_t t = a.links[(size_t) cand * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
+					bool need = j < a.lstride && t != LINK_NONE && t < a.n;
+					if (need && a.hcap) need = !hash_contains_bounded(mhtab, mhmask, t);  // visited is visited for good
+					uint32_t od = OD_MISSING;
+					bool score = need;
+					if (need && dc_lookup(mine.dc, cmask, t, od)) score = false;          // already scored for another element
+					const uint64_t sm = __ballot(score);
+					const uint32_t ns = (uint32_t) __builtin_popcountll(sm);
+					const uint32_t k = lane_rank(sm);
+					if (ns)
+					{
+						if (score) newid[k] = t;
+						wave_sync();
+						const uint32_t *ids = newid;
+						auto by_id = [ids](uint32_t r) { return ids[r]; };
+						score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, ns, newdist, lane);
+						wave_sync();
+						const uint32_t od_s = ord_f32(finish_dist<FUNC>(newdist[k & 63], newdist[OUT2 + (k & 63)], qnorm));
+						if (score) { od = od_s; dc_insert(mine.dc, cmask, t, od); }
+						dcount += ns;
+						wave_sync();
+					}
+					// bit 31 of the id = "the main had visited it when I looked" (ids stay below 2^31 in the beam form):
+					// visited is for good, so the main skips its own test for those
+					const bool seen = j < a.lstride && t != LINK_NONE && t < a.n && !need;
+					if (j < a.lstride) mine.pk[slot * a.lstride + j] = (uint64_t) (seen ? (t | PK_VISITED) : t) | ((uint64_t) od << 32);
+					const uint64_t nbk = (need && od != OD_MISSING) ? (((uint64_t) od << 32) | (uint32_t) ~t) : ~0ull;
+					bestnb = nbk < bestnb ? nbk : bestnb;
 				}
 				wave_sync();
-				const uint32_t od = ord_f32(finish_dist<FUNC>(newdist[lane], newdist[OUT2 + lane], qnorm));
-				if ((uint32_t) lane < nn) dc_insert(mine.dc, cmask, newid[lane], od);
-				dcount += nn;
-				wave_sync();
+				if (lane == 0) mine.hdr[slot] = (uint64_t) cand | ((uint64_t) LC_DONE << 32);
+				if (a.team_dbg && lane == 0)
+				{
+					atomicAdd(a.team_dbg + 11, 1u);
+					atomicAdd(a.team_dbg + 12, (uint32_t) (__builtin_amdgcn_s_memtime() - hc0));
+				}
+				if (depth) break;
+				bestnb = wave_min_u64(bestnb);
+				if (bestnb >= other) break;                                 // some known candidate is popped first
+				const uint32_t nb = ~(uint32_t) bestnb;
+				if (__builtin_amdgcn_readfirstlane(ctl[target].state) != 1 || team_find(smem, a, hm, nb, lane)) break;
+				cand = nb;
 			}
 			last_done = pick;
 		}
@@ -1460,6 +1464,9 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				ex |= ((uint32_t) lane == (cslot & 63)) ? (1u << (cslot >> 6)) : 0u;   // :73 pop
 				hops++;
 				TeamView h0v = {};
+				if (TEAM && a.team_dbg && lane == 0) { atomicAdd(a.team_dbg + 5, 1u); if (hm) atomicAdd(a.team_dbg + 0, 1u); }
+				uint64_t tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
+				if (TEAM && a.team_dbg) tc0 = __builtin_amdgcn_s_memtime();
 				if (TEAM && hm)                                             // publish the accepted set for the helpers
 				{
 					h0v = team_view(smem, a, (uint32_t) __builtin_ctz(hm));
@@ -1467,13 +1474,50 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 					for (int k = 0; k < UREG; k++) h0v.pub[k * 64 + lane] = uk[k];
 					h0v.ex[lane] = ex;
 				}
+				// a helper's package for this element?  (link list + distances of its unvisited neighbours)
+				bool have_pk = false;
+				const uint64_t *pkp = nullptr;
+				const uint64_t *pkh = nullptr;
+				if (TEAM && hm)
+				{
+					const uint64_t who = team_find(smem, a, hm, cur, lane);
+					if (who)
+					{
+						const TeamView pv = team_view(smem, a, (uint32_t) __builtin_ctzll(who));
+						const uint32_t sl = lc_slot(cur, a.tm_lcslots);
+						pkh = pv.hdr + sl;
+						pkp = pv.pk + (size_t) sl * a.lstride;
+						uint64_t u = uniform_u64(*pkh);
+						uint32_t spins = 0;                                 // in flight: the helper is ahead of any fetch started now
+						for (; spins < 4000 && (uint32_t) u == cur && (uint32_t) (u >> 32) == LC_CLAIMED; spins++)
+						{
+							__builtin_amdgcn_s_sleep(1);
+							u = uniform_u64(*pkh);
+						}
+						have_pk = u == ((uint64_t) cur | ((uint64_t) LC_DONE << 32));
+						if (a.team_dbg && spins && lane == 0) { atomicAdd(a.team_dbg + 6, spins); atomicAdd(a.team_dbg + 10, 1u); }
+					}
+				}
 
 				for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)               // :76-77
 				{
 					const uint32_t j = j0 + lane;
-					uint32_t t = 0;
-					if (!(TEAM && hm && team_links(smem, a, hm, cur, j, t)))
+					uint32_t t = 0, od_pk = OD_MISSING;
+					bool lhit = false;
+					if (TEAM && have_pk)
+					{
+						const uint64_t e = pkp[j < a.lstride ? j : a.lstride - 1];
+						wave_sync();                                        // the copy is read before the header is checked again
+						lhit = uniform_u64(*pkh) == ((uint64_t) cur | ((uint64_t) LC_DONE << 32));   // not re-claimed meanwhile: the copy is whole
+						if (lhit) { t = (uint32_t) e; od_pk = (uint32_t) (e >> 32); }
+					}
+					// neighbours the helper found visited need no test of their own (hnswalg.cpp:91: `continue`)
+					const bool pk_seen = TEAM && lhit && t != LINK_NONE && (t & PK_VISITED);
+					if (pk_seen) t = LINK_NONE;
+					if (!lhit)
 						t = a.links[(size_t) cur * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
+					if (TEAM && a.team_dbg && lhit && lane == 0) atomicAdd(a.team_dbg + 1, 1u);
+					if (TEAM && a.team_dbg) { __builtin_amdgcn_s_waitcnt(0); tc1 = __builtin_amdgcn_s_memtime(); }
 					bool isnew = false;
 					if (j < a.lstride && t != LINK_NONE)                    // :91-93
 					{
@@ -1493,6 +1537,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 					if (isnew)
 					{
 						newid[rank] = t;
+						if (TEAM && hm) reinterpret_cast<uint32_t *>(newdist)[rank] = od_pk;      // packaged distance, link order kept
 						if (spill)
 						{
 							const uint32_t lp = logn + rank;
@@ -1528,17 +1573,22 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 					uint32_t od_mine;
 					if (TEAM && hm)
 					{
-						// distances a helper has already computed come from its cache; only the misses are scored here
-						uint32_t od_c = 0;
+						// distances a helper packaged are taken as they are; only what is missing is scored here
 						const uint32_t myid = newid[lane];
-						bool hit = false;
-						if ((uint32_t) lane < nnew) hit = team_dist(smem, a, hm, myid, od_c);
+						const uint32_t od_c = reinterpret_cast<const uint32_t *>(newdist)[lane];
+						const bool hit = (uint32_t) lane < nnew && od_c != OD_MISSING;
 						const uint64_t all = nnew >= 64 ? ~0ull : ((1ull << nnew) - 1ull);
 						const uint64_t missm = ~__ballot(hit) & all;
 						const uint32_t nmiss = (uint32_t) __builtin_popcountll(missm);
 						const uint32_t krank = lane_rank(missm);
+						if (a.team_dbg && lane == 0)
+						{
+							atomicAdd(a.team_dbg + 2, nnew); atomicAdd(a.team_dbg + 3, nnew - nmiss);
+							if (nmiss) atomicAdd(a.team_dbg + 4, 1u);
+						}
 						if (nmiss)
 						{
+							wave_sync();                                    // od_c is in registers before newdist is reused
 							if (!hit && (uint32_t) lane < nnew) h0v.miss[krank] = myid;
 							wave_sync();
 							const uint32_t *ids = h0v.miss;
@@ -1546,8 +1596,12 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 							score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nmiss, newdist, lane);
 							wave_sync();
 						}
-						const uint32_t od_m = ord_f32(finish_dist<FUNC>(newdist[krank & 63], newdist[OUT2 + (krank & 63)], qnorm));
-						od_mine = hit ? od_c : od_m;
+						od_mine = od_c;
+						if (nmiss)
+						{
+							const uint32_t od_m = ord_f32(finish_dist<FUNC>(newdist[krank & 63], newdist[OUT2 + (krank & 63)], qnorm));
+							od_mine = hit ? od_c : od_m;
+						}
 					}
 					else
 					{
@@ -1558,6 +1612,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 						od_mine = ord_f32(finish_dist<FUNC>(newdist[lane], newdist[OUT2 + lane], qnorm));
 					}
 					evals += nnew;
+					if (TEAM && a.team_dbg) { __builtin_amdgcn_s_waitcnt(0); tc2 = __builtin_amdgcn_s_memtime(); }
 					const uint32_t t_mine = newid[lane];
 					// rows at or above a valid upper bound of lowerBound cannot be accepted (:99)
 					uint64_t todo = __ballot((uint32_t) lane < nnew && od_mine < bstale);
@@ -1583,6 +1638,13 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 						usize++;
 					}
 					wave_sync();
+					if (TEAM && a.team_dbg && lane == 0)
+					{
+						tc3 = __builtin_amdgcn_s_memtime();
+						atomicAdd(a.team_dbg + 7, (uint32_t) (tc1 - tc0));      // pop + stop test + publish + link list
+						atomicAdd(a.team_dbg + 8, (uint32_t) (tc2 - tc1));      // visited test + distances (cache or rows)
+						atomicAdd(a.team_dbg + 9, (uint32_t) (tc3 - tc2));      // accept loop
+					}
 				}
 			}
 		}

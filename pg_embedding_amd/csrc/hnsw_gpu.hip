@@ -73,6 +73,7 @@ struct SearchWs
 	uint32_t last_slots = 0;
 	uint32_t *done_next = nullptr;                       // completion flags for the next launch only
 	char kname[96] = "";                                 // symbol of the kernel the last launch used (as rocprofv3 prints it)
+	uint32_t *team_dbg = nullptr;                        // 8 launch-wide counters of the team form (HNSW_GPU_TEAM_COUNTERS=1)
 };
 
 static int ws_init(SearchWs *w)
@@ -93,6 +94,7 @@ static void ws_free(SearchWs *w)
 	if (w->beam) (void) hipFree(w->beam);
 	if (w->sets) (void) hipFree(w->sets);
 	if (w->vlog) (void) hipFree(w->vlog);
+	if (w->team_dbg) (void) hipFree(w->team_dbg);
 	if (w->ticket) (void) hipFree(w->ticket);
 	for (int i = 0; i < SearchWs::EV_RING; i++)
 	{
@@ -645,21 +647,25 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		const char *tmax = getenv("HNSW_GPU_TEAM_MAX_NQ");
 		const size_t auto_nq = tmax ? (size_t) atoll(tmax) : (size_t) ix->num_cu;
 		const size_t pub = (size_t) 64 * ucap / 64 * 8;                 // 64*UREG keys
-		uint32_t lcs = 8;
-		size_t o_ex = pub, o_miss = o_ex + 256, o_tag = o_miss + 256, o_state = 0, o_links = 0, o_dc = 0, dccap = 0;
+		// a donated region: [accepted-set copy | expanded bits | miss ids | package headers | packages | memo], all below
+		// off_newid.  As many package slots as leave a useful memo: an element packaged while it was 6th in line may
+		// be popped dozens of hops later, and a direct-mapped slot that was reused by then is a lost package.
+		uint32_t lcs = 32;
+		size_t o_ex = pub, o_miss = o_ex + 256, o_tag = round_up(o_miss + 256, 8), o_state = 0, o_links = 0, o_dc = 0, dccap = 0;
 		for (; lcs >= 4; lcs >>= 1)
 		{
-			o_state = o_tag + lcs * 4; o_links = o_state + lcs * 4;
-			o_dc = round_up(o_links + (size_t) lcs * a.lstride * 4, 16);
+			o_state = o_tag; o_links = o_tag + lcs * 8;                          // headers: lcs x u64; packages: lcs x lstride x u64
+			o_dc = round_up(o_links + (size_t) lcs * a.lstride * 8, 16);
+			const size_t want = lcs >= 16 ? 512 : (lcs == 8 ? 256 : 128);         // memo entries this many slots must leave
 			dccap = 0;
-			if (o_dc + 256 * 8 <= a.off_newid)
+			if (o_dc + want * 8 <= a.off_newid)
 			{
-				dccap = 256;
-				while (o_dc + dccap * 2 * 8 <= a.off_newid && dccap < 4096) dccap *= 2;
+				dccap = want;
+				while (o_dc + dccap * 2 * 8 <= a.off_newid && dccap < 2048) dccap *= 2;
 				break;
 			}
 		}
-		if (dccap >= 256 && treq != 0 && (treq > 0 || nq <= auto_nq))
+		if (dccap >= 128 && treq != 0 && (treq > 0 || nq <= auto_nq))
 		{
 			team = true;
 			a.tm_off_ex = (uint32_t) o_ex; a.tm_off_miss = (uint32_t) o_miss; a.tm_off_lctag = (uint32_t) o_tag;
@@ -740,6 +746,12 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		a.set_scratch = w->sets;
 	}
 	a.ticket = w->ticket;
+	if (team && getenv("HNSW_GPU_TEAM_COUNTERS"))
+	{
+		if (!w->team_dbg) HIPCHK(hipMalloc(&w->team_dbg, 64));
+		HIPCHK(hipMemsetAsync(w->team_dbg, 0, 64, stream));
+		a.team_dbg = w->team_dbg;
+	}
 	a.done = w->done_next;
 	w->done_next = nullptr;
 	HIPCHK(hipMemsetAsync(w->ticket, 0, 8, stream));
@@ -818,6 +830,17 @@ extern "C" int hnsw_gpu_last_search_kernel(hnsw_gpu_index *ix, char *buf, size_t
 {
 	if (!ix || !buf || len == 0) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
 	snprintf(buf, len, "%s", ix->ws.kname);
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_team_counters(hnsw_gpu_index *ix, uint32_t *out8)
+{
+	if (!ix || !out8) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	memset(out8, 0, 64);
+	if (!ix->ws.team_dbg) return HNSW_GPU_OK;
+	HIPCHK(hipSetDevice(ix->device));
+	HIPCHK(hipDeviceSynchronize());
+	HIPCHK(hipMemcpy(out8, ix->ws.team_dbg, 64, hipMemcpyDeviceToHost));
 	return HNSW_GPU_OK;
 }
 

@@ -196,6 +196,14 @@ class GpuIndex:
         check(self.L.hnsw_gpu_last_search_kernel(self._h, buf, 128), "hnsw_gpu_last_search_kernel")
         return buf.value.decode()
 
+    def team_counters(self):
+        """Launch-wide counters of the team form (needs HNSW_GPU_TEAM_COUNTERS=1): dict."""
+        v = (C.c_uint32 * 16)()
+        check(self.L.hnsw_gpu_team_counters(self._h, v), "hnsw_gpu_team_counters")
+        names = ("hops_with_helpers", "link_hits", "ids_looked_up", "dist_hits", "hops_that_scored", "hops", "wait_polls",
+                 "cyc_pop_links", "cyc_dists", "cyc_accept", "hops_that_waited", "helper_elements", "helper_cycles")
+        return {k: int(v[i]) for i, k in enumerate(names)}
+
     def gather_roof(self, loads_per_lane: int = 12, waves_per_cu: int = 16, iters: int = 200) -> float:
         """GB/s of a dependency-free random gather of whole rows of THIS mirror's row table — the practical
         roof of the search kernel's access pattern (csrc/device_roof.h)."""

@@ -33,7 +33,7 @@ variants = [("one-wave", {"HNSW_GPU_TEAM": "0"}),
             ("team wpb4", {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "4"}),
             ("team wpb2", {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "2"})]
 ref = {}
-for nq in (1, 16, 256, 1024, 2560, 10000, 40000):
+for nq in [int(x) for x in os.environ.get("EXP_NQS", "1,16,256,1024,2560,10000,40000").split(",")]:
     for name, env in variants:
         for k in ("HNSW_GPU_TEAM", "HNSW_GPU_TEAM_WPB"):
             os.environ.pop(k, None)
@@ -59,5 +59,12 @@ for nq in (1, 16, 256, 1024, 2560, 10000, 40000):
             same = True
         else:
             same = all((x == y).all() for x, y in zip(ref[nq], cur))
+        cnt = ""
+        if os.environ.get("HNSW_GPU_TEAM_COUNTERS") and name != "one-wave":
+            c = ix.team_counters()
+            cnt = (f" | hops {c['hops']} with helpers {c['hops_with_helpers']} link hits {c['link_hits']} ids {c['ids_looked_up']} "
+                   f"dist hits {c['dist_hits']} hops that scored {c['hops_that_scored']} waited {c['hops_that_waited']} polls {c['wait_polls']} "
+                   f"cyc pop+links {c['cyc_pop_links']} dists {c['cyc_dists']} accept {c['cyc_accept']} | helpers: {c['helper_elements']} elements, "
+                   f"{c['helper_cycles'] // max(c['helper_elements'], 1)} cyc each")
         print(f"dim {dim} nq={nq:6d} {name:10s} kernel {t:8.3f} ms {nq / t * 1e3:10.0f} q/s slots {ix.last_search_slots():5d} "
-              f"identical={same} [{ix.last_search_kernel()}]", flush=True)
+              f"identical={same} [{ix.last_search_kernel()}]{cnt}", flush=True)
