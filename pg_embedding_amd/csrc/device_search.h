@@ -1106,6 +1106,14 @@ __device__ __forceinline__ void beam_set(uint64_t (&uk)[U], uint32_t slot, uint6
 // only makes a helper fetch something useless.  Outputs, E_q and H_q equal the one-wave form
 // (tests/test_gpu_search.py::test_every_kernel_variant_is_exact, ::test_team_form_is_exact_at_every_launch_size).
 // =====================================================================================
+// launch-wide diagnostics of the team form (hnsw_gpu_team_counters): compiled in only with -DHNSW_TEAM_COUNTERS —
+// the cycle stamps and global atomics cost ~15 % of a single-query walk
+#ifdef HNSW_TEAM_COUNTERS
+constexpr bool TEAM_COUNT = true;
+#else
+constexpr bool TEAM_COUNT = false;
+#endif
+
 struct TeamCtl
 {
 	uint32_t state;        // 0 = has or may get a query but is not walking, 1 = walking, 2 = will never walk again
@@ -1303,7 +1311,7 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 			for (int depth = 0; depth < 2; depth++)
 			{
 				uint64_t hc0 = 0;
-				if (a.team_dbg) hc0 = __builtin_amdgcn_s_memtime();
+				if ((TEAM_COUNT && a.team_dbg)) hc0 = __builtin_amdgcn_s_memtime();
 				if (dcount + 2 * a.lstride > a.tm_dccap - a.tm_dccap / 4)   // memo nearly full: start over
 				{
 					for (uint32_t i = lane; i < a.tm_dccap; i += 64) mine.dc[i] = DC_EMPTY;
@@ -1348,7 +1356,7 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 				}
 				wave_sync();
 				if (lane == 0) mine.hdr[slot] = (uint64_t) cand | ((uint64_t) LC_DONE << 32);
-				if (a.team_dbg && lane == 0)
+				if ((TEAM_COUNT && a.team_dbg) && lane == 0)
 				{
 					atomicAdd(a.team_dbg + 11, 1u);
 					atomicAdd(a.team_dbg + 12, (uint32_t) (__builtin_amdgcn_s_memtime() - hc0));
@@ -1464,9 +1472,9 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				ex |= ((uint32_t) lane == (cslot & 63)) ? (1u << (cslot >> 6)) : 0u;   // :73 pop
 				hops++;
 				TeamView h0v = {};
-				if (TEAM && a.team_dbg && lane == 0) { atomicAdd(a.team_dbg + 5, 1u); if (hm) atomicAdd(a.team_dbg + 0, 1u); }
+				if (TEAM && (TEAM_COUNT && a.team_dbg) && lane == 0) { atomicAdd(a.team_dbg + 5, 1u); if (hm) atomicAdd(a.team_dbg + 0, 1u); }
 				uint64_t tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
-				if (TEAM && a.team_dbg) tc0 = __builtin_amdgcn_s_memtime();
+				if (TEAM && (TEAM_COUNT && a.team_dbg)) tc0 = __builtin_amdgcn_s_memtime();
 				if (TEAM && hm)                                             // publish the accepted set for the helpers
 				{
 					h0v = team_view(smem, a, (uint32_t) __builtin_ctz(hm));
@@ -1495,7 +1503,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 							u = uniform_u64(*pkh);
 						}
 						have_pk = u == ((uint64_t) cur | ((uint64_t) LC_DONE << 32));
-						if (a.team_dbg && spins && lane == 0) { atomicAdd(a.team_dbg + 6, spins); atomicAdd(a.team_dbg + 10, 1u); }
+						if ((TEAM_COUNT && a.team_dbg) && spins && lane == 0) { atomicAdd(a.team_dbg + 6, spins); atomicAdd(a.team_dbg + 10, 1u); }
 					}
 				}
 
@@ -1516,8 +1524,8 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 					if (pk_seen) t = LINK_NONE;
 					if (!lhit)
 						t = a.links[(size_t) cur * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
-					if (TEAM && a.team_dbg && lhit && lane == 0) atomicAdd(a.team_dbg + 1, 1u);
-					if (TEAM && a.team_dbg) { __builtin_amdgcn_s_waitcnt(0); tc1 = __builtin_amdgcn_s_memtime(); }
+					if (TEAM && (TEAM_COUNT && a.team_dbg) && lhit && lane == 0) atomicAdd(a.team_dbg + 1, 1u);
+					if (TEAM && (TEAM_COUNT && a.team_dbg)) { __builtin_amdgcn_s_waitcnt(0); tc1 = __builtin_amdgcn_s_memtime(); }
 					bool isnew = false;
 					if (j < a.lstride && t != LINK_NONE)                    // :91-93
 					{
@@ -1570,49 +1578,45 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 						}
 					}
 					wave_sync();
-					uint32_t od_mine;
+					// What still has to be scored here: everything (no helpers), or what no package held
+					const uint32_t *sids = newid;
+					uint32_t nscore = nnew, krank = (uint32_t) lane, od_c = 0;
+					bool hit = false;
 					if (TEAM && hm)
 					{
-						// distances a helper packaged are taken as they are; only what is missing is scored here
+						// distances a helper packaged are taken as they are (link order kept by the compaction above)
 						const uint32_t myid = newid[lane];
-						const uint32_t od_c = reinterpret_cast<const uint32_t *>(newdist)[lane];
-						const bool hit = (uint32_t) lane < nnew && od_c != OD_MISSING;
+						od_c = reinterpret_cast<const uint32_t *>(newdist)[lane];
+						hit = (uint32_t) lane < nnew && od_c != OD_MISSING;
 						const uint64_t all = nnew >= 64 ? ~0ull : ((1ull << nnew) - 1ull);
 						const uint64_t missm = ~__ballot(hit) & all;
-						const uint32_t nmiss = (uint32_t) __builtin_popcountll(missm);
-						const uint32_t krank = lane_rank(missm);
-						if (a.team_dbg && lane == 0)
+						nscore = (uint32_t) __builtin_popcountll(missm);
+						krank = lane_rank(missm);
+						if ((TEAM_COUNT && a.team_dbg) && lane == 0)
 						{
-							atomicAdd(a.team_dbg + 2, nnew); atomicAdd(a.team_dbg + 3, nnew - nmiss);
-							if (nmiss) atomicAdd(a.team_dbg + 4, 1u);
+							atomicAdd(a.team_dbg + 2, nnew); atomicAdd(a.team_dbg + 3, nnew - nscore);
+							if (nscore) atomicAdd(a.team_dbg + 4, 1u);
 						}
-						if (nmiss)
+						if (nscore)
 						{
 							wave_sync();                                    // od_c is in registers before newdist is reused
 							if (!hit && (uint32_t) lane < nnew) h0v.miss[krank] = myid;
 							wave_sync();
-							const uint32_t *ids = h0v.miss;
-							auto by_id = [ids](uint32_t r) { return ids[r]; };
-							score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nmiss, newdist, lane);
-							wave_sync();
 						}
-						od_mine = od_c;
-						if (nmiss)
-						{
-							const uint32_t od_m = ord_f32(finish_dist<FUNC>(newdist[krank & 63], newdist[OUT2 + (krank & 63)], qnorm));
-							od_mine = hit ? od_c : od_m;
-						}
+						sids = h0v.miss;
 					}
-					else
+					uint32_t od_mine = od_c;
+					if (nscore)
 					{
-						const uint32_t *ids = newid;
+						const uint32_t *ids = sids;
 						auto by_id = [ids](uint32_t r) { return ids[r]; };
-						score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nnew, newdist, lane);
+						score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nscore, newdist, lane);
 						wave_sync();
-						od_mine = ord_f32(finish_dist<FUNC>(newdist[lane], newdist[OUT2 + lane], qnorm));
+						const uint32_t od_m = ord_f32(finish_dist<FUNC>(newdist[krank & 63], newdist[OUT2 + (krank & 63)], qnorm));
+						od_mine = hit ? od_c : od_m;
 					}
 					evals += nnew;
-					if (TEAM && a.team_dbg) { __builtin_amdgcn_s_waitcnt(0); tc2 = __builtin_amdgcn_s_memtime(); }
+					if (TEAM && (TEAM_COUNT && a.team_dbg)) { __builtin_amdgcn_s_waitcnt(0); tc2 = __builtin_amdgcn_s_memtime(); }
 					const uint32_t t_mine = newid[lane];
 					// rows at or above a valid upper bound of lowerBound cannot be accepted (:99)
 					uint64_t todo = __ballot((uint32_t) lane < nnew && od_mine < bstale);
@@ -1638,7 +1642,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 						usize++;
 					}
 					wave_sync();
-					if (TEAM && a.team_dbg && lane == 0)
+					if (TEAM && (TEAM_COUNT && a.team_dbg) && lane == 0)
 					{
 						tc3 = __builtin_amdgcn_s_memtime();
 						atomicAdd(a.team_dbg + 7, (uint32_t) (tc1 - tc0));      // pop + stop test + publish + link list

@@ -633,12 +633,13 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 					a.wave_bytes, LDS_PER_CU);
 	uint32_t wpb = 4;
 	while (wpb > 1 && (size_t) wpb * a.wave_bytes > 64 * 1024) wpb >>= 1;
-	// Team form of the beam kernel (device_search.h, "Team form"): waves of a block that have no query help a
-	// sibling's walk through LDS caches carved out of their own (otherwise idle) regions.  Used when the launch
-	// cannot fill the chip anyway — fewer queries than resident waves — where a query's latency is what matters:
-	// the one-query call of the drop-in boundary (embedding.c:317) above all.  HNSW_GPU_TEAM=0/1 forces it off/on,
-	// HNSW_GPU_TEAM_MAX_NQ moves the automatic threshold, HNSW_GPU_TEAM_WPB the waves per block (default: 8 if the
-	// LDS of a block allows).
+	// Team form of the beam kernel (device_search.h, "Team form"): waves of a block that have no query (left) help a
+	// sibling's walk with packages prepared in their own, otherwise idle LDS regions.  Measured at 1M rows
+	// (profiles/r2_team_form.txt): rows wider than 320 floats gain at every launch size (one query 0.68 -> 0.47 ms,
+	// 256 queries -24 %, 10 000 -3 %, 40 000 -0.7 %: only the tail of a big launch has idle waves); narrow rows gain
+	// up to ~256 queries per launch and lose beyond (the larger kernel costs the 4-waves-per-SIMD steady state 10-16 %).
+	// HNSW_GPU_TEAM=0/1 forces it off/on, HNSW_GPU_TEAM_MAX_NQ moves the narrow-row threshold, HNSW_GPU_TEAM_WPB the
+	// waves per block (default 8 when the LDS of a block allows).
 	bool team = false;
 	if (rreg < 0)
 	{
@@ -665,7 +666,7 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 				break;
 			}
 		}
-		if (dccap >= 128 && treq != 0 && (treq > 0 || nq <= auto_nq))
+		if (dccap >= 128 && treq != 0 && (treq > 0 || ix->stride > 320 || nq <= auto_nq))
 		{
 			team = true;
 			a.tm_off_ex = (uint32_t) o_ex; a.tm_off_miss = (uint32_t) o_miss; a.tm_off_lctag = (uint32_t) o_tag;
