@@ -57,9 +57,13 @@ enum
 {
 	/* op            request                                              response                         */
 	HGS_OP_HELLO       = 1,  /* a0 = HGS_VERSION                               a0 = version, a1 = devices     */
-	HGS_OP_LOOKUP      = 2,  /* key                                            a0 = count, a1 = 1 present/0 absent, gen = current */
-	HGS_OP_UPLOAD      = 3,  /* key, gen, a0 = n, payload = HnswMetadata,
-	                            fd = memfd holding n element images (embedding.c:222-228); replaces the key's mirror */
+	HGS_OP_LOOKUP      = 2,  /* key                                            a0 = count, a1 = 1 present/0 absent, gen = current,
+	                                                                              payload = u64 content version (0 = absent): a
+	                                                                              server-wide sequence number, new at every change */
+	HGS_OP_UPLOAD      = 3,  /* key, gen, a0 = n, a1 = 0 or 1 + the content version of the LOOKUP this snapshot was walked
+	                            after, payload = HnswMetadata, fd = memfd holding n element images (embedding.c:222-228);
+	                            replaces the key's mirror — unless a1 is set and the mirror has changed since (an insert's
+	                            BIND, another upload, a DROP): then HGS_ERR_STALE and nothing happens */
 	HGS_OP_UPDATE      = 4,  /* key, gen = NEW generation, a0 = first, a1 = count, payload = u64 expected current
 	                            generation, fd = memfd with `count` images -> hnsw_gpu_index_update_from_flat */
 	HGS_OP_SEARCH      = 5,  /* key, gen (0 = any), aux = ef, a0 = 1 to get distances too, payload = dim floats

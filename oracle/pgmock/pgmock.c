@@ -8,6 +8,8 @@
  */
 #include "pgmock.h"
 
+Oid MyDatabaseId = 5;      /* one database in the mini-Postgres */
+
 #include <stdarg.h>
 
 int pgmock_module_magic = 1;

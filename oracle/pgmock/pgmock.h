@@ -169,6 +169,7 @@ typedef struct RelationData
 typedef RelationData *Relation;
 #define RelationNeedsWAL(rel) ((rel)->needs_wal)
 #define RelationGetRelid(rel) ((rel)->rd_id)
+extern Oid MyDatabaseId;                 /* miscadmin.h: OID of the database this backend is connected to */
 #define RelationGetSmgr(rel) (rel)
 BlockNumber RelationGetNumberOfBlocksInFork(Relation rel, ForkNumber fork);
 #define RelationGetNumberOfBlocks(rel) RelationGetNumberOfBlocksInFork(rel, MAIN_FORKNUM)

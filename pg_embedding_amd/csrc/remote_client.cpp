@@ -41,7 +41,7 @@ thread_local pid_t t_pid = 0;
 thread_local char  t_err[512] = "";
 thread_local std::vector<char> t_resp;    // payload of the last response
 
-struct Attachment { HnswMetadata *meta; uint64_t key, gen; };
+struct Attachment { HnswMetadata *meta; uint64_t key, gen; bool own = false; };   // own: a private mirror under an ephemeral key
 std::vector<Attachment> g_attached;
 std::vector<HnswMetadata *> g_building;   // metas between hnsw_gpu_remote_begin_build and ..._finish_build
 std::atomic<uint64_t> g_ephemeral{0};
@@ -245,7 +245,9 @@ bool find_attached(HnswMetadata *meta, Attachment *out)
 // explains why the walk must not probe element numbers past the end (the real host raises ERROR there)
 // and why leaving out unreachable elements changes no answer; element numbers that were not reached
 // (page-tail holes of embedding.c:229,693 among them) become vacuum-flagged placeholders.
-int walk_and_upload(HnswMetadata *meta, uint64_t key, uint64_t gen)
+// guard: 0 = replace whatever is there; otherwise 1 + the content version seen at the LOOKUP this walk follows
+// (the server refuses with HGS_ERR_STALE when the mirror was changed in between: hnsw_gpu_server.h, UPLOAD)
+int walk_and_upload(HnswMetadata *meta, uint64_t key, uint64_t gen, uint64_t guard = 0)
 {
 	// Per-thread and reused: a host callback that leaves by longjmp (elog(ERROR), embedding.c:715)
 	// must not leak the area — the next walk takes it back.
@@ -257,7 +259,7 @@ int walk_and_upload(HnswMetadata *meta, uint64_t key, uint64_t gen)
 	const size_t n = (size_t) walked;
 	hgs_hdr h, r;
 	memset(&h, 0, sizeof(h));
-	h.op = HGS_OP_UPLOAD; h.key = key; h.gen = gen; h.a0 = n;
+	h.op = HGS_OP_UPLOAD; h.key = key; h.gen = gen; h.a0 = n; h.a1 = guard;
 	int rc = rpc(&h, meta, sizeof(*meta), nullptr, 0, n ? shm.fd : -1, &r);
 	shm.release();
 	return rc;
@@ -423,19 +425,42 @@ static int hnsw_gpu_remote_stats_impl(hgs_stats *out)
 static int hnsw_gpu_remote_attach_impl(HnswMetadata *meta, uint64_t key, uint64_t generation)
 {
 	if (!meta) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
-	uint64_t have_gen = 0;
-	int present = 0;
-	int rc = hnsw_gpu_remote_lookup(key, &have_gen, nullptr, &present);
-	if (rc != HGS_OK) return rc;
-	if (!present || have_gen != generation)
 	{
-		rc = walk_and_upload(meta, key, generation);
+		// an aborted CREATE INDEX (elog(ERROR) between begin_build and finish_build) may have left this address
+		// registered; a meta that is being attached is not being bulk-built
+		std::lock_guard<std::mutex> lk(g_mu);
+		for (size_t i = 0; i < g_building.size(); i++)
+			if (g_building[i] == meta) { g_building[i] = g_building.back(); g_building.pop_back(); break; }
+	}
+	// LOOKUP -> (walk -> guarded UPLOAD): the server takes the snapshot only if nobody changed the mirror since the
+	// LOOKUP.  Backends that race (an inserter between "row stored" and "mirror renamed", two scanners uploading the
+	// same index) make one of them retry; after a few rounds the scan takes a private mirror instead of waiting.
+	bool own = false;
+	int rc = HGS_OK;
+	for (int round = 0;; round++)
+	{
+		hgs_hdr r;
+		rc = simple(HGS_OP_LOOKUP, key, 0, 0, 0, &r);
 		if (rc != HGS_OK) return rc;
+		if (r.a1 && r.gen == generation) break;                  // present and current
+		uint64_t version = 0;
+		if (t_resp.size() == sizeof(version)) memcpy(&version, t_resp.data(), sizeof(version));
+		if (round == 4)
+		{
+			key = ephemeral_key(); generation = 1; own = true;
+			rc = walk_and_upload(meta, key, generation);
+			if (rc != HGS_OK) return rc;
+			break;
+		}
+		rc = walk_and_upload(meta, key, generation, version + 1);
+		if (rc == HGS_OK) break;
+		if (rc != HGS_ERR_STALE) return rc;
 	}
 	std::lock_guard<std::mutex> lk(g_mu);
 	for (Attachment &a : g_attached)
-		if (a.meta == meta) { a.key = key; a.gen = generation; return HGS_OK; }
-	g_attached.push_back(Attachment{ meta, key, generation });
+		if (a.meta == meta) { a.key = key; a.gen = generation; a.own = own; return HGS_OK; }
+	Attachment at; at.meta = meta; at.key = key; at.gen = generation; at.own = own;
+	g_attached.push_back(at);
 	return HGS_OK;
 }
 
@@ -445,8 +470,9 @@ static int hnsw_gpu_remote_begin_build_impl(HnswMetadata *meta)
 {
 	if (!meta) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
 	std::lock_guard<std::mutex> lk(g_mu);
-	for (HnswMetadata *b : g_building)
-		if (b == meta) return HGS_OK;
+	// One build at a time per backend (CREATE INDEX is one statement): whatever an earlier build that left by
+	// elog(ERROR) registered is stale — its HnswIndex was freed and the address may be handed out again.
+	g_building.clear();
 	g_building.push_back(meta);
 	return HGS_OK;
 }
@@ -542,15 +568,22 @@ static int hnsw_gpu_remote_advance_impl(HnswMetadata *meta, uint64_t new_generat
 
 static int hnsw_gpu_remote_detach_impl(HnswMetadata *meta)
 {
-	std::lock_guard<std::mutex> lk(g_mu);
-	for (size_t i = 0; i < g_attached.size(); i++)
-		if (g_attached[i].meta == meta)
-		{
-			g_attached[i] = g_attached.back();
-			g_attached.pop_back();
-			return HGS_OK;
-		}
-	return fail(HNSW_GPU_ERR_ARG, "meta is not attached");
+	Attachment at;
+	bool found = false;
+	{
+		std::lock_guard<std::mutex> lk(g_mu);
+		for (size_t i = 0; i < g_attached.size(); i++)
+			if (g_attached[i].meta == meta)
+			{
+				at = g_attached[i]; found = true;
+				g_attached[i] = g_attached.back();
+				g_attached.pop_back();
+				break;
+			}
+	}
+	if (!found) return fail(HNSW_GPU_ERR_ARG, "meta is not attached");
+	if (at.own) (void) hnsw_gpu_remote_drop(at.key);               // the private mirror of a scan that lost the upload race
+	return HGS_OK;
 }
 
 // ---------------------------------------------------------------------------------------

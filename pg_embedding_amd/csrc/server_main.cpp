@@ -95,6 +95,8 @@ void logf(const char *fmt, ...)
 #define VLOG(...) do { if (g_opt.verbose) logf(__VA_ARGS__); } while (0)
 
 // ----------------------------------------------------------------------------- mirrors
+static std::atomic<uint64_t> g_vseq{0};          // content versions: never repeat within a server's life
+
 struct Entry
 {
 	uint64_t key = 0;
@@ -112,6 +114,11 @@ struct Entry
 	std::vector<hnsw_gpu_ctx *> ctx;             // one per dispatcher lane, made on first use
 	std::atomic<uint64_t> last_used{0};
 	std::atomic<size_t> count{0};
+	// Content version: a server-wide sequence number taken at creation and at every change (BIND, UPDATE, LINK,
+	// vacuum flag, rename).  LOOKUP reports it and an UPLOAD built from a walk that started at that LOOKUP is only
+	// accepted while it still holds (0 = no mirror): a snapshot can never silently replace a mirror that an
+	// inserter or another uploader has changed in between, whatever the generations are called.
+	std::atomic<uint64_t> version{0};
 
 	Entry() { memset(&meta, 0, sizeof(meta)); }
 	~Entry()
@@ -588,8 +595,22 @@ void do_upload(CReq &r)
 		if (!m.map(fd, false) || m.bytes / meta.size_data_per_element < n) { r.c->respond(r.h, HGS_ERR_PROTOCOL); return; }
 		elements = m.p;
 	}
+	// a1 = 1 + the content version the uploader saw at its LOOKUP (0 = unconditional): refuse a snapshot whose
+	// walk raced with a change of the mirror (an insert's BIND, another backend's upload, a VACUUM's DROP)
+	auto guard_ok = [&r]() {
+		if (r.h.a1 == 0) return true;
+		EntryP cur = find_entry(r.h.key);
+		return (cur ? cur->version.load() : 0) == r.h.a1 - 1;
+	};
+	if (!guard_ok())
+	{
+		EntryP cur = find_entry(r.h.key);
+		r.c->respond(r.h, HGS_ERR_STALE, cur ? cur->count.load() : 0, 0, nullptr, 0, nullptr, 0, cur ? cur->gen.load() : 0);
+		return;
+	}
 	EntryP e = std::make_shared<Entry>();
 	e->key = r.h.key; e->gen.store(r.h.gen); e->meta = meta;
+	e->version.store(++g_vseq);
 	int rc;
 	bool dropped_own = false;
 	while (true)
@@ -618,6 +639,8 @@ void do_upload(CReq &r)
 	e->count.store(n);
 	e->last_used.store(now_ns());
 	{
+		// (control requests are handled by one thread, so nothing changed the map since the guard was checked —
+		// except an eviction of this very key by the retry loop above, which the uploader asked for)
 		std::lock_guard<std::mutex> lk(g_map_mu);
 		g_map[r.h.key] = e;          // an older generation is freed when its last batch lets go
 	}
@@ -652,6 +675,7 @@ void do_update(CReq &r)
 		WriteLock wl(e.get());
 		rc = hnsw_gpu_index_update_from_flat(e->ix, m.p, first, count);
 		if (rc == HNSW_GPU_OK) { e->count.store(hnsw_gpu_index_count(e->ix)); e->gen.store(r.h.gen); }
+		e->version.store(++g_vseq);
 	}
 	if (rc != HNSW_GPU_OK) logf("update of key %llx failed: %s", (unsigned long long) r.h.key, hnsw_gpu_last_error());
 	g_cnt.updates++;
@@ -673,7 +697,10 @@ void do_bind(CReq &r)
 	{
 		WriteLock wl(e.get());
 		size_t have = hnsw_gpu_index_count(e->ix);
-		if (have < (size_t) idx)              // page-tail holes (embedding.c:229,693): dead placeholders
+		const size_t max_gap = std::max<size_t>(4096, 2 * (size_t) e->meta.elems_per_page);
+		if (have < (size_t) idx && (size_t) idx - have > max_gap)
+			rc = HNSW_GPU_ERR_ARG;                // not a page-tail hole: the mirror is not this index's
+		else if (have < (size_t) idx)         // page-tail holes (embedding.c:229,693): dead placeholders
 		{
 			const size_t gap = (size_t) idx - have;
 			std::vector<coord_t> zeros(gap * dim, 0.f);
@@ -688,7 +715,17 @@ void do_bind(CReq &r)
 			rc = hnsw_gpu_index_reserve(e->ix, (size_t) idx + 1 + (size_t) idx / 2);
 			if (rc == HNSW_GPU_OK) rc = hnsw_gpu_index_append(e->ix, point, &label, 1);
 		}
-		else if (rc == HNSW_GPU_OK && have != (size_t) idx + 1)
+		else if (rc == HNSW_GPU_OK && have == (size_t) idx + 1)
+		{
+			// the mirror came from a walk that ran after the host had stored the row: there the new element is
+			// still unlinked, hence unreachable, hence a zero placeholder (host_walk.h) — give it its row and label
+			std::vector<unsigned char> img(e->meta.size_data_per_element, 0);
+			memcpy(img.data() + e->meta.offset_data, point, dim * 4);
+			const label_t label = (label_t) r.h.a0;
+			memcpy(img.data() + e->meta.offset_label, &label, sizeof(label));
+			rc = hnsw_gpu_index_update_from_flat(e->ix, img.data(), idx, 1);
+		}
+		else if (rc == HNSW_GPU_OK)
 			rc = HNSW_GPU_ERR_ARG;
 		out.push_back(0);
 		if (rc == HNSW_GPU_OK && idx != 0)       // bindPoint: nothing to do for the first element, hnswalg.cpp:228
@@ -709,6 +746,7 @@ void do_bind(CReq &r)
 		}
 		e->count.store(hnsw_gpu_index_count(e->ix));
 		if (rc == HNSW_GPU_OK && r.h.a1) e->gen.store(r.h.a1);
+		e->version.store(++g_vseq);
 	}
 	g_cnt.binds++;
 	if (rc != HNSW_GPU_OK)
@@ -746,6 +784,7 @@ void do_control(CReq &r)
 		{
 			WriteLock wl(e.get());
 			rc = hnsw_gpu_index_link(e->ix, (size_t) r.h.a0, (size_t) r.h.a1, r.h.aux, 0, nullptr);
+			e->version.store(++g_vseq);
 			idx_t probe[4097];
 			if (rc == HNSW_GPU_OK && hnsw_gpu_index_count(e->ix) > 0)
 				rc = hnsw_gpu_index_get_links(e->ix, 0, probe);          // waits for the build
@@ -783,6 +822,7 @@ void do_control(CReq &r)
 			r.c->respond(r.h, HGS_ERR_STALE, 0, 0, nullptr, 0, nullptr, 0, expect);
 			break;
 		}
+		e->version.store(++g_vseq);
 		r.c->respond(r.h, HGS_OK, e->count.load());
 		break;
 	}
@@ -794,6 +834,7 @@ void do_control(CReq &r)
 		{
 			WriteLock wl(e.get());
 			rc = hnsw_gpu_index_set_deleted(e->ix, r.h.aux, r.h.a0 ? 1 : 0);
+			e->version.store(++g_vseq);
 		}
 		r.c->respond(r.h, rc);
 		break;
@@ -826,7 +867,13 @@ void control_main()
 			r = std::move(g_c.front());
 			g_c.pop_front();
 		}
-		do_control(r);
+		try { do_control(r); }
+		catch (const std::exception &ex)      // an allocation that failed must cost one request, not every mirror
+		{
+			logf("control request %u failed: %s", (unsigned) r.h.op, ex.what());
+			if (r.fd >= 0) { close(r.fd); r.fd = -1; }
+			r.c->respond(r.h, HNSW_GPU_ERR_NOMEM);
+		}
 	}
 	std::lock_guard<std::mutex> lk(g_c_mu);
 	for (CReq &r : g_c)
@@ -871,8 +918,9 @@ bool handle_message(const ConnP &c, const hgs_hdr &h, const char *payload)
 	case HGS_OP_LOOKUP:
 	{
 		EntryP e = find_entry(h.key);
-		if (e) c->respond(h, HGS_OK, e->count.load(), 1, nullptr, 0, nullptr, 0, e->gen.load());
-		else c->respond(h, HGS_OK, 0, 0);
+		const uint64_t ver = e ? e->version.load() : 0;      // payload: the content version an UPLOAD may be guarded by
+		if (e) c->respond(h, HGS_OK, e->count.load(), 1, &ver, sizeof(ver), nullptr, 0, e->gen.load());
+		else c->respond(h, HGS_OK, 0, 0, &ver, sizeof(ver));
 		return true;
 	}
 	case HGS_OP_STATS:
@@ -965,7 +1013,14 @@ bool on_readable(const ConnP &c)
 			memcpy(&h, c->in.data() + off, sizeof(h));
 			if (h.magic != HGS_MAGIC || h.len > HGS_MAX_PAYLOAD) return false;
 			if (c->in.size() - off < sizeof(h) + h.len) break;
-			if (!handle_message(c, h, c->in.data() + off + sizeof(h))) return false;
+			bool keep;
+			try { keep = handle_message(c, h, c->in.data() + off + sizeof(h)); }
+			catch (const std::exception &ex)     // e.g. bad_alloc while queueing a payload: this connection only
+			{
+				logf("request %u failed: %s", (unsigned) h.op, ex.what());
+				return false;
+			}
+			if (!keep) return false;
 			off += sizeof(h) + h.len;
 		}
 		if (off) c->in.erase(c->in.begin(), c->in.begin() + (long) off);

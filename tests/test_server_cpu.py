@@ -470,3 +470,82 @@ def test_server_stops_cleanly_on_sigterm(double_bin):
     with pytest.raises(RemoteError):
         c.stats()
     c.close()
+
+
+def _sealed_memfd(data: bytes) -> int:
+    import fcntl
+    fd = os.memfd_create("images", os.MFD_CLOEXEC | os.MFD_ALLOW_SEALING)
+    os.write(fd, data)
+    fcntl.fcntl(fd, fcntl.F_ADD_SEALS, fcntl.F_SEAL_SHRINK | fcntl.F_SEAL_GROW | fcntl.F_SEAL_WRITE)
+    return fd
+
+
+def test_a_snapshot_cannot_replace_a_mirror_that_changed_since_its_lookup(srv):
+    """a scan's walk can overlap an insert in another backend; its UPLOAD must not replace the
+    mirror the inserter has extended meanwhile (the new row would become a dead placeholder for good).  LOOKUP
+    reports a content version, the UPLOAD carries it, and the server refuses the snapshot when the mirror has
+    changed in between — whatever generation names are in play."""
+    dim, m, n, efs = 24, 5, 300, 24
+    port, X = port_index(n, dim, m, 24, efs, pg.DIST_L2, seed=71)
+    meta = pg.make_meta(dim, m, 24, efs, pg.DIST_L2)
+    hdr = struct.Struct("<IHhIIQQQQ")
+    key = 77
+
+    def call(op, aux=0, gen=0, a0=0, a1=0, payload=b"", fd=None):
+        s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
+        s.settimeout(10)
+        s.connect(srv.socket_path)
+        msg = hdr.pack(0x31534748, op, 0, len(payload), aux, key, gen, a0, a1) + payload
+        if fd is None:
+            s.sendall(msg)
+        else:
+            socket.send_fds(s, [msg], [fd])
+            os.close(fd)
+        buf = b""
+        while len(buf) < 48:
+            buf += s.recv(65536)
+        r = hdr.unpack(buf[:48])
+        while len(buf) < 48 + r[3]:
+            buf += s.recv(65536)
+        s.close()
+        return r, buf[48:48 + r[3]]
+
+    def version():
+        r, p = call(2)
+        return struct.unpack("<Q", p)[0], r
+
+    def upload(gen, guard, count=n):
+        img = port.raw()[:count * meta.size_data_per_element].tobytes()
+        return call(3, gen=gen, a0=count, a1=guard, payload=bytes(meta), fd=_sealed_memfd(img))[0]
+
+    v0, r = version()
+    assert v0 == 0 and r[8] == 0                                    # absent
+    assert upload(5, v0 + 1)[2] == 0                                # guarded by "absent": accepted
+    v1, r = version()
+    assert v1 != 0 and r[6] == 5 and r[7] == n
+    assert upload(6, 0 + 1)[2] == HGS_ERR_STALE                     # "I saw no mirror" — but there is one now
+    # another backend changes the mirror (here: a vacuum flag) between this backend's LOOKUP and its UPLOAD
+    c = RemoteClient(srv.socket_path)
+    c.set_deleted(key, 3, True)
+    r = upload(6, v1 + 1)
+    assert r[2] == HGS_ERR_STALE and r[6] == 5                      # refused; the answer names the current generation
+    assert c.lookup(key) == (True, 5, n)
+    v2, _ = version()
+    assert v2 != v1
+    assert upload(6, v2 + 1)[2] == 0                                # a walk that started after the change is taken
+    assert c.lookup(key) == (True, 6, n)
+    assert upload(7, 0)[2] == 0                                     # unguarded (a host that owns the key outright)
+    # an insert lands on a mirror that already holds the new row as the walk's zero placeholder (the host had
+    # stored it, still unlinked, when the snapshot was taken): BIND gives it its row, then links it
+    new = gmm(1, dim, k=20, seed=72)[0]
+    ph = np.zeros(meta.size_data_per_element, np.uint8)
+    ph[meta.offset_label:meta.offset_label + 8] = np.frombuffer(struct.pack("<Q", 1 << 48), np.uint8)   # dead placeholder
+    img = port.raw().tobytes() + ph.tobytes()
+    assert call(3, gen=8, a0=n + 1, payload=bytes(meta), fd=_sealed_memfd(img))[0][2] == 0
+    r, _ = call(9, aux=n, gen=8, a0=4242, payload=new.astype(np.float32).tobytes())
+    assert r[2] == 0
+    port.add(new[None, :], np.array([4242], np.uint64))
+    for q in list(X[:5]) + [new]:
+        assert (c.search(key, q, efs)[0] == port.search(q, efs)[0]).all()
+    assert 4242 in c.search(key, new, efs)[0].tolist()
+    c.close()
