@@ -71,12 +71,20 @@ inline int send_msg(int fd, const hgs_hdr *h, const void *p1, size_t l1, const v
 }
 
 // Blocking read of exactly n bytes; a descriptor that arrives on the way is stored in *got_fd
-// (extra ones are closed).  0 on success, -1 on error / EOF.
-inline int recv_exact(int fd, void *buf, size_t n, int *got_fd)
+// (extra ones are closed).  0 on success, -1 on error / EOF / nothing for `timeout_ms` (< 0 = wait for ever):
+// a backend must not hang for good on a server that has stopped answering.
+inline int recv_exact(int fd, void *buf, size_t n, int *got_fd, int timeout_ms = -1)
 {
 	char *p = (char *) buf;
 	while (n > 0)
 	{
+		if (timeout_ms >= 0)
+		{
+			struct pollfd pf = { fd, POLLIN, 0 };
+			const int pr = poll(&pf, 1, timeout_ms);
+			if (pr == 0) { errno = ETIMEDOUT; return -1; }
+			if (pr < 0) { if (errno == EINTR) continue; return -1; }
+		}
 		struct iovec iov = { p, n };
 		struct msghdr mh;
 		memset(&mh, 0, sizeof(mh));

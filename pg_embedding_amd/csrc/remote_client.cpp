@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -168,9 +169,26 @@ int rpc(hgs_hdr *h, const void *p1, size_t l1, const void *p2, size_t l2, int pa
 	// A connection that was fine at the last call may have died since (the server was restarted): one
 	// fresh connection, one retry — for everything that can be repeated without harm, i.e. all but BIND
 	// (an insert that may or may not have been applied is the caller's to sort out: it fails).
+	// A server that has stopped answering must not hang the backend for good (and an uninterruptible recv cannot
+	// be cancelled): PG_EMBEDDING_GPU_TIMEOUT_MS, default 10 minutes (bulk builds and uploads are the long requests),
+	// 0 = wait for ever.  A request that timed out is not retried — it may still be running.
+	static const int timeout_ms = [] {
+		const char *e = getenv("PG_EMBEDDING_GPU_TIMEOUT_MS");
+		const long v = e ? atol(e) : 600000;
+		return v <= 0 ? -1 : (int) v;
+	}();
 	for (int attempt = 0;; attempt++)
 	{
-		if (hgs::send_msg(t_fd, h, p1, l1, p2, l2, pass_fd) == 0 && hgs::recv_exact(t_fd, r, sizeof(*r), nullptr) == 0) break;
+		if (hgs::send_msg(t_fd, h, p1, l1, p2, l2, pass_fd) == 0)
+		{
+			errno = 0;
+			if (hgs::recv_exact(t_fd, r, sizeof(*r), nullptr, timeout_ms) == 0) break;
+			if (errno == ETIMEDOUT)
+			{
+				drop_connection();
+				return fail(HGS_ERR_IO, "hnsw_gpu_server did not answer request %u within %d ms", (unsigned) h->op, timeout_ms);
+			}
+		}
 		drop_connection();
 		if (attempt == 1 || h->op == HGS_OP_BIND || ensure_connected() != HGS_OK)
 			return fail(HGS_ERR_IO, "lost the connection to hnsw_gpu_server");
@@ -181,7 +199,7 @@ int rpc(hgs_hdr *h, const void *p1, size_t l1, const void *p2, size_t l2, int pa
 		return fail(HGS_ERR_PROTOCOL, "bad response from hnsw_gpu_server");
 	}
 	t_resp.resize(r->len);
-	if (r->len && hgs::recv_exact(t_fd, t_resp.data(), r->len, nullptr) != 0)
+	if (r->len && hgs::recv_exact(t_fd, t_resp.data(), r->len, nullptr, timeout_ms) != 0)
 	{
 		drop_connection();
 		return fail(HGS_ERR_IO, "lost the connection to hnsw_gpu_server");
@@ -443,6 +461,22 @@ static int hnsw_gpu_remote_attach_impl(HnswMetadata *meta, uint64_t key, uint64_
 		rc = simple(HGS_OP_LOOKUP, key, 0, 0, 0, &r);
 		if (rc != HGS_OK) return rc;
 		if (r.a1 && r.gen == generation) break;                  // present and current
+		if (r.a1 && round == 0)
+		{
+			// Present under another name: most often an insert in another backend is between "row stored" and
+			// "mirror renamed" (hnsw_gpu_remote_advance) and the server catches up within a millisecond or two.
+			// Re-walking and re-uploading the whole index (3 GB at 1M x 768) to win that race would replace the
+			// very mirror the inserter is extending, so give it a moment first.
+			bool caught_up = false;
+			for (int i = 0; i < 5 && !caught_up; i++)
+			{
+				struct timespec ts = { 0, 2000000 };
+				nanosleep(&ts, nullptr);
+				if (simple(HGS_OP_LOOKUP, key, 0, 0, 0, &r) != HGS_OK) break;
+				caught_up = r.a1 && r.gen == generation;
+			}
+			if (caught_up) break;
+		}
 		uint64_t version = 0;
 		if (t_resp.size() == sizeof(version)) memcpy(&version, t_resp.data(), sizeof(version));
 		if (round == 4)
