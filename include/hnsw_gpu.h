@@ -77,6 +77,10 @@ int hnsw_gpu_index_export_flat(hnsw_gpu_index *ix, void *elements);
 /* Set / clear the vacuum flag of one element's label (embedding.c:920-926). */
 int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int deleted);
 
+/* The same for `count` elements at once (what a VACUUM produces, embedding.c:883-946): one upload of the element
+ * numbers and one launch, instead of a blocking copy pair per element. */
+int hnsw_gpu_index_set_deleted_batch(hnsw_gpu_index *ix, const idx_t *idx, size_t count, int deleted);
+
 /* Replace / add the elements [first, first+count) from host element images (same layout as
  * create_from_flat; `elements` points at the image of element `first`).  For a host that knows
  * which elements changed (new rows, re-linked neighbours, vacuum flags): incremental mirror

@@ -68,7 +68,8 @@ def gpu_lib():
             f"{_build.GPU_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  pg_embedding_amd has no CPU fallback.")
     _preload_torch_runtime()
-    L = C.CDLL(_build.GPU_LIB, mode=C.RTLD_GLOBAL)
+    # PGEMB_GPU_LIB: an experiment build of the same library (build.py variant ...), for A/B runs of kernel variants
+    L = C.CDLL(os.environ.get("PGEMB_GPU_LIB") or _build.GPU_LIB, mode=C.RTLD_GLOBAL)
     vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
     MP = C.POINTER(HnswMetadata)
     L.hnsw_gpu_last_error.restype = C.c_char_p
@@ -83,6 +84,7 @@ def gpu_lib():
     L.hnsw_gpu_index_update_from_flat.argtypes = [vp, vp, sz, sz]
     L.hnsw_gpu_index_get_links.argtypes = [vp, C.c_uint32, vp]
     L.hnsw_gpu_index_set_deleted.argtypes = [vp, C.c_uint32, i32]
+    L.hnsw_gpu_index_set_deleted_batch.argtypes = [vp, _u32p, sz, i32]
     L.hnsw_gpu_index_count.restype = sz
     L.hnsw_gpu_index_count.argtypes = [vp]
     L.hnsw_gpu_index_device.argtypes = [vp]

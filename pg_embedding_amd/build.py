@@ -92,6 +92,21 @@ def build(force: bool = False, verbose: bool = False) -> None:
         _run(cmd)
 
 
+def build_variant(tag: str, defines) -> str:
+    """An experiment build of libhnsw_gpu.so with extra -D flags (lib/variants/libhnsw_gpu_<tag>.so);
+    PGEMB_GPU_LIB=<path> makes pg_embedding_amd load it instead of the product library."""
+    vdir = os.path.join(LIBDIR, "variants")
+    os.makedirs(vdir, exist_ok=True)
+    out = os.path.join(vdir, f"libhnsw_gpu_{tag}.so")
+    _run([_hipcc()] + HIPCC_FLAGS + [f"-D{d}" for d in defines] + ["-I", INC, "-I", CSRC,
+         os.path.join(CSRC, "hnsw_gpu.hip"), os.path.join(CSRC, "sort_pairs.hip"), "-o", out])
+    return out
+
+
 if __name__ == "__main__":
+    import sys
+    if len(sys.argv) > 2 and sys.argv[1] == "variant":      # build.py variant <tag> [DEFINE ...]
+        print("built", build_variant(sys.argv[2], sys.argv[3:]))
+        sys.exit(0)
     build(force=True, verbose=True)
     print("built", GPU_LIB, SHIM_LIB, CLIENT_LIB, SERVER_BIN)

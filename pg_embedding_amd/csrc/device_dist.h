@@ -100,6 +100,7 @@ __device__ __forceinline__ void acc_step(RowAcc &s, const float4 &q, const float
 	}
 }
 
+
 // Epilogue of one distance from its reduced sums, exactly as the reference writes it
 // (distfunc.c:64,117,129 / :144 / :154).  s0 = sum of squares | dot | sum of |.|; s1 = |x|^2
 // (cosine only); qnorm = |q|^2 in the same canonical order.  Pure per-lane arithmetic, so callers
@@ -261,6 +262,7 @@ __device__ __forceinline__ void score_rows_fit(const float *__restrict__ vec, si
 
 // Load-batch shapes by chunk-steps per row (kiters = ceil(dim/64)).
 struct Shape2x4  { static constexpr int KB = 2,  RPG = 4, MIN_WAVES = 4; };   // dim <= 128
+struct Shape2x2  { static constexpr int KB = 2,  RPG = 2, MIN_WAVES = 5; };   // dim <= 128, the hot beam form: 96 VGPRs, 5 waves/SIMD
 struct Shape4x2  { static constexpr int KB = 4,  RPG = 2, MIN_WAVES = 4; };   // dim <= 256
 struct Shape8x2  { static constexpr int KB = 8,  RPG = 2, MIN_WAVES = 2; };   // dim <= 512
 struct Shape12x1 { static constexpr int KB = 12, RPG = 1, MIN_WAVES = 2; };   // larger (768 = one batch)

@@ -80,6 +80,7 @@ struct SearchArgs
 	// register form only: exact visited hash set in LDS (power-of-two entries, 0 = off); ids that
 	// arrive after it is hmax full go to the HBM bitmap instead
 	uint32_t off_hash, hcap, hmax;
+	uint32_t hmagic;            // beam form: ceil(2^38 / buckets) of the bucketed set (hcap / 4 buckets of eight 16-bit tags)
 	uint64_t *beam_scratch;     // beam form: per-slot HBM scratch for the (rare) prune compaction, 64*UREG keys
 	uint64_t *set_scratch;      // generic form with its sets in HBM: per-slot area, set_stride keys apart
 	uint32_t out_stride;        // result slots per query in the output arrays (the caller's ef; a.ef may be clamped to n)
@@ -172,14 +173,17 @@ __device__ __forceinline__ uint32_t dpp_u32(uint32_t old, uint32_t v)
 }
 
 // min over the wavefront, returned uniformly
+// (`old` = the identity of min: lanes a masked row leaves unwritten see the identity, and hipcc folds each step into ONE
+// v_min_u32_dpp instead of v_mov + v_mov_dpp + v_min)
 __device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
 {
-	v = min(v, dpp_u32<0xB1>(v, v));           // lane ^ 1
-	v = min(v, dpp_u32<0x4E>(v, v));           // lane ^ 2
-	v = min(v, dpp_u32<0x141>(v, v));          // row_half_mirror
-	v = min(v, dpp_u32<0x140>(v, v));          // row_mirror: every lane of a row = row min
-	v = min(v, dpp_u32<0x142, 0xA>(v, v));     // row_bcast15 into rows 1 and 3
-	v = min(v, dpp_u32<0x143, 0xC>(v, v));     // row_bcast31 into rows 2 and 3
+	constexpr uint32_t ID = 0xFFFFFFFFu;
+	v = min(v, dpp_u32<0xB1>(ID, v));           // lane ^ 1
+	v = min(v, dpp_u32<0x4E>(ID, v));           // lane ^ 2
+	v = min(v, dpp_u32<0x141>(ID, v));          // row_half_mirror
+	v = min(v, dpp_u32<0x140>(ID, v));          // row_mirror: every lane of a row = row min
+	v = min(v, dpp_u32<0x142, 0xA>(ID, v));     // row_bcast15 into rows 1 and 3
+	v = min(v, dpp_u32<0x143, 0xC>(ID, v));     // row_bcast31 into rows 2 and 3
 	return (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
 }
 
@@ -334,6 +338,64 @@ __device__ __forceinline__ bool hash_contains(const uint32_t *tab, uint32_t mask
 		if (v == HASH_EMPTY) return false;
 		s = (s + 1) & mask;
 	}
+}
+
+// ---- exact visited set in LDS, bucketed (beam form): 16-byte buckets of eight 16-bit tags ---------------
+// bucket = id % nb, tag = id / nb + 1 (0 = free slot): bucket and tag together ARE the id, so the set is
+// exact.  A bucket fills front to back and never shrinks within a query, so ONE ds_read_b128 answers "seen?" and one
+// ds_cmpst on the word that holds the first free slot inserts — two LDS round trips whatever the fill, where linear
+// probing of 32-bit ids cost the slowest lane's chain (measured 2.2-2.6 k cycles per hop, profiles/r2k_*).  Twice the
+// entries in the same LDS; an id whose bucket is full goes to the HBM bitmap (exact: an id is only ever looked up in
+// the bitmap when its bucket is full, and was only ever put there when its bucket was full, and buckets never shrink).
+enum : int { TS_SEEN = 0, TS_NEW = 1, TS_FULL = 2, TS_AGAIN = 3 };
+
+// nonzero iff one of the eight 16-bit halves of w equals the tag replicated in tt (the classic zero-field test on
+// w ^ tt, exact for "is there one"); straight-line on purpose: `||` of four tests compiles to four divergent branches
+__device__ __forceinline__ uint32_t tag_match(const uint4 &w, uint32_t tt)
+{
+	const uint32_t x0 = w.x ^ tt, x1 = w.y ^ tt, x2 = w.z ^ tt, x3 = w.w ^ tt;
+	return (((x0 - 0x00010001u) & ~x0) | ((x1 - 0x00010001u) & ~x1) | ((x2 - 0x00010001u) & ~x2) | ((x3 - 0x00010001u) & ~x3)) & 0x80008000u;
+}
+
+// id -> (bucket, tag) for any bucket count nb in [128, 1024]: q = id / nb through a 38-bit reciprocal (magic =
+// ceil(2^38 / nb); exact for id < 2^28, and the host only enables the set while (n - 1) / nb + 1 fits 16 bits)
+__device__ __forceinline__ void tagset_split(uint32_t id, uint32_t nb, uint32_t magic, uint32_t &b, uint32_t &tag)
+{
+	const uint32_t q = (uint32_t) (((uint64_t) id * magic) >> 38);
+	b = id - q * nb;
+	tag = q + 1u;
+}
+
+__device__ __forceinline__ int tagset_test_and_set(uint32_t *tab, uint32_t nb, uint32_t magic, uint32_t id)
+{
+	uint32_t b, tag;
+	tagset_split(id, nb, magic, b, tag);
+	const uint32_t tt = tag * 0x00010001u;
+	int st;
+	do
+	{
+		const uint4 w = *reinterpret_cast<const uint4 *>(tab + 4u * b);
+		st = tag_match(w, tt) ? TS_SEEN : ((w.w >> 16) ? TS_FULL : TS_AGAIN);
+		if (st == TS_AGAIN)
+		{
+			// used slots are a prefix: the first word whose upper half is free holds the first free slot
+			const bool xo = (w.x >> 16) == 0u, yo = (w.y >> 16) == 0u, zo = (w.z >> 16) == 0u;
+			const uint32_t wi  = xo ? 0u : (yo ? 1u : (zo ? 2u : 3u));
+			const uint32_t old = xo ? w.x : (yo ? w.y : (zo ? w.z : w.w));
+			const uint32_t neu = old ? (old | (tag << 16)) : tag;
+			// a failed exchange = another lane's insert changed that word in between: look again (at most 8 rounds)
+			if (atomicCAS(tab + 4u * b + wi, old, neu) == old) st = TS_NEW;
+		}
+	} while (st == TS_AGAIN);
+	return st;
+}
+
+__device__ __forceinline__ bool tagset_contains(const uint32_t *tab, uint32_t nb, uint32_t magic, uint32_t id)
+{
+	uint32_t b, tag;
+	tagset_split(id, nb, magic, b, tag);
+	const uint4 w = *reinterpret_cast<const uint4 *>(tab + 4u * b);
+	return tag_match(w, tag * 0x00010001u) != 0u;
 }
 
 template <int FUNC, typename SH, int RREG>
@@ -990,33 +1052,57 @@ __device__ __forceinline__ uint32_t beam_count_lt(const uint64_t (&uk)[U], uint3
 }
 
 // Best unexpanded element: smallest (dist, ~idx).  Returns false when none is left.
+// The distance word decides alone unless two open elements share the smallest one (then the larger idx goes first,
+// as std::pair<-dist, idx> orders them): per-lane minimum of the open distance words, one wave minimum, and the slot
+// from UREG equality ballots — no 64-bit compares, no carried (key, register) pairs.
 template <int U>
 __device__ __forceinline__ bool beam_next(const uint64_t (&uk)[U], uint32_t ex, uint32_t &slot, uint64_t &ckey)
 {
-	uint64_t m = ~0ull;
-	uint32_t mk = 0;
+	uint32_t h[U];
+	uint32_t m = 0xFFFFFFFFu;
 #pragma unroll
 	for (int k = 0; k < U; k++)
 	{
-		const bool open = !((ex >> k) & 1u) && (uint32_t) (uk[k] >> 32) != 0xFFFFFFFFu;
-		const uint64_t c = open ? (uk[k] ^ 0xFFFFFFFFull) : ~0ull;
-		const bool lt = c < m;
-		m = lt ? c : m;
-		mk = lt ? (uint32_t) k : mk;
+		h[k] = ((ex >> k) & 1u) ? 0xFFFFFFFFu : (uint32_t) (uk[k] >> 32);      // unused slots hold ~0 already
+		m = min(m, h[k]);
 	}
-	const uint32_t h = (uint32_t) (m >> 32);
-	const uint32_t hmin = wave_min_u32(h);
+	const uint32_t hmin = wave_min_u32(m);
 	if (hmin == 0xFFFFFFFFu) return false;
-	uint64_t eq = __ballot(h == hmin);
-	if (__builtin_popcountll(eq) > 1)
+	uint64_t eq[U];
+	uint32_t cnt = 0;
+#pragma unroll
+	for (int k = 0; k < U; k++)
 	{
-		const uint32_t lo = (h == hmin) ? (uint32_t) m : 0xFFFFFFFFu;
-		const uint32_t lomin = wave_min_u32(lo);
-		eq = __ballot(h == hmin && lo == lomin);
+		eq[k] = __ballot(h[k] == hmin);
+		cnt += (uint32_t) __builtin_popcountll(eq[k]);
 	}
-	const uint32_t L = (uint32_t) __builtin_ctzll(eq);
-	slot = ((uint32_t) __builtin_amdgcn_readlane((int) mk, (int) L) << 6) | L;
-	ckey = readlane_u64(m, L);
+	if (cnt > 1)                                            // equal distances: larger idx first
+	{
+		uint32_t lo = 0xFFFFFFFFu;
+#pragma unroll
+		for (int k = 0; k < U; k++) lo = min(lo, h[k] == hmin ? ~(uint32_t) uk[k] : 0xFFFFFFFFu);
+		const uint32_t lomin = wave_min_u32(lo);
+#pragma unroll
+		for (int k = 0; k < U; k++) eq[k] = __ballot(h[k] == hmin && ~(uint32_t) uk[k] == lomin);
+	}
+	uint32_t ks = U - 1;
+	uint64_t em = eq[U - 1];
+#pragma unroll
+	for (int k = U - 2; k >= 0; k--)
+	{
+		ks = eq[k] ? (uint32_t) k : ks;
+		em = eq[k] ? eq[k] : em;
+	}
+	const uint32_t L = (uint32_t) __builtin_ctzll(em);
+	uint32_t idx = 0;
+#pragma unroll
+	for (int k = 0; k < U; k++)
+	{
+		const uint32_t t = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) uk[k], (int) L);
+		idx = ks == (uint32_t) k ? t : idx;
+	}
+	slot = (ks << 6) | L;
+	ckey = ((uint64_t) hmin << 32) | (uint32_t) ~idx;
 	return true;
 }
 
@@ -1113,6 +1199,20 @@ constexpr bool TEAM_COUNT = true;
 #else
 constexpr bool TEAM_COUNT = false;
 #endif
+// per-section cycle stamps of the walking wave (any beam kernel): compiled in only with -DHNSW_HOP_STAMPS
+// (scripts/build_variant.sh); sums in units of 64 cycles land in team_dbg[0..7]
+#ifdef HNSW_HOP_STAMPS
+constexpr bool HOP_STAMPS = true;
+#else
+constexpr bool HOP_STAMPS = false;
+#endif
+__device__ __forceinline__ uint32_t hop_stamp()
+{
+	__builtin_amdgcn_sched_barrier(0);
+	const uint32_t t = (uint32_t) __builtin_amdgcn_s_memtime();
+	__builtin_amdgcn_sched_barrier(0);
+	return t;
+}
 
 struct TeamCtl
 {
@@ -1168,20 +1268,6 @@ __device__ __forceinline__ uint64_t team_find(unsigned char *smem, const SearchA
 	uint64_t u = 0;
 	if (lane < TEAM_MAX_WPB && ((hmask >> lane) & 1u)) u = team_view(smem, a, (uint32_t) lane).hdr[lc_slot(c, a.tm_lcslots)];
 	return __ballot((uint32_t) u == c && (uint32_t) (u >> 32) >= LC_CLAIMED);
-}
-
-// helper's look at the main's visited set: bounded, because the main may be past its walk and have reused the area
-__device__ __forceinline__ bool hash_contains_bounded(const uint32_t *tab, uint32_t mask, uint32_t id)
-{
-	uint32_t s = hash_slot(id, mask);
-	for (uint32_t probe = 0; probe < 48; probe++)
-	{
-		const uint32_t v = tab[s];
-		if (v == id) return true;
-		if (v == HASH_EMPTY) return false;
-		s = (s + 1) & mask;
-	}
-	return false;
 }
 
 __device__ __forceinline__ bool dc_lookup(const uint64_t *dc, uint32_t cmask, uint32_t id, uint32_t &od)
@@ -1259,7 +1345,6 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 		unsigned char *mreg = smem + (size_t) target * a.wave_bytes;
 		const float4 *q4 = reinterpret_cast<const float4 *>(mreg);
 		const uint32_t *mhtab = reinterpret_cast<const uint32_t *>(mreg + a.off_hash);
-		const uint32_t mhmask = a.hcap - 1;
 		float qnorm = 0.f;
 		if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
 		uint32_t dcount = 0;
@@ -1327,7 +1412,7 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 					const uint32_t j = j0 + lane;
 					const uint32_t t = a.links[(size_t) cand * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
 					bool need = j < a.lstride && t != LINK_NONE && t < a.n;
-					if (need && a.hcap) need = !hash_contains_bounded(mhtab, mhmask, t);  // visited is visited for good
+					if (need && a.hcap) need = !tagset_contains(mhtab, a.hcap / 4u, a.hmagic, t);
 					uint32_t od = OD_MISSING;
 					bool score = need;
 					if (need && dc_lookup(mine.dc, cmask, t, od)) score = false;          // already scored for another element
@@ -1429,10 +1514,13 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		uint32_t usize = 0, logn = 0, evals = 0, hops = 0, hcount = 0;
 		uint32_t bstale = 0xFFFFFFFFu;       // ord() of a valid upper bound of the reference's lowerBound
 		bool spill = a.hcap == 0;
+		uint32_t hs_pop = 0, hs_link = 0, hs_vis = 0, hs_score = 0, hs_acc = 0, hs_q0 = 0;
+		if (HOP_STAMPS && a.team_dbg) hs_q0 = hop_stamp();
+		const uint32_t hnb = a.hcap / 4u;                                  // buckets of the visited set
 		if (a.hcap)
 		{
 			uint4 *h4 = reinterpret_cast<uint4 *>(htab);
-			for (uint32_t i = lane; i < a.hcap / 4; i += 64) h4[i] = make_uint4(HASH_EMPTY, HASH_EMPTY, HASH_EMPTY, HASH_EMPTY);
+			for (uint32_t i = lane; i < a.hcap / 4; i += 64) h4[i] = make_uint4(0u, 0u, 0u, 0u);
 			wave_sync();
 		}
 
@@ -1451,7 +1539,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 			if (lane == 0)
 			{
 				if (spill) { vis[ep >> 5] = 1u << (ep & 31); vlog[0] = ep; }
-				else htab[hash_slot(ep, hmask)] = ep;
+				else { uint32_t eb, et; tagset_split(ep, hnb, a.hmagic, eb, et); htab[4u * eb] = et; }   // empty table: slot 0 of its bucket
 			}
 			logn = spill ? 1 : 0;
 			hcount = 1;
@@ -1465,12 +1553,15 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				if (TEAM) hm = __builtin_amdgcn_readfirstlane(ctl[wib].helpers);
 				uint32_t cslot;
 				uint64_t ckey;
+				uint32_t hs0 = 0, hs1 = 0;
+				if (HOP_STAMPS && a.team_dbg) hs0 = hop_stamp();
 				if (!beam_next<UREG>(uk, ex, cslot, ckey)) break;          // candidateSet empty
 				const uint32_t cd = (uint32_t) (ckey >> 32);
 				if (beam_count_lt<UREG>(uk, cd) >= ef) break;              // :70-71  best candidate > lowerBound
 				const uint32_t cur = ~(uint32_t) ckey;
 				ex |= ((uint32_t) lane == (cslot & 63)) ? (1u << (cslot >> 6)) : 0u;   // :73 pop
 				hops++;
+				if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_pop += hs1 - hs0; hs0 = hs1; }
 				TeamView h0v = {};
 				if (TEAM && (TEAM_COUNT && a.team_dbg) && lane == 0) { atomicAdd(a.team_dbg + 5, 1u); if (hm) atomicAdd(a.team_dbg + 0, 1u); }
 				uint64_t tc0 = 0, tc1 = 0, tc2 = 0, tc3 = 0;
@@ -1526,56 +1617,46 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 						t = a.links[(size_t) cur * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
 					if (TEAM && (TEAM_COUNT && a.team_dbg) && lhit && lane == 0) atomicAdd(a.team_dbg + 1, 1u);
 					if (TEAM && (TEAM_COUNT && a.team_dbg)) { __builtin_amdgcn_s_waitcnt(0); tc1 = __builtin_amdgcn_s_memtime(); }
+					if (HOP_STAMPS && a.team_dbg) { __builtin_amdgcn_s_waitcnt(0); hs1 = hop_stamp(); hs_link += hs1 - hs0; hs0 = hs1; }
 					bool isnew = false;
+					bool tobits = false;                                    // this id lives in the HBM bitmap (bucket full, or no LDS set)
 					if (j < a.lstride && t != LINK_NONE)                    // :91-93
 					{
+						tobits = spill;
 						if (!spill)
-							isnew = hash_test_and_set(htab, hmask, t);
-						else
+						{
+							const int r = tagset_test_and_set(htab, hnb, a.hmagic, t);
+							isnew = r == TS_NEW;
+							tobits = r == TS_FULL;
+						}
+						if (tobits)
 						{
 							const uint32_t bit = 1u << (t & 31);
 							const uint32_t old = atomicOr(&vis[t >> 5], bit);
 							isnew = !(old & bit);
 						}
 					}
+					{
+						const uint64_t lm = __ballot(isnew && tobits);      // bits to undo after the query
+						if (lm)
+						{
+							const uint32_t lp = logn + lane_rank(lm);
+							if (isnew && tobits && lp < a.logcap) vlog[lp] = t;
+							logn += (uint32_t) __builtin_popcountll(lm);
+						}
+					}
 					const uint64_t mask = __ballot(isnew);
 					const uint32_t nnew = (uint32_t) __builtin_popcountll(mask);
-					if (nnew == 0) continue;
+					if (nnew == 0)
+					{
+						if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_vis += hs1 - hs0; hs0 = hs1; }
+						continue;
+					}
 					const uint32_t rank = lane_rank(mask);
 					if (isnew)
 					{
 						newid[rank] = t;
 						if (TEAM && hm) reinterpret_cast<uint32_t *>(newdist)[rank] = od_pk;      // packaged distance, link order kept
-						if (spill)
-						{
-							const uint32_t lp = logn + rank;
-							if (lp < a.logcap) vlog[lp] = t;
-						}
-					}
-					if (spill) logn += nnew;
-					else
-					{
-						hcount += nnew;
-						if (hcount + 64 > a.hmax)
-						{
-							// the LDS set is nearly full: move it to this slot's HBM bitmap once and carry on
-							// there (so a long traversal costs what the bitmap-only form costs)
-							wave_sync();
-							for (uint32_t i0 = 0; i0 < a.hcap; i0 += 64)
-							{
-								const uint32_t h = htab[i0 + lane];
-								const bool used = h != HASH_EMPTY;
-								const uint64_t um = __ballot(used);
-								if (used)
-								{
-									atomicOr(&vis[h >> 5], 1u << (h & 31));
-									const uint32_t lp = logn + lane_rank(um);
-									if (lp < a.logcap) vlog[lp] = h;
-								}
-								logn += (uint32_t) __builtin_popcountll(um);
-							}
-							spill = true;
-						}
 					}
 					wave_sync();
 					// What still has to be scored here: everything (no helpers), or what no package held
@@ -1606,6 +1687,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 						sids = h0v.miss;
 					}
 					uint32_t od_mine = od_c;
+					if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_vis += hs1 - hs0; hs0 = hs1; }
 					if (nscore)
 					{
 						const uint32_t *ids = sids;
@@ -1618,6 +1700,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 					evals += nnew;
 					if (TEAM && (TEAM_COUNT && a.team_dbg)) { __builtin_amdgcn_s_waitcnt(0); tc2 = __builtin_amdgcn_s_memtime(); }
 					const uint32_t t_mine = newid[lane];
+					if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_score += hs1 - hs0; hs0 = hs1; }
 					// rows at or above a valid upper bound of lowerBound cannot be accepted (:99)
 					uint64_t todo = __ballot((uint32_t) lane < nnew && od_mine < bstale);
 					while (todo)                                            // :99-108, in link order
@@ -1642,6 +1725,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 						usize++;
 					}
 					wave_sync();
+					if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_acc += hs1 - hs0; hs0 = hs1; }
 					if (TEAM && (TEAM_COUNT && a.team_dbg) && lane == 0)
 					{
 						tc3 = __builtin_amdgcn_s_memtime();
@@ -1654,6 +1738,8 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		}
 
 		if (TEAM && lane == 0) ctl[wib].state = 0u;                       // walk over: helpers let go
+		uint32_t hs_walk = 0;
+		if (HOP_STAMPS && a.team_dbg) hs_walk = hop_stamp();
 		// ---- emit: the ef smallest (dist, idx) keys of the set, then the reference's output order ----
 		uint32_t rsize = usize;
 		if (usize > ef)
@@ -1666,19 +1752,22 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		{
 			const uint32_t i = (uint32_t) k * 64 + lane;
 			if (i < rsize) srt_key[i] = uk[k];
+			else if (i < rsize + 3) srt_key[i] = ~0ull;                  // padding of the 4-wide rank loop: never below a key
 		}
 		wave_sync();
 		const size_t obase = (size_t) qi * a.out_stride;
 		uint32_t nout = 0;
-		// rank by (dist, idx); only ranks < ef are results (topCandidates, hnswalg.cpp:237-240)
+		// rank by (dist, idx); only ranks < ef are results (topCandidates, hnswalg.cpp:237-240).  Four broadcast
+		// keys per step: the loop is a chain of LDS round trips, not of compares.
 		uint32_t myrank[UREG];
 #pragma unroll
 		for (int k = 0; k < UREG; k++) myrank[k] = 0;
-		for (uint32_t jx = 0; jx < rsize; jx++)
+		for (uint32_t jx = 0; jx < rsize; jx += 4)
 		{
-			const uint64_t kj = srt_key[jx];
+			const uint64_t k0 = srt_key[jx], k1 = srt_key[jx + 1], k2 = srt_key[jx + 2], k3 = srt_key[jx + 3];
 #pragma unroll
-			for (int k = 0; k < UREG; k++) myrank[k] += (kj < uk[k]) ? 1u : 0u;
+			for (int k = 0; k < UREG; k++)
+				myrank[k] += ((k0 < uk[k]) ? 1u : 0u) + ((k1 < uk[k]) ? 1u : 0u) + ((k2 < uk[k]) ? 1u : 0u) + ((k3 < uk[k]) ? 1u : 0u);
 		}
 #pragma unroll
 		for (int k = 0; k < UREG; k++)
@@ -1777,6 +1866,18 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_s_waitcnt(0);
 		wave_sync();
+		if (HOP_STAMPS && a.team_dbg && lane == 0)
+		{
+			const uint32_t hs_end = hop_stamp();
+			atomicAdd(a.team_dbg + 0, hops);
+			atomicAdd(a.team_dbg + 1, hs_pop >> 6);
+			atomicAdd(a.team_dbg + 2, hs_link >> 6);
+			atomicAdd(a.team_dbg + 3, hs_vis >> 6);
+			atomicAdd(a.team_dbg + 4, hs_score >> 6);
+			atomicAdd(a.team_dbg + 5, hs_acc >> 6);
+			atomicAdd(a.team_dbg + 6, (hs_walk - hs_q0) >> 6);      // query start .. walk over (incl. set-up and entry point)
+			atomicAdd(a.team_dbg + 7, (hs_end - hs_walk) >> 6);     // emit + bitmap clean-up
+		}
 	}
 	if (TEAM)
 	{

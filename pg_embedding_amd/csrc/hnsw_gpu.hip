@@ -301,10 +301,12 @@ __global__ __launch_bounds__(256) void append_rows_kernel(const float *__restric
 	if (lane == 0) labels[e] = src_labels ? src_labels[w] : (uint64_t) e;
 }
 
-static const size_t STAGE_BYTES = (size_t) 256 << 20;   // host<->device staging granule
+static const size_t STAGE_BYTES = (size_t) 128 << 20;   // host<->device staging granule (two of them for uploads)
 
 // Re-import `count` host element images into element numbers [first, first+count); the mirror
-// grows to cover them.  n_total bounds the link targets that are accepted.
+// grows to cover them.  n_total bounds the link targets that are accepted.  Two staging buffers, a copy
+// stream and a kernel stream: the copy of granule i+1 runs while granule i is scattered into the mirror, and
+// nothing waits for the whole device (other mirrors' searches keep running).
 static int import_range(hnsw_gpu_index *ix, const void *elements, size_t first, size_t count, size_t n_total)
 {
 	const HnswMetadata *meta = &ix->meta;
@@ -313,23 +315,67 @@ static int import_range(hnsw_gpu_index *ix, const void *elements, size_t first, 
 	uint32_t *bad = ix->misc;
 	if (count == 0) return HNSW_GPU_OK;
 	HIPCHK(hipMemset(bad, 0, 4));
-	int rc0 = ensure_scratch(ix, std::min(per, count) * esz);      // staging lives in the mirror's scratch
+	const size_t nbuf = count > per ? 2 : 1;
+	const size_t buf_bytes = round_up(std::min(per, count) * esz, 256);
+	int rc0 = ensure_scratch(ix, nbuf * buf_bytes);                // staging lives in the mirror's scratch
 	if (rc0) return rc0;
-	uint32_t *stage = (uint32_t *) ix->scratch;
+	hipStream_t s_copy = nullptr, s_kern = nullptr;
+	hipEvent_t copied[2] = { nullptr, nullptr }, used[2] = { nullptr, nullptr };
 	hipError_t e = hipSuccess;
-	for (size_t off = 0; off < count && e == hipSuccess; off += per)
+	if (nbuf == 1)
+	{
+		// one granule (incremental updates, small mirrors): no pipeline to build — copy, scatter, and the read-back
+		// of the error counter below waits for the kernel on the default stream
+		e = hipMemcpy(ix->scratch, elements, count * esz, hipMemcpyHostToDevice);
+		if (e == hipSuccess)
+		{
+			hipLaunchKernelGGL(import_elements_kernel, dim3((uint32_t) ((count + 3) / 4)), dim3(256), 0, 0, (const uint32_t *) ix->scratch,
+							   esz / 4, (uint32_t) first, (uint32_t) count, (uint32_t) n_total, (uint32_t) meta->dim, ix->stride,
+							   (uint32_t) meta->maxM, ix->lstride, ix->vec, ix->links, ix->labels, bad);
+			e = hipGetLastError();
+		}
+		uint32_t nb1 = 0;
+		if (e == hipSuccess) e = hipMemcpy(&nb1, bad, 4, hipMemcpyDeviceToHost);
+		if (e != hipSuccess) return fail(HNSW_GPU_ERR_HIP, "index upload failed: %s", hipGetErrorString(e));
+		if (nb1) return fail(HNSW_GPU_ERR_ARG, "element image is corrupt: %u bad link counts / link targets", nb1);
+		return HNSW_GPU_OK;
+	}
+	e = hipStreamCreate(&s_copy);
+	if (e == hipSuccess) e = hipStreamCreate(&s_kern);
+	for (int b = 0; b < 2 && e == hipSuccess; b++)
+	{
+		e = hipEventCreateWithFlags(&copied[b], hipEventDisableTiming);
+		if (e == hipSuccess) e = hipEventCreateWithFlags(&used[b], hipEventDisableTiming);
+	}
+	size_t chunk = 0;
+	for (size_t off = 0; off < count && e == hipSuccess; off += per, chunk++)
 	{
 		const size_t cnt = std::min(per, count - off);
-		e = hipMemcpy(stage, (const char *) elements + off * esz, cnt * esz, hipMemcpyHostToDevice);
+		const int b = (int) (chunk % nbuf);
+		uint32_t *stage = (uint32_t *) ((char *) ix->scratch + (size_t) b * buf_bytes);
+		if (chunk >= nbuf) e = hipStreamWaitEvent(s_copy, used[b], 0);       // the kernel that read this buffer is done
+		if (e == hipSuccess) e = hipMemcpyAsync(stage, (const char *) elements + off * esz, cnt * esz, hipMemcpyHostToDevice, s_copy);
+		if (e == hipSuccess) e = hipEventRecord(copied[b], s_copy);
+		if (e == hipSuccess) e = hipStreamWaitEvent(s_kern, copied[b], 0);
 		if (e != hipSuccess) break;
 		const uint32_t blocks = (uint32_t) ((cnt + 3) / 4);
-		hipLaunchKernelGGL(import_elements_kernel, dim3(blocks), dim3(256), 0, 0, stage, esz / 4, (uint32_t) (first + off),
+		hipLaunchKernelGGL(import_elements_kernel, dim3(blocks), dim3(256), 0, s_kern, stage, esz / 4, (uint32_t) (first + off),
 						   (uint32_t) cnt, (uint32_t) n_total, (uint32_t) meta->dim, ix->stride, (uint32_t) meta->maxM,
 						   ix->lstride, ix->vec, ix->links, ix->labels, bad);
-		e = hipDeviceSynchronize();
+		e = hipGetLastError();
+		if (e == hipSuccess) e = hipEventRecord(used[b], s_kern);
 	}
+	if (s_copy) { const hipError_t e2 = hipStreamSynchronize(s_copy); if (e == hipSuccess) e = e2; }
+	if (s_kern) { const hipError_t e2 = hipStreamSynchronize(s_kern); if (e == hipSuccess) e = e2; }
 	uint32_t nbad = 0;
 	if (e == hipSuccess) e = hipMemcpy(&nbad, bad, 4, hipMemcpyDeviceToHost);
+	for (int b = 0; b < 2; b++)
+	{
+		if (copied[b]) (void) hipEventDestroy(copied[b]);
+		if (used[b]) (void) hipEventDestroy(used[b]);
+	}
+	if (s_copy) (void) hipStreamDestroy(s_copy);
+	if (s_kern) (void) hipStreamDestroy(s_kern);
 	if (e != hipSuccess) return fail(HNSW_GPU_ERR_HIP, "index upload failed: %s", hipGetErrorString(e));
 	if (nbad) return fail(HNSW_GPU_ERR_ARG, "element image is corrupt: %u bad link counts / link targets", nbad);
 	return HNSW_GPU_OK;
@@ -427,17 +473,41 @@ extern "C" int hnsw_gpu_index_export_flat(hnsw_gpu_index *ix, void *elements)
 	return HNSW_GPU_OK;
 }
 
-extern "C" int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int deleted)
+// vacuum flags of a batch of elements: one upload of the element numbers + one launch (a VACUUM flags many rows,
+// embedding.c:883-946; doing them one blocking copy pair at a time is a synchronisation storm)
+__global__ __launch_bounds__(256) void set_deleted_kernel(uint64_t *__restrict__ labels, const uint32_t *__restrict__ idx,
+														 size_t count, int deleted)
+{
+	const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+	if (i >= count) return;
+	const unsigned long long bit = 1ull << HNSW_LABEL_DELETED_BIT;
+	unsigned long long *l = reinterpret_cast<unsigned long long *>(labels + idx[i]);
+	if (deleted) atomicOr(l, bit); else atomicAnd(l, ~bit);        // atomic: the same element may be listed twice
+}
+
+extern "C" int hnsw_gpu_index_set_deleted_batch(hnsw_gpu_index *ix, const idx_t *idx, size_t count, int deleted)
 {
 	std::unique_lock<std::recursive_mutex> lock_;
 	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
-	if (!ix || idx >= ix->n) return fail(HNSW_GPU_ERR_ARG, "bad element %u", (unsigned) idx);
+	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
+	if (count == 0) return HNSW_GPU_OK;
+	if (!idx) return fail(HNSW_GPU_ERR_ARG, "NULL element list");
+	for (size_t i = 0; i < count; i++)
+		if (idx[i] >= ix->n) return fail(HNSW_GPU_ERR_ARG, "bad element %u", (unsigned) idx[i]);
 	HIPCHK(hipSetDevice(ix->device));
-	uint64_t l;
-	HIPCHK(hipMemcpy(&l, ix->labels + idx, 8, hipMemcpyDeviceToHost));
-	if (deleted) l |= (uint64_t) 1 << HNSW_LABEL_DELETED_BIT; else l &= ~((uint64_t) 1 << HNSW_LABEL_DELETED_BIT);
-	HIPCHK(hipMemcpy(ix->labels + idx, &l, 8, hipMemcpyHostToDevice));
+	int rc = ensure_scratch(ix, count * sizeof(uint32_t));
+	if (rc) return rc;
+	HIPCHK(hipMemcpy(ix->scratch, idx, count * sizeof(uint32_t), hipMemcpyHostToDevice));
+	hipLaunchKernelGGL(set_deleted_kernel, dim3((uint32_t) ((count + 255) / 256)), dim3(256), 0, 0,
+					   ix->labels, (const uint32_t *) ix->scratch, count, deleted);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(0));
 	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int deleted)
+{
+	return hnsw_gpu_index_set_deleted_batch(ix, &idx, 1, deleted);
 }
 
 // ------------------------------------------------------------------------------------
@@ -506,11 +576,18 @@ static search_kernel_t pick_search_kernel_s(int func, int rreg, bool team)
 	}
 }
 
-static search_kernel_t pick_search_kernel(int func, uint32_t kiters, int rreg, bool team)
+static search_kernel_t pick_search_kernel(int func, uint32_t kiters, int rreg, bool team, bool narrow5)
 {
 	switch (shape_index(kiters))
 	{
-		case 0:  return pick_search_kernel_s<Shape2x4>(func, rreg, team);
+		case 0:
+			if (narrow5 && !team)               // the hot narrow-row form: 8 rows per pass, 96 VGPRs, 5 waves/SIMD
+				switch (func)
+				{
+					case F_L2: return rreg == -2 ? hnsw_search_kernel_beam<F_L2, Shape2x2, 2, false> : hnsw_search_kernel_beam<F_L2, Shape2x2, 4, false>;
+					default:   return rreg == -2 ? hnsw_search_kernel_beam<F_MANHATTAN, Shape2x2, 2, false> : hnsw_search_kernel_beam<F_MANHATTAN, Shape2x2, 4, false>;
+				}
+			return pick_search_kernel_s<Shape2x4>(func, rreg, team);
 		case 1:  return pick_search_kernel_s<Shape4x2>(func, rreg, team);
 		case 2:  return pick_search_kernel_s<Shape8x2>(func, rreg, team);
 		default:
@@ -577,6 +654,16 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	else if (use_beam && (ef <= 256 || beam16)) rreg = ef <= 64 ? -2 : (ef <= 128 ? -4 : (ef <= 256 ? -8 : -16));
 	else rreg = ef <= 128 ? 2 : (ef <= 256 ? 4 : 0);
 	const size_t ucap = rreg < 0 ? (size_t) 64 * (size_t) -rreg : 0;      // beam form: slots of the accepted set
+	// Team form wanted for this launch?  (decided for good further down, once the LDS carve is known)
+	const char *tenv = getenv("HNSW_GPU_TEAM");
+	const int treq = tenv ? atoi(tenv) : -1;
+	const char *tmax = getenv("HNSW_GPU_TEAM_MAX_NQ");
+	const size_t auto_nq = tmax ? (size_t) atoll(tmax) : (size_t) ix->num_cu;
+	const bool team_wanted = rreg < 0 && treq != 0 && (treq > 0 || ix->stride > 320 || nq <= auto_nq);
+	// narrow rows, hot form: beam kernel with <= 4 set registers, one sum per row (L2 / Manhattan), not a team
+	const char *n5 = getenv("HNSW_GPU_NARROW5");
+	const bool narrow5 = shape_index(a.kiters) == 0 && (rreg == -2 || rreg == -4) && (int) ix->meta.dist_func != F_COSINE &&
+						 !team_wanted && !(n5 && atoi(n5) == 0);
 	size_t off = (size_t) a.qpad_floats * 4;
 	if (rreg)
 	{
@@ -584,20 +671,35 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		const size_t fixed = off + 64 * 4 + 128 * 4;
 		// Rows of >= 1.25 KiB make the traversal HBM-bound, and there the LDS set pays (no L2
 		// atomics, ~10 % less HBM traffic; measured 5.4 -> 7.5 TB/s at 768 dims) at 8 waves per CU.
-		// Narrow rows are latency-bound and want 16 waves per CU: the beam form gives them a
-		// 2048-entry set (fits 16 x 10 KiB) and moves to the bitmap when a traversal outgrows it; the
-		// two-set register form keeps the bitmap only (profiles/r1g_visited_set_by_dim.txt,
-		// profiles/r1i_beam_form.md).
+		// Narrow rows are latency-bound and want 16-20 waves per CU: the beam form gives them a bucketed set of
+		// 3456-4096 16-bit tags (ids whose bucket is full go to the bitmap); the two-set register form keeps the
+		// bitmap only (profiles/r1g_visited_set_by_dim.txt, profiles/r1i_beam_form.md, profiles/r2m_*).
+		// (rows of up to 128 floats in the beam form with ef <= 128, L2 / Manhattan, launches that will not run as
+		// teams: 5 waves/SIMD with the 8-rows-per-pass shape — measured +6-10 % over 4 waves, profiles/r2m_*)
 		const bool wide = ix->stride > 320;
-		const size_t want_waves = wide ? 8 : 16;
+		const size_t want_waves = wide ? 8 : (narrow5 ? 20 : 16);
 		uint32_t hcap = wide ? 4096 : (rreg < 0 ? 2048 : 0);
 		const char *henv = getenv("HNSW_GPU_HASH_ENTRIES");
 		if (henv) hcap = (uint32_t) atoi(henv);
 		// emit scratch: [keys | labels]; the beam form sorts up to `ucap` survivors (ties at the bound)
 		const size_t nkeys = ucap ? ucap : ef;
 		const size_t emit = round_up(nkeys * 8, 16) + round_up(ef * 8, 16);
-		while (hcap >= 512 && want_waves * (fixed + std::max<size_t>(hcap * 4, emit)) > LDS_PER_CU) hcap >>= 1;
-		if (hcap < 512 || (hcap & (hcap - 1))) hcap = 0;
+		if (rreg < 0)
+		{
+			// beam form: hcap/4 buckets (any count, 128-byte steps of LDS) of eight 16-bit tags (device_search.h,
+			// "bucketed"); tag = id / buckets + 1 must fit 16 bits and the 38-bit reciprocal must be exact (ids below
+			// 2^28), else the kernel runs on the HBM bitmap alone
+			hcap = std::min<uint32_t>(hcap, 4096);
+			while (hcap >= 512 && want_waves * (fixed + std::max<size_t>(hcap * 4, emit)) > LDS_PER_CU) hcap -= 128;
+			hcap &= ~31u;
+			if (hcap < 512 || (uint64_t) ix->cap > (uint64_t) 65535 * (hcap / 4) || ix->cap >= (1u << 28)) hcap = 0;
+			a.hmagic = hcap ? (uint32_t) ((((uint64_t) 1 << 38) + hcap / 4 - 1) / (hcap / 4)) : 0;
+		}
+		else
+		{
+			while (hcap >= 512 && want_waves * (fixed + std::max<size_t>(hcap * 4, emit)) > LDS_PER_CU) hcap >>= 1;
+			if (hcap < 512 || (hcap & (hcap - 1))) hcap = 0;
+		}
 		a.hcap = hcap;
 		a.hmax = hcap - hcap / 4;
 		a.off_hash = (uint32_t) off;
@@ -643,10 +745,6 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	bool team = false;
 	if (rreg < 0)
 	{
-		const char *tenv = getenv("HNSW_GPU_TEAM");
-		const int treq = tenv ? atoi(tenv) : -1;
-		const char *tmax = getenv("HNSW_GPU_TEAM_MAX_NQ");
-		const size_t auto_nq = tmax ? (size_t) atoll(tmax) : (size_t) ix->num_cu;
 		const size_t pub = (size_t) 64 * ucap / 64 * 8;                 // 64*UREG keys
 		// a donated region: [accepted-set copy | expanded bits | miss ids | package headers | packages | memo], all below
 		// off_newid.  As many package slots as leave a useful memo: an element packaged while it was 6th in line may
@@ -666,7 +764,7 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 				break;
 			}
 		}
-		if (dccap >= 128 && treq != 0 && (treq > 0 || ix->stride > 320 || nq <= auto_nq))
+		if (dccap >= 128 && team_wanted)
 		{
 			team = true;
 			a.tm_off_ex = (uint32_t) o_ex; a.tm_off_miss = (uint32_t) o_miss; a.tm_off_lctag = (uint32_t) o_tag;
@@ -684,10 +782,11 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	if (!team) { wpb = 4; while (wpb > 1 && (size_t) wpb * a.wave_bytes > 64 * 1024) wpb >>= 1; }
 	a.off_ctl = (uint32_t) ((size_t) wpb * a.wave_bytes);
 	const size_t lds = (size_t) wpb * a.wave_bytes + (team ? wpb * sizeof(TeamCtl) : 0);
-	search_kernel_t kern = pick_search_kernel((int) ix->meta.dist_func, a.kiters, rreg, team);
+	search_kernel_t kern = pick_search_kernel((int) ix->meta.dist_func, a.kiters, rreg, team, narrow5);
 	{
 		static const char *const shapes[4] = { "Shape2x4", "Shape4x2", "Shape8x2", "Shape12x2" };
 		const char *shp = (shape_index(a.kiters) == 3 && getenv("HNSW_GPU_SHAPE_12X1")) ? "Shape12x1" : shapes[shape_index(a.kiters)];
+		if (narrow5 && !team) shp = "Shape2x2";
 		if (rreg < 0) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_beam<%d, pgemb::%s, %d, %s>", (int) ix->meta.dist_func, shp, -rreg, team ? "true" : "false");
 		else if (rreg >= 2) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_reg<%d, pgemb::%s, %d>", (int) ix->meta.dist_func, shp, rreg);
 		else snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_lds<%d, pgemb::%s, %s>", (int) ix->meta.dist_func, shp, rreg == 1 ? "true" : "false");
@@ -747,7 +846,7 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		a.set_scratch = w->sets;
 	}
 	a.ticket = w->ticket;
-	if (team && getenv("HNSW_GPU_TEAM_COUNTERS"))
+	if (getenv("HNSW_GPU_TEAM_COUNTERS"))
 	{
 		if (!w->team_dbg) HIPCHK(hipMalloc(&w->team_dbg, 64));
 		HIPCHK(hipMemsetAsync(w->team_dbg, 0, 64, stream));

@@ -140,6 +140,12 @@ class GpuIndex:
     def set_deleted(self, idx: int, deleted: bool = True) -> None:
         check(self.L.hnsw_gpu_index_set_deleted(self._h, idx, int(deleted)), "hnsw_gpu_index_set_deleted")
 
+    def set_deleted_many(self, idx, deleted: bool = True) -> None:
+        """Vacuum flags of many elements in one call (hnsw_gpu_index_set_deleted_batch)."""
+        a = np.ascontiguousarray(idx, dtype=np.uint32)
+        check(self.L.hnsw_gpu_index_set_deleted_batch(self._h, a.ctypes.data_as(C.POINTER(C.c_uint32)), a.size, int(deleted)),
+              "hnsw_gpu_index_set_deleted_batch")
+
     # -------------------------------------------------------------------- search
     def search(self, queries: np.ndarray, ef: Optional[int] = None):
         """Batch of hnsw_search() calls with host buffers.
@@ -203,6 +209,14 @@ class GpuIndex:
         names = ("hops_with_helpers", "link_hits", "ids_looked_up", "dist_hits", "hops_that_scored", "hops", "wait_polls",
                  "cyc_pop_links", "cyc_dists", "cyc_accept", "hops_that_waited", "helper_elements", "helper_cycles")
         return {k: int(v[i]) for i, k in enumerate(names)}
+
+    def debug_counters(self):
+        """The 16 raw launch-wide debug counters (HNSW_GPU_TEAM_COUNTERS=1; -DHNSW_HOP_STAMPS builds put the per-section
+        cycle sums of the walking waves there: hops, then pop / link wait / visited / scoring / accept / walk / emit in
+        units of 64 cycles)."""
+        v = (C.c_uint32 * 16)()
+        check(self.L.hnsw_gpu_team_counters(self._h, v), "hnsw_gpu_team_counters")
+        return [int(x) for x in v]
 
     def gather_roof(self, loads_per_lane: int = 12, waves_per_cu: int = 16, iters: int = 200) -> float:
         """GB/s of a dependency-free random gather of whole rows of THIS mirror's row table — the practical

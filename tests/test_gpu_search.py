@@ -145,6 +145,28 @@ def test_deleted_labels_are_filtered_after_search():
     ix.close()
 
 
+def test_vacuum_flags_in_one_batch():
+    """hnsw_gpu_index_set_deleted_batch: what a VACUUM does to many rows (embedding.c:883-946), set and cleared again,
+    with a repeated element in the list; results track the oracle's flags."""
+    port, X = build_port(1200, 32, 6, 32, pg.DIST_L2, seed=19)
+    ix = mirror(port, pg.DIST_L2)
+    Q = gmm(80, 32, k=50, seed=19, stream=1)
+    rng = np.random.default_rng(19)
+    dead = rng.choice(1200, 500, replace=False).astype(np.uint32)
+    ix.set_deleted_many(np.concatenate([dead, dead[:7]]))
+    for i in dead:
+        port.set_deleted(int(i))
+    labels, _, counts = assert_same_as_oracle(ix, port, Q, 48)
+    assert (counts < 48).any()
+    ix.set_deleted_many(dead[:250], deleted=False)
+    for i in dead[:250]:
+        port.set_deleted(int(i), False)
+    assert_same_as_oracle(ix, port, Q, 48)
+    with pytest.raises(Exception):
+        ix.set_deleted_many(np.array([5, 1200], np.uint32))      # past the end: refused, nothing half-applied to check here
+    ix.close()
+
+
 @pytest.mark.parametrize("func", [pg.DIST_L2, pg.DIST_MANHATTAN])
 def test_exact_ties_follow_the_pair_order(func):
     """Integer data and duplicated rows: distances tie exactly, so results are decided by the
