@@ -59,6 +59,8 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target CPU-baseline sample time")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--recall-queries", type=int, default=1000)
+    ap.add_argument("--no-side-configs", action="store_true",
+                    help="skip the other BASELINE configs and the stress datasets (reported extras, N=1 only)")
     ap.add_argument("--hostile-rows", type=int, default=8_000_000,
                     help="second timed dataset whose rows do not repeat inside a launch (rows; clusters scale with it so "
                          "cluster size stays 1000); 0 = skip; skipped for N>1")
@@ -392,10 +394,89 @@ def main():
     # ---- a dataset whose rows do not repeat inside a launch (N=1 only): the Infinity-Cache share made visible
     if rank == 0 and world == 1 and args.hostile_rows > 0:
         result["roofline"]["cache_hostile"] = hostile(args, dev, local, func)
+    # ---- the other BASELINE configs and the stress datasets of SURVEY.md §8(d), same kernels, N=1 only (extras, not `value`)
+    if rank == 0 and world == 1 and not args.no_side_configs:
+        result["other_configs"] = side_configs(args, dev, local)
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
         dist.destroy_process_group()
+
+
+def side_configs(args, dev, local):
+    """BASELINE.json configs 2, 3 and 5 at 1M rows, and two stress datasets for the headline shape: i.i.d. Gaussian rows
+    (no cluster structure: E_q several times larger, recall far below the gate — SURVEY.md §8d says report it, never gate
+    on it) and low-rank rows (16-d latent + noise).  One launch size each, kernel time from the library's HIP events."""
+    import numpy as np
+    import torch
+    import pg_embedding_amd as pg
+    from pg_embedding_amd.datasets import gmm_torch, recall_at_k
+    n = min(args.n, 1_000_000)
+
+    def rows_gmm(cnt, dim, stream):
+        return gmm_torch(cnt, dim, k=1000, sigma=0.3, seed=42, stream=stream, device=dev)
+
+    def rows_sift(cnt, dim, stream):          # SIFT-1M stand-in: clustered integers in [0, 218] stored as fp32
+        return torch.clamp(torch.round(40.0 + 35.0 * rows_gmm(cnt, dim, stream)), 0, 218)
+
+    def rows_iid(cnt, dim, stream):
+        g = torch.Generator(device=dev)
+        g.manual_seed(4242 + stream)
+        return torch.randn((cnt, dim), generator=g, device=dev, dtype=torch.float32)
+
+    def rows_lowrank(cnt, dim, stream):
+        g = torch.Generator(device=dev)
+        g.manual_seed(777)
+        basis = torch.randn((16, dim), generator=g, device=dev, dtype=torch.float32)
+        g.manual_seed(778 + stream)
+        out = torch.empty((cnt, dim), device=dev, dtype=torch.float32)
+        for i in range(0, cnt, 1 << 18):
+            m = min(1 << 18, cnt - i)
+            out[i:i + m] = torch.randn((m, 16), generator=g, device=dev) @ basis + 0.05 * torch.randn((m, dim), generator=g, device=dev)
+        return out
+
+    cases = [
+        ("C2_sift_like_1Mx128_l2_m16", 128, 16, "l2", rows_sift, 40000),
+        ("C3_1Mx768_cosine_m32", 768, 32, "cosine", rows_gmm, 40000),
+        ("C5_1Mx1536_cosine_m32_Q1024", 1536, 32, "cosine", rows_gmm, 1024),
+        ("stress_iid_1Mx768_l2_m16", 768, 16, "l2", rows_iid, 10000),
+        ("stress_lowrank16_1Mx768_l2_m16", 768, 16, "l2", rows_lowrank, 40000),
+    ]
+    res = {}
+    for name, dim, m, metric, gen, nq in cases:
+        func = {"l2": pg.DIST_L2, "cosine": pg.DIST_COSINE}[metric]
+        t0 = time.time()
+        X = gen(n, dim, 0)
+        ix = pg.GpuIndex.empty(pg.make_meta(dim, m, args.efc, args.ef, func), n, device=local)
+        ix.append_torch(X)
+        del X
+        ix.link(0, n, args.max_batch, args.ratio, torch.cuda.current_stream(dev).cuda_stream)
+        torch.cuda.synchronize()
+        t_build = time.time() - t0
+        Q = gen(nq, dim, 1)
+        out = ix.search_torch(Q, args.ef, stats=True)
+        torch.cuda.synchronize()
+        st = out["stats"].cpu().numpy().astype(np.int64)
+        cnt = out["counts"].cpu().numpy().astype(np.int64)
+        bq = alg_bytes(st, cnt, dim, m)
+        nrec = min(256, nq)
+        truth, _ = ix.bruteforce_torch(Q[:nrec].contiguous(), 10, mfma=True)
+        rec = recall_at_k(out["labels"][:nrec].cpu().numpy(), truth.cpu().numpy(), 10)
+        ms = []
+        for _ in range(4):
+            ix.search_torch(Q, args.ef, out=out)
+            ms.append(ix.last_search_ms())
+        kms = float(np.median(ms[1:]))
+        ach = float(bq.sum()) / (kms * 1e-3) / 1e9
+        res[name] = {"rows": n, "dims": dim, "m": m, "metric": metric, "efsearch": args.ef, "queries_per_launch": nq,
+                     "queries_per_s": nq / kms * 1e3, "kernel_ms_per_launch": kms, "achieved_GBps": ach,
+                     "frac_of_8TBps": ach / HBM_PEAK_GBS, "evals_per_query": float(st[:, 0].mean()),
+                     "hops_per_query": float(st[:, 1].mean()), "recall_at_10": rec, "kernel": ix.last_search_kernel(),
+                     "datagen_plus_build_seconds": t_build}
+        ix.close()
+        del ix, out, Q
+        torch.cuda.empty_cache()
+    return res
 
 
 def hostile(args, dev, local, func):

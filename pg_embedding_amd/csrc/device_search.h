@@ -1556,7 +1556,8 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				uint32_t hs0 = 0, hs1 = 0;
 				if (HOP_STAMPS && a.team_dbg) hs0 = hop_stamp();
 				if (!beam_next<UREG>(uk, ex, cslot, ckey)) break;          // candidateSet empty
-				const uint32_t cd = (uint32_t) (ckey >> 32);
+				uint32_t cd = (uint32_t) (ckey >> 32);
+				asm volatile("" : "+s"(cd));     // an opaque 32-bit scalar: hipcc otherwise compares (key >> 32) with (ckey >> 32) as 64-bit pairs
 				if (beam_count_lt<UREG>(uk, cd) >= ef) break;              // :70-71  best candidate > lowerBound
 				const uint32_t cur = ~(uint32_t) ckey;
 				ex |= ((uint32_t) lane == (cslot & 63)) ? (1u << (cslot >> 6)) : 0u;   // :73 pop
