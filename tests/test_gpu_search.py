@@ -329,6 +329,35 @@ def test_every_kernel_variant_is_exact(env, monkeypatch):
     ix.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"HNSW_GPU_HASH_ENTRIES": "512"}, {"HNSW_GPU_NARROW5": "0"}])
+@pytest.mark.parametrize("func", [pg.DIST_L2, pg.DIST_MANHATTAN])
+@pytest.mark.parametrize("dim", [128, 72])
+def test_narrow_rows_five_waves_form_is_exact(dim, func, env, monkeypatch):
+    """Rows of up to 128 floats, ef <= 128, launches too large for the team form: the beam kernel runs the 8-rows-per-pass
+    shape at 5 waves/SIMD with a bucketed visited set whose bucket count is not a power of two (432 at the default LDS
+    budget; with 128 buckets and E_q of 300-600 ids per query a bucket of eight overflows into the bitmap in most queries).
+    ids, distance bits, E_q, H_q = the oracle's; the same with the form switched off (HNSW_GPU_NARROW5=0: 16 rows per
+    pass, 4 waves/SIMD)."""
+    import torch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    port, X = build_port(12000, dim, 16, 64, func, k=60, seed=500 + dim)
+    Q = gmm(900, dim, k=60, seed=500 + dim, stream=1)
+    ix = mirror(port, func)
+    dQ = torch.from_numpy(Q).cuda()
+    for ef in (48, 128):
+        want = port.search_many(Q, ef, nthreads=8)
+        for rep in range(2):                 # second launch: the bitmap bits of overflowing buckets were undone
+            out = ix.search_torch(dQ, ef, stats=True)
+            torch.cuda.synchronize()
+            assert ("Shape2x2" in ix.last_search_kernel()) == (env.get("HNSW_GPU_NARROW5") != "0")
+            assert (out["labels"].cpu().numpy().view(np.uint64) == want["labels"]).all()
+            assert (bits(out["dists"].cpu().numpy()) == bits(want["dists"])).all()
+            st = out["stats"].cpu().numpy().astype(np.uint32)
+            assert (st[:, 0] == want["evals"]).all() and (st[:, 1] == want["hops"]).all()
+    ix.close()
+
+
 @pytest.mark.parametrize("func", FUNCS)
 @pytest.mark.parametrize("dim,m", [(128, 16), (768, 16), (1536, 32), (100, 40)])
 def test_team_form_is_exact_at_every_launch_size(func, dim, m, monkeypatch):
