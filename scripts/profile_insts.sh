@@ -7,7 +7,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/insts_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-BENCH="python $R/bench.py --no-cpu --hostile-rows 0 --steps 3 $*"
+BENCH="python $R/bench.py --no-cpu --no-side-configs --hostile-rows 0 --steps 3 $*"
 for PASS in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
             "SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SMEM GRBM_GUI_ACTIVE"; do
   N=$(echo $PASS | tr ' ' '_' | cut -c1-40)
