@@ -26,6 +26,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <unordered_map>
 
 #include "hnsw_gpu.h"
 #include "hnsw_gpu_shim.h"
@@ -37,10 +38,8 @@ namespace {
 std::mutex g_mu;
 int g_device = -1;                 // chosen by hnsw_init_dist_func
 
-struct Attachment { HnswMetadata *meta; hnsw_gpu_index *ix; };
-const int MAX_ATTACH = 64;
-Attachment g_attached[MAX_ATTACH];
-int g_nattached = 0;
+// attached mirrors by the address of the host's HnswMetadata (one per open scan / insert in the host); any number
+std::unordered_map<HnswMetadata *, hnsw_gpu_index *> *g_attached = nullptr;     // (leaked on purpose: no static destructor order issues at exit)
 
 int pick_device()
 {
@@ -56,9 +55,9 @@ int pick_device()
 
 hnsw_gpu_index *find_attached(HnswMetadata *meta)
 {
-	for (int i = 0; i < g_nattached; i++)
-		if (g_attached[i].meta == meta) return g_attached[i].ix;
-	return nullptr;
+	if (!g_attached) return nullptr;
+	auto it = g_attached->find(meta);
+	return it == g_attached->end() ? nullptr : it->second;
 }
 
 // Staging buffer for the callback walk.  Static and reused so that a host callback which
@@ -106,25 +105,19 @@ extern "C" int hnsw_gpu_shim_attach(HnswMetadata *meta, hnsw_gpu_index *ix)
 {
 	if (!meta || !ix) return HNSW_GPU_ERR_ARG;
 	std::lock_guard<std::mutex> lk(g_mu);
-	for (int i = 0; i < g_nattached; i++)
-		if (g_attached[i].meta == meta) { g_attached[i].ix = ix; return HNSW_GPU_OK; }
-	if (g_nattached == MAX_ATTACH) return HNSW_GPU_ERR_NOMEM;
-	g_attached[g_nattached].meta = meta;
-	g_attached[g_nattached].ix = ix;
-	g_nattached++;
+	try
+	{
+		if (!g_attached) g_attached = new std::unordered_map<HnswMetadata *, hnsw_gpu_index *>();
+		(*g_attached)[meta] = ix;
+	}
+	catch (...) { return HNSW_GPU_ERR_NOMEM; }
 	return HNSW_GPU_OK;
 }
 
 extern "C" int hnsw_gpu_shim_detach(HnswMetadata *meta)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
-	for (int i = 0; i < g_nattached; i++)
-		if (g_attached[i].meta == meta)
-		{
-			g_attached[i] = g_attached[g_nattached - 1];
-			g_nattached--;
-			return HNSW_GPU_OK;
-		}
+	if (g_attached && g_attached->erase(meta)) return HNSW_GPU_OK;
 	return HNSW_GPU_ERR_ARG;
 }
 
@@ -211,7 +204,11 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 	// receive the row itself.
 	if (idx == 0 && !ix) return true;
 	const size_t maxM = meta->maxM;
-	if (maxM > 4096) return false;
+	if (maxM > 4096)                                     // (the mirror itself refuses such an index too: check_meta)
+	{
+		fprintf(stderr, "pg_embedding_amd: hnsw_bind_point: maxM = %zu is not supported (at most 4096, i.e. m <= 2048)\n", maxM);
+		return false;
+	}
 	static thread_local idx_t mine[4097], other[4097];
 	bool ok = false;
 	do
