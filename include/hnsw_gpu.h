@@ -179,6 +179,16 @@ int  hnsw_gpu_search_batch_ctx_flags(hnsw_gpu_ctx *ctx, const coord_t *d_queries
 									 label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
 									 uint32_t *d_done);
 int  hnsw_gpu_ctx_idle(hnsw_gpu_ctx *ctx);
+
+/* One query together with its walk: the results of hnsw_gpu_search_batch plus the sequence of elements the walk expanded
+ * (candidateSet pops, hnswalg.cpp:73; *npops of them, the first min(*npops, pops_cap) stored) and the number of distance
+ * evaluations.  A walk is a deterministic function of the elements it touched — the expanded ones and their link
+ * targets — so a caller that finds those byte-identical in another copy of the index (the host's pages) knows that the
+ * reference's own walk over that copy returns the same answer: the basis of the drop-in library's validated mirror cache
+ * (embedding_shim.cpp).  base != 0: searchBaseLayer only, `labels` receives element numbers (hnsw_gpu_search_base_dev's
+ * output widened to 64 bits).  Host pointers. */
+int  hnsw_gpu_search_trace(hnsw_gpu_index *ix, const coord_t *query, size_t ef, int base, label_t *labels, dist_t *dists,
+						   uint32_t *count, idx_t *pops, size_t pops_cap, uint32_t *npops, uint32_t *nevals);
 /* Pinned host memory for the host-pointer entry points (NULL on failure). */
 void *hnsw_gpu_host_alloc(size_t bytes);
 void  hnsw_gpu_host_free(void *p);

@@ -25,6 +25,14 @@ int hnsw_gpu_shim_snapshot(HnswMetadata *meta, hnsw_gpu_index **out);
 int hnsw_gpu_shim_attach(HnswMetadata *meta, hnsw_gpu_index *ix);
 int hnsw_gpu_shim_detach(HnswMetadata *meta);
 
+/* Without an attached mirror the four symbols run on a validated cache (csrc/shim_cache.h): a mirror kept across
+ * calls whose every answer is checked against the host's pages along the walk that produced it, and patched where the
+ * host has changed.  Counters of the calling thread's cache: snapshots (full walks), searches, search rounds, inserts,
+ * insert rounds, elements patched, fallbacks to a full walk, elements read for validation.  PG_EMBEDDING_GPU_CACHE=0
+ * switches the cache off (every call re-mirrors the index). */
+void hnsw_gpu_shim_cache_stats(uint64_t out[8]);
+void hnsw_gpu_shim_cache_clear(void);
+
 #ifdef __cplusplus
 }
 #endif

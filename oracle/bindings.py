@@ -82,6 +82,9 @@ def _port():
         L.port_search_base.restype = C.c_int
         L.port_search_base.argtypes = [C.c_void_p, _f32p, C.c_size_t, _u32p, _f32p,
                                        C.POINTER(C.c_size_t), _u32p, _u32p]
+        L.port_search_trace.restype = C.c_int
+        L.port_search_trace.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_int, _u64p, _f32p, C.POINTER(C.c_size_t),
+                                        _u32p, _u32p, C.c_size_t, _u32p]
         L.port_search_many.restype = C.c_double
         L.port_search_many.argtypes = [C.c_void_p, _f32p, C.c_size_t, C.c_size_t, C.c_int,
                                        _u64p, _f32p, _u32p, _u32p, _u32p]
@@ -198,6 +201,18 @@ class PortIndex:
         self.L.port_search_base(self.h, _ptr(q, _f32p), ef, _ptr(idx, _u32p), _ptr(dst, _f32p),
                                 C.byref(n), C.byref(ev), C.byref(hp))
         return idx[:n.value].copy(), dst[:n.value].copy(), ev.value, hp.value
+
+    def search_trace(self, q, ef: int, base: bool = False, pops_cap: int = 1 << 16):
+        """hnsw_search (or searchBaseLayer) with the walk's pop sequence: (labels or idx, dists, pops, evals)."""
+        q = _f32(q)
+        lab = np.empty(ef, np.uint64)
+        dst = np.empty(ef, np.float32)
+        pops = np.empty(pops_cap, np.uint32)
+        n = C.c_size_t(0)
+        ev, npops = C.c_uint32(0), C.c_uint32(0)
+        self.L.port_search_trace(self.h, _ptr(q, _f32p), ef, int(base), _ptr(lab, _u64p), _ptr(dst, _f32p), C.byref(n),
+                                 C.byref(ev), _ptr(pops, _u32p), pops_cap, C.byref(npops))
+        return lab[:n.value].copy(), dst[:n.value].copy(), pops[:min(npops.value, pops_cap)].copy(), ev.value
 
     def search_many(self, Q, ef: Optional[int] = None, nthreads: int = 1) -> dict:
         ef = ef or self.efs

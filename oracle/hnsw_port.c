@@ -286,8 +286,10 @@ static void heap_pop(Heap *h)
  * walk's own arithmetic, between the two values that decision compared.  Up to that decision both arithmetics
  * walk identically (same heaps, element for element), so: div_kind == 0  =>  the second arithmetic returns the
  * same ids; and a query whose ids differ has div_kind != 0, with div_margin = how close the call was. */
-typedef struct { uint64_t evals, hops; float min_margin; int div_kind; float div_margin; } PortStats;
-#define PORT_STATS_INIT { 0, 0, INFINITY, 0, INFINITY }
+typedef struct { uint64_t evals, hops; float min_margin; int div_kind; float div_margin;
+                 uint32_t *pops; size_t pops_cap;      /* optional: the pop sequence (hnswalg.cpp:73), first pops_cap of them */
+               } PortStats;
+#define PORT_STATS_INIT { 0, 0, INFINITY, 0, INFINITY, NULL, 0 }
 
 static inline float rel_gap(float a, float b)
 {
@@ -356,6 +358,7 @@ static void port_search_base_layer(const PortIndex *ix, const float *q, size_t e
 		heap_pop(&cand);                                            /* :73 */
 		const uint32_t *links = el_links(ix, (uint32_t) cur.k);     /* :76 */
 		size_t size = links[0];                                     /* :77 */
+		if (st->pops && st->hops < st->pops_cap) st->pops[st->hops] = (uint32_t) cur.k;
 		st->hops++;
 		/* pass 1 (:79-88) only prefetches; pass 2 (:89-110): */
 		for (size_t j = 0; j < size; j++)
@@ -434,6 +437,7 @@ static int port_search_m(PortIndex *ix, const float *q, size_t ef, uint64_t *lab
 {
 	Heap top, res;
 	PortStats st = PORT_STATS_INIT;
+	if (st_out) { st.pops = st_out->pops; st.pops_cap = st_out->pops_cap; }   /* (a caller that wants the pop sequence) */
 	if (!ix->dist2) d2 = NULL;
 	port_search_base_layer(ix, q, ef, &top, &st, d2);        /* :237 */
 	while (top.n > ef) heap_pop(&top);                       /* :238-240 */
@@ -480,6 +484,40 @@ static int port_search_m(PortIndex *ix, const float *q, size_t ef, uint64_t *lab
 	if (hops)  *hops = (uint32_t) st.hops;
 	if (st_out) *st_out = st;
 	return 0;
+}
+
+/* hnsw_search plus the walk's pop sequence (what hnsw_gpu_search_trace returns on the device); base != 0: searchBaseLayer
+ * only, element numbers in label_out. */
+int port_search_trace(PortIndex *ix, const float *q, size_t ef, int base, uint64_t *label_out, float *dist_out,
+					  size_t *n_out, uint32_t *evals, uint32_t *pops, size_t pops_cap, uint32_t *npops)
+{
+	PortStats st = PORT_STATS_INIT;
+	st.pops = pops; st.pops_cap = pops_cap;
+	if (base)
+	{
+		Heap top;
+		port_search_base_layer(ix, q, ef, &top, &st, NULL);
+		size_t n = top.n;
+		for (size_t i = n; i-- != 0;)
+		{
+			HPair p = heap_top(&top);
+			label_out[i] = p.k;
+			if (dist_out) dist_out[i] = p.d;
+			heap_pop(&top);
+		}
+		heap_free(&top);
+		*n_out = n;
+		if (evals) *evals = (uint32_t) st.evals;
+		*npops = (uint32_t) st.hops;
+		return 0;
+	}
+	uint32_t ev = 0, hp = 0;
+	PortStats out = PORT_STATS_INIT;
+	out.pops = pops; out.pops_cap = pops_cap;
+	int rc = port_search_m(ix, q, ef, label_out, dist_out, n_out, &ev, &hp, &out, NULL);
+	if (evals) *evals = ev;
+	*npops = hp;
+	return rc;
 }
 
 int port_search(PortIndex *ix, const float *q, size_t ef, uint64_t *label_out, float *dist_out,
@@ -645,7 +683,7 @@ static void *port_worker(void *arg)
 	float *d2 = j->ix->dist2 ? (float *) malloc((j->ix->n ? j->ix->n : 1) * 4) : NULL;
 	for (size_t q = j->q0; q < j->q1; q++)
 	{
-		size_t n; uint32_t ev, hp; PortStats st;
+		size_t n; uint32_t ev, hp; PortStats st = PORT_STATS_INIT;
 		port_search_m(j->ix, j->Q + q * j->ix->dim, j->ef, lab, dst, &n, &ev, &hp, &st, d2);
 		if (j->margins) j->margins[q] = st.min_margin;
 		if (j->div_kind) j->div_kind[q] = st.div_kind;

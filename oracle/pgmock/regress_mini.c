@@ -495,6 +495,9 @@ static void run(char *line)
 	else pgmock_error("syntax error at or near \"%s\"", tok[0]);
 }
 
+/* the in-process drop-in library's cache counters, when that is what is linked underneath (include/hnsw_gpu_shim.h) */
+extern void hnsw_gpu_shim_cache_stats(uint64_t out[8]) __attribute__((weak));
+
 int main(void)
 {
 	static char line[1 << 20];
@@ -528,6 +531,15 @@ int main(void)
 		}
 		pgmock_error_jmp = NULL;
 		fflush(stdout);
+	}
+	if (hnsw_gpu_shim_cache_stats && getenv("PGEMB_PRINT_CACHE_STATS"))
+	{
+		uint64_t c[8];
+		hnsw_gpu_shim_cache_stats(c);
+		fprintf(stderr, "shim cache: snapshots %llu searches %llu search_rounds %llu inserts %llu insert_rounds %llu patched %llu "
+				"fallbacks %llu elements_read %llu\n", (unsigned long long) c[0], (unsigned long long) c[1], (unsigned long long) c[2],
+				(unsigned long long) c[3], (unsigned long long) c[4], (unsigned long long) c[5], (unsigned long long) c[6],
+				(unsigned long long) c[7]);
 	}
 	return 0;
 }

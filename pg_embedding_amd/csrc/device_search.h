@@ -67,6 +67,8 @@ struct SearchArgs
 	float    *out_dists;        // nq*ef or null
 	uint32_t *out_counts;       // nq
 	uint32_t *out_stats;        // nq*2 {evals, hops} or null
+	uint32_t *out_pops;         // null, or nq * pops_cap element numbers: the walk's pop sequence (hnswalg.cpp:73), for callers that
+	uint32_t  pops_cap;         // validate a walk against the host (hnsw_gpu_search_trace); out_stats' hop count says how many
 	uint32_t *done;             // null, or nq completion flags (host-visible): 1 is stored with system scope
 	                            // once query i's outputs are complete (hnsw_gpu_search_batch_ctx_flags)
 	// per-slot workspace
@@ -492,6 +494,7 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 					cand_set<CREG>(ck, last, ~0ull, lane);
 					csize = last;
 				}
+				if (a.out_pops && hops < a.pops_cap && lane == 0) a.out_pops[(size_t) qi * a.pops_cap + hops] = cur;
 				hops++;
 
 				for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)               // :76-77
@@ -848,6 +851,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 				csize--;                                                    // :73 pop = last entry into the hole
 				if (lane == 0) stk<G>(&cand[cpos], ldk<G>(&cand[csize]));
 				set_sync<G>();
+				if (a.out_pops && hops < a.pops_cap && lane == 0) a.out_pops[(size_t) qi * a.pops_cap + hops] = cur;
 				hops++;
 
 				for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)               // :76-77
@@ -1561,6 +1565,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				if (beam_count_lt<UREG>(uk, cd) >= ef) break;              // :70-71  best candidate > lowerBound
 				const uint32_t cur = ~(uint32_t) ckey;
 				ex |= ((uint32_t) lane == (cslot & 63)) ? (1u << (cslot >> 6)) : 0u;   // :73 pop
+				if (a.out_pops && hops < a.pops_cap && lane == 0) a.out_pops[(size_t) qi * a.pops_cap + hops] = cur;
 				hops++;
 				if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_pop += hs1 - hs0; hs0 = hs1; }
 				TeamView h0v = {};

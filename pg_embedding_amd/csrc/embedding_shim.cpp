@@ -32,6 +32,7 @@
 #include "hnsw_gpu_shim.h"
 #include "host_walk.h"
 #include "host_dist.h"
+#include "shim_cache.h"
 
 namespace {
 
@@ -147,6 +148,28 @@ static bool hnsw_search_impl(HnswMetadata *meta, const coord_t *point, size_t *n
 		std::lock_guard<std::mutex> lk(g_mu);
 		ix = find_attached(meta);
 	}
+	if (!ix && ef != 0 && shimcache::enabled())
+	{
+		// no mirror attached: the validated cache (shim_cache.h) — a mirror kept across calls, every answer checked
+		// against the host's pages along the walk that produced it
+		const int dev = pick_device();
+		if (dev < 0)
+		{
+			fprintf(stderr, "pg_embedding_amd: no HIP device visible; the GPU hot path has no CPU fallback\n");
+			return false;
+		}
+		label_t *cbuf = (label_t *) malloc(ef * sizeof(label_t));   // caller frees (embedding.c:327)
+		uint32_t cnt = 0;
+		if (cbuf && shimcache::search(meta, point, ef, cbuf, &cnt, dev))
+		{
+			*n_results = cnt;
+			*results = cbuf;
+			return true;
+		}
+		fprintf(stderr, "pg_embedding_amd: hnsw_search failed: %s\n", hnsw_gpu_last_error());
+		free(cbuf);
+		return false;
+	}
 	if (!ix)
 	{
 		if (hnsw_gpu_shim_snapshot(meta, &ix) != HNSW_GPU_OK)
@@ -211,8 +234,18 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 	}
 	static thread_local idx_t mine[4097], other[4097];
 	bool ok = false;
+	shimcache::Entry *ce = nullptr;                      // cached mirror (unmodified glue): its shadow follows the insert
 	do
 	{
+		if (!ix && shimcache::enabled())
+		{
+			const int dev = pick_device();
+			if (dev < 0) { fprintf(stderr, "pg_embedding_amd: no HIP device visible; the GPU hot path has no CPU fallback\n"); break; }
+			ce = shimcache::prepare_insert(meta, point, idx, dev);   // every element the insert will read == the host's
+			if (!ce) break;
+			ix = ce->ix;
+			ce->suspect = true;                          // until the write-back below has completed
+		}
 		if (!ix)                                         // no attached mirror: mirror what the search can reach;
 		{                                                // the new element is not linked yet, so it is added below
 			if (hnsw_gpu_shim_snapshot(meta, &ix) != HNSW_GPU_OK) break;
@@ -240,6 +273,7 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 				hnsw_end_read(meta);
 				if (hnsw_gpu_index_reserve(ix, (size_t) idx + 1 + (size_t) idx / 2) != HNSW_GPU_OK) break;
 				if (hnsw_gpu_index_append(ix, point, &label, 1) != HNSW_GPU_OK) break;
+				if (ce && !shimcache::shadow_append(meta, ce, (size_t) idx + 1, idx, point, label)) break;
 			}
 			else if (have != (size_t) idx + 1)
 			{
@@ -259,6 +293,7 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 			hnsw_begin_write(meta, mine[1 + j], &dst, nullptr, nullptr);
 			memcpy(dst, other, (maxM + 1) * sizeof(idx_t));
 			hnsw_end_write(meta);
+			if (ce) shimcache::shadow_set_links(meta, ce, mine[1 + j], other);
 		}
 		if (failed) break;
 		{                                                   // ... then the element itself (:169-181)
@@ -266,9 +301,15 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 			hnsw_begin_write(meta, idx, &dst, nullptr, nullptr);
 			memcpy(dst, mine, (maxM + 1) * sizeof(idx_t));
 			hnsw_end_write(meta);
+			if (ce) shimcache::shadow_set_links(meta, ce, idx, mine);
 		}
 		ok = true;
 	} while (0);
+	if (ce)
+	{
+		if (ok) ce->suspect = false;
+		else shimcache::drop(ce);                        // mirror and host may have parted: never reuse it
+	}
 	if (!ok)
 		fprintf(stderr, "pg_embedding_amd: hnsw_bind_point(%u) failed: %s\n", (unsigned) idx, hnsw_gpu_last_error());
 	if (own && ix) hnsw_gpu_index_destroy(ix);
@@ -280,6 +321,17 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 // failure inside the library (std::bad_alloc) becomes an ordinary failure, as the reference turns
 // every exception into `false` at the same place (hnswalg.cpp:258-276, 281-290).
 // ---------------------------------------------------------------------------------------
+extern "C" void hnsw_gpu_shim_cache_stats(uint64_t out[8])
+{
+	const shimcache::Stats &s = shimcache::stats();
+	out[0] = s.snapshots; out[1] = s.searches; out[2] = s.search_rounds; out[3] = s.inserts; out[4] = s.insert_rounds;
+	out[5] = s.patched; out[6] = s.fallbacks; out[7] = s.elements_read;
+}
+extern "C" void hnsw_gpu_shim_cache_clear(void)
+{
+	try { while (!shimcache::table().empty()) shimcache::drop(shimcache::table().back()); } catch (...) {}
+	shimcache::stats() = shimcache::Stats{};
+}
 extern "C" int hnsw_gpu_shim_snapshot(HnswMetadata *meta, hnsw_gpu_index **out) { try { return hnsw_gpu_shim_snapshot_impl(meta, out); } catch (...) { return HNSW_GPU_ERR_NOMEM; } }
 extern "C" bool hnsw_search(HnswMetadata *meta, const coord_t *point, size_t *n_results, label_t **results) { try { return hnsw_search_impl(meta, point, n_results, results); } catch (...) { return false; } }
 extern "C" bool hnsw_bind_point(HnswMetadata *meta, const coord_t *point, idx_t idx) { try { return hnsw_bind_point_impl(meta, point, idx); } catch (...) { return false; } }

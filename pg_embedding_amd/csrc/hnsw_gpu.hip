@@ -72,6 +72,7 @@ struct SearchWs
 	uint64_t launches = 0;
 	uint32_t last_slots = 0;
 	uint32_t *done_next = nullptr;                       // completion flags for the next launch only
+	uint32_t *pops_next = nullptr; uint32_t pops_cap_next = 0;   // pop-sequence output for the next launch only
 	char kname[96] = "";                                 // symbol of the kernel the last launch used (as rocprofv3 prints it)
 	uint32_t *team_dbg = nullptr;                        // 8 launch-wide counters of the team form (HNSW_GPU_TEAM_COUNTERS=1)
 };
@@ -857,6 +858,8 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	}
 	a.done = w->done_next;
 	w->done_next = nullptr;
+	a.out_pops = w->pops_next; a.pops_cap = w->pops_cap_next;
+	w->pops_next = nullptr; w->pops_cap_next = 0;
 	HIPCHK(hipMemsetAsync(w->ticket, 0, 8, stream));
 
 	const int evi = (int) (w->launches % SearchWs::EV_RING);
@@ -954,6 +957,63 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 	HIPCHK(hipMemcpy(labels, dl, nq * ef * 8, hipMemcpyDeviceToHost));
 	if (dists) HIPCHK(hipMemcpy(dists, dd, nq * ef * 4, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(counts, dc, nq * 4, hipMemcpyDeviceToHost));
+	return HNSW_GPU_OK;
+}
+
+// One query with its walk: results as hnsw_gpu_search_batch gives them, plus the sequence of elements the walk expanded
+// (hnswalg.cpp:73) and its evaluation count.  Host pointers; same polled zero-copy mechanics as the few-queries path.
+extern "C" int hnsw_gpu_search_trace(hnsw_gpu_index *ix, const coord_t *query, size_t ef, int base, label_t *labels, dist_t *dists,
+									 uint32_t *count, idx_t *pops, size_t pops_cap, uint32_t *npops, uint32_t *nevals)
+{
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
+	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
+	if (!query || !labels || !count || !pops || !npops || pops_cap == 0) return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
+	if (ef == 0 || ef >= 0xFFFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "ef %zu out of range", ef);
+	if (pops_cap > ((size_t) 1 << 24)) return fail(HNSW_GPU_ERR_ARG, "pops_cap %zu too large", pops_cap);
+	HIPCHK(hipSetDevice(ix->device));
+	const size_t dim = ix->meta.dim;
+	const size_t qb = round_up(dim * 4, 256), lb = round_up(ef * 8, 256), db = round_up(ef * 4, 256), cb = 256, sb = 256,
+				 pb = round_up(pops_cap * 4, 256), fb = 256;
+	const size_t need = qb + lb + db + cb + sb + pb + fb;
+	if (ix->pin_bytes < need)
+	{
+		if (ix->pin) (void) hipHostFree(ix->pin);
+		ix->pin = nullptr; ix->pin_bytes = 0;
+		HIPCHK(hipHostMalloc((void **) &ix->pin, need, hipHostMallocDefault));
+		ix->pin_bytes = need;
+	}
+	char *h = ix->pin;
+	float *hq = (float *) h; uint64_t *hl = (uint64_t *) (h + qb); float *hd = (float *) (h + qb + lb);
+	uint32_t *hc = (uint32_t *) (h + qb + lb + db), *hs = (uint32_t *) (h + qb + lb + db + cb),
+			 *hp = (uint32_t *) (h + qb + lb + db + cb + sb);
+	volatile uint32_t *hf = (volatile uint32_t *) (h + qb + lb + db + cb + sb + pb);
+	memcpy(hq, query, dim * 4);
+	hf[0] = 0;
+	ix->ws.done_next = (uint32_t *) hf;
+	ix->ws.pops_next = hp; ix->ws.pops_cap_next = (uint32_t) pops_cap;
+	int rc = base ? launch_search(ix, &ix->ws, hq, dim, 1, ef, 1, nullptr, (uint32_t *) hl, hd, hc, hs, nullptr)
+				  : launch_search(ix, &ix->ws, hq, dim, 1, ef, 0, hl, nullptr, hd, hc, hs, nullptr);
+	ix->ws.done_next = nullptr; ix->ws.pops_next = nullptr; ix->ws.pops_cap_next = 0;
+	if (rc) return rc;
+	uint64_t spins = 0;
+	while (hf[0] == 0)
+	{
+		__builtin_ia32_pause();
+		if ((++spins & 0xFFFF) == 0 && hipStreamQuery(nullptr) != hipErrorNotReady)
+		{
+			HIPCHK(hipStreamSynchronize(nullptr));
+			if (hf[0] == 0) return fail(HNSW_GPU_ERR_INTERNAL, "search kernel ended without completing the query");
+		}
+	}
+	__atomic_thread_fence(__ATOMIC_ACQUIRE);
+	if (base) { const uint32_t *hi = (const uint32_t *) hl; for (size_t i = 0; i < ef; i++) labels[i] = hi[i]; }
+	else memcpy(labels, hl, ef * 8);
+	if (dists) memcpy(dists, hd, ef * 4);
+	*count = hc[0];
+	*npops = hs[1];
+	if (nevals) *nevals = hs[0];
+	memcpy(pops, hp, std::min<size_t>(hs[1], pops_cap) * 4);
 	return HNSW_GPU_OK;
 }
 

@@ -160,6 +160,20 @@ class GpuIndex:
                                            dists.ctypes.data, counts.ctypes.data), "hnsw_gpu_search_batch")
         return labels, dists, counts
 
+    def search_trace(self, query: np.ndarray, ef: Optional[int] = None, base: bool = False, pops_cap: int = 1 << 16):
+        """One query with its walk (hnsw_gpu_search_trace): (labels-or-element-numbers[count] u64, dists[count] f32,
+        pops[npops] u32 = the elements the walk expanded in order, evals)."""
+        ef = int(ef or self.meta.efSearch)
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(self.meta.dim)
+        labels = np.empty(ef, np.uint64)
+        dists = np.empty(ef, np.float32)
+        pops = np.empty(pops_cap, np.uint32)
+        cnt, npops, nev = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        check(self.L.hnsw_gpu_search_trace(self._h, q.ctypes.data, ef, int(base), labels.ctypes.data, dists.ctypes.data,
+                                           C.byref(cnt), pops.ctypes.data_as(C.POINTER(C.c_uint32)), pops_cap,
+                                           C.byref(npops), C.byref(nev)), "hnsw_gpu_search_trace")
+        return labels[:cnt.value], dists[:cnt.value], pops[:min(npops.value, pops_cap)], int(nev.value)
+
     def search_torch(self, queries, ef: Optional[int] = None, out=None, stats: bool = False, base: bool = False):
         """Same with everything resident in HBM (torch tensors only carry the pointers).
         `out` may be a dict from a previous call to reuse its buffers.  With base=True runs

@@ -151,6 +151,56 @@ int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int deleted)
 	return HNSW_GPU_OK;
 }
 
+int hnsw_gpu_index_set_deleted_batch(hnsw_gpu_index *ix, const idx_t *idx, size_t count, int deleted)
+{
+	for (size_t i = 0; i < count; i++)
+		if (idx[i] >= port_count(ix->p)) return HNSW_GPU_ERR_ARG;
+	for (size_t i = 0; i < count; i++) port_set_deleted(ix->p, idx[i], deleted);
+	return HNSW_GPU_OK;
+}
+
+/* host-pointer searches: what libembedding_gpu.so (embedding_shim.cpp) calls; tests/server_util.py links that source
+ * against this file for the CPU tests of its validated mirror cache */
+int port_search_trace(PortIndex *ix, const float *q, size_t ef, int base, uint64_t *label_out, float *dist_out,
+					  size_t *n_out, uint32_t *evals, uint32_t *pops, size_t pops_cap, uint32_t *npops);
+
+int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries, size_t nq, size_t ef, label_t *labels, dist_t *dists,
+						  uint32_t *counts)
+{
+	float *d = (float *) malloc((ef ? ef : 1) * sizeof(float));
+	if (!d) return HNSW_GPU_ERR_NOMEM;
+	for (size_t i = 0; i < nq; i++)
+	{
+		size_t n = 0;
+		for (size_t k = 0; k < ef; k++) labels[i * ef + k] = ~(label_t) 0;
+		if (port_search(ix->p, queries + i * ix->meta.dim, ef, labels + i * ef, d, &n, NULL, NULL) != 0) { free(d); return HNSW_GPU_ERR_INTERNAL; }
+		if (dists) memcpy(dists + i * ef, d, n * sizeof(float));
+		counts[i] = (uint32_t) n;
+	}
+	free(d);
+	return HNSW_GPU_OK;
+}
+
+int hnsw_gpu_search_trace(hnsw_gpu_index *ix, const coord_t *query, size_t ef, int base, label_t *labels, dist_t *dists,
+						  uint32_t *count, idx_t *pops, size_t pops_cap, uint32_t *npops, uint32_t *nevals)
+{
+	/* as on the device, a beam wider than the index is a beam of the index size */
+	const size_t have = port_count(ix->p), eff = ef < (have ? have : 1) ? ef : (have ? have : 1);
+	float *d = (float *) malloc((ef ? ef : 1) * sizeof(float));
+	uint64_t *l = (uint64_t *) malloc((ef ? ef : 1) * sizeof(uint64_t));
+	if (!d || !l) { free(d); free(l); return HNSW_GPU_ERR_NOMEM; }
+	size_t n = 0;
+	int rc = port_search_trace(ix->p, query, eff, base, l, d, &n, nevals, pops, pops_cap, npops);
+	if (rc == 0)
+	{
+		memcpy(labels, l, n * sizeof(uint64_t));
+		if (dists) memcpy(dists, d, n * sizeof(float));
+		*count = (uint32_t) n;
+	}
+	free(d); free(l);
+	return rc == 0 ? HNSW_GPU_OK : HNSW_GPU_ERR_INTERNAL;
+}
+
 int hnsw_gpu_ctx_create(hnsw_gpu_index *ix, hnsw_gpu_ctx **out)
 {
 	hnsw_gpu_ctx *c = (hnsw_gpu_ctx *) calloc(1, sizeof(*c));

@@ -104,9 +104,39 @@ def have_pg_glue() -> bool:
 PG_GLUE_PATCHED = os.path.join(ROOT, "oracle", "_ref", "embedding_patched.o")
 
 
+def build_shim_double() -> str:
+    """embedding_shim.cpp (the in-process drop-in library, with its validated mirror cache) linked against the
+    oracle-backed engine double instead of libhnsw_gpu.so: tests/_build/libembedding_gpu_double.so.  CPU tests of the
+    shim's own logic; the product library links libhnsw_gpu.so and has no switch to get here."""
+    src = [os.path.join(CSRC, "embedding_shim.cpp"), os.path.join(CSRC, "shim_cache.h"), os.path.join(CSRC, "host_walk.h"),
+           os.path.join(CSRC, "host_dist.h"), os.path.join(ROOT, "tests", "double", "engine_double.c"),
+           os.path.join(ROOT, "oracle", "hnsw_port.c"), os.path.join(INC, "hnsw_gpu_shim.h"), os.path.join(INC, "hnsw_gpu.h")]
+    lib = os.path.join(OUT, "libembedding_gpu_double.so")
+    with _Lock():
+        if _stale(lib, src):
+            objs = []
+            for name, c, flags in (
+                    ("engine_double_pic.o", src[4], ["-O2", "-std=gnu11", "-fPIC"]),
+                    ("hnsw_port_pic.o", src[5], ["-O3", "-mavx2", "-mfma", "-ffp-contract=off", "-fno-fast-math", "-std=gnu11", "-fPIC"])):
+                o = os.path.join(OUT, name)
+                _run(["gcc"] + flags + ["-I", INC, "-c", c, "-o", o])
+                objs.append(o)
+            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-I", INC, "-I", CSRC, src[0]] + objs +
+                 ["-o", lib, "-lpthread", "-lm"])
+    return lib
+
+
 def build_pg_regress(variant: str) -> str:
     """variant 'gpu': libembedding_gpu.so (in-process device); 'client': libembedding_gpuc.so (hnsw_gpu_server);
-    'patched': the glue with integration/embedding_gpu_server.patch applied + libembedding_gpuc.so."""
+    'patched': the glue with integration/embedding_gpu_server.patch applied + libembedding_gpuc.so;
+    'shimdouble': the in-process library's own source over the CPU engine double (build_shim_double)."""
+    if variant == "shimdouble":
+        lib = build_shim_double()
+        exe = os.path.join(OUT, "pg_regress_shimdouble")
+        with _Lock():
+            if _stale(exe, PG_GLUE_OBJS + [lib]):
+                _run(["g++"] + PG_GLUE_OBJS + ["-o", exe, "-L", OUT, "-lembedding_gpu_double", f"-Wl,-rpath,{OUT}", "-lpthread", "-lm"])
+        return exe
     libs = {"gpu": ["-lembedding_gpu", "-lhnsw_gpu"], "client": ["-lembedding_gpuc"], "patched": ["-lembedding_gpuc"]}[variant]
     objs = [PG_GLUE_PATCHED] + PG_GLUE_OBJS[1:] if variant == "patched" else PG_GLUE_OBJS
     exe = os.path.join(OUT, "pg_regress_" + variant)

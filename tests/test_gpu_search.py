@@ -145,6 +145,32 @@ def test_deleted_labels_are_filtered_after_search():
     ix.close()
 
 
+@pytest.mark.parametrize("env", [{}, {"HNSW_GPU_BEAM": "0"}, {"HNSW_GPU_FORCE_LDS_HEAPS": "1"}, {"HNSW_GPU_TEAM": "0"}])
+@pytest.mark.parametrize("dim", [64, 768])
+def test_search_trace_reports_the_walk(dim, env, monkeypatch):
+    """hnsw_gpu_search_trace: results as hnsw_search gives them plus the walk's pop sequence (hnswalg.cpp:73) — equal, element
+    for element, to the oracle's; in every kernel form (beam / team, two-set registers, LDS arrays), for hnsw_search
+    and for searchBaseLayer alone.  This sequence is what the drop-in library validates against the host's pages."""
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    port, X = build_port(5000, dim, 8, 40, pg.DIST_L2, seed=31 + dim)
+    for i in (3, 77, 400):
+        port.set_deleted(i)
+    ix = mirror(port, pg.DIST_L2)
+    Q = gmm(24, dim, k=50, seed=31 + dim, stream=1)
+    for ef in (10, 64, 300):
+        for q in Q:
+            for base in (False, True):
+                lab, dst, pops, ev = ix.search_trace(q, ef, base=base)
+                wl, wd, wp, wev = port.search_trace(q, ef, base=base)
+                assert (lab == wl).all() and (bits(dst) == bits(wd)).all()
+                assert len(pops) == len(wp) and (pops == wp).all() and ev == wev
+    # a capacity smaller than the walk: the count is still the walk's, the stored prefix is its beginning
+    lab, dst, pops, ev = ix.search_trace(Q[0], 64, pops_cap=5)
+    assert (pops == port.search_trace(Q[0], 64)[2][:5]).all()
+    ix.close()
+
+
 def test_vacuum_flags_in_one_batch():
     """hnsw_gpu_index_set_deleted_batch: what a VACUUM does to many rows (embedding.c:883-946), set and cleared again,
     with a repeated element in the list; results track the oracle's flags."""

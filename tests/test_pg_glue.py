@@ -244,6 +244,46 @@ def test_glue_over_the_server_client_library(name):
     assert got == expected(name)
 
 
+@needs_glue
+@pytest.mark.parametrize("name", SCRIPTS)
+def test_glue_over_the_in_process_library_and_its_validated_cache(name):
+    """embedding.c (unmodified) + the in-process library's own source (embedding_shim.cpp, shim_cache.h) over the CPU
+    engine double: without attach calls every hnsw_search / hnsw_bind_point runs on a mirror kept across calls and
+    validated against the host's pages along the walk.  Same bytes as the reference's objects — and
+    the index is walked in full only a handful of times, not once per call."""
+    exe = SU.build_pg_regress("shimdouble")
+    cmd = open(os.path.join(GOLD, name + ".cmd")).read()
+    r = subprocess.run([exe], input=cmd, capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, PGEMB_PRINT_CACHE_STATS="1"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert r.stdout == expected(name)
+    m = re.search(r"shim cache: snapshots (\d+) searches (\d+) search_rounds (\d+) inserts (\d+) insert_rounds (\d+) patched (\d+) "
+                  r"fallbacks (\d+) elements_read (\d+)", r.stderr)
+    assert m, r.stderr[-500:]
+    snaps, searches, _, inserts, _, _, fallbacks, _ = map(int, m.groups())
+    if name == "scenario":
+        assert searches + inserts > 1000 and snaps + fallbacks < 40, m.group(0)
+    # and with the cache switched off (a full walk per call, the round-1 behaviour): the same bytes
+    if name in ("knn", "gh-3"):
+        off = subprocess.run([exe], input=cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, PG_EMBEDDING_GPU_CACHE="0"))
+        assert off.returncode == 0 and off.stdout == expected(name)
+
+
+@needs_glue
+@pytest.mark.skipif(not os.path.exists(SU.PG_REGRESS_REF), reason="reference-linked driver not built")
+@pytest.mark.parametrize("seed", range(16))
+def test_random_sessions_through_the_validated_cache(seed):
+    """Differential fuzz of the validated cache: random sessions (inserts, deletes + VACUUM, TRUNCATE, several indexes over
+    one table — same reloptions, so the cache sees several indexes behind one key — scans with and without LIMIT) print the
+    reference's bytes."""
+    script = random_session(5000 + seed)
+    want = subprocess.run([SU.PG_REGRESS_REF], input=script, capture_output=True, text=True, timeout=600)
+    assert want.returncode == 0, want.stderr[-1500:]
+    got = subprocess.run([SU.build_pg_regress("shimdouble")], input=script, capture_output=True, text=True, timeout=600)
+    assert got.returncode == 0, (got.stdout[-1500:], got.stderr[-1500:])
+    assert got.stdout == want.stdout
+
+
 def run_patched(name, server):
     from pg_embedding_amd.server import RemoteClient
     exe = SU.build_pg_regress("patched")
