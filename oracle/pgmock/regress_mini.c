@@ -515,7 +515,8 @@ int main(void)
 		if (setjmp(trap) == 0)
 		{
 			struct timespec t0, t1;
-			const bool timed = strncmp(line, "create_index", 12) == 0 || strncmp(line, "generate", 8) == 0;
+			const bool timed = strncmp(line, "create_index", 12) == 0 || strncmp(line, "generate", 8) == 0 ||
+							   (strncmp(line, "select", 6) == 0 && getenv("PGEMB_TIME_SELECTS"));
 			char what[64];
 			snprintf(what, sizeof(what), "%.60s", line);
 			clock_gettime(CLOCK_MONOTONIC, &t0);
