@@ -94,6 +94,11 @@ int hnsw_gpu_index_reserve(hnsw_gpu_index *ix, size_t capacity);
  * (embedding.c:222-226).  `out` holds maxM + 1 values. */
 int hnsw_gpu_index_get_links(hnsw_gpu_index *ix, idx_t idx, idx_t *out);
 
+/* The same for element `idx` AND each of its neighbours in one launch: mine = list of idx (maxM + 1 values), others =
+ * mine[0] lists of maxM + 1 values each, the j-th being the list of element mine[1 + j] — everything an insert of idx
+ * changed (hnswalg.cpp:169-222), for the write-back of hnsw_bind_point.  `others` holds maxM * (maxM + 1) values. */
+int hnsw_gpu_index_get_link_lists(hnsw_gpu_index *ix, idx_t idx, idx_t *mine, idx_t *others);
+
 size_t hnsw_gpu_index_count(const hnsw_gpu_index *ix);
 int    hnsw_gpu_index_device(const hnsw_gpu_index *ix);
 void   hnsw_gpu_index_destroy(hnsw_gpu_index *ix);

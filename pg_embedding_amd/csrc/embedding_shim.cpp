@@ -27,6 +27,7 @@
 #include <mutex>
 #include <new>
 #include <unordered_map>
+#include <vector>
 
 #include "hnsw_gpu.h"
 #include "hnsw_gpu_shim.h"
@@ -232,7 +233,7 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 		fprintf(stderr, "pg_embedding_amd: hnsw_bind_point: maxM = %zu is not supported (at most 4096, i.e. m <= 2048)\n", maxM);
 		return false;
 	}
-	static thread_local idx_t mine[4097], other[4097];
+	static thread_local idx_t mine[4097];
 	bool ok = false;
 	shimcache::Entry *ce = nullptr;                      // cached mirror (unmodified glue): its shadow follows the insert
 	do
@@ -284,11 +285,13 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 		}
 		if (idx == 0) { ok = true; break; }
 		if (hnsw_gpu_index_link(ix, idx, 1, 1, 0, nullptr) != HNSW_GPU_OK) break;
-		if (hnsw_gpu_index_get_links(ix, idx, mine) != HNSW_GPU_OK) break;
+		static thread_local std::vector<idx_t> others;            // the neighbours' lists, all fetched in one launch
+		others.resize(maxM * (maxM + 1));
+		if (hnsw_gpu_index_get_link_lists(ix, idx, mine, others.data()) != HNSW_GPU_OK) break;
 		bool failed = false;
 		for (uint32_t j = 0; j < mine[0] && !failed; j++)   // neighbours first, like hnswalg.cpp:183-222 ...
 		{
-			if (hnsw_gpu_index_get_links(ix, mine[1 + j], other) != HNSW_GPU_OK) { failed = true; break; }
+			const idx_t *other = others.data() + (size_t) j * (maxM + 1);
 			idx_t *dst = nullptr;
 			hnsw_begin_write(meta, mine[1 + j], &dst, nullptr, nullptr);
 			memcpy(dst, other, (maxM + 1) * sizeof(idx_t));

@@ -1696,6 +1696,57 @@ extern "C" int hnsw_gpu_index_get_links(hnsw_gpu_index *ix, idx_t idx, idx_t *ou
 	return HNSW_GPU_OK;
 }
 
+// The link list of one element and the lists of all its neighbours in one launch + one wait: what an insert changed
+// (hnswalg.cpp:169-222: the new element's list and a reverse link in each neighbour's), for the write-back of
+// hnsw_bind_point.  Rows land in the mirror's pinned staging; block 0 = the element, block 1+j = its j-th link slot.
+__global__ __launch_bounds__(64) void gather_link_lists_kernel(const uint32_t *__restrict__ links, uint32_t lstride, uint32_t idx,
+															   uint32_t n, uint32_t *__restrict__ out)
+{
+	uint32_t src = idx;
+	if (blockIdx.x > 0)
+	{
+		src = links[(size_t) idx * lstride + (blockIdx.x - 1)];
+		if (src == LINK_NONE || src >= n) { for (uint32_t j = threadIdx.x; j < lstride; j += 64) out[(size_t) blockIdx.x * lstride + j] = LINK_NONE; return; }
+	}
+	for (uint32_t j = threadIdx.x; j < lstride; j += 64) out[(size_t) blockIdx.x * lstride + j] = links[(size_t) src * lstride + j];
+}
+
+extern "C" int hnsw_gpu_index_get_link_lists(hnsw_gpu_index *ix, idx_t idx, idx_t *mine, idx_t *others)
+{
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
+	if (!ix || !mine || !others || idx >= ix->n) return fail(HNSW_GPU_ERR_ARG, "bad element %u", (unsigned) idx);
+	HIPCHK(hipSetDevice(ix->device));
+	const size_t maxM = ix->meta.maxM, ls = ix->lstride;
+	const size_t need = (maxM + 1) * ls * 4;
+	if (ix->pin_bytes < need)
+	{
+		if (ix->pin) (void) hipHostFree(ix->pin);
+		ix->pin = nullptr; ix->pin_bytes = 0;
+		HIPCHK(hipHostMalloc((void **) &ix->pin, std::max<size_t>(need, 64 << 10), hipHostMallocDefault));
+		ix->pin_bytes = std::max<size_t>(need, 64 << 10);
+	}
+	uint32_t *h = (uint32_t *) ix->pin;
+	hipLaunchKernelGGL(gather_link_lists_kernel, dim3((uint32_t) maxM + 1), dim3(64), 0, 0, ix->links, (uint32_t) ls, (uint32_t) idx,
+					   (uint32_t) ix->n, h);
+	HIPCHK(hipGetLastError());
+	HIPCHK(hipStreamSynchronize(nullptr));
+	auto compact = [&](const uint32_t *row, idx_t *out)
+	{
+		uint32_t cnt = 0;
+		for (size_t j = 0; j < maxM; j++)
+			if (row[j] != LINK_NONE) out[1 + cnt++] = row[j];
+		out[0] = cnt;
+		for (size_t j = cnt; j < maxM; j++) out[1 + j] = 0;
+	};
+	compact(h, mine);
+	// neighbour j of the compacted list sits in link slot s_j of the row (slots may hold holes)
+	size_t k = 0;
+	for (size_t s = 0; s < maxM && k < mine[0]; s++)
+		if (h[s] != LINK_NONE) { compact(h + (1 + s) * ls, others + k * (maxM + 1)); k++; }
+	return HNSW_GPU_OK;
+}
+
 // Refresh part of the mirror from the host: element images of [first, first+count) replace what
 // the mirror holds (links, vector, label); elements past the current end are added.  This is the
 // incremental counterpart of create_from_flat for a host that tracks which pages changed

@@ -138,6 +138,14 @@ int hnsw_gpu_index_get_links(hnsw_gpu_index *ix, idx_t idx, idx_t *out)
 	return HNSW_GPU_OK;
 }
 
+int hnsw_gpu_index_get_link_lists(hnsw_gpu_index *ix, idx_t idx, idx_t *mine, idx_t *others)
+{
+	const size_t maxM = ix->meta.maxM;
+	int rc = hnsw_gpu_index_get_links(ix, idx, mine);
+	for (uint32_t j = 0; rc == HNSW_GPU_OK && j < mine[0]; j++) rc = hnsw_gpu_index_get_links(ix, mine[1 + j], others + (size_t) j * (maxM + 1));
+	return rc;
+}
+
 int hnsw_gpu_index_export_flat(hnsw_gpu_index *ix, void *elements)
 {
 	memcpy(elements, port_data(ix->p), port_count(ix->p) * port_elem_size(ix->p));
