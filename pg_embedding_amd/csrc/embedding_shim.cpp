@@ -149,7 +149,16 @@ static bool hnsw_search_impl(HnswMetadata *meta, const coord_t *point, size_t *n
 		std::lock_guard<std::mutex> lk(g_mu);
 		ix = find_attached(meta);
 	}
-	if (!ix && ef != 0 && shimcache::enabled())
+	if (ef == 0)
+	{
+		// searchKnn trims to k = 0 results (hnswalg.cpp:238-240): nothing to mirror or launch for that
+		label_t *none = (label_t *) malloc(1);
+		if (!none) return false;
+		*n_results = 0;
+		*results = none;
+		return true;
+	}
+	if (!ix && shimcache::enabled())
 	{
 		// no mirror attached: the validated cache (shim_cache.h) — a mirror kept across calls, every answer checked
 		// against the host's pages along the walk that produced it
