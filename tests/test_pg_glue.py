@@ -284,6 +284,22 @@ def test_random_sessions_through_the_validated_cache(seed):
     assert got.stdout == want.stdout
 
 
+def test_validated_cache_follows_changes_made_behind_its_back():
+    """tests/cache_foreign_changes.py (own process): a flat host whose memory is rewritten between calls — other backends'
+    inserts, a vacuum, a rebuild, a shrinking rebuild — while hnsw_search / hnsw_bind_point go through the library's validated
+    cache.  Answers always equal the reference algorithm's over the current bytes, own inserts leave the reference's graph in
+    the host byte for byte, and local changes are repaired along the walks without a full re-walk."""
+    import json
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(SU.ROOT, "tests", "cache_foreign_changes.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    st = json.loads(r.stdout.strip().splitlines()[-1])
+    assert st["checks"] == 300
+    assert st["after_foreign_changes"]["snapshots"] == 1 and st["after_foreign_changes"]["patched"] > 100
+    assert st["after_mixed_inserts"]["snapshots"] == 1 and st["after_mixed_inserts"]["fallbacks"] == 0
+    assert st["after_rebuild"]["snapshots"] == 2
+
+
 def run_patched(name, server):
     from pg_embedding_amd.server import RemoteClient
     exe = SU.build_pg_regress("patched")
