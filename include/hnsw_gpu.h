@@ -194,6 +194,15 @@ int  hnsw_gpu_ctx_idle(hnsw_gpu_ctx *ctx);
  * output widened to 64 bits).  Host pointers. */
 int  hnsw_gpu_search_trace(hnsw_gpu_index *ix, const coord_t *query, size_t ef, int base, label_t *labels, dist_t *dists,
 						   uint32_t *count, idx_t *pops, size_t pops_cap, uint32_t *npops, uint32_t *nevals);
+/* The same in three steps, for a caller that checks the walk WHILE it runs (the kernel stores every pop into pinned host
+ * memory as it happens): _begin launches; _poll copies out the pops that have become visible since the last poll, in
+ * order (*finished = the walk is over and every stored pop has been handed out); _end waits and returns the results
+ * (*npops = pops of the whole walk, of which at most pops_cap were stored).  One trace at a time per mirror, all three
+ * calls from one thread, nothing else on that mirror in between.  No lock is held between the calls; a trace that is
+ * never ended (the caller was thrown out of its own code) is waited for by the next _begin. */
+int  hnsw_gpu_search_trace_begin(hnsw_gpu_index *ix, const coord_t *query, size_t ef, int base, size_t pops_cap);
+int  hnsw_gpu_search_trace_poll(hnsw_gpu_index *ix, idx_t *pops, size_t max, size_t *got, int *finished);
+int  hnsw_gpu_search_trace_end(hnsw_gpu_index *ix, label_t *labels, dist_t *dists, uint32_t *count, uint32_t *npops, uint32_t *nevals);
 /* Pinned host memory for the host-pointer entry points (NULL on failure). */
 void *hnsw_gpu_host_alloc(size_t bytes);
 void  hnsw_gpu_host_free(void *p);

@@ -494,7 +494,8 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 					cand_set<CREG>(ck, last, ~0ull, lane);
 					csize = last;
 				}
-				if (a.out_pops && hops < a.pops_cap && lane == 0) a.out_pops[(size_t) qi * a.pops_cap + hops] = cur;
+				if (a.out_pops && hops < a.pops_cap && lane == 0)       // (system scope: a host that polls the sequence sees it as the walk goes)
+					__hip_atomic_store(a.out_pops + (size_t) qi * a.pops_cap + hops, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 				hops++;
 
 				for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)               // :76-77
@@ -851,7 +852,8 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 				csize--;                                                    // :73 pop = last entry into the hole
 				if (lane == 0) stk<G>(&cand[cpos], ldk<G>(&cand[csize]));
 				set_sync<G>();
-				if (a.out_pops && hops < a.pops_cap && lane == 0) a.out_pops[(size_t) qi * a.pops_cap + hops] = cur;
+				if (a.out_pops && hops < a.pops_cap && lane == 0)       // (system scope: a host that polls the sequence sees it as the walk goes)
+					__hip_atomic_store(a.out_pops + (size_t) qi * a.pops_cap + hops, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 				hops++;
 
 				for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)               // :76-77
@@ -1565,7 +1567,8 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				if (beam_count_lt<UREG>(uk, cd) >= ef) break;              // :70-71  best candidate > lowerBound
 				const uint32_t cur = ~(uint32_t) ckey;
 				ex |= ((uint32_t) lane == (cslot & 63)) ? (1u << (cslot >> 6)) : 0u;   // :73 pop
-				if (a.out_pops && hops < a.pops_cap && lane == 0) a.out_pops[(size_t) qi * a.pops_cap + hops] = cur;
+				if (a.out_pops && hops < a.pops_cap && lane == 0)       // (system scope: a host that polls the sequence sees it as the walk goes)
+					__hip_atomic_store(a.out_pops + (size_t) qi * a.pops_cap + hops, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 				hops++;
 				if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_pop += hs1 - hs0; hs0 = hs1; }
 				TeamView h0v = {};

@@ -127,6 +127,8 @@ struct hnsw_gpu_index
 	void *scratch = nullptr; size_t scratch_bytes = 0;
 	// pinned host staging of the few-queries host-pointer path (the kernel reads and writes it directly)
 	char *pin = nullptr; size_t pin_bytes = 0;
+	// hnsw_gpu_search_trace_begin .. _end
+	bool trace_active = false; size_t trace_ef = 0, trace_cap = 0, trace_seen = 0; int trace_base = 0;
 	// builder scratch (hnsw_gpu_index_link)
 	void *bld = nullptr; size_t bld_batch = 0; size_t bld_tmp_bytes = 0;
 	// exhaustive MFMA scorer: |row|^2 cache + scratch
@@ -961,21 +963,36 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 }
 
 // One query with its walk: results as hnsw_gpu_search_batch gives them, plus the sequence of elements the walk expanded
-// (hnswalg.cpp:73) and its evaluation count.  Host pointers; same polled zero-copy mechanics as the few-queries path.
-extern "C" int hnsw_gpu_search_trace(hnsw_gpu_index *ix, const coord_t *query, size_t ef, int base, label_t *labels, dist_t *dists,
-									 uint32_t *count, idx_t *pops, size_t pops_cap, uint32_t *npops, uint32_t *nevals)
+// (hnswalg.cpp:73) and its evaluation count.  Host pointers; the polled zero-copy mechanics of the few-queries path.
+// Three steps so that a caller can consume the sequence WHILE the walk runs (the kernel stores each pop with system
+// scope into pinned host memory): begin = launch, poll = the pops that have become visible since the last poll,
+// end = wait + results.  One trace at a time per mirror, from one thread; no library lock is held between the steps
+// (the caller may run host callbacks that leave by longjmp in between: a trace that is never ended is waited for by the
+// next begin).
+static const uint32_t POP_NONE = 0xFFFFFFFFu;
+
+struct TraceLayout { size_t qb, lb, db, cb, sb, pb, fb; };
+static TraceLayout trace_layout(size_t dim, size_t ef, size_t pops_cap)
+{
+	TraceLayout t;
+	t.qb = round_up(dim * 4, 256); t.lb = round_up(ef * 8, 256); t.db = round_up(ef * 4, 256); t.cb = 256; t.sb = 256;
+	t.pb = round_up(pops_cap * 4, 256); t.fb = 256;
+	return t;
+}
+
+extern "C" int hnsw_gpu_search_trace_begin(hnsw_gpu_index *ix, const coord_t *query, size_t ef, int base, size_t pops_cap)
 {
 	std::unique_lock<std::recursive_mutex> lock_;
 	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
-	if (!query || !labels || !count || !pops || !npops || pops_cap == 0) return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
+	if (!query || pops_cap == 0) return fail(HNSW_GPU_ERR_ARG, "NULL buffer");
 	if (ef == 0 || ef >= 0xFFFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "ef %zu out of range", ef);
 	if (pops_cap > ((size_t) 1 << 24)) return fail(HNSW_GPU_ERR_ARG, "pops_cap %zu too large", pops_cap);
 	HIPCHK(hipSetDevice(ix->device));
+	if (ix->trace_active) { HIPCHK(hipStreamSynchronize(nullptr)); ix->trace_active = false; }   // an abandoned trace still writes its buffers
 	const size_t dim = ix->meta.dim;
-	const size_t qb = round_up(dim * 4, 256), lb = round_up(ef * 8, 256), db = round_up(ef * 4, 256), cb = 256, sb = 256,
-				 pb = round_up(pops_cap * 4, 256), fb = 256;
-	const size_t need = qb + lb + db + cb + sb + pb + fb;
+	const TraceLayout t = trace_layout(dim, ef, pops_cap);
+	const size_t need = t.qb + t.lb + t.db + t.cb + t.sb + t.pb + t.fb;
 	if (ix->pin_bytes < need)
 	{
 		if (ix->pin) (void) hipHostFree(ix->pin);
@@ -984,11 +1001,12 @@ extern "C" int hnsw_gpu_search_trace(hnsw_gpu_index *ix, const coord_t *query, s
 		ix->pin_bytes = need;
 	}
 	char *h = ix->pin;
-	float *hq = (float *) h; uint64_t *hl = (uint64_t *) (h + qb); float *hd = (float *) (h + qb + lb);
-	uint32_t *hc = (uint32_t *) (h + qb + lb + db), *hs = (uint32_t *) (h + qb + lb + db + cb),
-			 *hp = (uint32_t *) (h + qb + lb + db + cb + sb);
-	volatile uint32_t *hf = (volatile uint32_t *) (h + qb + lb + db + cb + sb + pb);
+	float *hq = (float *) h; uint64_t *hl = (uint64_t *) (h + t.qb); float *hd = (float *) (h + t.qb + t.lb);
+	uint32_t *hc = (uint32_t *) (h + t.qb + t.lb + t.db), *hs = (uint32_t *) (h + t.qb + t.lb + t.db + t.cb),
+			 *hp = (uint32_t *) (h + t.qb + t.lb + t.db + t.cb + t.sb);
+	volatile uint32_t *hf = (volatile uint32_t *) (h + t.qb + t.lb + t.db + t.cb + t.sb + t.pb);
 	memcpy(hq, query, dim * 4);
+	memset(hp, 0xFF, pops_cap * 4);                 // POP_NONE: a slot the walk has not reached yet
 	hf[0] = 0;
 	ix->ws.done_next = (uint32_t *) hf;
 	ix->ws.pops_next = hp; ix->ws.pops_cap_next = (uint32_t) pops_cap;
@@ -996,6 +1014,49 @@ extern "C" int hnsw_gpu_search_trace(hnsw_gpu_index *ix, const coord_t *query, s
 				  : launch_search(ix, &ix->ws, hq, dim, 1, ef, 0, hl, nullptr, hd, hc, hs, nullptr);
 	ix->ws.done_next = nullptr; ix->ws.pops_next = nullptr; ix->ws.pops_cap_next = 0;
 	if (rc) return rc;
+	ix->trace_active = true; ix->trace_ef = ef; ix->trace_base = base; ix->trace_cap = pops_cap; ix->trace_seen = 0;
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_search_trace_poll(hnsw_gpu_index *ix, idx_t *pops, size_t max, size_t *got, int *finished)
+{
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
+	if (!ix || !pops || !got || !finished) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	if (!ix->trace_active) return fail(HNSW_GPU_ERR_ARG, "no trace in flight");
+	const TraceLayout t = trace_layout(ix->meta.dim, ix->trace_ef, ix->trace_cap);
+	char *h = ix->pin;
+	const volatile uint32_t *hp = (const volatile uint32_t *) (h + t.qb + t.lb + t.db + t.cb + t.sb);
+	const volatile uint32_t *hf = (const volatile uint32_t *) (h + t.qb + t.lb + t.db + t.cb + t.sb + t.pb);
+	const bool done = hf[0] != 0;                   // read BEFORE the scan: everything the walk stored precedes the flag
+	__atomic_thread_fence(__ATOMIC_ACQUIRE);
+	size_t k = 0;
+	while (k < max && ix->trace_seen < ix->trace_cap)
+	{
+		const uint32_t v = hp[ix->trace_seen];
+		if (v == POP_NONE) break;
+		pops[k++] = v;
+		ix->trace_seen++;
+	}
+	*got = k;
+	*finished = (done && (ix->trace_seen >= ix->trace_cap || hp[ix->trace_seen] == POP_NONE)) ? 1 : 0;
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_search_trace_end(hnsw_gpu_index *ix, label_t *labels, dist_t *dists, uint32_t *count, uint32_t *npops,
+										 uint32_t *nevals)
+{
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
+	if (!ix || !labels || !count || !npops) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	if (!ix->trace_active) return fail(HNSW_GPU_ERR_ARG, "no trace in flight");
+	HIPCHK(hipSetDevice(ix->device));
+	const size_t ef = ix->trace_ef;
+	const TraceLayout t = trace_layout(ix->meta.dim, ef, ix->trace_cap);
+	char *h = ix->pin;
+	const uint64_t *hl = (const uint64_t *) (h + t.qb); const float *hd = (const float *) (h + t.qb + t.lb);
+	const uint32_t *hc = (const uint32_t *) (h + t.qb + t.lb + t.db), *hs = (const uint32_t *) (h + t.qb + t.lb + t.db + t.cb);
+	const volatile uint32_t *hf = (const volatile uint32_t *) (h + t.qb + t.lb + t.db + t.cb + t.sb + t.pb);
 	uint64_t spins = 0;
 	while (hf[0] == 0)
 	{
@@ -1003,17 +1064,31 @@ extern "C" int hnsw_gpu_search_trace(hnsw_gpu_index *ix, const coord_t *query, s
 		if ((++spins & 0xFFFF) == 0 && hipStreamQuery(nullptr) != hipErrorNotReady)
 		{
 			HIPCHK(hipStreamSynchronize(nullptr));
-			if (hf[0] == 0) return fail(HNSW_GPU_ERR_INTERNAL, "search kernel ended without completing the query");
+			if (hf[0] == 0) { ix->trace_active = false; return fail(HNSW_GPU_ERR_INTERNAL, "search kernel ended without completing the query"); }
 		}
 	}
 	__atomic_thread_fence(__ATOMIC_ACQUIRE);
-	if (base) { const uint32_t *hi = (const uint32_t *) hl; for (size_t i = 0; i < ef; i++) labels[i] = hi[i]; }
+	ix->trace_active = false;
+	if (ix->trace_base) { const uint32_t *hi = (const uint32_t *) hl; for (size_t i = 0; i < ef; i++) labels[i] = hi[i]; }
 	else memcpy(labels, hl, ef * 8);
 	if (dists) memcpy(dists, hd, ef * 4);
 	*count = hc[0];
 	*npops = hs[1];
 	if (nevals) *nevals = hs[0];
-	memcpy(pops, hp, std::min<size_t>(hs[1], pops_cap) * 4);
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_search_trace(hnsw_gpu_index *ix, const coord_t *query, size_t ef, int base, label_t *labels, dist_t *dists,
+									 uint32_t *count, idx_t *pops, size_t pops_cap, uint32_t *npops, uint32_t *nevals)
+{
+	if (!ix || !pops || !npops) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	std::unique_lock<std::recursive_mutex> lock_(ix->mu);          // the three steps as one
+	int rc = hnsw_gpu_search_trace_begin(ix, query, ef, base, pops_cap);
+	if (rc) return rc;
+	rc = hnsw_gpu_search_trace_end(ix, labels, dists, count, npops, nevals);
+	if (rc) return rc;
+	const TraceLayout t = trace_layout(ix->meta.dim, ef, pops_cap);
+	memcpy(pops, ix->pin + t.qb + t.lb + t.db + t.cb + t.sb, std::min<size_t>(*npops, pops_cap) * 4);
 	return HNSW_GPU_OK;
 }
 

@@ -157,19 +157,27 @@ inline Entry *pick(HnswMetadata *meta, bool *empty)
 	return hit;
 }
 
-// Compare with the host every element the walk touched: the entry point and all link targets of the elements in
-// `expand` that were themselves found identical.  Differences are collected in patches() (host images).  Returns the
-// number of differing elements, or -1 when the host no longer has an element the mirror's graph names (another index
-// behind the same parameters: the caller re-mirrors).
-inline long validate(HnswMetadata *meta, Entry *e, const uint32_t *expand, size_t nexpand)
+// Compare with the host every element a walk touches: the entry point and all link targets of the expanded elements that
+// were themselves found identical.  Incremental, so that the comparison runs WHILE the device walks (the expanded elements
+// arrive through hnsw_gpu_search_trace_poll as the kernel reports them).  Differences are collected in patches() (host
+// images).  `missing`: the host no longer has an element the mirror's graph names (another index behind the same
+// parameters: the caller re-mirrors).
+struct Validator
 {
-	const size_t esz = meta->size_data_per_element, maxM = meta->maxM;
-	Patches &pt = patches();
-	pt.clear();
-	if (++e->epoch >= 0x7FFFFFF0u) { std::fill(e->stamp.begin(), e->stamp.end(), 0u); e->epoch = 1; }
-	const uint32_t clean = 2 * e->epoch, dirty = clean + 1;
+	HnswMetadata *meta;
+	Entry *e;
+	size_t esz, maxM;
+	uint32_t clean, dirty;
 	bool missing = false;
-	auto visit = [&](uint32_t id)
+
+	Validator(HnswMetadata *m, Entry *en) : meta(m), e(en), esz(m->size_data_per_element), maxM(m->maxM)
+	{
+		patches().clear();
+		if (++e->epoch >= 0x7FFFFFF0u) { std::fill(e->stamp.begin(), e->stamp.end(), 0u); e->epoch = 1; }
+		clean = 2 * e->epoch; dirty = clean + 1;
+		visit(meta->enterpoint_node);
+	}
+	void visit(uint32_t id)
 	{
 		if ((size_t) id < e->stamp.size() && (e->stamp[id] == clean || e->stamp[id] == dirty)) return;
 		if ((size_t) id >= e->stamp.size()) e->stamp.resize((size_t) id + 1 + e->stamp.size() / 4, 0);
@@ -177,29 +185,64 @@ inline long validate(HnswMetadata *meta, Entry *e, const uint32_t *expand, size_
 		if (!hnsw_begin_read(meta, (idx_t) id, &links, nullptr, nullptr)) { missing = true; e->stamp[id] = dirty; return; }
 		stats().elements_read++;
 		const bool same = (size_t) id < e->n && memcmp(e->shadow.data() + (size_t) id * esz, links, esz) == 0;
-		if (!same) pt.add(id, links, esz);                      // the element image is contiguous from its link count on
+		if (!same) patches().add(id, links, esz);              // the element image is contiguous from its link count on
 		hnsw_end_read(meta);
 		e->stamp[id] = same ? clean : dirty;
-	};
-	visit(meta->enterpoint_node);
-	for (size_t i = 0; i < nexpand && !missing; i++)
+	}
+	void expand(uint32_t x)
 	{
-		const uint32_t x = expand[i];
-		if ((size_t) x >= e->stamp.size() || e->stamp[x] != clean) continue;     // never follow links that are not the host's
+		if (missing || (size_t) x >= e->stamp.size() || e->stamp[x] != clean) return;   // never follow links that are not the host's
 		const uint32_t *l = reinterpret_cast<const uint32_t *>(e->shadow.data() + (size_t) x * esz);
 		const uint32_t cnt = l[0] <= maxM ? l[0] : (uint32_t) maxM;
+		// the copies to compare against lie scattered over an image of the whole index: start their cache misses together
+		for (uint32_t j = 1; j <= cnt; j++)
+			if ((size_t) l[j] < e->n)
+			{
+				const char *img = e->shadow.data() + (size_t) l[j] * esz;
+				__builtin_prefetch(img);
+				__builtin_prefetch(img + 64);
+				__builtin_prefetch(img + (esz > 256 ? 256 : 0));
+			}
 		for (uint32_t j = 1; j <= cnt && !missing; j++) visit(l[j]);
 	}
-	return missing ? -1 : (long) pt.ids.size();
-}
+	long result() const { return missing ? -1 : (long) patches().ids.size(); }
+};
 
-// every element of `expand` was reached and found identical (holds after a validation without differences)
-inline bool all_clean(const Entry *e, const uint32_t *expand, size_t nexpand)
+// One traced walk on the mirror, validated while it runs.  `extra_results`: the results are expanded too (inserts).
+// Returns the number of differing elements (0 = the answer in labels/count is the host's), -1 = re-mirror, -2 = failure.
+inline long traced_walk(HnswMetadata *meta, Entry *e, const coord_t *point, size_t ef, int base, label_t *labels, uint32_t *count,
+						std::vector<uint32_t> &pops, size_t cap, bool expand_results)
 {
-	const uint32_t clean = 2 * e->epoch;
-	for (size_t i = 0; i < nexpand; i++)
-		if ((size_t) expand[i] >= e->stamp.size() || e->stamp[expand[i]] != clean) return false;
-	return true;
+	if (hnsw_gpu_search_trace_begin(e->ix, point, ef, base, cap) != HNSW_GPU_OK) return -2;
+	Validator v(meta, e);                                       // (host callbacks from here on: no library lock is held)
+	size_t have = 0;
+	for (;;)
+	{
+		size_t got = 0;
+		int finished = 0;
+		if (hnsw_gpu_search_trace_poll(e->ix, pops.data() + have, cap - have, &got, &finished) != HNSW_GPU_OK) return -2;
+		for (size_t i = 0; i < got; i++) v.expand(pops[have + i]);
+		have += got;
+		if (finished) break;
+		if (got == 0) __builtin_ia32_pause();
+	}
+	uint32_t npops = 0;
+	if (hnsw_gpu_search_trace_end(e->ix, labels, nullptr, count, &npops, nullptr) != HNSW_GPU_OK) return -2;
+	if (npops > cap || have != npops) return -1;                // a walk too long to validate
+	if (expand_results)
+	{
+		if ((size_t) npops + *count > pops.size()) return -1;
+		for (uint32_t i = 0; i < *count; i++) { pops[have + i] = (uint32_t) labels[i]; v.expand(pops[have + i]); }
+		have += *count;
+	}
+	const long diff = v.result();
+	if (diff == 0)
+	{
+		const uint32_t ok = 2 * e->epoch;
+		for (size_t i = 0; i < have; i++)
+			if ((size_t) pops[i] >= e->stamp.size() || e->stamp[pops[i]] != ok) return -1;   // cannot happen after a clean validation
+	}
+	return diff;
 }
 
 // Put the collected host images into the shadow and the mirror.  No host callback runs in here.
@@ -247,7 +290,7 @@ inline bool apply_patches(HnswMetadata *meta, Entry *e)
 	return true;
 }
 
-constexpr size_t POPS_CAP = 1 << 16;
+constexpr size_t POPS_CAP = 1 << 14;       // pops of one walk that can be validated (ef = 128: ~150; scans that double ef: thousands)
 inline std::vector<uint32_t> &popbuf() { static thread_local std::vector<uint32_t> b; return b; }
 
 // hnsw_search over the cache.  labels: ef entries.  Returns false on failure (message on stderr by the caller).
@@ -264,21 +307,14 @@ inline bool search(HnswMetadata *meta, const coord_t *point, size_t ef, label_t 
 		return hnsw_gpu_search_batch(e->ix, point, 1, ef, labels, nullptr, count) == HNSW_GPU_OK;   // just built from the host
 	}
 	std::vector<uint32_t> &pops = popbuf();
-	if (pops.size() < POPS_CAP) pops.resize(POPS_CAP);
+	if (pops.size() < POPS_CAP + 64) pops.resize(POPS_CAP + 64);
 	for (int round = 0; round < 12; round++)
 	{
-		uint32_t npops = 0;
 		stats().search_rounds++;
-		if (hnsw_gpu_search_trace(e->ix, point, ef, 0, labels, nullptr, count, pops.data(), POPS_CAP, &npops, nullptr) != HNSW_GPU_OK)
-			return false;
-		if (npops > POPS_CAP) break;                             // a walk too long to validate: re-mirror
-		const long diff = validate(meta, e, pops.data(), npops);
+		const long diff = traced_walk(meta, e, point, ef, 0, labels, count, pops, POPS_CAP, false);
+		if (diff == -2) return false;
 		if (diff < 0) break;
-		if (diff == 0)
-		{
-			if (!all_clean(e, pops.data(), npops)) break;
-			return true;
-		}
+		if (diff == 0) return true;
 		if ((size_t) diff > 64 + e->n / 4) break;                // mostly another index: re-mirroring is cheaper
 		if (!apply_patches(meta, e)) break;
 	}
@@ -303,24 +339,17 @@ inline Entry *prepare_insert(HnswMetadata *meta, const coord_t *point, idx_t idx
 	if (!e) return resnapshot(meta, nullptr, device);
 	const size_t efc = std::max<size_t>(meta->efConstruction, 1);
 	std::vector<uint32_t> &pops = popbuf();
-	if (pops.size() < POPS_CAP) pops.resize(POPS_CAP);
+	if (pops.size() < POPS_CAP + efc + 64) pops.resize(POPS_CAP + efc + 64);
 	static thread_local std::vector<label_t> res;
 	res.resize(efc);
 	for (int round = 0; round < 12; round++)
 	{
-		uint32_t npops = 0, cnt = 0;
+		uint32_t cnt = 0;
 		stats().insert_rounds++;
-		if (hnsw_gpu_search_trace(e->ix, point, efc, 1, res.data(), nullptr, &cnt, pops.data(), POPS_CAP, &npops, nullptr) != HNSW_GPU_OK)
-			return nullptr;
-		if ((size_t) npops + cnt > POPS_CAP) break;
-		for (uint32_t i = 0; i < cnt; i++) pops[npops + i] = (uint32_t) res[i];
-		const long diff = validate(meta, e, pops.data(), (size_t) npops + cnt);
+		const long diff = traced_walk(meta, e, point, efc, 1, res.data(), &cnt, pops, POPS_CAP, true);
+		if (diff == -2) return nullptr;
 		if (diff < 0) break;
-		if (diff == 0)
-		{
-			if (!all_clean(e, pops.data(), (size_t) npops + cnt)) break;
-			return e;
-		}
+		if (diff == 0) return e;
 		if ((size_t) diff > 64 + e->n / 4) break;
 		if (!apply_patches(meta, e)) break;
 	}

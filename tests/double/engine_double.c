@@ -209,6 +209,45 @@ int hnsw_gpu_search_trace(hnsw_gpu_index *ix, const coord_t *query, size_t ef, i
 	return rc == 0 ? HNSW_GPU_OK : HNSW_GPU_ERR_INTERNAL;
 }
 
+/* the three-step form: the double walks at _begin and hands the sequence out in slices, so that the caller's incremental
+ * consumption is exercised */
+static __thread struct { hnsw_gpu_index *ix; size_t ef, cap, seen; int base; uint64_t *lab; float *dst; uint32_t *pops; uint32_t cnt, npops, nev; } t_tr;
+
+int hnsw_gpu_search_trace_begin(hnsw_gpu_index *ix, const coord_t *query, size_t ef, int base, size_t pops_cap)
+{
+	free(t_tr.lab); free(t_tr.dst); free(t_tr.pops);
+	memset(&t_tr, 0, sizeof(t_tr));
+	t_tr.lab = (uint64_t *) malloc((ef ? ef : 1) * 8); t_tr.dst = (float *) malloc((ef ? ef : 1) * 4); t_tr.pops = (uint32_t *) malloc(pops_cap * 4);
+	if (!t_tr.lab || !t_tr.dst || !t_tr.pops) return HNSW_GPU_ERR_NOMEM;
+	t_tr.ix = ix; t_tr.ef = ef; t_tr.cap = pops_cap; t_tr.base = base;
+	return hnsw_gpu_search_trace(ix, query, ef, base, t_tr.lab, t_tr.dst, &t_tr.cnt, t_tr.pops, pops_cap, &t_tr.npops, &t_tr.nev);
+}
+
+int hnsw_gpu_search_trace_poll(hnsw_gpu_index *ix, idx_t *pops, size_t max, size_t *got, int *finished)
+{
+	if (ix != t_tr.ix) return HNSW_GPU_ERR_ARG;
+	const size_t have = t_tr.npops < t_tr.cap ? t_tr.npops : t_tr.cap;
+	size_t k = have - t_tr.seen;
+	if (k > max) k = max;
+	if (k > 7) k = 7;                                   /* slices: several polls per walk */
+	memcpy(pops, t_tr.pops + t_tr.seen, k * 4);
+	t_tr.seen += k;
+	*got = k;
+	*finished = t_tr.seen == have;
+	return HNSW_GPU_OK;
+}
+
+int hnsw_gpu_search_trace_end(hnsw_gpu_index *ix, label_t *labels, dist_t *dists, uint32_t *count, uint32_t *npops, uint32_t *nevals)
+{
+	if (ix != t_tr.ix) return HNSW_GPU_ERR_ARG;
+	memcpy(labels, t_tr.lab, t_tr.cnt * 8);
+	if (dists) memcpy(dists, t_tr.dst, t_tr.cnt * 4);
+	*count = t_tr.cnt; *npops = t_tr.npops;
+	if (nevals) *nevals = t_tr.nev;
+	t_tr.ix = NULL;
+	return HNSW_GPU_OK;
+}
+
 int hnsw_gpu_ctx_create(hnsw_gpu_index *ix, hnsw_gpu_ctx **out)
 {
 	hnsw_gpu_ctx *c = (hnsw_gpu_ctx *) calloc(1, sizeof(*c));
