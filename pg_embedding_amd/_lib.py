@@ -86,6 +86,9 @@ def gpu_lib():
     L.hnsw_gpu_index_set_deleted.argtypes = [vp, C.c_uint32, i32]
     L.hnsw_gpu_index_set_deleted_batch.argtypes = [vp, _u32p, sz, i32]
     L.hnsw_gpu_search_trace.argtypes = [vp, vp, sz, i32, vp, vp, _u32p, _u32p, sz, _u32p, _u32p]
+    L.hnsw_gpu_search_trace_begin.argtypes = [vp, vp, sz, i32, sz]
+    L.hnsw_gpu_search_trace_poll.argtypes = [vp, _u32p, sz, C.POINTER(sz), C.POINTER(i32)]
+    L.hnsw_gpu_search_trace_end.argtypes = [vp, vp, vp, _u32p, _u32p, _u32p]
     L.hnsw_gpu_index_count.restype = sz
     L.hnsw_gpu_index_count.argtypes = [vp]
     L.hnsw_gpu_index_device.argtypes = [vp]

@@ -174,6 +174,31 @@ class GpuIndex:
                                            C.byref(npops), C.byref(nev)), "hnsw_gpu_search_trace")
         return labels[:cnt.value], dists[:cnt.value], pops[:min(npops.value, pops_cap)], int(nev.value)
 
+    def search_trace_polled(self, query: np.ndarray, ef: Optional[int] = None, base: bool = False, pops_cap: int = 1 << 14,
+                            slice_: int = 5):
+        """The same through hnsw_gpu_search_trace_begin / _poll / _end: the pops are taken while the kernel runs, at most
+        `slice_` per poll.  Returns (labels, dists, pops, evals, polls)."""
+        ef = int(ef or self.meta.efSearch)
+        q = np.ascontiguousarray(query, dtype=np.float32).reshape(self.meta.dim)
+        check(self.L.hnsw_gpu_search_trace_begin(self._h, q.ctypes.data, ef, int(base), pops_cap), "hnsw_gpu_search_trace_begin")
+        pops = np.empty(pops_cap + slice_, np.uint32)
+        have, polls = 0, 0
+        got, fin = C.c_size_t(0), C.c_int(0)
+        while True:
+            check(self.L.hnsw_gpu_search_trace_poll(self._h, pops[have:].ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                    min(slice_, pops_cap - have), C.byref(got), C.byref(fin)), "hnsw_gpu_search_trace_poll")
+            have += got.value
+            polls += 1
+            if fin.value:
+                break
+        labels = np.empty(ef, np.uint64)
+        dists = np.empty(ef, np.float32)
+        cnt, npops, nev = C.c_uint32(0), C.c_uint32(0), C.c_uint32(0)
+        check(self.L.hnsw_gpu_search_trace_end(self._h, labels.ctypes.data, dists.ctypes.data, C.byref(cnt), C.byref(npops), C.byref(nev)),
+              "hnsw_gpu_search_trace_end")
+        assert have == min(npops.value, pops_cap)
+        return labels[:cnt.value], dists[:cnt.value], pops[:have].copy(), int(nev.value), polls
+
     def search_torch(self, queries, ef: Optional[int] = None, out=None, stats: bool = False, base: bool = False):
         """Same with everything resident in HBM (torch tensors only carry the pointers).
         `out` may be a dict from a previous call to reuse its buffers.  With base=True runs

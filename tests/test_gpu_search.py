@@ -168,6 +168,16 @@ def test_search_trace_reports_the_walk(dim, env, monkeypatch):
     # a capacity smaller than the walk: the count is still the walk's, the stored prefix is its beginning
     lab, dst, pops, ev = ix.search_trace(Q[0], 64, pops_cap=5)
     assert (pops == port.search_trace(Q[0], 64)[2][:5]).all()
+    # the three-step form: pops handed out while the kernel runs (system-scope stores into pinned host memory)
+    for q in Q[:8]:
+        lab, dst, pops, ev, polls = ix.search_trace_polled(q, 64)
+        wl, wd, wp, wev = port.search_trace(q, 64)
+        assert (lab == wl).all() and (bits(dst) == bits(wd)).all() and len(pops) == len(wp) and (pops == wp).all() and ev == wev
+        assert polls >= len(wp) // 5
+    # a trace that is begun and never ended (its caller was thrown out of its own code) does not disturb the next one
+    ix.L.hnsw_gpu_search_trace_begin(ix._h, np.ascontiguousarray(Q[1]).ctypes.data, 64, 0, 1 << 10)
+    lab, dst, pops, ev = ix.search_trace(Q[2], 64)
+    assert (pops == port.search_trace(Q[2], 64)[2]).all()
     ix.close()
 
 
