@@ -476,6 +476,10 @@ def side_configs(args, dev, local):
         ix.close()
         del ix, out, Q
         torch.cuda.empty_cache()
+    res["_note"] = ("achieved_GBps = algorithmic bytes (SURVEY 8d) / kernel time, frac_of_8TBps = that over the nominal HBM peak; rows that "
+                    "many queries of a launch share are served by L2 / Infinity Cache, so the figure can exceed what HBM delivers "
+                    "(the i.i.d. set: every walk crosses the same hub rows) -- roofline.measured_gather_GBps and roofline.cache_hostile "
+                    "of the headline workload show the HBM-only picture")
     return res
 
 
