@@ -119,7 +119,9 @@ inline Entry *resnapshot(HnswMetadata *meta, Entry *e, int device)
 	e->key = *meta;
 	e->ix = ix;
 	e->n = (size_t) n;
-	e->shadow.assign(wb.data(), wb.data() + (size_t) n * meta->size_data_per_element);
+	e->shadow.swap(wb);                                        // the walk's image becomes the shadow: no second copy of the index
+	e->shadow.resize((size_t) n * meta->size_data_per_element);
+	std::vector<char>().swap(wb);
 	e->stamp.assign((size_t) n, 0);
 	e->epoch = 0;
 	e->suspect = false;
