@@ -57,7 +57,7 @@ def build(force: bool = False, verbose: bool = False) -> None:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(BINDIR, exist_ok=True)
     hdrs = [os.path.join(INC, h) for h in ("hnsw_abi.h", "hnsw_gpu.h", "hnsw_gpu_shim.h", "hnsw_gpu_server.h")]
-    gpu_src = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) and f not in ("hgs_io.h", "host_walk.h", "host_dist.h")] + hdrs
+    gpu_src = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) and f not in ("hgs_io.h", "host_walk.h", "host_dist.h", "shim_cache.h")] + hdrs
     if force or not _newer(GPU_LIB, gpu_src):
         cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INC, "-I", CSRC,
                                           os.path.join(CSRC, "hnsw_gpu.hip"),
@@ -66,7 +66,7 @@ def build(force: bool = False, verbose: bool = False) -> None:
             print(" ".join(cmd))
         _run(cmd)
     host_dist = os.path.join(CSRC, "host_dist.h")
-    shim_src = [os.path.join(CSRC, "embedding_shim.cpp"), os.path.join(CSRC, "host_walk.h"), host_dist] + hdrs
+    shim_src = [os.path.join(CSRC, "embedding_shim.cpp"), os.path.join(CSRC, "host_walk.h"), os.path.join(CSRC, "shim_cache.h"), host_dist] + hdrs
     if force or not _newer(SHIM_LIB, shim_src + [GPU_LIB]):
         cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I", INC, "-I", CSRC,
                os.path.join(CSRC, "embedding_shim.cpp"), "-o", SHIM_LIB,
