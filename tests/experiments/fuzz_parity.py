@@ -38,7 +38,7 @@ def one_case(rng, idx):
         port.set_deleted(int(i))
     meta = pg.make_meta(dim, m, efc, ef, func)
     ix = pg.GpuIndex.from_flat(meta, port.raw(), n)
-    nq = int(rng.integers(1, 80))
+    nq = int(rng.choice([1, 3, 16, 17, 60, 300, 700]))       # <= 16: polled zero-copy call; > one per CU: the 5-waves narrow-row kernel
     Q = gmm(nq, dim, k=k, seed=1000 + idx, stream=1)
     if func == 1:
         Q[(Q * Q).sum(axis=1) == 0] = 1.0
@@ -49,6 +49,11 @@ def one_case(rng, idx):
         c = int(W["counts"][q])
         ok = ok and (L[q, :c] == W["labels"][q, :c]).all() and \
             (D[q, :c].view(np.uint32) == W["dists"][q, :c].view(np.uint32)).all()
+    # the walk itself: pop sequence and evaluation count of one query, one-step and three-step form (round 2)
+    tl, td, tp, tev = ix.search_trace(Q[0], ef)
+    wl, wd, wp, wev = port.search_trace(Q[0], min(ef, n))
+    _, _, tp2, _, _ = ix.search_trace_polled(Q[0], ef)
+    ok = ok and len(tp) == len(wp) and (tp == wp).all() and tev == wev and (tl == wl).all() and len(tp2) == len(wp) and (tp2 == wp).all()
     ix.close()
     # serial device insert == oracle graph (small prefix to keep it quick)
     nb = min(n, 250)
