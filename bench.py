@@ -476,6 +476,55 @@ def side_configs(args, dev, local):
         ix.close()
         del ix, out, Q
         torch.cuda.empty_cache()
+    # ---- BASELINE config 4 functionally, on ONE device: 10M x 768 as 8 row shards (independent graphs), the native one-process
+    # sharded search of the C ABI (per-shard searchKnn + device merge).  One GPU does the work of eight here; the 8-GPU form is
+    # `bench.py --mode sharded --gpus 8` (one packed all-gather over RCCL).
+    if args.n >= 1_000_000:
+        from pg_embedding_amd.index import LocalShardedIndex
+        n4, shards, nq4, dim = 10_000_000, 8, 1024, 768
+        t0 = time.time()
+        meta = pg.make_meta(dim, 16, args.efc, args.ef, pg.DIST_L2)
+        idx = []
+        for r in range(shards):
+            lo, hi = n4 * r // shards, n4 * (r + 1) // shards
+            rows = gmm_torch(hi - lo, dim, k=1000, sigma=0.3, seed=42, stream=100 + r, device=dev)
+            ix = pg.GpuIndex.empty(meta, hi - lo, device=local)
+            ix.append_torch(rows, torch.arange(lo, hi, dtype=torch.int64, device=dev))
+            del rows
+            ix.link(0, hi - lo, args.max_batch, args.ratio, torch.cuda.current_stream(dev).cuda_stream)
+            idx.append(ix)
+        torch.cuda.synchronize()
+        t_build = time.time() - t0
+        sh = LocalShardedIndex(idx)
+        Q = gmm_torch(nq4, dim, k=1000, sigma=0.3, seed=42, stream=1, device=dev)
+        ml, md, mc = sh.search_torch(Q, args.ef)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(4):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ml, md, mc = sh.search_torch(Q, args.ef)
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t1)
+        dt = float(np.median(ts[1:]))
+        cand_i, cand_d = [], []
+        for r, ix in enumerate(idx):                      # exhaustive truth per shard (MFMA scorer), merged
+            ti, td = ix.bruteforce_torch(Q[:256].contiguous(), 10, mfma=True)
+            cand_i.append(ti.long() + n4 * r // shards)
+            cand_d.append(td)
+        ci, cd = torch.cat(cand_i, 1), torch.cat(cand_d, 1)
+        truth = torch.gather(ci, 1, torch.argsort(cd, dim=1)[:, :10])
+        rec = recall_at_k(ml[:256].cpu().numpy(), truth.cpu().numpy(), 10)
+        res["C4_10Mx768_l2_8shards_on_ONE_device"] = {
+            "rows": n4, "dims": dim, "m": 16, "shards": shards, "queries_per_batch": nq4, "efsearch": args.ef,
+            "entry_point": "hnsw_gpu_sharded_search_dev (one process, per-shard search + strided device merge)",
+            "ms_per_batch_all_shards_plus_merge": dt * 1e3, "queries_per_s": nq4 / dt, "recall_at_10": rec,
+            "results_per_query_full": bool((mc == args.ef).all().item()), "datagen_plus_build_seconds": t_build}
+        sh.close()
+        for ix in idx:
+            ix.close()
+        del idx, Q
+        torch.cuda.empty_cache()
     res["_note"] = ("achieved_GBps = algorithmic bytes (SURVEY 8d) / kernel time, frac_of_8TBps = that over the nominal HBM peak; rows that "
                     "many queries of a launch share are served by L2 / Infinity Cache, so the figure can exceed what HBM delivers "
                     "(the i.i.d. set: every walk crosses the same hub rows) -- roofline.measured_gather_GBps and roofline.cache_hostile "
