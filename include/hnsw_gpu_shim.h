@@ -29,7 +29,8 @@ int hnsw_gpu_shim_detach(HnswMetadata *meta);
  * calls whose every answer is checked against the host's pages along the walk that produced it, and patched where the
  * host has changed.  Counters of the calling thread's cache: snapshots (full walks), searches, search rounds, inserts,
  * insert rounds, elements patched, fallbacks to a full walk, elements read for validation.  PG_EMBEDDING_GPU_CACHE=0
- * switches the cache off (every call re-mirrors the index). */
+ * switches the cache off (every call re-mirrors the index); PG_EMBEDDING_GPU_CACHE_MAX_MB (default 16384) bounds the host
+ * memory one cached index may keep (its flat image, N x element size): a larger index is mirrored per call. */
 void hnsw_gpu_shim_cache_stats(uint64_t out[8]);
 void hnsw_gpu_shim_cache_clear(void);
 

@@ -319,8 +319,8 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 	} while (0);
 	if (ce)
 	{
-		if (ok) ce->suspect = false;
-		else shimcache::drop(ce);                        // mirror and host may have parted: never reuse it
+		if (ok && !ce->ephemeral) ce->suspect = false;
+		else shimcache::drop(ce);                        // mirror and host may have parted (or the index is too large to keep): never reuse it
 	}
 	if (!ok)
 		fprintf(stderr, "pg_embedding_amd: hnsw_bind_point(%u) failed: %s\n", (unsigned) idx, hnsw_gpu_last_error());

@@ -49,6 +49,7 @@ struct Entry
 	uint32_t epoch = 0;
 	uint64_t last_use = 0;
 	bool suspect = false;              // an insert was interrupted half-way (a callback left by longjmp)
+	bool ephemeral = false;            // larger than the cache may keep: used for this call only, then dropped
 };
 
 inline std::vector<Entry *> &table() { static thread_local std::vector<Entry *> t; return t; }
@@ -58,6 +59,15 @@ inline bool enabled()
 {
 	const char *e = getenv("PG_EMBEDDING_GPU_CACHE");
 	return !(e && atoi(e) == 0);
+}
+
+// Host bytes one cached index may keep beside its mirror (the flat image it is validated against).  An index above
+// the limit is mirrored for the call that needs it and dropped again — the round-1 behaviour, for that index only.
+inline size_t max_shadow_bytes()
+{
+	const char *e = getenv("PG_EMBEDDING_GPU_CACHE_MAX_MB");
+	const long long mb = e ? atoll(e) : 16384;
+	return mb <= 0 ? 0 : (size_t) mb << 20;
 }
 
 inline bool same_key(const HnswMetadata &a, const HnswMetadata &b)
@@ -125,6 +135,7 @@ inline Entry *resnapshot(HnswMetadata *meta, Entry *e, int device)
 	e->stamp.assign((size_t) n, 0);
 	e->epoch = 0;
 	e->suspect = false;
+	e->ephemeral = e->shadow.size() > max_shadow_bytes();
 	e->last_use = ++clock_();
 	stats().snapshots++;
 	return e;
@@ -146,7 +157,7 @@ inline Entry *pick(HnswMetadata *meta, bool *empty)
 	Entry *hit = nullptr;
 	for (Entry *e : table())
 	{
-		if (e->suspect || !same_key(e->key, *meta) || e->n <= meta->enterpoint_node) continue;
+		if (e->suspect || e->ephemeral || !same_key(e->key, *meta) || e->n <= meta->enterpoint_node) continue;
 		const char *simg = e->shadow.data() + (size_t) meta->enterpoint_node * esz;
 		uint64_t slab;
 		memcpy(&slab, simg + meta->offset_label, 8);
@@ -306,7 +317,9 @@ inline bool search(HnswMetadata *meta, const coord_t *point, size_t ef, label_t 
 	{
 		e = resnapshot(meta, nullptr, device);
 		if (!e) return false;
-		return hnsw_gpu_search_batch(e->ix, point, 1, ef, labels, nullptr, count) == HNSW_GPU_OK;   // just built from the host
+		const bool ok = hnsw_gpu_search_batch(e->ix, point, 1, ef, labels, nullptr, count) == HNSW_GPU_OK;   // just built from the host
+		if (e->ephemeral) drop(e);
+		return ok;
 	}
 	std::vector<uint32_t> &pops = popbuf();
 	if (pops.size() < POPS_CAP + 64) pops.resize(POPS_CAP + 64);
@@ -323,7 +336,9 @@ inline bool search(HnswMetadata *meta, const coord_t *point, size_t ef, label_t 
 	stats().fallbacks++;
 	e = resnapshot(meta, e, device);
 	if (!e) return false;
-	return hnsw_gpu_search_batch(e->ix, point, 1, ef, labels, nullptr, count) == HNSW_GPU_OK;
+	const bool ok = hnsw_gpu_search_batch(e->ix, point, 1, ef, labels, nullptr, count) == HNSW_GPU_OK;
+	if (e->ephemeral) drop(e);
+	return ok;
 }
 
 // Before hnsw_bind_point(idx) runs on the device: a mirror in which every element the insert will read equals the

@@ -267,6 +267,12 @@ def test_glue_over_the_in_process_library_and_its_validated_cache(name):
     if name in ("knn", "gh-3"):
         off = subprocess.run([exe], input=cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, PG_EMBEDDING_GPU_CACHE="0"))
         assert off.returncode == 0 and off.stdout == expected(name)
+        # an index larger than the cache may keep (limit 0 MB here): mirrored for each call, dropped again
+        eph = subprocess.run([exe], input=cmd, capture_output=True, text=True, timeout=900,
+                             env=dict(os.environ, PG_EMBEDDING_GPU_CACHE_MAX_MB="0", PGEMB_PRINT_CACHE_STATS="1"))
+        assert eph.returncode == 0 and eph.stdout == expected(name)
+        m2 = re.search(r"shim cache: snapshots (\d+) searches (\d+) search_rounds (\d+) inserts (\d+)", eph.stderr)
+        assert m2 and int(m2.group(1)) == int(m2.group(2)) + int(m2.group(4))
 
 
 @needs_glue
