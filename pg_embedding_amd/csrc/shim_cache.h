@@ -264,6 +264,8 @@ inline bool apply_patches(HnswMetadata *meta, Entry *e)
 	const size_t esz = meta->size_data_per_element, maxM = meta->maxM;
 	Patches &pt = patches();
 	const label_t dead = (label_t) 1 << HNSW_LABEL_DELETED_BIT;
+	e->suspect = true;      // shadow and mirror change in steps: if this function is left half-way (an allocation fails, an upload
+							// fails and the re-mirror after it fails too) the entry is never picked again
 	// the mirror must hold every element number the new images name (link targets are checked on upload)
 	size_t need = e->n;
 	for (size_t i = 0; i < pt.ids.size(); i++)
@@ -300,6 +302,7 @@ inline bool apply_patches(HnswMetadata *meta, Entry *e)
 		i = j;
 	}
 	stats().patched += pt.ids.size();
+	e->suspect = false;
 	return true;
 }
 
