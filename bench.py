@@ -468,9 +468,11 @@ def side_configs(args, dev, local):
             ms.append(ix.last_search_ms())
         kms = float(np.median(ms[1:]))
         ach = float(bq.sum()) / (kms * 1e-3) / 1e9
+        g_roof, g_cfg = gather_roof(ix)          # dependency-free gather of whole rows of THIS table (its width, its size)
         res[name] = {"rows": n, "dims": dim, "m": m, "metric": metric, "efsearch": args.ef, "queries_per_launch": nq,
                      "queries_per_s": nq / kms * 1e3, "kernel_ms_per_launch": kms, "achieved_GBps": ach,
-                     "frac_of_8TBps": ach / HBM_PEAK_GBS, "evals_per_query": float(st[:, 0].mean()),
+                     "frac_of_8TBps": ach / HBM_PEAK_GBS, "measured_gather_GBps": g_roof,
+                     "frac_of_measured_gather": ach / g_roof if g_roof else None, "evals_per_query": float(st[:, 0].mean()),
                      "hops_per_query": float(st[:, 1].mean()), "recall_at_10": rec, "kernel": ix.last_search_kernel(),
                      "datagen_plus_build_seconds": t_build}
         ix.close()
