@@ -126,7 +126,7 @@ select t <-> {1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1} id 2 ; the row inserted after the
 
 
 @needs_glue
-@pytest.mark.parametrize("variant", ["ref", "client", "patched"])
+@pytest.mark.parametrize("variant", ["ref", "client", "patched", "shimdouble", pytest.param("gpu", marks=pytest.mark.gpu)])
 def test_an_error_inside_a_storage_callback_leaves_everything_usable(variant):
     """The host's callbacks may leave by longjmp (elog(ERROR), e.g. an I/O error in ReadBuffer): the hot
     path must hold nothing that the abort does not reclaim.  A failing statement prints ERROR; the next
@@ -136,6 +136,10 @@ def test_an_error_inside_a_storage_callback_leaves_everything_usable(variant):
         if not os.path.exists(SU.PG_REGRESS_REF):
             pytest.skip("reference-linked driver not built")
         r = subprocess.run([SU.PG_REGRESS_REF], input=FAULT_SCRIPT, capture_output=True, text=True)
+    elif variant in ("shimdouble", "gpu"):
+        # the in-process library (its own source over the CPU engine double / the product on the device): the failing read hits
+        # its validation of a cached walk — on the device while the traced kernel is still in flight — and an insert's preparation
+        r = subprocess.run([SU.build_pg_regress(variant)], input=FAULT_SCRIPT, capture_output=True, text=True, timeout=600)
     else:
         if variant == "patched" and not os.path.exists(SU.PG_GLUE_PATCHED):
             pytest.skip("patched glue not built")
