@@ -776,6 +776,13 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 			a.tm_off_ex = (uint32_t) o_ex; a.tm_off_miss = (uint32_t) o_miss; a.tm_off_lctag = (uint32_t) o_tag;
 			a.tm_off_lcstate = (uint32_t) o_state; a.tm_off_lclinks = (uint32_t) o_links; a.tm_lcslots = lcs;
 			a.tm_off_dc = (uint32_t) o_dc; a.tm_dccap = (uint32_t) dccap;
+			{
+				// helpers of rank < tm_spec prepare packages ahead of the walk; the others score slices of its many-row hops
+				// (measured, profiles/r2zg_*: wide rows, 8 rows per pass: 5 + 2 of 7 helpers, one query 0.46 -> 0.44 ms, 256 queries -4 %;
+				// narrow rows score 16 rows per pass themselves and keep every helper speculating)
+				const char *senv = getenv("HNSW_GPU_TEAM_SPEC");
+				a.tm_spec = senv ? (uint32_t) std::max(0, atoi(senv)) : (ix->stride > 320 ? 5u : 8u);
+			}
 			int maxlds = 64 * 1024;
 			(void) hipDeviceGetAttribute(&maxlds, hipDeviceAttributeMaxSharedMemoryPerBlock, ix->device);
 			const char *wenv = getenv("HNSW_GPU_TEAM_WPB");
