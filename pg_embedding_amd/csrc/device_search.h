@@ -1778,6 +1778,28 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 					if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_score += hs1 - hs0; hs0 = hs1; }
 					// rows at or above a valid upper bound of lowerBound cannot be accepted (:99)
 					uint64_t todo = __ballot((uint32_t) lane < nnew && od_mine < bstale);
+					// While the accepted set is below ef every row is accepted whatever its distance (hnswalg.cpp:99: size < ef), one by
+					// one in the reference; the set is unordered here, so a hop whose rows ALL fit below ef is appended in one step:
+					// row r goes to slot usize + r, fetched by the lane that owns that slot (ds_bpermute), no count, no per-row loop.
+					// The first ~ef accepts of every walk — the many-row hops of the descent from the entry point — go this way.
+					if (usize + nnew <= ef && (uint32_t) __builtin_popcountll(todo) == nnew)
+					{
+#pragma unroll
+						for (int k = 0; k < UREG; k++)
+						{
+							const uint32_t lo = (uint32_t) k * 64u;
+							if (usize + nnew > lo && usize < lo + 64u)          // (wave-uniform) this register receives rows
+							{
+								const int r = (int) (lo + (uint32_t) lane) - (int) usize;
+								const uint32_t od_r = (uint32_t) __builtin_amdgcn_ds_bpermute((r & 63) << 2, (int) od_mine);
+								const uint32_t id_r = (uint32_t) __builtin_amdgcn_ds_bpermute((r & 63) << 2, (int) t_mine);
+								const bool take = r >= 0 && (uint32_t) r < nnew;
+								uk[k] = take ? (((uint64_t) od_r << 32) | id_r) : uk[k];
+							}
+						}
+						usize += nnew;
+						todo = 0;
+					}
 					while (todo)                                            // :99-108, in link order
 					{
 						const uint32_t r = (uint32_t) __builtin_ctzll(todo);
