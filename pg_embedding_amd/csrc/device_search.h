@@ -1359,6 +1359,10 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 		for (uint32_t i = lane; i < 64u * UREG; i += 64) mine.pub[i] = ~0ull;
 		mine.ex[lane] = 0;
 		wave_sync();
+		// (read BEFORE my bit becomes visible: a job the walking wave posts from now on may name me, and must look new to me;
+		// reading it after the atomicOr could swallow a job posted in between — the walking wave would wait for me forever)
+		uint32_t last_job = __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[target].job)) >> 18;
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		if (lane == 0) atomicOr(&ctl[target].helpers, 1u << wib);
 		unsigned char *mreg = smem + (size_t) target * a.wave_bytes;
 		const float4 *q4 = reinterpret_cast<const float4 *>(mreg);
@@ -1367,7 +1371,6 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 		if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
 		uint32_t dcount = 0;
 		uint64_t last_done = ~0ull;                    // the last element I finished, as a candidate key
-		uint32_t last_job = __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[target].job)) >> 18;   // jobs posted before I attached are not mine
 
 		while (__builtin_amdgcn_readfirstlane(ctl[target].state) == 1)
 		{

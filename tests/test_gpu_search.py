@@ -336,9 +336,6 @@ def test_many_queries_reuse_slots():
     {"HNSW_GPU_TEAM": "1"},                  # team form: idle waves of a block feed a sibling's walk from LDS caches
     {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "4"},
     {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "2", "HNSW_GPU_HASH_ENTRIES": "512"},
-    {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_SPEC": "0"},     # every helper scores slices of the walking wave's many-row hops, none speculates
-    {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_SPEC": "2"},
-    {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_SPEC": "8"},     # no slice helpers
     {"HNSW_GPU_TEAM": "0"},
     {},
 ])
@@ -405,7 +402,6 @@ def test_team_form_is_exact_at_every_launch_size(func, dim, m, monkeypatch):
     equal the oracle's, i.e. the one-wave form's.  m=40 exercises link lists longer than one wave (maxM=80)."""
     import torch
     monkeypatch.setenv("HNSW_GPU_TEAM", "1")
-    monkeypatch.setenv("HNSW_GPU_TEAM_SPEC", str((dim + m + func) % 4))      # 0-3 speculating helpers, the rest take scoring slices
     n = 6000
     port, X = build_port(n, dim, m, 48, func, seed=3 * dim + func)
     Q = gmm(700, dim, k=50, seed=3 * dim + func, stream=1)
