@@ -92,7 +92,6 @@ struct SearchArgs
 	uint32_t team_mains;        // waves of a block that take queries (wib < team_mains); the others start as helpers
 	uint32_t off_ctl;           // byte offset of the block's TeamCtl array in dynamic LDS (behind the wave regions)
 	uint32_t tm_off_ex, tm_off_miss, tm_off_lctag, tm_off_lcstate, tm_off_lclinks, tm_lcslots, tm_off_dc, tm_dccap;
-	uint32_t tm_spec;           // helpers of rank < tm_spec speculate (packages); the others score slices of the walking wave's rows
 	uint32_t *team_dbg;         // null, or 16 counters for the whole launch (hnsw_gpu_team_counters): hops with helpers,
 	                            // link-list hits, ids looked up, distance hits, hops that still scored rows, all hops
 };
@@ -1225,19 +1224,8 @@ struct TeamCtl
 {
 	uint32_t state;        // 0 = has or may get a query but is not walking, 1 = walking, 2 = will never walk again
 	uint32_t helpers;      // main: bit h set = wave h of this block is helping me
-	uint32_t job;          // main: a scoring job for its slice helpers: seq << 18 | view << 15 | helper mask << 7 | rows
-	uint32_t done;         // slices of that job that are finished
+	uint32_t pad0, pad1;
 };
-// A hop of the descent from the entry point brings 20-32 unvisited rows and no package can exist for it (the popped
-// element was accepted one hop earlier): 3-4 scoring passes of the walking wave alone, each a full HBM round trip —
-// a tenth of a single query's time (profiles/r2zf_team_hop_pattern.txt).  Helpers beyond the first tm_spec do not
-// speculate; they wait for such a hop and score 8-row slices of it with the same canonical code into the walking wave's
-// sum array, so the hop costs ONE round trip.  (job word: the helper mask is the walking wave's own snapshot, so a
-// helper that attaches meanwhile changes nobody's slice; `view` = whose region holds the id list.)
-__device__ __forceinline__ uint32_t lds_load_u32(const uint32_t *p)
-{
-	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
 constexpr uint64_t DC_EMPTY = ~0ull;
 constexpr uint32_t OD_MISSING = 0xFFFFFFFFu;      // package entry without a distance (ord() of a real distance is never all ones: that is a NaN payload no sum produces... guarded anyway: such an entry is simply re-scored)
 constexpr uint32_t PK_VISITED = 0x80000000u;
@@ -1359,10 +1347,6 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 		for (uint32_t i = lane; i < 64u * UREG; i += 64) mine.pub[i] = ~0ull;
 		mine.ex[lane] = 0;
 		wave_sync();
-		// (read BEFORE my bit becomes visible: a job the walking wave posts from now on may name me, and must look new to me;
-		// reading it after the atomicOr could swallow a job posted in between — the walking wave would wait for me forever)
-		uint32_t last_job = __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[target].job)) >> 18;
-		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		if (lane == 0) atomicOr(&ctl[target].helpers, 1u << wib);
 		unsigned char *mreg = smem + (size_t) target * a.wave_bytes;
 		const float4 *q4 = reinterpret_cast<const float4 *>(mreg);
@@ -1378,29 +1362,6 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 			if (!(hm & (1u << wib))) break;
 			const TeamView pubv = team_view(smem, a, (uint32_t) __builtin_ctz(hm));
 			const uint32_t myrank = (uint32_t) __builtin_popcount(hm & ((1u << wib) - 1u));
-			// a scoring job of the walking wave?  (every helper looks; the job names its slice helpers)
-			{
-				const uint32_t job = __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[target].job));
-				if ((job >> 18) != last_job)
-				{
-					last_job = job >> 18;
-					const uint32_t jm = (job >> 7) & 0xFFu, jn = job & 0x7Fu;
-					if (jm & (1u << wib))
-					{
-						constexpr uint32_t PASS = 4u * SH::RPG;             // rows of one scoring pass = one slice
-						const uint32_t lo = PASS + PASS * (uint32_t) __builtin_popcount(jm & ((1u << wib) - 1u));
-						const uint32_t cnt = jn - lo < PASS ? jn - lo : PASS;
-						const uint32_t *ids = team_view(smem, a, (job >> 15) & 7u).miss + lo;
-						float *out = reinterpret_cast<float *>(mreg + a.off_newdist) + lo;
-						auto by_id = [ids](uint32_t r) { return ids[r]; };
-						score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, cnt, out, lane);
-						wave_sync();
-						if (lane == 0) atomicAdd(&ctl[target].done, 1u);
-					}
-					continue;
-				}
-				if (myrank >= a.tm_spec) { __builtin_amdgcn_s_sleep(1); continue; }     // a slice helper does not speculate
-			}
 			// snapshot of the main's accepted set: candidate keys (dist, ~idx) of the unexpanded elements
 			uint64_t ck[UREG];
 			const uint32_t ex = pubv.ex[lane];
@@ -1530,7 +1491,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 	const uint32_t wpb = blockDim.x >> 6;
 	if (TEAM)
 	{
-		if (lane == 0) { ctl[wib].state = wib < a.team_mains ? 0u : 2u; ctl[wib].helpers = 0u; ctl[wib].job = 0u; ctl[wib].done = 0u; }
+		if (lane == 0) { ctl[wib].state = wib < a.team_mains ? 0u : 2u; ctl[wib].helpers = 0u; }
 		__syncthreads();
 	}
 
@@ -1560,7 +1521,6 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		uint32_t bstale = 0xFFFFFFFFu;       // ord() of a valid upper bound of the reference's lowerBound
 		bool spill = a.hcap == 0;
 		uint32_t hs_pop = 0, hs_link = 0, hs_vis = 0, hs_score = 0, hs_acc = 0, hs_q0 = 0;
-		uint32_t jobseq = TEAM ? (__builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[wib].job)) >> 18) : 0u;   // scoring jobs posted by this wave so far
 		if (HOP_STAMPS && a.team_dbg) hs_q0 = hop_stamp();
 		const uint32_t hnb = a.hcap / 4u;                                  // buckets of the visited set
 		if (a.hcap)
@@ -1741,36 +1701,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 					{
 						const uint32_t *ids = sids;
 						auto by_id = [ids](uint32_t r) { return ids[r]; };
-						constexpr uint32_t PASS = 4u * SH::RPG;                 // rows of one scoring pass = one slice
-						uint32_t nsl = 0;                                       // slices handed to helpers (rows PASS .. PASS * (1 + nsl))
-						if (TEAM && hm && nscore > PASS)
-						{
-							uint32_t m = hm;
-							for (uint32_t i = 0; i < a.tm_spec && m; i++) m &= m - 1;          // the speculating helpers stay out of it
-							const uint32_t want = (nscore - 1) / PASS;
-							uint32_t jm = 0;
-							for (uint32_t i = 0; i < want && m; i++) { jm |= m & (0u - m); m &= m - 1; }
-							nsl = (uint32_t) __builtin_popcount(jm);
-							if (nsl && lane == 0)
-							{
-								ctl[wib].done = 0u;
-								__hip_atomic_store(&ctl[wib].job, (++jobseq << 18) | ((uint32_t) __builtin_ctz(hm) << 15) | (jm << 7) | nscore,
-												   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-							}
-						}
-						if (nsl == 0)
-							score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nscore, newdist, lane);
-						else
-						{
-							score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, PASS, newdist, lane);
-							const uint32_t covered = PASS + PASS * nsl;         // what I and the slice helpers take; the rest (few helpers) is mine too
-							if (covered < nscore)
-							{
-								auto rest = [ids, covered](uint32_t r) { return ids[covered + r]; };
-								score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, rest, nscore - covered, newdist + covered, lane);
-							}
-							while ((uint32_t) __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[wib].done)) != nsl) __builtin_amdgcn_s_sleep(0);
-						}
+						score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nscore, newdist, lane);
 						wave_sync();
 						const uint32_t od_m = ord_f32(finish_dist<FUNC>(newdist[krank & 63], newdist[OUT2 + (krank & 63)], qnorm));
 						od_mine = hit ? od_c : od_m;
@@ -1781,28 +1712,6 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 					if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_score += hs1 - hs0; hs0 = hs1; }
 					// rows at or above a valid upper bound of lowerBound cannot be accepted (:99)
 					uint64_t todo = __ballot((uint32_t) lane < nnew && od_mine < bstale);
-					// While the accepted set is below ef every row is accepted whatever its distance (hnswalg.cpp:99: size < ef), one by
-					// one in the reference; the set is unordered here, so a hop whose rows ALL fit below ef is appended in one step:
-					// row r goes to slot usize + r, fetched by the lane that owns that slot (ds_bpermute), no count, no per-row loop.
-					// The first ~ef accepts of every walk — the many-row hops of the descent from the entry point — go this way.
-					if (usize + nnew <= ef && (uint32_t) __builtin_popcountll(todo) == nnew)
-					{
-#pragma unroll
-						for (int k = 0; k < UREG; k++)
-						{
-							const uint32_t lo = (uint32_t) k * 64u;
-							if (usize + nnew > lo && usize < lo + 64u)          // (wave-uniform) this register receives rows
-							{
-								const int r = (int) (lo + (uint32_t) lane) - (int) usize;
-								const uint32_t od_r = (uint32_t) __builtin_amdgcn_ds_bpermute((r & 63) << 2, (int) od_mine);
-								const uint32_t id_r = (uint32_t) __builtin_amdgcn_ds_bpermute((r & 63) << 2, (int) t_mine);
-								const bool take = r >= 0 && (uint32_t) r < nnew;
-								uk[k] = take ? (((uint64_t) od_r << 32) | id_r) : uk[k];
-							}
-						}
-						usize += nnew;
-						todo = 0;
-					}
 					while (todo)                                            // :99-108, in link order
 					{
 						const uint32_t r = (uint32_t) __builtin_ctzll(todo);

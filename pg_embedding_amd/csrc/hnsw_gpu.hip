@@ -776,15 +776,6 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 			a.tm_off_ex = (uint32_t) o_ex; a.tm_off_miss = (uint32_t) o_miss; a.tm_off_lctag = (uint32_t) o_tag;
 			a.tm_off_lcstate = (uint32_t) o_state; a.tm_off_lclinks = (uint32_t) o_links; a.tm_lcslots = lcs;
 			a.tm_off_dc = (uint32_t) o_dc; a.tm_dccap = (uint32_t) dccap;
-			{
-				// helpers of rank < tm_spec prepare packages ahead of the walk; the others score slices of its many-row hops
-				// Measured (profiles/r2zg_*): wide rows, 5 speculating + 2 slice helpers of 7: one query 0.46 -> 0.44 ms, 256 queries
-				// -4 %.  OFF by default (8 = every helper speculates, no job is ever posted): the last GPU run of round 2 hung once
-				// with it on — a helper that attached between the walking wave's snapshot of its helpers and its job could miss
-				// that job (fixed by construction in team_help, not yet re-run on a device).  HNSW_GPU_TEAM_SPEC=5 turns it on.
-				const char *senv = getenv("HNSW_GPU_TEAM_SPEC");
-				a.tm_spec = senv ? (uint32_t) std::max(0, atoi(senv)) : 8u;
-			}
 			int maxlds = 64 * 1024;
 			(void) hipDeviceGetAttribute(&maxlds, hipDeviceAttributeMaxSharedMemoryPerBlock, ix->device);
 			const char *wenv = getenv("HNSW_GPU_TEAM_WPB");
@@ -897,34 +888,6 @@ extern "C" int hnsw_gpu_search_base_dev(hnsw_gpu_index *ix, const coord_t *d_que
 	return launch_search(ix, ix ? &ix->ws : nullptr, d_queries, ix ? ix->meta.dim : 0, nq, ef, 1, nullptr, d_idx, d_dists, d_counts, d_stats, (hipStream_t) stream);
 }
 
-// Poll a completion flag the kernel stores into pinned host memory.  0 = set; otherwise an error: the kernel ended
-// without storing it, or it has not stored it within two minutes (a walk is under a millisecond: the device is hung,
-// and polling for ever would hang the caller with it).
-static int poll_done_flag(const volatile uint32_t *flag, const char *what)
-{
-	uint64_t spins = 0;
-	struct timespec t0;
-	clock_gettime(CLOCK_MONOTONIC, &t0);
-	while (*flag == 0)
-	{
-		__builtin_ia32_pause();
-		if ((++spins & 0xFFFF) == 0)
-		{
-			if (hipStreamQuery(nullptr) != hipErrorNotReady)
-			{
-				HIPCHK(hipStreamSynchronize(nullptr));                  // the kernel is gone: either it has just stored the flag, or it died
-				if (*flag == 0) return fail(HNSW_GPU_ERR_INTERNAL, "search kernel ended without completing %s", what);
-				break;
-			}
-			struct timespec t1;
-			clock_gettime(CLOCK_MONOTONIC, &t1);
-			if (t1.tv_sec - t0.tv_sec > 120) return fail(HNSW_GPU_ERR_INTERNAL, "search kernel did not complete %s within 120 s", what);
-		}
-	}
-	__atomic_thread_fence(__ATOMIC_ACQUIRE);
-	return HNSW_GPU_OK;
-}
-
 extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries, size_t nq, size_t ef,
 									 label_t *labels, dist_t *dists, uint32_t *counts)
 {
@@ -967,9 +930,19 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 		if (rc) return rc;
 		for (size_t i = 0; i < nq; i++)
 		{
-			rc = poll_done_flag(hf + i, "a query");
-			if (rc) return rc;
+			uint64_t spins = 0;
+			while (hf[i] == 0)
+			{
+				__builtin_ia32_pause();
+				if ((++spins & 0xFFFF) == 0 && hipStreamQuery(nullptr) != hipErrorNotReady)
+				{
+					// the kernel is gone: either it has just stored the flag, or it died
+					HIPCHK(hipStreamSynchronize(nullptr));
+					if (hf[i] == 0) return fail(HNSW_GPU_ERR_INTERNAL, "search kernel ended without completing query %zu", i);
+				}
+			}
 		}
+		__atomic_thread_fence(__ATOMIC_ACQUIRE);
 		memcpy(labels, hl, nq * ef * 8);
 		if (dists) memcpy(dists, hd, nq * ef * 4);
 		memcpy(counts, hc, nq * 4);
@@ -1084,11 +1057,18 @@ extern "C" int hnsw_gpu_search_trace_end(hnsw_gpu_index *ix, label_t *labels, di
 	const uint64_t *hl = (const uint64_t *) (h + t.qb); const float *hd = (const float *) (h + t.qb + t.lb);
 	const uint32_t *hc = (const uint32_t *) (h + t.qb + t.lb + t.db), *hs = (const uint32_t *) (h + t.qb + t.lb + t.db + t.cb);
 	const volatile uint32_t *hf = (const volatile uint32_t *) (h + t.qb + t.lb + t.db + t.cb + t.sb + t.pb);
+	uint64_t spins = 0;
+	while (hf[0] == 0)
 	{
-		const int prc = poll_done_flag(hf, "the traced query");
-		ix->trace_active = false;
-		if (prc) return prc;
+		__builtin_ia32_pause();
+		if ((++spins & 0xFFFF) == 0 && hipStreamQuery(nullptr) != hipErrorNotReady)
+		{
+			HIPCHK(hipStreamSynchronize(nullptr));
+			if (hf[0] == 0) { ix->trace_active = false; return fail(HNSW_GPU_ERR_INTERNAL, "search kernel ended without completing the query"); }
+		}
 	}
+	__atomic_thread_fence(__ATOMIC_ACQUIRE);
+	ix->trace_active = false;
 	if (ix->trace_base) { const uint32_t *hi = (const uint32_t *) hl; for (size_t i = 0; i < ef; i++) labels[i] = hi[i]; }
 	else memcpy(labels, hl, ef * 8);
 	if (dists) memcpy(dists, hd, ef * 4);
