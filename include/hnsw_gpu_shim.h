@@ -3,9 +3,10 @@
  * exports the reference's own four symbols (hnsw_abi.h) on top of libhnsw_gpu.so.
  *
  * They exist because HnswMetadata (embedding.h:28-42) identifies no relation and is
- * re-created for every scan (embedding.c:254): without them the drop-in hnsw_search()
- * must re-mirror the index on every call.  INTEGRATION.md shows where the Postgres
- * glue would call them.
+ * re-created for every scan (embedding.c:254): a host that can say "this is the same,
+ * unchanged index" (attach) saves the drop-in hnsw_search() the validation reads of
+ * its cache (below; round 1 had no cache and re-mirrored the index on every call).
+ * INTEGRATION.md shows where the Postgres glue would call them.
  */
 #ifndef PG_EMBEDDING_AMD_HNSW_GPU_SHIM_H
 #define PG_EMBEDDING_AMD_HNSW_GPU_SHIM_H
