@@ -911,6 +911,7 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 	const size_t fb = round_up(nq * 4, 256);
 	if (nq <= 16 && qb + lb + db + cb + fb <= ((size_t) 4 << 20) && !getenv("HNSW_GPU_NO_POLL"))
 	{
+		if (ix->trace_active) { HIPCHK(hipStreamSynchronize(nullptr)); ix->trace_active = false; }   // an abandoned trace still writes these buffers
 		if (ix->pin_bytes < qb + lb + db + cb + fb)
 		{
 			if (ix->pin) (void) hipHostFree(ix->pin);
