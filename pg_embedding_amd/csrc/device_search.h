@@ -1546,6 +1546,12 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 			{
 				if (spill) { vis[ep >> 5] = 1u << (ep & 31); vlog[0] = ep; }
 				else { uint32_t eb, et; tagset_split(ep, hnb, a.hmagic, eb, et); htab[4u * eb] = et; }   // empty table: slot 0 of its bucket
+				// Nobody helps this walk yet.  A helper of my PREVIOUS walk that was in the middle of a step when that walk ended
+				// may not have seen state 0 in between (1 -> 0 -> 1): its region still holds packages scored against the previous
+				// query, and its bit would make me read them.  Without its bit it leaves at its next look (team_help) and attaches
+				// again with a clean region.  (Only a wave that takes a second query while siblings help can meet this: a small
+				// launch whose other blocks started late.)
+				if (TEAM) ctl[wib].helpers = 0u;
 			}
 			logn = spill ? 1 : 0;
 			hcount = 1;
