@@ -11,7 +11,7 @@
 //      for a helper it named?   Model flag `early`: the helper reads the job counter BEFORE its bit becomes visible
 //      (the patch) instead of after (the version whose last device run never returned).
 //
-// usage: team_protocol_model <clear 0|1> <early 0|1> <slices 0|1> <walks> <seed>
+// usage: team_protocol_model <clear 0|1> <early 0|1> <slices 0|1> <walks> <seed> [hang limit in ms, default 20000]
 // prints: stale=<packages of another query that were consumed> hangs=<jobs never completed> jobs=<posted> pk=<consumed>
 // exit status 0 when both are zero.
 #include <atomic>
@@ -46,6 +46,7 @@ std::atomic<int> loaded_query{-1};      // the query in the walking wave's regio
 std::atomic<uint32_t> slice_mark[64];   // the walking wave's sum array: which job scored row r
 std::atomic<uint64_t> stale{0}, hangs{0}, jobs{0}, consumed{0};
 bool opt_clear, opt_early, opt_slices;
+int opt_limit_ms = 20000;           // a job not completed after this long counts as a hang
 
 struct Rng
 {
@@ -67,7 +68,7 @@ void helper(int wib, uint64_t seed)
 	{
 		const uint32_t st = ctl.state.load();
 		if (st == 2) return;
-		if (st != 1) { r.spin(20); continue; }
+		if (st != 1) { r.spin(20); std::this_thread::yield(); continue; }
 		// my region becomes that walk's package store
 		region[wib].pkg.store(0);
 		r.spin(60);                                             // (clearing the memo, the package headers ...)
@@ -98,7 +99,7 @@ void helper(int wib, uint64_t seed)
 					}
 					continue;
 				}
-				if (myrank >= 5) { r.spin(10); continue; }      // a slice helper does not speculate
+				if (myrank >= 5) { r.spin(10); std::this_thread::yield(); continue; }      // a slice helper does not speculate
 			}
 			// one speculation step: link list + scoring against the query that is in the walking wave's region NOW
 			const int q = loaded_query.load();
@@ -152,8 +153,11 @@ void walker(int walks, uint64_t seed)
 					r.spin(300);                                // (my own pass)
 					const auto t0 = std::chrono::steady_clock::now();
 					bool hung = false;
-					while (ctl.done.load() != nsl)
-						if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(300)) { hung = true; break; }
+					while (ctl.done.load() != nsl)                 // (a true hang is for ever: the limit only has to outlast a busy machine)
+					{
+						if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(opt_limit_ms)) { hung = true; break; }
+						std::this_thread::yield();
+					}
 					if (hung)
 					{
 						hangs++;
@@ -181,6 +185,7 @@ int main(int argc, char **argv)
 	opt_clear = atoi(argv[1]) != 0; opt_early = atoi(argv[2]) != 0; opt_slices = atoi(argv[3]) != 0;
 	const int walks = atoi(argv[4]);
 	const uint64_t seed = strtoull(argv[5], nullptr, 10) | 1u;
+	if (argc > 6) opt_limit_ms = atoi(argv[6]);
 	for (auto &m : slice_mark) m.store(0);
 	std::vector<std::thread> th;
 	for (int h = 1; h <= HELPERS; h++) th.emplace_back(helper, h, seed);
