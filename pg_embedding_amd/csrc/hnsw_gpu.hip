@@ -812,6 +812,11 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		blocks = std::min<size_t>(nq, (size_t) per_cu * ix->num_cu);
 		a.team_mains = (uint32_t) std::min<size_t>(wpb, (nq + blocks - 1) / blocks);
 	}
+	// (test knob: fewer blocks than the launch would get, so that the waves with queries take SEVERAL each through the
+	// ticket counter while their siblings help — the schedule of a small launch whose other blocks start late,
+	// tests/experiments/team_second_walk_stress.py)
+	if (const char *mb = getenv("HNSW_GPU_MAX_BLOCKS"))
+		if (atoi(mb) > 0) blocks = std::min<size_t>(blocks, (size_t) atoi(mb));
 
 	// workspace: one bitmap + log per resident wave
 	const size_t words = std::max<size_t>(1, (ix->cap + 31) / 32);   // by capacity: stable while the index grows
