@@ -20,7 +20,7 @@ from pg_embedding_amd.datasets import gmm_torch
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 60000
 dev = torch.device("cuda", 0)
-KEYS = ("HNSW_GPU_TEAM", "HNSW_GPU_TEAM_WPB", "HNSW_GPU_MAX_BLOCKS", "HNSW_GPU_TEAM_SPEC")
+KEYS = ("HNSW_GPU_TEAM", "HNSW_GPU_TEAM_WPB", "HNSW_GPU_MAX_BLOCKS")      # (HNSW_GPU_TEAM_SPEC of the pending patch: as the caller set it)
 
 
 def setenv(env):
