@@ -31,7 +31,9 @@ int hnsw_gpu_shim_detach(HnswMetadata *meta);
  * host has changed.  Counters of the calling thread's cache: snapshots (full walks), searches, search rounds, inserts,
  * insert rounds, elements patched, fallbacks to a full walk, elements read for validation.  PG_EMBEDDING_GPU_CACHE=0
  * switches the cache off (every call re-mirrors the index); PG_EMBEDDING_GPU_CACHE_MAX_MB (default 16384) bounds the host
- * memory one cached index may keep (its flat image, N x element size): a larger index is mirrored per call. */
+ * memory one cached index may keep (its flat image, N x element size): a larger index is mirrored per call.
+ * The cache belongs to the calling thread (a Postgres backend is one): at most four indexes, least recently used first out;
+ * a host that ends threads calls hnsw_gpu_shim_cache_clear() on them first, or their mirrors stay allocated. */
 void hnsw_gpu_shim_cache_stats(uint64_t out[8]);
 void hnsw_gpu_shim_cache_clear(void);
 
