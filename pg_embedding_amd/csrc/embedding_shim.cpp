@@ -190,26 +190,15 @@ static bool hnsw_search_impl(HnswMetadata *meta, const coord_t *point, size_t *n
 		own = true;
 	}
 	bool ok = false;
-	label_t *buf = nullptr;
-	if (ef == 0)
+	label_t *buf = (label_t *) malloc(ef * sizeof(label_t));   // caller frees (embedding.c:327)
+	uint32_t cnt = 0;
+	if (buf && hnsw_gpu_search_batch(ix, point, 1, ef, buf, nullptr, &cnt) == HNSW_GPU_OK)
 	{
-		// searchKnn trims to k = 0 results (hnswalg.cpp:238-240)
-		buf = (label_t *) malloc(1);
-		*n_results = 0;
-		ok = buf != nullptr;
+		*n_results = cnt;
+		ok = true;
 	}
 	else
-	{
-		buf = (label_t *) malloc(ef * sizeof(label_t));   // caller frees (embedding.c:327)
-		uint32_t cnt = 0;
-		if (buf && hnsw_gpu_search_batch(ix, point, 1, ef, buf, nullptr, &cnt) == HNSW_GPU_OK)
-		{
-			*n_results = cnt;
-			ok = true;
-		}
-		else
-			fprintf(stderr, "pg_embedding_amd: hnsw_search failed: %s\n", hnsw_gpu_last_error());
-	}
+		fprintf(stderr, "pg_embedding_amd: hnsw_search failed: %s\n", hnsw_gpu_last_error());
 	if (own) hnsw_gpu_index_destroy(ix);
 	if (!ok) { free(buf); return false; }
 	*results = buf;
@@ -297,8 +286,7 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 		static thread_local std::vector<idx_t> others;            // the neighbours' lists, all fetched in one launch
 		others.resize(maxM * (maxM + 1));
 		if (hnsw_gpu_index_get_link_lists(ix, idx, mine, others.data()) != HNSW_GPU_OK) break;
-		bool failed = false;
-		for (uint32_t j = 0; j < mine[0] && !failed; j++)   // neighbours first, like hnswalg.cpp:183-222 ...
+		for (uint32_t j = 0; j < mine[0]; j++)               // neighbours first, like hnswalg.cpp:183-222 ...
 		{
 			const idx_t *other = others.data() + (size_t) j * (maxM + 1);
 			idx_t *dst = nullptr;
@@ -307,7 +295,6 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 			hnsw_end_write(meta);
 			if (ce) shimcache::shadow_set_links(meta, ce, mine[1 + j], other);
 		}
-		if (failed) break;
 		{                                                   // ... then the element itself (:169-181)
 			idx_t *dst = nullptr;
 			hnsw_begin_write(meta, idx, &dst, nullptr, nullptr);
