@@ -15,11 +15,13 @@
 // caller left is the SQL operator, one pair per call, embedding.c:1037), not a fallback.
 //
 // Where does the index come from?  HnswMetadata carries no relation identity and Postgres
-// rebuilds it for every scan (embedding.c:254), so by default each hnsw_search() call walks the
-// host's elements through hnsw_begin_read/hnsw_end_read (one pin at a time: the host allows at
-// most 4, embedding.c:40,714-715) into a fresh device mirror: always correct, O(N) per call.
-// A host that knows its index is unchanged attaches a mirror once (hnsw_gpu_shim_attach) and
-// every later search through the drop-in symbol is a single kernel launch — see INTEGRATION.md.
+// rebuilds it for every scan (embedding.c:254).  A mirror is built by walking the host's elements
+// through hnsw_begin_read/hnsw_end_read (one pin at a time: the host allows at most 4,
+// embedding.c:40,714-715).  Without further help from the host it is kept across calls and every
+// answer is validated against the host's pages along the walk that produced it (shim_cache.h;
+// PG_EMBEDDING_GPU_CACHE=0: a fresh mirror per call, O(N), the round-1 behaviour).  A host that
+// knows its index is unchanged attaches a mirror once (hnsw_gpu_shim_attach) and every later search
+// through the drop-in symbol is a single kernel launch — see INTEGRATION.md.
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
