@@ -11,8 +11,8 @@
 // Three forms of the same algorithm (the host picks one per launch, hnsw_gpu.hip launch_search):
 //   hnsw_search_kernel_beam (ef <= 256; <= 512 on wide rows; the hot one): ONE unordered set of accepted
 //                           elements in registers, every decision of the reference restated as a count
-//                           over it (banner further down); visited set = exact hash set in LDS with
-//                           the HBM bitmap behind it;
+//                           over it (banner further down); visited set = exact bucketed tag set in LDS
+//                           (banner at tagset_split) with the HBM bitmap behind it;
 //   hnsw_search_kernel_reg  (ef <= 256, fallback): result set sorted + candidate set unsorted, both in
 //                           registers;
 //   hnsw_search_kernel_lds  (any ef): both sets as unsorted arrays, in LDS or (large ef) in HBM;
@@ -33,13 +33,15 @@
 // so with capacity >= 2*ef the largest key of an overfull set is always dead and may be dropped.
 //
 // Visited set (hnswalg.cpp:45-50,82-93: a growable bitmap in the reference).
-//   * LDS hash set (register forms): open addressing, lock-free ds_cmpst insert = the test and the
-//     set of :91-93 in one LDS operation, no HBM traffic.  4096 entries for rows >= 1.25 KiB (8 waves
-//     per CU), 2048 for narrower rows in the beam form (16 waves per CU);
+//   * beam form: bucketed tag set in LDS — 16-byte buckets of eight 16-bit tags, bucket and tag together are
+//     the id; one ds_read_b128 tests, one ds_cmpst inserts, whatever the fill; an id whose bucket is full
+//     lives in the HBM bitmap instead (exact, see the banner at tagset_split);
+//   * two-set register form: LDS hash set of 32-bit ids, open addressing, lock-free ds_cmpst insert = the
+//     test and the set of :91-93 in one LDS operation;
 //   * per-slot bitmap in HBM: returning atomic OR (safe when two neighbours share a word), bits
-//     undone through a log after the query.  It is the only set of the generic form, and takes over
-//     from the hash set once that is 3/4 full (wide rows: both are consulted from then on; narrow rows:
-//     the hash set is flushed into the bitmap once).
+//     undone through a log after the query.  It is the only set of the generic form; in the two-set
+//     register form it takes over from the hash set once that is 3/4 full (wide rows: both are consulted
+//     from then on; narrow rows: the hash set is flushed into the bitmap once).
 // Link lists are de-duplicated at upload (first occurrence kept), which is behaviour-preserving
 // because a repeated id is always already visited when reached again in pass 2 (:89-93).
 #pragma once
