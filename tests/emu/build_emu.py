@@ -1,0 +1,73 @@
+"""Build tests/_build/libhnsw_gpu_simt.so: the product's own sources (pg_embedding_amd/csrc/hnsw_gpu.hip + device headers),
+unmodified, compiled for the host against the SIMT emulator in tests/emu/hip/hip_runtime.h.  Test infrastructure only.
+
+The one textual change: an inline-asm register pin of the kernel uses the AMDGPU constraint "+s" (scalar register), which no
+host compiler knows; it becomes "+r".  Everything else is the product's text.
+
+build()                       the shipped sources
+build_tree(csrc, tag, edit)   another source tree (e.g. with scripts/pending applied), or the shipped one with a textual
+                              edit (a deliberately broken variant that shows a test has teeth)"""
+import os
+import shutil
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+CSRC = os.path.join(ROOT, "pg_embedding_amd", "csrc")
+EMU = os.path.join(ROOT, "tests", "emu")
+OUT = os.path.join(ROOT, "tests", "_build")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def _deps(csrc):
+    return [os.path.join(csrc, f) for f in sorted(os.listdir(csrc)) if f.endswith((".h", ".hip"))] + \
+           [os.path.join(EMU, "hip", "hip_runtime.h"), os.path.join(EMU, "sort_pairs_emu.cpp"), os.path.abspath(__file__)]
+
+
+def build_tree(csrc=CSRC, tag="", edit=None, force=False, verbose=False):
+    lib = os.path.join(OUT, f"libhnsw_gpu_simt{('_' + tag) if tag else ''}.so")
+    if not force and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(s) for s in _deps(csrc)):
+        return lib
+    src = os.path.join(OUT, "emu_src" + (("_" + tag) if tag else ""))
+    shutil.rmtree(src, ignore_errors=True)
+    os.makedirs(src)
+    pins = 0
+    for f in sorted(os.listdir(csrc)):                      # copies, so that quoted includes resolve among them
+        if f.endswith(".h") or f == "hnsw_gpu.hip":
+            txt = open(os.path.join(csrc, f)).read()
+            pins += txt.count('"+s"')
+            txt = txt.replace('"+s"', '"+r"')
+            if edit:
+                txt = edit(f, txt)
+            open(os.path.join(src, "hnsw_gpu_emu.cpp" if f == "hnsw_gpu.hip" else f), "w").write(txt)
+    assert pins == 1, "the emulator build expects exactly one scalar-register asm pin"
+    cxx = CLANG if os.path.exists(CLANG) else "clang++"
+    cmd = [cxx, "-x", "c++", "-O0", "-std=c++17", "-mavx2", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
+           "-Wno-unused-value", "-Wno-pass-failed", "-Wno-unknown-attributes",
+           "-I", src, "-I", EMU, "-I", os.path.join(ROOT, "include"),
+           os.path.join(src, "hnsw_gpu_emu.cpp"), os.path.join(EMU, "sort_pairs_emu.cpp"), "-o", lib]
+    if verbose:
+        print(" ".join(cmd))
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("SIMT emulator build failed:\n" + r.stderr[-6000:])
+    return lib
+
+
+def build(force=False, verbose=False):
+    return build_tree(force=force, verbose=verbose)
+
+
+def build_with_patch(patch, tag, force=False):
+    """the shipped csrc with `patch` (a git diff against the repository root) applied to a copy"""
+    lib = os.path.join(OUT, f"libhnsw_gpu_simt_{tag}.so")
+    if not force and os.path.exists(lib) and all(os.path.getmtime(lib) >= os.path.getmtime(s) for s in _deps(CSRC) + [patch]):
+        return lib
+    tree = os.path.join(OUT, "emu_tree_" + tag)
+    shutil.rmtree(tree, ignore_errors=True)
+    shutil.copytree(CSRC, os.path.join(tree, "pg_embedding_amd", "csrc"))
+    subprocess.run(["git", "apply", "--include=pg_embedding_amd/csrc/*", os.path.abspath(patch)], cwd=tree, check=True)
+    return build_tree(os.path.join(tree, "pg_embedding_amd", "csrc"), tag, force=True)
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -1,0 +1,90 @@
+"""One scenario on the SIMT-emulated library (tests/emu/hip/hip_runtime.h): the product's own kernel source executed on
+host threads, compared with the oracle bit for bit.  Run as a subprocess by tests/test_simt_emu.py (the library is chosen
+by environment before pg_embedding_amd is imported).  Prints one JSON line.
+
+    python tests/emu/run_emu_case.py forms|second_walk [emulated-library]
+"""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+import build_emu                                           # noqa: E402
+
+os.environ["PGEMB_GPU_LIB"] = sys.argv[2] if len(sys.argv) > 2 else build_emu.build()
+import numpy as np                                         # noqa: E402
+import pg_embedding_amd as pg                              # noqa: E402
+import util as U                                           # noqa: E402
+from pg_embedding_amd.datasets import gmm                  # noqa: E402
+
+KEYS = ("HNSW_GPU_TEAM", "HNSW_GPU_TEAM_WPB", "HNSW_GPU_MAX_BLOCKS", "HNSW_GPU_NARROW5", "HNSW_GPU_HASH_ENTRIES", "HNSW_GPU_BEAM",
+        "HNSW_GPU_BEAM16", "HNSW_GPU_FORCE_LDS_HEAPS", "SIMT_EMU_CUS", "SIMT_EMU_JITTER", "SIMT_EMU_JITTER_US", "SIMT_EMU_SEED")
+
+
+def setenv(env):
+    for k in KEYS:
+        os.environ.pop(k, None)
+    os.environ.update(env)
+
+
+def wrong(got, want, nq, stats=None):
+    l2, d2, c2 = got
+    bad = 0
+    for q in range(nq):
+        same = (l2[q] == want["labels"][q]).all() and (U.bits(d2[q]) == U.bits(want["dists"][q])).all() and c2[q] == want["counts"][q]
+        bad += 0 if same else 1
+    return bad
+
+
+def forms():
+    """every kernel form the host can pick, three metrics, odd and even row widths: ids, distance bits and counts == oracle"""
+    out = []
+    variants = [{}, {"HNSW_GPU_TEAM": "0"}, {"HNSW_GPU_TEAM": "0", "HNSW_GPU_NARROW5": "0"}, {"HNSW_GPU_TEAM": "1"},
+                {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "4"}, {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "2", "HNSW_GPU_HASH_ENTRIES": "512"},
+                {"HNSW_GPU_HASH_ENTRIES": "0"}, {"HNSW_GPU_BEAM": "0"}, {"HNSW_GPU_FORCE_LDS_HEAPS": "1"}, {"HNSW_GPU_TEAM": "1", "SIMT_EMU_CUS": "64"}]
+    for dim, m, func, efs in ((32, 8, pg.DIST_L2, (10, 100)), (100, 16, pg.DIST_COSINE, (40,)), (200, 8, pg.DIST_MANHATTAN, (40, 300)), (768, 16, pg.DIST_L2, (64,))):
+        n, nq = (1200, 12) if dim < 700 else (500, 6)
+        port, X = U.build_port(n, dim, m, 40, func, k=10, seed=dim)
+        Q = gmm(nq, dim, k=10, seed=dim + 1)
+        for ef in efs:
+            ix = U.mirror(port, func, efs=ef)
+            want = port.search_many(Q, ef, nthreads=4)
+            for env in variants:
+                setenv(env)
+                t0 = time.time()
+                got = ix.search(Q, ef)
+                out.append({"dim": dim, "func": int(func), "ef": ef, "env": env, "kernel": ix.last_search_kernel(), "wrong": wrong(got, want, nq),
+                            "seconds": round(time.time() - t0, 2)})
+            ix.close()
+    return out
+
+
+def second_walk():
+    """ONE wave walks 32 neighbouring queries one after the other with seven helpers attached (a launch squeezed into one
+    block on an emulated 256-CU device): a helper that slept through the gap between two walks must not feed the next one."""
+    n, dim, m, ef = 3000, 96, 16, 48
+    port, X = U.build_port(n, dim, m, 40, pg.DIST_L2, k=10, seed=3)
+    os.environ["SIMT_EMU_CUS"] = "256"                     # (a mirror remembers its device's CU count)
+    ix = U.mirror(port, pg.DIST_L2, efs=ef)
+    rng = np.random.default_rng(5)
+    base = X[rng.integers(0, n, size=4)]
+    Q = (np.repeat(base, 8, axis=0) + 0.01 * rng.standard_normal((32, dim))).astype(np.float32)
+    want = port.search_many(Q, ef, nthreads=4)
+    out = []
+    for env in ({"HNSW_GPU_TEAM": "1", "HNSW_GPU_MAX_BLOCKS": "1", "SIMT_EMU_CUS": "256"},
+                {"HNSW_GPU_TEAM": "1", "HNSW_GPU_MAX_BLOCKS": "1", "SIMT_EMU_CUS": "256", "SIMT_EMU_JITTER": "500", "SIMT_EMU_JITTER_US": "3000"},
+                {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "4", "HNSW_GPU_MAX_BLOCKS": "2", "SIMT_EMU_CUS": "256"}):
+        bad = 0
+        for rep in range(2):
+            setenv(dict(env, SIMT_EMU_SEED=str(rep)))
+            bad += wrong(ix.search(Q, ef), want, 32)
+        out.append({"env": env, "kernel": ix.last_search_kernel(), "walks": 64, "wrong": bad, "blocks_x_waves": ix.last_search_slots()})
+    return out
+
+
+if __name__ == "__main__":
+    print(json.dumps({"forms": forms, "second_walk": second_walk}[sys.argv[1]]()))
