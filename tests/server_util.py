@@ -126,16 +126,42 @@ def build_shim_double() -> str:
     return lib
 
 
+def build_shim_emu() -> str:
+    """embedding_shim.cpp (the in-process drop-in library) linked against the SIMT-emulated engine (tests/emu: the
+    product's kernel source compiled for the host): tests/_build/libembedding_gpu_emu.so.  The whole in-process product —
+    shim, validated cache, C-ABI host code, kernels — on the CPU, for tests only."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    engine = build_emu.build()
+    src = [os.path.join(CSRC, "embedding_shim.cpp"), os.path.join(CSRC, "shim_cache.h"), os.path.join(CSRC, "host_walk.h"),
+           os.path.join(CSRC, "host_dist.h"), os.path.join(INC, "hnsw_gpu_shim.h"), os.path.join(INC, "hnsw_gpu.h"), engine]
+    lib = os.path.join(OUT, "libembedding_gpu_emu.so")
+    with _Lock():
+        if _stale(lib, src):
+            _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wall", "-I", INC, "-I", CSRC, src[0],
+                  "-o", lib, "-L", OUT, "-lhnsw_gpu_simt", f"-Wl,-rpath,{OUT}", "-lpthread", "-lm"])
+    return lib
+
+
 def build_pg_regress(variant: str) -> str:
     """variant 'gpu': libembedding_gpu.so (in-process device); 'client': libembedding_gpuc.so (hnsw_gpu_server);
     'patched': the glue with integration/embedding_gpu_server.patch applied + libembedding_gpuc.so;
-    'shimdouble': the in-process library's own source over the CPU engine double (build_shim_double)."""
+    'shimdouble': the in-process library's own source over the CPU engine double (build_shim_double);
+    'shimemu': the same source over the SIMT-emulated engine (build_shim_emu)."""
     if variant == "shimdouble":
         lib = build_shim_double()
         exe = os.path.join(OUT, "pg_regress_shimdouble")
         with _Lock():
             if _stale(exe, PG_GLUE_OBJS + [lib]):
                 _run(["g++"] + PG_GLUE_OBJS + ["-o", exe, "-L", OUT, "-lembedding_gpu_double", f"-Wl,-rpath,{OUT}", "-lpthread", "-lm"])
+        return exe
+    if variant == "shimemu":
+        lib = build_shim_emu()
+        exe = os.path.join(OUT, "pg_regress_shimemu")
+        with _Lock():
+            if _stale(exe, PG_GLUE_OBJS + [lib]):
+                _run(["g++"] + PG_GLUE_OBJS + ["-o", exe, "-L", OUT, "-lembedding_gpu_emu", "-lhnsw_gpu_simt", f"-Wl,-rpath,{OUT}", "-lpthread", "-lm"])
         return exe
     libs = {"gpu": ["-lembedding_gpu", "-lhnsw_gpu"], "client": ["-lembedding_gpuc"], "patched": ["-lembedding_gpuc"]}[variant]
     objs = [PG_GLUE_PATCHED] + PG_GLUE_OBJS[1:] if variant == "patched" else PG_GLUE_OBJS

@@ -126,7 +126,7 @@ select t <-> {1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1} id 2 ; the row inserted after the
 
 
 @needs_glue
-@pytest.mark.parametrize("variant", ["ref", "client", "patched", "shimdouble", pytest.param("gpu", marks=pytest.mark.gpu)])
+@pytest.mark.parametrize("variant", ["ref", "client", "patched", "shimdouble", "shimemu", pytest.param("gpu", marks=pytest.mark.gpu)])
 def test_an_error_inside_a_storage_callback_leaves_everything_usable(variant):
     """The host's callbacks may leave by longjmp (elog(ERROR), e.g. an I/O error in ReadBuffer): the hot
     path must hold nothing that the abort does not reclaim.  A failing statement prints ERROR; the next
@@ -136,8 +136,9 @@ def test_an_error_inside_a_storage_callback_leaves_everything_usable(variant):
         if not os.path.exists(SU.PG_REGRESS_REF):
             pytest.skip("reference-linked driver not built")
         r = subprocess.run([SU.PG_REGRESS_REF], input=FAULT_SCRIPT, capture_output=True, text=True)
-    elif variant in ("shimdouble", "gpu"):
-        # the in-process library (its own source over the CPU engine double / the product on the device): the failing read hits
+    elif variant in ("shimdouble", "shimemu", "gpu"):
+        # the in-process library (its own source over the CPU engine double / over the SIMT-emulated kernels / the product on the
+        # device): the failing read hits
         # its validation of a cached walk — on the device while the traced kernel is still in flight — and an insert's preparation
         r = subprocess.run([SU.build_pg_regress(variant)], input=FAULT_SCRIPT, capture_output=True, text=True, timeout=600)
     else:
@@ -277,6 +278,22 @@ def test_glue_over_the_in_process_library_and_its_validated_cache(name):
         assert eph.returncode == 0 and eph.stdout == expected(name)
         m2 = re.search(r"shim cache: snapshots (\d+) searches (\d+) search_rounds (\d+) inserts (\d+)", eph.stderr)
         assert m2 and int(m2.group(1)) == int(m2.group(2)) + int(m2.group(4))
+
+
+@needs_glue
+@pytest.mark.parametrize("name", ["knn", "gh-2", "gh-3"])
+def test_glue_over_the_whole_in_process_product_on_the_simt_emulator(name):
+    """embedding.c (unmodified) + the in-process product as it ships — embedding_shim.cpp, its validated cache, the C-ABI host
+    code of hnsw_gpu.hip and the kernels themselves (search with the streamed pop sequence, device insert, link-list gather) —
+    with the kernels' source compiled for the host against the SIMT emulator (tests/emu).  The reference's
+    bytes, on the CPU.  (The long scripts pass too — exhaust 36 s, defaults 48 s, scenario 12 min — and are left to the
+    device tier.)"""
+    exe = SU.build_pg_regress("shimemu")
+    cmd = open(os.path.join(GOLD, name + ".cmd")).read()
+    r = subprocess.run([exe], input=cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ, PGEMB_PRINT_CACHE_STATS="1"))
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    assert r.stdout == expected(name)
+    assert "shim cache: snapshots" in r.stderr
 
 
 @needs_glue
