@@ -86,5 +86,56 @@ def second_walk():
     return out
 
 
+def others():
+    """the other kernels behind the C-ABI: serial device insert (graph bytes == the oracle's), batched insert (searchable),
+    the walk's pop sequence, vacuum flags, export, the canonical exhaustive scan"""
+    import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_build import live_image
+    out = {}
+    setenv({})
+    for func, dim, m, efc, n in ((pg.DIST_L2, 12, 4, 16, 260), (pg.DIST_COSINE, 9, 1, 5, 150), (pg.DIST_MANHATTAN, 20, 3, 40, 200)):
+        X = gmm(n, dim, k=10, seed=dim)
+        labels = np.arange(n, dtype=np.uint64) * 7 + 5
+        port = oracle.PortIndex(dim, m, efc, 64, func)
+        port.add(X, labels)
+        meta = pg.make_meta(dim, m, efc, 64, func)
+        ix = pg.GpuIndex.empty(meta, n)
+        ix.append(X[:100], labels[:100])
+        ix.link(0, 100, max_batch=1)
+        ix.append(X[100:], labels[100:])
+        ix.link(100, n - 100, max_batch=1)
+        got = ix.export_flat().reshape(n, -1)
+        want = live_image(port.raw(), meta, n)
+        out[f"serial_insert_{func}_{dim}"] = int((got != want).any(axis=1).sum())
+        # the walk itself: pops and evaluation count
+        q = gmm(1, dim, k=10, seed=99)[0]
+        gl, gd, gp, ge = ix.search_trace(q, 24)
+        wl, wd, wp, we = port.search_trace(q, 24)
+        out[f"trace_{func}_{dim}"] = int(not (len(gp) == len(wp) and (gp == wp).all() and ge == we and (gl == wl).all() and (U.bits(gd) == U.bits(wd)).all()))
+        # vacuum flags: flagged elements leave the results, the walk stays
+        dead = [int(x) for x in gl[:3] // 7]
+        ix.set_deleted_many(np.asarray(dead, np.uint32), True)
+        for d in dead:
+            port.set_deleted(d, True)
+        l2, d2, c2 = ix.search(q.reshape(1, -1), 24)
+        w2 = port.search_many(q.reshape(1, -1), 24)
+        c = int(c2[0])
+        out[f"vacuum_{func}_{dim}"] = int(not (c == w2["counts"][0] and c < 24 and (l2[0][:c] == w2["labels"][0][:c]).all()))
+        ix.close()
+    # batched insert: not the reference's order, but a graph the search finds its way in (recall against the exact scan)
+    n, dim = 1500, 24
+    X = gmm(n, dim, k=10, seed=4)
+    ix = pg.GpuIndex.empty(pg.make_meta(dim, 8, 40, 40, pg.DIST_L2), n)
+    ix.append(X)
+    ix.link(0, n)
+    Q = gmm(16, dim, k=10, seed=5)
+    lab, dist, cnt = ix.search(Q, 40)
+    exact = np.argsort(((Q[:, None, :] - X[None, :, :]) ** 2).sum(-1), axis=1)[:, :10]
+    out["batched_insert_recall_at_10"] = float(np.mean([len(set(map(int, lab[i][:10])) & set(map(int, exact[i]))) / 10 for i in range(16)]))
+    ix.close()
+    return out
+
+
 if __name__ == "__main__":
-    print(json.dumps({"forms": forms, "second_walk": second_walk}[sys.argv[1]]()))
+    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others}[sys.argv[1]]()))

@@ -44,6 +44,18 @@ def test_every_kernel_form_walks_and_emits_like_the_oracle(emu_lib):
         assert any(needle in k for k in kernels), (needle, sorted(kernels))
 
 
+def test_the_other_kernels_behind_the_c_abi(emu_lib):
+    """serial device insert == the oracle's graph bytes, the walk's pop sequence, vacuum flags, a batched build that the
+    search finds its way in; and the distance entry points: the device tier's own test file, unchanged, on the emulated library"""
+    res = run_case("others", emu_lib)
+    recall = res.pop("batched_insert_recall_at_10")
+    assert all(v == 0 for v in res.values()), res
+    assert recall > 0.6, recall
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_dist.py"), "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider"],
+                       capture_output=True, text=True, timeout=900, env=dict(os.environ, PGEMB_GPU_LIB=emu_lib))
+    assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
+
+
 def test_a_wave_that_walks_many_queries_with_helpers_attached(emu_lib):
     """one wave, 32 neighbouring queries, seven helpers (with and without schedule jitter; two waves with three helpers each)"""
     res = run_case("second_walk", emu_lib)
