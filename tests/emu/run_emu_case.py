@@ -94,7 +94,7 @@ def others():
     from test_gpu_build import live_image
     out = {}
     setenv({})
-    for func, dim, m, efc, n in ((pg.DIST_L2, 12, 4, 16, 260), (pg.DIST_COSINE, 9, 1, 5, 150), (pg.DIST_MANHATTAN, 20, 3, 40, 200)):
+    for func, dim, m, efc, n in ((pg.DIST_L2, 12, 4, 16, 180), (pg.DIST_COSINE, 9, 1, 5, 120), (pg.DIST_MANHATTAN, 20, 3, 40, 140)):
         X = gmm(n, dim, k=10, seed=dim)
         labels = np.arange(n, dtype=np.uint64) * 7 + 5
         port = oracle.PortIndex(dim, m, efc, 64, func)
@@ -124,7 +124,7 @@ def others():
         out[f"vacuum_{func}_{dim}"] = int(not (c == w2["counts"][0] and c < 24 and (l2[0][:c] == w2["labels"][0][:c]).all()))
         ix.close()
     # batched insert: not the reference's order, but a graph the search finds its way in (recall against the exact scan)
-    n, dim = 1500, 24
+    n, dim = 800, 24
     X = gmm(n, dim, k=10, seed=4)
     ix = pg.GpuIndex.empty(pg.make_meta(dim, 8, 40, 40, pg.DIST_L2), n)
     ix.append(X)

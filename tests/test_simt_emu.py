@@ -76,11 +76,11 @@ def test_the_same_without_the_helper_bit_clear_is_reported(capsys):
         print("\n[simt emulator] without the helper-bit clear: " + "; ".join(f"{r['wrong']} of {r['walks']} answers wrong" for r in res))
 
 
-@pytest.mark.parametrize("spec", ["8", "5", "0"])
+@pytest.mark.parametrize("spec", ["5", "0"])
 def test_pending_slice_helpers_and_hop_wide_append_are_exact_under_emulation(spec):
     """scripts/pending (not shipped: it waits for a device run): helpers scoring slices of the walking wave's rows, one-step
     append below ef — every kernel form still equals the oracle, and the many-walks schedule completes (no job left waiting)
-    with every helper speculating (8), five of seven (5: the measured setting) and none (0: all of them take slices)."""
+    with five of seven helpers speculating (5: the measured setting) and none (0: all of them take slices)."""
     lib = build_emu.build_with_patch(PENDING, "pending")
     env = {"HNSW_GPU_TEAM_SPEC": spec}
     res = run_case("second_walk", lib, env, timeout=600)
