@@ -68,8 +68,14 @@ def gpu_lib():
             f"{_build.GPU_LIB} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  pg_embedding_amd has no CPU fallback.")
     _preload_torch_runtime()
-    # PGEMB_GPU_LIB: an experiment build of the same library (build.py variant ...), for A/B runs of kernel variants
-    L = C.CDLL(os.environ.get("PGEMB_GPU_LIB") or _build.GPU_LIB, mode=C.RTLD_GLOBAL)
+    # PGEMB_GPU_LIB: another build of the same C-ABI instead of the product library — an experiment build for A/B runs of kernel
+    # variants (build.py variant ...), or the test tier's SIMT-emulated build of the kernel source (tests/emu).  Never silent:
+    # whoever reads the output of such a run sees which library it used.
+    override = os.environ.get("PGEMB_GPU_LIB")
+    if override:
+        import sys
+        print(f"pg_embedding_amd: PGEMB_GPU_LIB is set: using {override} instead of the product library", file=sys.stderr)
+    L = C.CDLL(override or _build.GPU_LIB, mode=C.RTLD_GLOBAL)
     vp, sz, i32 = C.c_void_p, C.c_size_t, C.c_int
     MP = C.POINTER(HnswMetadata)
     L.hnsw_gpu_last_error.restype = C.c_char_p
