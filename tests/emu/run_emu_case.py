@@ -46,7 +46,10 @@ def forms():
     variants = [{}, {"HNSW_GPU_TEAM": "0"}, {"HNSW_GPU_TEAM": "0", "HNSW_GPU_NARROW5": "0"}, {"HNSW_GPU_TEAM": "1"},
                 {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "4"}, {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "2", "HNSW_GPU_HASH_ENTRIES": "512"},
                 {"HNSW_GPU_HASH_ENTRIES": "0"}, {"HNSW_GPU_BEAM": "0"}, {"HNSW_GPU_FORCE_LDS_HEAPS": "1"}, {"HNSW_GPU_TEAM": "1", "SIMT_EMU_CUS": "64"}]
-    for dim, m, func, efs in ((32, 8, pg.DIST_L2, (10, 100)), (100, 16, pg.DIST_COSINE, (40,)), (200, 8, pg.DIST_MANHATTAN, (40, 300)), (768, 16, pg.DIST_L2, (64,))):
+    cfgs = ((32, 8, pg.DIST_L2, (10, 100)), (100, 16, pg.DIST_COSINE, (40,)), (200, 8, pg.DIST_MANHATTAN, (40, 300)), (768, 16, pg.DIST_L2, (64,)))
+    if os.environ.get("EMU_FORMS_QUICK"):
+        cfgs = (cfgs[1], cfgs[3])
+    for dim, m, func, efs in cfgs:
         n, nq = (1200, 12) if dim < 700 else (500, 6)
         port, X = U.build_port(n, dim, m, 40, func, k=10, seed=dim)
         Q = gmm(nq, dim, k=10, seed=dim + 1)

@@ -86,5 +86,5 @@ def test_pending_slice_helpers_and_hop_wide_append_are_exact_under_emulation(spe
     res = run_case("second_walk", lib, env, timeout=600)
     assert all(r["wrong"] == 0 for r in res), res
     if spec == "5":
-        res = run_case("forms", lib, env)
+        res = run_case("forms", lib, dict(env, EMU_FORMS_QUICK="1"))
         assert not [r for r in res if r["wrong"]], [r for r in res if r["wrong"]]
