@@ -17,9 +17,9 @@ scaling.  --mode sharded (BASELINE config C4): the rows are partitioned over the
 searches every query on its shard, ONE packed all-gather + the device merge kernel -> strong scaling.
 
 Prints ONE JSON line on rank 0 (see the contract in the task description) with two extra
-objects: "roofline" (dominant kernel vs the HBM roof — nominal peak AND the measured dependency-free gather
-roof of the same row table — from HIP events on the kernel's own stream, for the headline dataset and for
-a cache-hostile one) and "cpu_baseline" (the reference's CPU path on the same graph bytes, bounded sample,
+objects: "roofline" (dominant kernel vs the HBM roof from HIP events on the kernel's own stream: algorithmic bytes over
+the nominal peak, the REPLAY of the launch's own row trace as the roof the kernel cannot beat, the share of its reads no
+cache can hold, and the same on a cache-hostile table: roofline.hbm_only) and "cpu_baseline" (the reference's CPU path on the same graph bytes, bounded sample,
 host cores of this box, with every id mismatch against the reference classified).
 """
 from __future__ import annotations
@@ -35,6 +35,8 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+from pg_embedding_amd import watchdog                      # noqa: E402
+watchdog.arm(default_seconds=3000.0)                       # --timeout SECONDS: a hung launch ends the run with status 124, not never
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 REL_TOL = 1e-5            # north-star tolerance (BASELINE.json)
@@ -62,8 +64,8 @@ def parse():
     ap.add_argument("--no-side-configs", action="store_true",
                     help="skip the other BASELINE configs and the stress datasets (reported extras, N=1 only)")
     ap.add_argument("--hostile-rows", type=int, default=8_000_000,
-                    help="second timed dataset whose rows do not repeat inside a launch (rows; clusters scale with it so "
-                         "cluster size stays 1000); 0 = skip; skipped for N>1")
+                    help="rows of the second timed dataset (roofline.hbm_only): clusters of 200 rows, every query of a launch from a "
+                         "cluster of its own, far larger than the caches; 0 = skip; skipped for N>1")
     ap.add_argument("--mode", default="replicas", choices=["replicas", "sharded"],
                     help="replicas: index mirrored on every GPU, queries sharded (headline metric). sharded: rows partitioned "
                          "across GPUs (config C4), every GPU searches every query, one packed RCCL all-gather + merge kernel")
@@ -149,8 +151,10 @@ def alg_bytes(stats, counts, dim, m):
     return E * dim * 4 + H * (2 * m + 1) * 4 + dim * 4 + counts * 8
 
 
-def gather_roof(ix):
-    """best dependency-free random-row gather rate on this mirror's own row table (csrc/device_roof.h)"""
+def random_gather(ix):
+    """best dependency-free gather rate of RANDOM whole rows of this mirror's row table (csrc/device_roof.h).  Informational
+    only: random rows share nothing, a launch's rows do (the queries of a launch cross the same hubs and clusters), so this is
+    NOT a roof of the search kernel — the replay of the launch's own trace (trace_roof) is."""
     best, cfg = 0.0, None
     for wpc in (8, 16):
         for t in (8, 12, 16, 24):
@@ -158,6 +162,82 @@ def gather_roof(ix):
             if g > best:
                 best, cfg = g, {"loads_per_lane": t, "waves_per_cu": wpc}
     return best, cfg
+
+
+MALL_BYTES = 256 << 20        # Infinity Cache of one MI355X (memory-side)
+L2_BYTES = 8 * (4 << 20)      # 8 XCDs x 4 MB
+
+
+def trace_roof(ix, Q, ef):
+    """Replay roof + reuse analysis of ONE launch's own evaluation trace (include/hnsw_gpu.h, hnsw_gpu_search_traced_dev /
+    hnsw_gpu_replay_roof).
+
+    replay: the rows the launch scored, gathered again by the same number of resident waves in the same query order with the
+      search kernel's load shape and NOTHING in between (no pop, link list, visited test, accept loop).  Same bytes, same
+      locality between concurrent queries, no dependent chain: kernel_ms / replay_ms is what the chain costs (<= 1 by
+      construction), replay GB/s is what the memory system gives this trace.
+    reuse: every row read gets a time (its query's start/end device-clock stamps, spread evenly over the query's reads); a
+      read is `far` when the same row was not read within the last 256 MB of the launch's row traffic (first touch
+      included): no cache on the chip can hold it, so it comes from HBM.  `hbm_lower_bound_GBps` = far bytes / kernel time:
+      what HBM provably delivered; the rest of `achieved` MAY be cache service."""
+    import torch
+    nq = Q.shape[0]
+    cap = 4096
+    tr = ix.search_traced_torch(Q, ef, evals_cap=cap)
+    torch.cuda.synchronize()
+    E = tr["stats"][:, 0].to(torch.int64)
+    if int(E.max().item()) > cap:                            # rare: long walks; one retry with room for all of them
+        cap = int(E.max().item()) + 64
+        tr = ix.search_traced_torch(Q, ef, evals_cap=cap)
+        torch.cuda.synchronize()
+        E = tr["stats"][:, 0].to(torch.int64)
+    slots = ix.last_search_slots()
+    row_bytes = int(ix.meta.dim + 3) // 4 * 16
+    best = None
+    for lpl in (24, 16, 8):
+        ms, by = ix.replay_roof(tr, slots, lpl)
+        if best is None or ms < best[0]:
+            best = (ms, by, lpl)
+    rms, rbytes, rlpl = best
+    out = {"replay_ms": rms, "replay_row_bytes": rbytes, "replay_GBps": rbytes / rms / 1e6, "replay_loads_per_lane": rlpl,
+           "replay_slots": slots}
+    # ---- reuse distances, on the device with torch (tens of millions of reads) ----
+    j = torch.arange(cap, device=Q.device, dtype=torch.int64)[None, :]
+    valid = j < E[:, None]
+    t0 = tr["times"][:, 0].to(torch.float64)[:, None]
+    t1 = tr["times"][:, 1].to(torch.float64)[:, None]
+    t = (t0 + (t1 - t0) * (j.to(torch.float64) + 0.5) / E.clamp(min=1)[:, None].to(torch.float64))[valid]
+    rows = tr["evals"].to(torch.int64)[valid]
+    del valid, j
+    nreads = rows.numel()
+    order = torch.argsort(t)                                  # time order of all reads of the launch
+    rank = torch.empty_like(order)
+    rank[order] = torch.arange(nreads, device=Q.device)
+    del order, t
+    key, _ = torch.sort(rows * (1 << 32) + rank)              # by row, then by time
+    r_sorted, k_sorted = key >> 32, key & 0xFFFFFFFF
+    same = torch.zeros(nreads, dtype=torch.bool, device=Q.device)
+    same[1:] = r_sorted[1:] == r_sorted[:-1]
+    gap = torch.full((nreads,), 1 << 40, dtype=torch.int64, device=Q.device)
+    gap[1:] = torch.where(same[1:], (k_sorted[1:] - k_sorted[:-1]) * row_bytes, gap[1:])
+    distinct = int((~same).sum().item())
+    far_mall = float((gap > MALL_BYTES).double().mean().item())
+    far_l2 = float((gap > L2_BYTES).double().mean().item())
+    out.update({"row_reads": nreads, "distinct_rows": distinct, "reads_per_distinct_row": nreads / max(distinct, 1),
+                "reads_beyond_infinity_cache_reach": far_mall, "reads_beyond_l2_reach": far_l2, "_far_bytes": far_mall * nreads * row_bytes,
+                "traced_launch_clock_span_ms": float((tr["times"][:, 1].max() - tr["times"][:, 0].min()).item()) / 1e5})
+    del tr
+    return out
+
+
+def finish_trace_roof(tr, kernel_ms, alg_bytes_launch):
+    """ratios of an (untraced) launch of `kernel_ms` against its trace's replay and reuse figures"""
+    tr = dict(tr)
+    far_bytes = tr.pop("_far_bytes")
+    tr["replay_ms_over_kernel_ms"] = tr["replay_ms"] / kernel_ms                       # <= 1: the rest is the dependent chain
+    tr["frac_of_replay"] = (alg_bytes_launch / kernel_ms) / (tr["replay_row_bytes"] / tr["replay_ms"])
+    tr["hbm_lower_bound_GBps"] = far_bytes / kernel_ms / 1e6
+    return tr
 
 
 def copy_roof(dev):
@@ -293,8 +373,11 @@ def main():
                   "kernel": ix.last_search_kernel()}
 
     # ---- roofs measured on this device: dependency-free gather of this table's rows, plain copy
-    g_roof, g_cfg = gather_roof(ix)
+    g_rand, g_cfg = random_gather(ix)
     copy_gbps = copy_roof(dev)
+    # ---- this launch's own trace: replay roof + reuse distances (BEFORE the timed region: the traced launch stores 6 KB
+    # more per query and must not be one of the launches the timing and profiles/ summarise)
+    tr_raw = trace_roof(ix, Q, args.ef) if rank == 0 else None
 
     # ---- timed region -----------------------------------------------------------------
     bufs = ix.search_torch(Q, args.ef)           # allocate outputs once
@@ -328,7 +411,7 @@ def main():
     qps = total_queries / elapsed
 
     achieved = bytes_launch / (kms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(args)
+    traffic, traffic_src = pmc_traffic(args, kernel_name)
     result = {
         "metric": "queries/sec at recall@10>=0.95, 1Mx768 L2 efsearch=128",
         "value": qps,
@@ -372,12 +455,13 @@ def main():
             "traffic_source": traffic_src,
             "alg_bytes_per_launch": bytes_launch,
             "kernel_ms_per_launch": kms,
-            # what the memory system gives this access pattern with nothing depending on anything, on the same
-            # row table (csrc/device_roof.h), and a plain copy: `achieved` above the gather roof is Infinity
-            # Cache / L2 service of rows that queries of one launch share (this dataset: ~58 reads per row per launch)
-            "measured_gather_GBps": g_roof,
-            "measured_gather_config": g_cfg,
-            "frac_of_measured_gather": achieved / g_roof if g_roof else None,
+            # `achieved` is ALGORITHMIC bytes over kernel time: rows that queries of one launch share may be served by L2 /
+            # Infinity Cache.  `replay` = the launch's own row trace gathered again with nothing in between (the kernel
+            # cannot beat it: frac_of_replay <= 1) + how many of its reads no cache can hold (hbm_lower_bound_GBps);
+            # `hbm_only` below = the same figures on the cache-hostile table.
+            "replay": finish_trace_roof(tr_raw, kms, bytes_launch) if tr_raw else None,
+            "random_row_gather_GBps": g_rand,
+            "random_row_gather_config": g_cfg,
             "measured_copy_GBps": copy_gbps,
         },
         "smaller_launch": small,
@@ -393,7 +477,7 @@ def main():
 
     # ---- a dataset whose rows do not repeat inside a launch (N=1 only): the Infinity-Cache share made visible
     if rank == 0 and world == 1 and args.hostile_rows > 0:
-        result["roofline"]["cache_hostile"] = hostile(args, dev, local, func)
+        result["roofline"]["hbm_only"] = hostile(args, dev, local, func)
     # ---- the other BASELINE configs and the stress datasets of SURVEY.md §8(d), same kernels, N=1 only (extras, not `value`)
     if rank == 0 and world == 1 and not args.no_side_configs:
         result["other_configs"] = side_configs(args, dev, local)
@@ -489,11 +573,12 @@ def side_configs(args, dev, local):
             ms.append(ix.last_search_ms())
         kms = float(np.median(ms[1:]))
         ach = float(bq.sum()) / (kms * 1e-3) / 1e9
-        g_roof, g_cfg = gather_roof(ix)          # dependency-free gather of whole rows of THIS table (its width, its size)
+        tr = finish_trace_roof(trace_roof(ix, Q, args.ef), kms, float(bq.sum()))   # replay of this launch's own row trace
         res[name] = {"rows": n, "dims": dim, "m": m, "metric": metric, "efsearch": args.ef, "queries_per_launch": nq,
                      "queries_per_s": nq / kms * 1e3, "kernel_ms_per_launch": kms, "achieved_GBps": ach,
-                     "frac_of_8TBps": ach / HBM_PEAK_GBS, "measured_gather_GBps": g_roof,
-                     "frac_of_measured_gather": ach / g_roof if g_roof else None, "evals_per_query": float(st[:, 0].mean()),
+                     "frac_of_8TBps": ach / HBM_PEAK_GBS, "replay_GBps": tr["replay_GBps"], "frac_of_replay": tr["frac_of_replay"],
+                     "reads_beyond_infinity_cache_reach": tr["reads_beyond_infinity_cache_reach"],
+                     "hbm_lower_bound_GBps": tr["hbm_lower_bound_GBps"], "evals_per_query": float(st[:, 0].mean()),
                      "hops_per_query": float(st[:, 1].mean()), "recall_at_10": rec, "kernel": ix.last_search_kernel(),
                      "datagen_plus_build_seconds": t_build}
         if mfma:
@@ -552,22 +637,26 @@ def side_configs(args, dev, local):
         torch.cuda.empty_cache()
     res["_note"] = ("achieved_GBps = algorithmic bytes (SURVEY 8d) / kernel time, frac_of_8TBps = that over the nominal HBM peak; rows that "
                     "many queries of a launch share are served by L2 / Infinity Cache, so the figure can exceed what HBM delivers "
-                    "(the i.i.d. set: every walk crosses the same hub rows) -- roofline.measured_gather_GBps and roofline.cache_hostile "
-                    "of the headline workload show the HBM-only picture")
+                    "(the i.i.d. set: every walk crosses the same hub rows) -- replay_GBps is the launch's own row trace gathered again "
+                    "with nothing in between (frac_of_replay <= 1 by construction), hbm_lower_bound_GBps the reads no cache can hold "
+                    "over the kernel's time; roofline.hbm_only is the cache-hostile table of the headline shape")
     return res
 
 
 def hostile(args, dev, local, func):
-    """Same kernel, same row width, but a table 8x larger with 8x more clusters (cluster size unchanged):
-    a launch's queries land in mostly different clusters and the ~24 GB working set dwarfs the 256 MB
-    Infinity Cache, so (almost) every row read comes from HBM."""
+    """Same kernel, same row width, on a table built to defeat the caches: `--hostile-rows` rows (default 8 M = 24.6 GB, two
+    orders of magnitude above the 256 MB Infinity Cache) in clusters of 200, and every query of the launch from a cluster of its
+    OWN (a random permutation of the clusters).  Rows still repeat inside a launch — every walk starts at the same entry point,
+    and a walk of ~1 800 rows crosses its neighbours' clusters; a table in which 40 000 walks never meet would need > 70 M rows —
+    but almost never within cache reach: the launch's own trace says how many reads had their row read less than 256 MB of
+    traffic earlier (`reads_beyond_infinity_cache_reach` is the complement), and what HBM provably delivered."""
     import numpy as np
     import torch
     from pg_embedding_amd.datasets import gmm_torch, recall_at_k
     n = args.hostile_rows
-    clusters = max(1, n // 1000)
+    clusters = max(args.nq, n // 200)
     ix, t_gen, t_build = build_index(args, n, clusters, dev, local, func)
-    Q = gmm_torch(args.nq, args.dim, k=clusters, sigma=0.3, seed=42, stream=1, device=dev)
+    Q = gmm_torch(args.nq, args.dim, k=clusters, sigma=0.3, seed=42, stream=1, device=dev, distinct_clusters=True)
     out = ix.search_torch(Q, args.ef, stats=True)
     torch.cuda.synchronize()
     stats = out["stats"].cpu().numpy().astype(np.int64)
@@ -576,18 +665,24 @@ def hostile(args, dev, local, func):
     nrec = min(500, args.nq)
     truth, _ = ix.bruteforce_torch(Q[:nrec].contiguous(), 10, mfma=True)
     rec = recall_at_k(out["labels"][:nrec].cpu().numpy(), truth.cpu().numpy(), 10)
-    g_roof, g_cfg = gather_roof(ix)
+    g_rand, g_cfg = random_gather(ix)
+    tr_raw = trace_roof(ix, Q, args.ef)
     ms = []
     for _ in range(max(3, args.steps)):
         ix.search_torch(Q, args.ef, out=out)
         ms.append(ix.last_search_ms())
     kms = float(np.mean(ms[1:]))
     ach = float(bq.sum()) / (kms * 1e-3) / 1e9
-    res = {"workload": f"{n}x{args.dim} fp32 GMM({clusters}, sigma 0.3), {args.metric}, m={args.m}, efsearch={args.ef}, "
-                       f"{args.nq} queries/launch",
-           "kernel": ix.last_search_kernel(), "achieved": ach, "frac": ach / HBM_PEAK_GBS,
-           "measured_gather_GBps": g_roof, "measured_gather_config": g_cfg,
-           "frac_of_measured_gather": ach / g_roof if g_roof else None,
+    tr = finish_trace_roof(tr_raw, kms, float(bq.sum()))
+    res = {"workload": f"{n}x{args.dim} fp32 GMM({clusters} clusters, sigma 0.3), {args.metric}, m={args.m}, efsearch={args.ef}, "
+                       f"{args.nq} queries/launch, one per cluster",
+           "kernel": ix.last_search_kernel(),
+           # what HBM provably delivered: the reads no cache on the chip could hold, over the kernel's time
+           "achieved": tr["hbm_lower_bound_GBps"], "frac": tr["hbm_lower_bound_GBps"] / HBM_PEAK_GBS,
+           "replay_roof": tr["replay_GBps"],
+           "algorithmic_GBps": ach, "algorithmic_frac": ach / HBM_PEAK_GBS, "frac_of_replay": tr["frac_of_replay"],
+           "trace": tr,
+           "random_row_gather_GBps": g_rand, "random_row_gather_config": g_cfg,
            "kernel_ms_per_launch": kms, "queries_per_s": args.nq / kms * 1e3,
            "alg_bytes_per_launch": float(bq.sum()), "evals_per_query": float(stats[:, 0].mean()),
            "hops_per_query": float(stats[:, 1].mean()), "recall_at_10": rec,
@@ -676,20 +771,39 @@ def main_sharded(args):
         dist.destroy_process_group()
 
 
-def pmc_traffic(args):
+def kernel_source_digest():
+    """sha256 of the sources the search kernels are made of: a traffic figure belongs to exactly one version of them"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("device_dist.h", "device_search.h"):
+        with open(os.path.join(ROOT, "pg_embedding_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(args, kernel_name):
     """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of THIS command
     ((2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 FETCH_SIZE correction of the micro-arch guide).  The
     counters cannot be collected from inside the timed process, so the value measured by
-    scripts/profile_bench.sh is committed as profiles/traffic.json and reported here — with its source
-    named — only when it was taken for the same workload; otherwise null."""
+    scripts/profile_bench.sh is committed as profiles/traffic.json and reported here — with its source and the kernel
+    time of the profiled run named — only when it was taken for the same workload, the same kernel symbol as this run's
+    dominant kernel AND the same bytes of the kernel sources; otherwise null (a stale file is refused, not reported)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
             t = json.load(f)
         same = all(t["workload"].get(k) == getattr(args, k) for k in ("n", "dim", "m", "efc", "ef", "nq", "metric"))
         if not same:
-            return None, None
-        return float(t["hbm_bytes_per_launch"]), f"profiles/traffic.json ({t.get('run', 'scripts/profile_bench.sh')}): " + t["source"]
+            return None, "profiles/traffic.json is for another workload: not reported"
+        if t.get("kernel") != kernel_name:
+            return None, f"profiles/traffic.json was taken for kernel {t.get('kernel')}, this run's is {kernel_name}: not reported"
+        if t.get("kernel_source_digest") != kernel_source_digest():
+            return None, (f"profiles/traffic.json was taken for another version of the kernel sources ({t.get('kernel_source_digest')} vs "
+                          f"{kernel_source_digest()}): not reported; regenerate with scripts/profile_bench.sh")
+        src = f"profiles/traffic.json ({t.get('run', 'scripts/profile_bench.sh')}): " + t["source"]
+        if t.get("kernel_ms_per_launch_of_that_run"):
+            src += f"; kernel time of that run {t['kernel_ms_per_launch_of_that_run']:.3f} ms"
+        return float(t["hbm_bytes_per_launch"]), src
     except Exception:
         return None, None
 

@@ -152,6 +152,39 @@ int hnsw_gpu_last_search_kernel(hnsw_gpu_index *ix, char *buf, size_t len);
  * helpers finished, [12] helper cycles spent on them.  `out` holds 16 values. */
 int hnsw_gpu_team_counters(hnsw_gpu_index *ix, uint32_t *out16);
 
+/* Measurement: the same launch as hnsw_gpu_search_batch_dev that also writes its EVALUATION TRACE — d_evals[i * evals_cap + j] =
+ * the j-th row query i scored (j < d_stats[2 * i]; truncated at evals_cap), d_times[2 * i], [2 * i + 1] = the device's
+ * constant-rate clock (100 MHz) at the start of query i and at the end of its walk (d_times may be NULL) — and the REPLAY ROOF
+ * made from it: the rows of such a trace gathered again by `slots` resident waves (hnsw_gpu_last_search_slots of the traced
+ * launch) in the same query order, with the search kernel's load shape (`loads_per_lane` 16-byte loads in flight per lane: 8,
+ * 16 or 24) and nothing in between.  *ms = best of three repetitions, *bytes = row bytes one repetition reads.  The search
+ * kernel cannot beat the replay of its own trace: search time / replay time is the cost of the walk's dependent chain,
+ * bytes / replay time what the memory system gives this access pattern (bench.py: roofline.replay). */
+int hnsw_gpu_search_traced_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t ef,
+                               label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
+                               idx_t *d_evals, size_t evals_cap, uint64_t *d_times, void *stream);
+int hnsw_gpu_replay_roof(hnsw_gpu_index *ix, const idx_t *d_evals, size_t evals_cap, const uint32_t *d_stats, size_t nq,
+                         unsigned slots, int loads_per_lane, float *ms, double *bytes);
+
+/* Health of the mirror's default search workspace (8 words).  out8[0] = 1 while an abort request is pending, [1] = slices a
+ * team helper did not deliver in time and [2] = helper packages that stayed "claimed" past the bound (both were then
+ * computed by the walking wave itself: results are unaffected, the counts say a protocol is slower than designed;
+ * 0 in a healthy life), [3] = waves that left a launch because of an abort request, [4] = slices team helpers scored
+ * for walking waves (says that mechanism is in use), [5..7] = 0 (totals since the mirror exists). */
+int hnsw_gpu_index_health(hnsw_gpu_index *ix, uint32_t *out8);
+
+/* Ask the search launches in flight to end: every wave looks at its workspace's abort word at the top of a query
+ * and every 256 hops of a walk, and leaves.  No wait in the kernels is unbounded, so this is for the unknown: a
+ * launch that never ends costs its caller's patience, not the device.  The outputs of an aborted launch are undefined
+ * (counts / completion flags of unfinished queries are not written); the workspace is re-zeroed by the next launch.
+ * Callable from ANY thread, also while another thread is blocked inside a search call on the same mirror.
+ * hnsw_gpu_abort_all: every workspace of every mirror and context of this process; returns how many it reached.
+ * HNSW_GPU_WATCHDOG_S=<seconds> in the environment makes the library do this by itself for a search launch that has
+ * been running longer than that (a helper thread, off by default); the polled host-pointer calls do it after
+ * HNSW_GPU_POLL_LIMIT_S (default 120). */
+int hnsw_gpu_index_abort(hnsw_gpu_index *ix);
+int hnsw_gpu_abort_all(void);
+
 /* Resident query slots (waves) the last search launch used — occupancy figure. */
 int hnsw_gpu_last_search_slots(hnsw_gpu_index *ix, uint32_t *slots);
 

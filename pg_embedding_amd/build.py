@@ -10,6 +10,7 @@ to the GPU box with the tree.
 """
 from __future__ import annotations
 
+import hashlib
 import os
 import shutil
 import subprocess
@@ -40,11 +41,33 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (need ROCm with gfx950 support)")
 
 
-def _newer(target: str, sources) -> bool:
-    if not os.path.exists(target):
+def _digest(sources, cmd) -> str:
+    h = hashlib.sha256(" ".join(cmd).encode())
+    for s in sorted(sources):
+        h.update(os.path.basename(s).encode())
+        with open(s, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _stamp(target: str) -> str:
+    return target + ".stamp"
+
+
+def _current(target: str, digest: str) -> bool:
+    """Up to date = the artefact exists and was built from exactly these source BYTES with this command (a stamp file
+    beside it holds the digest taken when its build STARTED).  Not by modification time: a source edited while its build
+    was running would look older than the artefact, and a tree copied to another box (gpurun) gets new times."""
+    try:
+        with open(_stamp(target)) as f:
+            return os.path.exists(target) and f.read().strip() == digest
+    except OSError:
         return False
-    t = os.path.getmtime(target)
-    return all(os.path.getmtime(s) <= t for s in sources)
+
+
+def _built(target: str, digest: str) -> None:
+    with open(_stamp(target), "w") as f:
+        f.write(digest + "\n")
 
 
 def _run(cmd) -> None:
@@ -57,39 +80,35 @@ def build(force: bool = False, verbose: bool = False) -> None:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(BINDIR, exist_ok=True)
     hdrs = [os.path.join(INC, h) for h in ("hnsw_abi.h", "hnsw_gpu.h", "hnsw_gpu_shim.h", "hnsw_gpu_server.h")]
-    gpu_src = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) and f not in ("hgs_io.h", "host_walk.h", "host_dist.h", "shim_cache.h")] + hdrs
-    if force or not _newer(GPU_LIB, gpu_src):
-        cmd = [_hipcc()] + HIPCC_FLAGS + ["-I", INC, "-I", CSRC,
-                                          os.path.join(CSRC, "hnsw_gpu.hip"),
-                                          os.path.join(CSRC, "sort_pairs.hip"), "-o", GPU_LIB]
+    host_only = ("hgs_io.h", "host_walk.h", "host_dist.h", "shim_cache.h")
+    gpu_src = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) and f not in host_only] + hdrs
+
+    def step(target, sources, cmd):
+        d = _digest(sources, [os.path.relpath(c, ROOT) if c.startswith(ROOT + os.sep) else c for c in cmd])   # (the tree may live anywhere)
+        if not force and _current(target, d):
+            return
         if verbose:
             print(" ".join(cmd))
         _run(cmd)
+        _built(target, d)
+
+    step(GPU_LIB, gpu_src, [_hipcc()] + HIPCC_FLAGS + ["-I", INC, "-I", CSRC, os.path.join(CSRC, "hnsw_gpu.hip"),
+                                                     os.path.join(CSRC, "sort_pairs.hip"), "-o", GPU_LIB])
     host_dist = os.path.join(CSRC, "host_dist.h")
+    gpu_stamp = [_stamp(GPU_LIB)]                            # the host libraries link against the device library
     shim_src = [os.path.join(CSRC, "embedding_shim.cpp"), os.path.join(CSRC, "host_walk.h"), os.path.join(CSRC, "shim_cache.h"), host_dist] + hdrs
-    if force or not _newer(SHIM_LIB, shim_src + [GPU_LIB]):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I", INC, "-I", CSRC,
-               os.path.join(CSRC, "embedding_shim.cpp"), "-o", SHIM_LIB,
-               "-L", LIBDIR, "-lhnsw_gpu", "-Wl,-rpath,$ORIGIN", "-lpthread"]
-        if verbose:
-            print(" ".join(cmd))
-        _run(cmd)
+    step(SHIM_LIB, shim_src + gpu_stamp,
+         ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I", INC, "-I", CSRC,
+          os.path.join(CSRC, "embedding_shim.cpp"), "-o", SHIM_LIB, "-L", LIBDIR, "-lhnsw_gpu", "-Wl,-rpath,$ORIGIN", "-lpthread"])
     io_h = os.path.join(CSRC, "hgs_io.h")
     client_src = [os.path.join(CSRC, "remote_client.cpp"), io_h, os.path.join(CSRC, "host_walk.h"), host_dist] + hdrs
-    if force or not _newer(CLIENT_LIB, client_src):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-ffp-contract=off", "-I", INC, "-I", CSRC,
-               os.path.join(CSRC, "remote_client.cpp"), "-o", CLIENT_LIB, "-lpthread"]
-        if verbose:
-            print(" ".join(cmd))
-        _run(cmd)
+    step(CLIENT_LIB, client_src,
+         ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", "-ffp-contract=off", "-I", INC, "-I", CSRC,
+          os.path.join(CSRC, "remote_client.cpp"), "-o", CLIENT_LIB, "-lpthread"])
     server_src = [os.path.join(CSRC, "server_main.cpp"), io_h] + hdrs
-    if force or not _newer(SERVER_BIN, server_src + [GPU_LIB]):
-        cmd = ["g++", "-O2", "-std=c++17", "-Wall", "-I", INC, "-I", CSRC,
-               os.path.join(CSRC, "server_main.cpp"), "-o", SERVER_BIN,
-               "-L", LIBDIR, "-lhnsw_gpu", "-Wl,-rpath,$ORIGIN/../lib", "-lpthread"]
-        if verbose:
-            print(" ".join(cmd))
-        _run(cmd)
+    step(SERVER_BIN, server_src + gpu_stamp,
+         ["g++", "-O2", "-std=c++17", "-Wall", "-I", INC, "-I", CSRC, os.path.join(CSRC, "server_main.cpp"), "-o", SERVER_BIN,
+          "-L", LIBDIR, "-lhnsw_gpu", "-Wl,-rpath,$ORIGIN/../lib", "-lpthread"])
 
 
 def build_variant(tag: str, defines) -> str:

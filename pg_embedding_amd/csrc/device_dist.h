@@ -142,7 +142,8 @@ __device__ __forceinline__ float query_norm(const float4 *q4, uint32_t nchunks, 
 //   row r lives at vec + rowid(r) * stride (floats; stride % 4 == 0, zero padded)
 //   q4     : query in LDS as float4 chunks, zero padded to a multiple of KB*16 chunks
 //   out[r] : REDUCED SUM of row r (sum of squares | dot | sum of |.|), written by the first lane
-//            of the owning group; cosine also writes |x|^2 to out[OUT2 + r].  The caller turns the
+//            of the owning group; cosine also writes |x|^2 to out[O2 + r] (O2 = OUT2 unless the caller's
+//            array is a short one: the slice areas of the team form).  The caller turns the
 //            sums into distances with finish_dist(), one row per lane.
 // Shape <KB, RPG>: every 16-lane group owns RPG rows per pass (4*RPG rows per wave-pass) and
 // issues KB chunk-steps of ALL its rows before the first use, i.e. KB*RPG independent
@@ -151,7 +152,7 @@ __device__ __forceinline__ float query_norm(const float4 *q4, uint32_t nchunks, 
 // to cover a whole row per trip when it fits: 768 dims = <12,1>, 128 dims = <2,4>.
 constexpr uint32_t OUT2 = 64;      // offset of the second sum (cosine |x|^2) in a score_rows output array
 
-template <int FUNC, int KB, int RPG, typename RowId>
+template <int FUNC, int KB, int RPG, uint32_t O2 = OUT2, typename RowId>
 __device__ __forceinline__ void score_rows(const float *__restrict__ vec, size_t stride,
 										   const float4 *q4, uint32_t nchunks, uint32_t kiters,
 										   RowId rowid, uint32_t nrows, float *out, int lane)
@@ -232,7 +233,7 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ vec, size_t
 			if (sub == 0 && v[rr])
 			{
 				out[r] = s0;
-				if (FUNC == F_COSINE) out[OUT2 + r] = s1;
+				if (FUNC == F_COSINE) out[O2 + r] = s1;
 			}
 		}
 	}
@@ -242,22 +243,22 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ vec, size_t
 // pass with RPG/2 or RPG/4 rows per group when that covers the remainder.  A hop yields 5-9 new rows on
 // average, so without this most passes issue (clamped, L1-hit) loads and arithmetic for absent rows.
 // The per-row summation order does not depend on RPG, so results are unchanged bit for bit.
-template <int FUNC, int KB, int RPG, typename RowId>
+template <int FUNC, int KB, int RPG, uint32_t O2 = OUT2, typename RowId>
 __device__ __forceinline__ void score_rows_fit(const float *__restrict__ vec, size_t stride,
 											   const float4 *q4, uint32_t nchunks, uint32_t kiters,
 											   RowId rowid, uint32_t nrows, float *out, int lane)
 {
 	const uint32_t full = nrows / (4 * RPG) * (4 * RPG);
-	if (full) score_rows<FUNC, KB, RPG>(vec, stride, q4, nchunks, kiters, rowid, full, out, lane);
+	if (full) score_rows<FUNC, KB, RPG, O2>(vec, stride, q4, nchunks, kiters, rowid, full, out, lane);
 	const uint32_t rem = nrows - full;
 	if (rem == 0) return;
 	auto shifted = [rowid, full](uint32_t r) { return rowid(full + r); };
 	if (RPG >= 4 && rem > 8)
-		score_rows<FUNC, KB, RPG>(vec, stride, q4, nchunks, kiters, shifted, rem, out + full, lane);
+		score_rows<FUNC, KB, RPG, O2>(vec, stride, q4, nchunks, kiters, shifted, rem, out + full, lane);
 	else if (RPG >= 2 && rem > 4)
-		score_rows<FUNC, KB, 2>(vec, stride, q4, nchunks, kiters, shifted, rem, out + full, lane);
+		score_rows<FUNC, KB, 2, O2>(vec, stride, q4, nchunks, kiters, shifted, rem, out + full, lane);
 	else
-		score_rows<FUNC, KB, 1>(vec, stride, q4, nchunks, kiters, shifted, rem, out + full, lane);
+		score_rows<FUNC, KB, 1, O2>(vec, stride, q4, nchunks, kiters, shifted, rem, out + full, lane);
 }
 
 // Load-batch shapes by chunk-steps per row (kiters = ceil(dim/64)).

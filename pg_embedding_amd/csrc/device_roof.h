@@ -47,4 +47,51 @@ __global__ __launch_bounds__(256) void gather_roof_kernel(const float4 *__restri
 	if (acc == 12345.678f) out[0] = acc;    // keeps the loads alive
 }
 
+// Replay roof: the rows ONE search launch scored (its per-query evaluation trace, hnsw_gpu_search_traced_dev), gathered again
+// by the same number of resident waves in the same query order (an atomic ticket, as the search kernel) with the search
+// kernel's own load shape — whole rows, 16 lanes per row, 16-byte loads, as many rows per pass as cover the same bytes in
+// flight per wave — and NOTHING in between: no pop, no link list, no visited test, no accept loop; the addresses of
+// pass k+1 do not depend on the data of pass k.  Same bytes, same temporal locality between the queries of a launch
+// (what the caches see is the same), no dependencies: search time / replay time is what the walk's dependent chain costs,
+// replay bytes / replay time is what the memory system gives this trace.  The search kernel cannot beat it.
+// T = 16-byte loads per lane per pass (search kernel: KB * RPG: 24 at 768 dims); a row is row_f4 float4 = row_f4/16 loads
+// per lane of its 16-lane group; the 4 groups of a wave take 4 * (T / (row_f4/16)) rows per pass.
+template <int T>
+__global__ __launch_bounds__(256) void replay_roof_kernel(const float4 *__restrict__ base, uint32_t row_f4, const uint32_t *__restrict__ evals,
+														   uint32_t evals_cap, const uint32_t *__restrict__ nevals, uint32_t nq,
+														   uint32_t *ticket, float *out)
+{
+	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t g = lane >> 4, sub = lane & 15;
+	const uint32_t lpr = (row_f4 + 15) / 16;                 // loads per lane per row
+	const uint32_t rpg = T / lpr ? T / lpr : 1;              // rows per group per pass
+	float acc = 0.f;
+	for (;;)
+	{
+		uint32_t qi = 0;
+		if (lane == 0) qi = atomicAdd(ticket, 1u);
+		qi = __builtin_amdgcn_readfirstlane(qi);
+		if (qi >= nq) break;
+		const uint32_t *ids = evals + (size_t) qi * evals_cap;
+		uint32_t ne = nevals[2 * (size_t) qi];               // (the search kernel's stats array: {evals, hops} per query)
+		ne = ne < evals_cap ? ne : evals_cap;
+		for (uint32_t r0 = 0; r0 < ne; r0 += 4 * rpg)
+		{
+			float4 v[T];
+#pragma unroll
+			for (int t = 0; t < T; t++)
+			{
+				const uint32_t rr = (uint32_t) t / lpr, c = ((uint32_t) t % lpr) * 16 + sub;
+				uint32_t r = r0 + rr * 4 + g;
+				r = r < ne ? r : ne - 1;                     // (clamped re-load of the last row, as the search kernel does)
+				const uint32_t row = ids[r];
+				v[t] = base[(size_t) row * row_f4 + (c < row_f4 ? c : row_f4 - 1)];
+			}
+#pragma unroll
+			for (int t = 0; t < T; t++) acc += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+		}
+	}
+	if (acc == 12345.678f) out[0] = acc;    // keeps the loads alive
+}
+
 }  // namespace pgemb

@@ -71,6 +71,9 @@ struct SearchArgs
 	uint32_t *out_stats;        // nq*2 {evals, hops} or null
 	uint32_t *out_pops;         // null, or nq * pops_cap element numbers: the walk's pop sequence (hnswalg.cpp:73), for callers that
 	uint32_t  pops_cap;         // validate a walk against the host (hnsw_gpu_search_trace); out_stats' hop count says how many
+	uint32_t *out_evals;        // null, or nq * evals_cap element numbers: the rows the walk scored, in scoring order (out_stats' evaluation
+	uint32_t  evals_cap;        // count says how many), and out_times[2*qi], [2*qi+1] = s_memrealtime at the query's start and at the end of
+	uint64_t *out_times;        // its walk — the trace the replay roof and the reuse analysis of bench.py are made from (hnsw_gpu_search_traced_dev)
 	uint32_t *done;             // null, or nq completion flags (host-visible): 1 is stored with system scope
 	                            // once query i's outputs are complete (hnsw_gpu_search_batch_ctx_flags)
 	// per-slot workspace
@@ -94,9 +97,33 @@ struct SearchArgs
 	uint32_t team_mains;        // waves of a block that take queries (wib < team_mains); the others start as helpers
 	uint32_t off_ctl;           // byte offset of the block's TeamCtl array in dynamic LDS (behind the wave regions)
 	uint32_t tm_off_ex, tm_off_miss, tm_off_lctag, tm_off_lcstate, tm_off_lclinks, tm_lcslots, tm_off_dc, tm_dccap;
+	uint32_t tm_spec;           // helpers of rank < tm_spec speculate (packages); the others score slices of the walking wave's rows
+	const uint32_t *abort_word; // null, or the workspace's abort word in pinned host memory (banner at abort_requested)
+	uint32_t *health;           // HEALTH_WORDS device words: time-out and abort counters of the workspace
 	uint32_t *team_dbg;         // null, or 16 counters for the whole launch (hnsw_gpu_team_counters): hops with helpers,
 	                            // link-list hits, ids looked up, distance hits, hops that still scored rows, all hops
 };
+
+// Abort word + health words of a search workspace.
+//   abort_word (PINNED HOST memory, so the host sets it with a plain store from any thread and the device's read can never be
+//     served from a cache): non-zero = the host asks the launches of this workspace to end (hnsw_gpu_index_abort / the
+//     library's watchdog).  Every wave looks at the top of a query and every 256 hops of a walk — a read across the host
+//     link, ~2 us, a fraction of a percent of a walk — and leaves.  Outputs of that launch are undefined and the workspace
+//     is re-zeroed before the next one.  Nothing in the kernels waits without a bound, so this is for the unknown: a hung
+//     launch costs its caller's timeout, not the device.
+//   health (device memory, totals of the workspace's life, all zero in a healthy one):
+//   [HEALTH_SLICE_TIMEOUTS]   team form: slices a helper did not deliver within SLICE_WAIT_POLLS (scored by the walking wave)
+//   [HEALTH_PACKAGE_TIMEOUTS] team form: packages still "claimed" after 4000 polls (fetched by the walking wave)
+//   [HEALTH_ABORTED_WAVES]    waves that left a launch because of the abort word
+//   [HEALTH_SLICES_DELIVERED] team form: slices helpers scored for walking waves (says the mechanism is in use; one
+//                             non-returning atomic per job)
+enum : uint32_t { HEALTH_SLICE_TIMEOUTS = 1, HEALTH_PACKAGE_TIMEOUTS = 2, HEALTH_ABORTED_WAVES = 3, HEALTH_SLICES_DELIVERED = 4, HEALTH_WORDS = 16 };
+
+__device__ __forceinline__ bool abort_requested(const SearchArgs &a)
+{
+	if (!a.abort_word) return false;
+	return __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0u;
+}
 
 // Streamed completion: everything this wave wrote for the query becomes visible system-wide, then
 // the flag.  Once per query, outside the hop loop.
@@ -424,6 +451,7 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 	uint32_t *vis  = a.vis + (size_t) slot * a.vis_words;
 	uint32_t *vlog = a.vlog + (size_t) slot * a.logcap;
 	const uint32_t ef = a.ef;
+	bool aborted = false;              // the host asked this launch to end (abort word)
 
 	for (;;)
 	{
@@ -431,6 +459,8 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 		if (lane == 0) qi = atomicAdd(a.ticket, 1u);
 		qi = __builtin_amdgcn_readfirstlane(qi);
 		if (qi >= a.nq) break;
+		if (abort_requested(a)) { aborted = true; break; }
+		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi] = __builtin_amdgcn_s_memrealtime();
 
 		const float *qsrc = a.queries + (size_t) qi * a.q_stride;
 		for (uint32_t e = lane; e < a.qpad_floats; e += 64)
@@ -467,6 +497,7 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 			wave_sync();
 			float lowerBound = finish_dist<FUNC>(newdist[0], newdist[OUT2], qnorm);
 			evals = 1;
+			if (a.out_evals && a.evals_cap && lane == 0) a.out_evals[(size_t) qi * a.evals_cap] = ep;
 			{
 				const uint64_t hi = (uint64_t) ord_f32(lowerBound) << 32;
 				res_insert<RREG>(rk, hi | ep, lane);
@@ -499,6 +530,7 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 				if (a.out_pops && hops < a.pops_cap && lane == 0)       // (system scope: a host that polls the sequence sees it as the walk goes)
 					__hip_atomic_store(a.out_pops + (size_t) qi * a.pops_cap + hops, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 				hops++;
+				if ((hops & 255u) == 0u && abort_requested(a)) { aborted = true; break; }
 
 				for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)               // :76-77
 				{
@@ -523,6 +555,7 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 					if (isnew)
 					{
 						newid[rank] = t;
+						if (a.out_evals && evals + rank < a.evals_cap) a.out_evals[(size_t) qi * a.evals_cap + evals + rank] = t;   // (measurement: the rows this walk scores, in order)
 						if (spill)                                          // only bitmap bits need undoing
 						{
 							const uint32_t lp = logn + rank;
@@ -576,6 +609,8 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 			}
 		}
 
+		if (aborted) break;
+		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi + 1] = __builtin_amdgcn_s_memrealtime();
 		// ---- emit -------------------------------------------------------------------------
 		const size_t obase = (size_t) qi * a.out_stride;
 		uint32_t nout = 0;
@@ -689,6 +724,7 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 		__builtin_amdgcn_s_waitcnt(0);
 		wave_sync();
 	}
+	if (aborted && lane == 0) atomicAdd(a.health + HEALTH_ABORTED_WAVES, 1u);
 }
 
 
@@ -802,6 +838,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 	uint32_t *vis  = a.vis + (size_t) slot * a.vis_words;
 	uint32_t *vlog = a.vlog + (size_t) slot * a.logcap;
 	const uint32_t ef = a.ef;
+	bool aborted = false;              // the host asked this launch to end (abort word)
 
 	for (;;)
 	{
@@ -809,6 +846,8 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 		if (lane == 0) qi = atomicAdd(a.ticket, 1u);
 		qi = __builtin_amdgcn_readfirstlane(qi);
 		if (qi >= a.nq) break;
+		if (abort_requested(a)) { aborted = true; break; }
+		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi] = __builtin_amdgcn_s_memrealtime();
 
 		const float *qsrc = a.queries + (size_t) qi * a.q_stride;
 		for (uint32_t e = lane; e < a.qpad_floats; e += 64)
@@ -833,6 +872,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 			set_sync<G>();
 			float lowerBound = finish_dist<FUNC>(newdist[0], newdist[OUT2], qnorm);
 			evals = 1;
+			if (a.out_evals && a.evals_cap && lane == 0) a.out_evals[(size_t) qi * a.evals_cap] = ep;
 			if (lane == 0)
 			{
 				const uint32_t o = ord_f32(lowerBound);
@@ -857,6 +897,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 				if (a.out_pops && hops < a.pops_cap && lane == 0)       // (system scope: a host that polls the sequence sees it as the walk goes)
 					__hip_atomic_store(a.out_pops + (size_t) qi * a.pops_cap + hops, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 				hops++;
+				if ((hops & 255u) == 0u && abort_requested(a)) { aborted = true; break; }
 
 				for (uint32_t j0 = 0; j0 < a.maxM; j0 += 64)               // :76-77
 				{
@@ -876,6 +917,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 					if (isnew)
 					{
 						newid[rank] = t;
+						if (a.out_evals && evals + rank < a.evals_cap) a.out_evals[(size_t) qi * a.evals_cap + evals + rank] = t;   // (measurement: the rows this walk scores, in order)
 						const uint32_t lp = logn + rank;
 						if (lp < a.logcap) vlog[lp] = t;
 					}
@@ -932,6 +974,8 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 			}
 		}
 
+		if (aborted) break;
+		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi + 1] = __builtin_amdgcn_s_memrealtime();
 		// ---- emit: rank-sort the unsorted result array ----------------------------------------
 		// (G: the arrays are final now; drop this CU's L1 copies of them once — an earlier query of this slot
 		// read them through L1 here — and read them with plain, freely pipelined loads)
@@ -1015,6 +1059,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 		__builtin_amdgcn_s_waitcnt(0);   // drain: the next query's atomics must see the zeros
 		set_sync<G>();
 	}
+	if (aborted && lane == 0) atomicAdd(a.health + HEALTH_ABORTED_WAVES, 1u);
 }
 
 
@@ -1222,12 +1267,38 @@ __device__ __forceinline__ uint32_t hop_stamp()
 	return t;
 }
 
+constexpr uint32_t SLICE_ROWS = 16;             // rows of the widest scoring pass (4 * RPG, RPG <= 4) = the largest slice
 struct TeamCtl
 {
 	uint32_t state;        // 0 = has or may get a query but is not walking, 1 = walking, 2 = will never walk again
 	uint32_t helpers;      // main: bit h set = wave h of this block is helping me
-	uint32_t pad0, pad1;
+	uint32_t job;          // main: a scoring job for its slice helpers: view << 15 | helper mask << 7 | rows ...
+	uint32_t jobseq;       // ... and its number (written after `job`, read before and after it: a helper never pairs one
+	                       //     job's number with another job's description)
+	uint32_t done;         // helper: number of the last job whose slice I finished (my sums are in `slice`)
+	uint32_t pad0, pad1, pad2;
+	float    slice[2 * SLICE_ROWS];     // helper: sums of my slice [0, SLICE_ROWS) and, cosine, |x|^2 behind them
 };
+// A hop of the descent from the entry point brings 20-32 unvisited rows and no package can exist for it (the popped
+// element was accepted one hop earlier): 3-4 scoring passes of the walking wave alone, each a full HBM round trip —
+// a tenth of a single query's time (profiles/r2zf_team_hop_pattern.txt).  Helpers beyond the first tm_spec do not
+// speculate; they wait for such a hop and score 8-row slices of it with the same canonical code, so the hop costs ONE
+// round trip.  Protocol (every wait in it is BOUNDED; what a helper does not deliver in time the walking wave scores
+// itself, so a protocol mistake costs time, never a hang and never a wrong sum):
+//   main    writes the id list (its view's `miss` array), then ctl[main].job, then ++ctl[main].jobseq; scores the first
+//           pass itself; then, per named helper, polls ctl[helper].done == jobseq (bounded), copies that helper's
+//           `slice` into its own sum array — or, after the bound, scores the slice itself;
+//   helper  sees jobseq change (it remembered the number from BEFORE its helper bit became visible, so a job that names
+//           it always looks new), reads job between two reads of jobseq, scores its slice into ITS OWN ctl[me].slice
+//           (never into the main's arrays: a helper that is late for a job the main gave up on writes where nobody
+//           reads), then stores ctl[me].done = that job's number.  A late `done` never equals a later job's number.
+// (job word: the helper mask is the walking wave's own snapshot, so a helper that attaches meanwhile changes nobody's
+// slice; `view` = whose region holds the id list.)
+constexpr uint32_t SLICE_WAIT_POLLS = 20000;    // ~1 ms of polling: two orders of magnitude above a slice's round trip
+__device__ __forceinline__ uint32_t lds_load_u32(const uint32_t *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 constexpr uint64_t DC_EMPTY = ~0ull;
 constexpr uint32_t OD_MISSING = 0xFFFFFFFFu;      // package entry without a distance (ord() of a real distance is never all ones: that is a NaN payload no sum produces... guarded anyway: such an entry is simply re-scored)
 constexpr uint32_t PK_VISITED = 0x80000000u;
@@ -1349,6 +1420,10 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 		for (uint32_t i = lane; i < 64u * UREG; i += 64) mine.pub[i] = ~0ull;
 		mine.ex[lane] = 0;
 		wave_sync();
+		// (read BEFORE my bit becomes visible: a job the walking wave posts from now on may name me, and must look new to me;
+		// reading it after the atomicOr could swallow a job posted in between — the walking wave would wait for me forever)
+		uint32_t last_job = __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[target].jobseq));
+		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		if (lane == 0) atomicOr(&ctl[target].helpers, 1u << wib);
 		unsigned char *mreg = smem + (size_t) target * a.wave_bytes;
 		const float4 *q4 = reinterpret_cast<const float4 *>(mreg);
@@ -1364,6 +1439,33 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 			if (!(hm & (1u << wib))) break;
 			const TeamView pubv = team_view(smem, a, (uint32_t) __builtin_ctz(hm));
 			const uint32_t myrank = (uint32_t) __builtin_popcount(hm & ((1u << wib) - 1u));
+			// a scoring job of the walking wave?  (every helper looks; the job names its slice helpers)
+			{
+				const uint32_t js = __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[target].jobseq));
+				if (js != last_job)
+				{
+					wave_sync();
+					const uint32_t job = __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[target].job));
+					wave_sync();
+					if ((uint32_t) __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[target].jobseq)) != js) continue;   // a newer job is being written: look again
+					last_job = js;
+					const uint32_t jm = (job >> 7) & 0xFFu, jn = job & 0x7Fu;
+					constexpr uint32_t PASS = 4u * SH::RPG;             // rows of one scoring pass = one slice
+					static_assert(PASS <= SLICE_ROWS, "slice area too small for this shape");
+					const uint32_t lo = PASS + PASS * (uint32_t) __builtin_popcount(jm & ((1u << wib) - 1u));
+					if ((jm & (1u << wib)) && lo < jn)
+					{
+						const uint32_t cnt = jn - lo < PASS ? jn - lo : PASS;
+						const uint32_t *ids = team_view(smem, a, (job >> 15) & 7u).miss + lo;
+						auto by_id = [ids](uint32_t r) { return ids[r]; };
+						score_rows_fit<FUNC, SH::KB, SH::RPG, SLICE_ROWS>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, cnt, ctl[wib].slice, lane);
+						wave_sync();
+						if (lane == 0) __hip_atomic_store(&ctl[wib].done, js, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+					}
+					continue;
+				}
+				if (myrank >= a.tm_spec) { __builtin_amdgcn_s_sleep(1); continue; }     // a slice helper does not speculate
+			}
 			// snapshot of the main's accepted set: candidate keys (dist, ~idx) of the unexpanded elements
 			uint64_t ck[UREG];
 			const uint32_t ex = pubv.ex[lane];
@@ -1489,11 +1591,12 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 	uint32_t *vlog = a.vlog + (size_t) slot * a.logcap;
 	uint64_t *scratch = a.beam_scratch + (size_t) slot * UCAP;
 	const uint32_t ef = a.ef;
+	bool aborted = false;              // the host asked this launch to end (abort word)
 	TeamCtl *ctl = reinterpret_cast<TeamCtl *>(smem + a.off_ctl);
 	const uint32_t wpb = blockDim.x >> 6;
 	if (TEAM)
 	{
-		if (lane == 0) { ctl[wib].state = wib < a.team_mains ? 0u : 2u; ctl[wib].helpers = 0u; }
+		if (lane == 0) { ctl[wib].state = wib < a.team_mains ? 0u : 2u; ctl[wib].helpers = 0u; ctl[wib].job = 0u; ctl[wib].jobseq = 0u; ctl[wib].done = 0u; }
 		__syncthreads();
 	}
 
@@ -1504,6 +1607,8 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		if (lane == 0) qi = atomicAdd(a.ticket, 1u);
 		qi = __builtin_amdgcn_readfirstlane(qi);
 		if (qi >= a.nq) break;
+		if (abort_requested(a)) { aborted = true; break; }
+		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi] = __builtin_amdgcn_s_memrealtime();
 
 		const float *qsrc = a.queries + (size_t) qi * a.q_stride;
 		for (uint32_t e = lane; e < a.qpad_floats; e += 64)
@@ -1523,6 +1628,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		uint32_t bstale = 0xFFFFFFFFu;       // ord() of a valid upper bound of the reference's lowerBound
 		bool spill = a.hcap == 0;
 		uint32_t hs_pop = 0, hs_link = 0, hs_vis = 0, hs_score = 0, hs_acc = 0, hs_q0 = 0;
+		uint32_t jobseq = TEAM ? (uint32_t) __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[wib].jobseq)) : 0u;   // scoring jobs posted by this wave so far
 		if (HOP_STAMPS && a.team_dbg) hs_q0 = hop_stamp();
 		const uint32_t hnb = a.hcap / 4u;                                  // buckets of the visited set
 		if (a.hcap)
@@ -1542,6 +1648,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 			wave_sync();
 			const float d0 = finish_dist<FUNC>(newdist[0], newdist[OUT2], qnorm);
 			evals = 1;
+			if (a.out_evals && a.evals_cap && lane == 0) a.out_evals[(size_t) qi * a.evals_cap] = ep;
 			beam_set<UREG>(uk, 0, ((uint64_t) ord_f32(d0) << 32) | ep, lane);
 			usize = 1;
 			if (lane == 0)
@@ -1550,10 +1657,10 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				else { uint32_t eb, et; tagset_split(ep, hnb, a.hmagic, eb, et); htab[4u * eb] = et; }   // empty table: slot 0 of its bucket
 				// Nobody helps this walk yet.  A helper of my PREVIOUS walk that was in the middle of a step when that walk ended
 				// may not have seen state 0 in between (1 -> 0 -> 1): its region still holds packages scored against the previous
-				// query, and its bit would make me read them.  Without its bit it leaves at its next look (team_help) and attaches
-				// again with a clean region.  (Only a wave that takes a second query while siblings help can meet this: a small
-				// launch whose other blocks started late.)
-				if (TEAM) ctl[wib].helpers = 0u;
+				// query, and its bit would make me read them (and name it in a scoring job).  Without its bit it leaves at its next
+				// look (team_help) and attaches again with a clean region.  (Only a wave that takes a second query while siblings
+				// help can meet this: a small launch whose other blocks started late.)
+				if (TEAM) __hip_atomic_store(&ctl[wib].helpers, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (lane 0 only; helpers set their bits with atomicOr)
 			}
 			logn = spill ? 1 : 0;
 			hcount = 1;
@@ -1578,6 +1685,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				if (a.out_pops && hops < a.pops_cap && lane == 0)       // (system scope: a host that polls the sequence sees it as the walk goes)
 					__hip_atomic_store(a.out_pops + (size_t) qi * a.pops_cap + hops, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 				hops++;
+				if ((hops & 255u) == 0u && abort_requested(a)) { aborted = true; break; }
 				if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_pop += hs1 - hs0; hs0 = hs1; }
 				TeamView h0v = {};
 				if (TEAM && (TEAM_COUNT && a.team_dbg) && lane == 0) { atomicAdd(a.team_dbg + 5, 1u); if (hm) atomicAdd(a.team_dbg + 0, 1u); }
@@ -1611,6 +1719,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 							u = uniform_u64(*pkh);
 						}
 						have_pk = u == ((uint64_t) cur | ((uint64_t) LC_DONE << 32));
+						if (spins == 4000 && a.health && lane == 0) atomicAdd(a.health + HEALTH_PACKAGE_TIMEOUTS, 1u);
 						if ((TEAM_COUNT && a.team_dbg) && spins && lane == 0) { atomicAdd(a.team_dbg + 6, spins); atomicAdd(a.team_dbg + 10, 1u); }
 					}
 				}
@@ -1673,6 +1782,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 					if (isnew)
 					{
 						newid[rank] = t;
+						if (a.out_evals && evals + rank < a.evals_cap) a.out_evals[(size_t) qi * a.evals_cap + evals + rank] = t;   // (measurement: the rows this walk scores, in order)
 						if (TEAM && hm) reinterpret_cast<uint32_t *>(newdist)[rank] = od_pk;      // packaged distance, link order kept
 					}
 					wave_sync();
@@ -1709,7 +1819,66 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 					{
 						const uint32_t *ids = sids;
 						auto by_id = [ids](uint32_t r) { return ids[r]; };
-						score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nscore, newdist, lane);
+						constexpr uint32_t PASS = 4u * SH::RPG;                 // rows of one scoring pass = one slice
+						uint32_t jm = 0;                                        // helpers given slice k = rows PASS * (1 + k) .. (banner at TeamCtl)
+						if (TEAM && hm && nscore > PASS)
+						{
+							uint32_t m = hm;
+							for (uint32_t i = 0; i < a.tm_spec && m; i++) m &= m - 1;          // the speculating helpers stay out of it
+							const uint32_t want = (nscore - 1) / PASS;
+							for (uint32_t i = 0; i < want && m; i++) { jm |= m & (0u - m); m &= m - 1; }
+							if (jm)
+							{
+								++jobseq;
+								if (lane == 0)
+									__hip_atomic_store(&ctl[wib].job, ((uint32_t) __builtin_ctz(hm) << 15) | (jm << 7) | nscore, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+								wave_sync();                                    // (one wave's LDS operations are served in issue order)
+								if (lane == 0)
+									__hip_atomic_store(&ctl[wib].jobseq, jobseq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+							}
+						}
+						if (jm == 0)
+							score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, nscore, newdist, lane);
+						else
+						{
+							score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, PASS, newdist, lane);
+							const uint32_t covered = PASS + PASS * (uint32_t) __builtin_popcount(jm);   // what I and the slice helpers take; the rest (few helpers) is mine too
+							if (covered < nscore)
+							{
+								auto rest = [ids, covered](uint32_t r) { return ids[covered + r]; };
+								score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, rest, nscore - covered, newdist + covered, lane);
+							}
+							uint32_t lo = PASS, ngot = 0;
+							for (uint32_t mm = jm; mm; mm &= mm - 1, lo += PASS)
+							{
+								const uint32_t h = (uint32_t) __builtin_ctz(mm);
+								const uint32_t cnt = nscore - lo < PASS ? nscore - lo : PASS;
+								uint32_t polls = 0;
+								bool got = (uint32_t) __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[h].done)) == jobseq;
+								for (; !got && polls < SLICE_WAIT_POLLS; polls++)
+								{
+									__builtin_amdgcn_s_sleep(0);
+									got = (uint32_t) __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[h].done)) == jobseq;
+								}
+								wave_sync();
+								if (got)
+								{
+									ngot++;
+									if ((uint32_t) lane < cnt)
+									{
+										newdist[lo + lane] = ctl[h].slice[lane];
+										if (FUNC == F_COSINE) newdist[OUT2 + lo + lane] = ctl[h].slice[SLICE_ROWS + lane];
+									}
+								}
+								else                                            // not delivered: the slice is mine (and whatever that helper writes later goes to its own area)
+								{
+									if (a.health && lane == 0) atomicAdd(a.health + HEALTH_SLICE_TIMEOUTS, 1u);
+									auto part = [ids, lo](uint32_t r) { return ids[lo + r]; };
+									score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, part, cnt, newdist + lo, lane);
+								}
+							}
+							if (a.health && ngot && lane == 0) atomicAdd(a.health + HEALTH_SLICES_DELIVERED, ngot);
+						}
 						wave_sync();
 						const uint32_t od_m = ord_f32(finish_dist<FUNC>(newdist[krank & 63], newdist[OUT2 + (krank & 63)], qnorm));
 						od_mine = hit ? od_c : od_m;
@@ -1720,6 +1889,28 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 					if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_score += hs1 - hs0; hs0 = hs1; }
 					// rows at or above a valid upper bound of lowerBound cannot be accepted (:99)
 					uint64_t todo = __ballot((uint32_t) lane < nnew && od_mine < bstale);
+					// While the accepted set is below ef every row is accepted whatever its distance (hnswalg.cpp:99: size < ef), one by
+					// one in the reference; the set is unordered here, so a hop whose rows ALL fit below ef is appended in one step:
+					// row r goes to slot usize + r, fetched by the lane that owns that slot (ds_bpermute), no count, no per-row loop.
+					// The first ~ef accepts of every walk — the many-row hops of the descent from the entry point — go this way.
+					if (usize + nnew <= ef && (uint32_t) __builtin_popcountll(todo) == nnew)
+					{
+#pragma unroll
+						for (int k = 0; k < UREG; k++)
+						{
+							const uint32_t lo = (uint32_t) k * 64u;
+							if (usize + nnew > lo && usize < lo + 64u)          // (wave-uniform) this register receives rows
+							{
+								const int r = (int) (lo + (uint32_t) lane) - (int) usize;
+								const uint32_t od_r = (uint32_t) __builtin_amdgcn_ds_bpermute((r & 63) << 2, (int) od_mine);
+								const uint32_t id_r = (uint32_t) __builtin_amdgcn_ds_bpermute((r & 63) << 2, (int) t_mine);
+								const bool take = r >= 0 && (uint32_t) r < nnew;
+								uk[k] = take ? (((uint64_t) od_r << 32) | id_r) : uk[k];
+							}
+						}
+						usize += nnew;
+						todo = 0;
+					}
 					while (todo)                                            // :99-108, in link order
 					{
 						const uint32_t r = (uint32_t) __builtin_ctzll(todo);
@@ -1755,6 +1946,8 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		}
 
 		if (TEAM && lane == 0) ctl[wib].state = 0u;                       // walk over: helpers let go
+		if (aborted) break;
+		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi + 1] = __builtin_amdgcn_s_memrealtime();
 		uint32_t hs_walk = 0;
 		if (HOP_STAMPS && a.team_dbg) hs_walk = hop_stamp();
 		// ---- emit: the ef smallest (dist, idx) keys of the set, then the reference's output order ----
@@ -1896,6 +2089,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 			atomicAdd(a.team_dbg + 7, (hs_end - hs_walk) >> 6);     // emit + bitmap clean-up
 		}
 	}
+	if (aborted && lane == 0) atomicAdd(a.health + HEALTH_ABORTED_WAVES, 1u);
 	if (TEAM)
 	{
 		if (lane == 0) ctl[wib].state = 2u;

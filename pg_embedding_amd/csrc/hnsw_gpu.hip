@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <thread>
+#include <chrono>
 #include <new>
 #include <vector>
 
@@ -73,24 +75,122 @@ struct SearchWs
 	uint32_t last_slots = 0;
 	uint32_t *done_next = nullptr;                       // completion flags for the next launch only
 	uint32_t *pops_next = nullptr; uint32_t pops_cap_next = 0;   // pop-sequence output for the next launch only
+	uint32_t *evals_next = nullptr; uint32_t evals_cap_next = 0; uint64_t *times_next = nullptr;   // evaluation trace, next launch only
 	char kname[96] = "";                                 // symbol of the kernel the last launch used (as rocprofv3 prints it)
 	uint32_t *team_dbg = nullptr;                        // 8 launch-wide counters of the team form (HNSW_GPU_TEAM_COUNTERS=1)
+	// abort word (pinned host memory) + health counters (device memory): device_search.h, banner at abort_requested
+	uint32_t *abort_host = nullptr;
+	uint32_t *health = nullptr;
+	int device = 0;
+	int abort_sent = 0;                                  // (atomic) an abort was requested: the next launch re-zeroes the workspace
+	int64_t busy_since_ms = 0;                           // (atomic) steady-clock ms of the last launch, 0 = known idle (watchdog)
 };
+
+// ------------------------------------------------------------------------------------
+// Abort + watchdog.  No wait inside the kernels is unbounded, so a launch that never ends would be a
+// bug nobody has thought of; the abort word makes such a launch cost its caller's patience instead of
+// the device: every wave reads the abort word at the top of a query / every 256 hops and leaves.
+// Every workspace is registered here so that ANY thread (a test watchdog, a signal-safe helper thread,
+// the library's own watchdog: HNSW_GPU_WATCHDOG_S=<seconds>) can reach it without the mirror's lock —
+// the thread that owns the lock is the one that is stuck.
+// ------------------------------------------------------------------------------------
+static std::mutex g_ws_mu;
+static std::vector<SearchWs *> g_ws_all;
+static bool g_watchdog_started = false;
+
+static int64_t now_ms()
+{
+	return (int64_t) std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// g_ws_mu held.  The abort word lives in pinned host memory: a plain store, no HIP call, nothing that could queue behind
+// the launch it is meant to end.
+static int abort_ws_locked(SearchWs *w)
+{
+	if (!w->abort_host) return 0;
+	__atomic_store_n(&w->abort_sent, 1, __ATOMIC_SEQ_CST);
+	__atomic_store_n(w->abort_host, 1u, __ATOMIC_SEQ_CST);
+	return 1;
+}
+
+extern "C" int hnsw_gpu_abort_all(void)
+{
+	std::lock_guard<std::mutex> g(g_ws_mu);
+	int n = 0;
+	for (SearchWs *w : g_ws_all) n += abort_ws_locked(w);
+	return n;
+}
+
+static void watchdog_main(int limit_s)
+{
+	for (;;)
+	{
+		std::this_thread::sleep_for(std::chrono::milliseconds(500));
+		std::lock_guard<std::mutex> g(g_ws_mu);
+		const int64_t now = now_ms();
+		for (SearchWs *w : g_ws_all)
+		{
+			const int64_t since = __atomic_load_n(&w->busy_since_ms, __ATOMIC_SEQ_CST);
+			if (since == 0 || now - since < (int64_t) limit_s * 1000 || __atomic_load_n(&w->abort_sent, __ATOMIC_SEQ_CST)) continue;
+			const uint64_t l = __atomic_load_n(&w->launches, __ATOMIC_SEQ_CST);
+			if (l == 0) continue;
+			hipEvent_t ev = w->ev1[(l - 1) % SearchWs::EV_RING];
+			if (!ev || hipEventQuery(ev) != hipErrorNotReady)
+			{
+				// finished (or unknown): idle unless a newer launch has stamped it meanwhile
+				int64_t expect = since;
+				(void) __atomic_compare_exchange_n(&w->busy_since_ms, &expect, (int64_t) 0, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+				continue;
+			}
+			fprintf(stderr, "hnsw_gpu watchdog: search kernel %s on device %d has been running for %lld s (limit %d s): aborting it\n",
+					w->kname, w->device, (long long) ((now - since) / 1000), limit_s);
+			(void) abort_ws_locked(w);
+		}
+	}
+}
+
+// g_ws_mu NOT held
+static void ws_register(SearchWs *w)
+{
+	std::lock_guard<std::mutex> g(g_ws_mu);
+	g_ws_all.push_back(w);
+	if (!g_watchdog_started)
+	{
+		g_watchdog_started = true;
+		const char *e = getenv("HNSW_GPU_WATCHDOG_S");
+		if (e && atoi(e) > 0) std::thread(watchdog_main, atoi(e)).detach();
+	}
+}
+
+static void ws_unregister(SearchWs *w)
+{
+	std::lock_guard<std::mutex> g(g_ws_mu);
+	g_ws_all.erase(std::remove(g_ws_all.begin(), g_ws_all.end(), w), g_ws_all.end());
+}
 
 static int ws_init(SearchWs *w)
 {
 	HIPCHK(hipMalloc(&w->ticket, 64));
 	HIPCHK(hipMemset(w->ticket, 0, 64));
+	HIPCHK(hipMalloc(&w->health, HEALTH_WORDS * 4));
+	HIPCHK(hipMemset(w->health, 0, HEALTH_WORDS * 4));
+	HIPCHK(hipHostMalloc((void **) &w->abort_host, 64, hipHostMallocDefault));
+	memset(w->abort_host, 0, 64);
+	(void) hipGetDevice(&w->device);
 	for (int i = 0; i < SearchWs::EV_RING; i++)
 	{
 		HIPCHK(hipEventCreate(&w->ev0[i]));
 		HIPCHK(hipEventCreate(&w->ev1[i]));
 	}
+	ws_register(w);
 	return HNSW_GPU_OK;
 }
 
 static void ws_free(SearchWs *w)
 {
+	ws_unregister(w);
+	if (w->health) (void) hipFree(w->health);
+	if (w->abort_host) (void) hipHostFree(w->abort_host);
 	if (w->vis) (void) hipFree(w->vis);
 	if (w->beam) (void) hipFree(w->beam);
 	if (w->sets) (void) hipFree(w->sets);
@@ -776,6 +876,13 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 			a.tm_off_ex = (uint32_t) o_ex; a.tm_off_miss = (uint32_t) o_miss; a.tm_off_lctag = (uint32_t) o_tag;
 			a.tm_off_lcstate = (uint32_t) o_state; a.tm_off_lclinks = (uint32_t) o_links; a.tm_lcslots = lcs;
 			a.tm_off_dc = (uint32_t) o_dc; a.tm_dccap = (uint32_t) dccap;
+			{
+				// helpers of rank < tm_spec prepare packages ahead of the walk; the others score slices of its many-row hops
+				// (device_search.h, banner at TeamCtl).  HNSW_GPU_TEAM_SPEC overrides (8 = every helper speculates, no job is
+				// ever posted).
+				const char *senv = getenv("HNSW_GPU_TEAM_SPEC");
+				a.tm_spec = senv ? (uint32_t) std::max(0, atoi(senv)) : 5u;
+			}
 			int maxlds = 64 * 1024;
 			(void) hipDeviceGetAttribute(&maxlds, hipDeviceAttributeMaxSharedMemoryPerBlock, ix->device);
 			const char *wenv = getenv("HNSW_GPU_TEAM_WPB");
@@ -835,6 +942,16 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		HIPCHK(hipMemsetAsync(w->vis, 0, slots * words * 4, stream));
 		w->vis_slots = slots; w->vis_words = words; w->logcap = logcap;
 	}
+	if (__atomic_load_n(&w->abort_sent, __ATOMIC_SEQ_CST))
+	{
+		// the previous launch of this workspace was asked to end early: its waves left their bitmaps as they were
+		HIPCHK(hipStreamSynchronize(stream));
+		if (stream) HIPCHK(hipStreamSynchronize(nullptr));
+		if (w->vis) HIPCHK(hipMemset(w->vis, 0, w->vis_slots * w->vis_words * 4));
+		__atomic_store_n(w->abort_host, 0u, __ATOMIC_SEQ_CST);
+		__atomic_store_n(&w->abort_sent, 0, __ATOMIC_SEQ_CST);
+	}
+	a.health = w->health; a.abort_word = w->abort_host;
 	a.vis = w->vis; a.vis_words = words; a.vlog = w->vlog; a.logcap = w->logcap;
 	if (ucap && slots * ucap > w->beam_keys)
 	{
@@ -867,14 +984,17 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	w->done_next = nullptr;
 	a.out_pops = w->pops_next; a.pops_cap = w->pops_cap_next;
 	w->pops_next = nullptr; w->pops_cap_next = 0;
+	a.out_evals = w->evals_next; a.evals_cap = w->evals_cap_next; a.out_times = w->times_next;
+	w->evals_next = nullptr; w->evals_cap_next = 0; w->times_next = nullptr;
 	HIPCHK(hipMemsetAsync(w->ticket, 0, 8, stream));
 
 	const int evi = (int) (w->launches % SearchWs::EV_RING);
 	HIPCHK(hipEventRecord(w->ev0[evi], stream));
+	__atomic_store_n(&w->busy_since_ms, now_ms(), __ATOMIC_SEQ_CST);
 	hipLaunchKernelGGL(kern, dim3((uint32_t) blocks), dim3(wpb * 64), lds, stream, a);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(w->ev1[evi], stream));
-	w->launches++;
+	__atomic_store_n(&w->launches, w->launches + 1, __ATOMIC_SEQ_CST);
 	w->last_slots = (uint32_t) slots;
 	return HNSW_GPU_OK;
 }
@@ -886,11 +1006,67 @@ extern "C" int hnsw_gpu_search_batch_dev(hnsw_gpu_index *ix, const coord_t *d_qu
 	return launch_search(ix, ix ? &ix->ws : nullptr, d_queries, ix ? ix->meta.dim : 0, nq, ef, 0, d_labels, nullptr, d_dists, d_counts, d_stats, (hipStream_t) stream);
 }
 
+// The same launch as hnsw_gpu_search_batch_dev that also writes its evaluation trace: d_evals[i * evals_cap + j] = the j-th row
+// query i scored (j < d_stats[2 * i], truncated at evals_cap), d_times[2 * i], [2 * i + 1] = the device's constant-rate clock
+// (100 MHz) at the start of query i and at the end of its walk.  Measurement only (bench.py: replay roof, reuse distances).
+extern "C" int hnsw_gpu_search_traced_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t ef,
+										  label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
+										  idx_t *d_evals, size_t evals_cap, uint64_t *d_times, void *stream)
+{
+	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
+	if (!d_evals || evals_cap == 0 || evals_cap > 0xFFFFFFFFull || !d_stats) return fail(HNSW_GPU_ERR_ARG, "trace buffers missing");
+	std::lock_guard<std::recursive_mutex> g(ix->mu);
+	ix->ws.evals_next = d_evals; ix->ws.evals_cap_next = (uint32_t) evals_cap; ix->ws.times_next = d_times;
+	const int rc = launch_search(ix, &ix->ws, d_queries, ix->meta.dim, nq, ef, 0, d_labels, nullptr, d_dists, d_counts, d_stats, (hipStream_t) stream);
+	ix->ws.evals_next = nullptr; ix->ws.evals_cap_next = 0; ix->ws.times_next = nullptr;
+	return rc;
+}
+
 extern "C" int hnsw_gpu_search_base_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t ef,
 										idx_t *d_idx, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
 										void *stream)
 {
 	return launch_search(ix, ix ? &ix->ws : nullptr, d_queries, ix ? ix->meta.dim : 0, nq, ef, 1, nullptr, d_idx, d_dists, d_counts, d_stats, (hipStream_t) stream);
+}
+
+// Poll a completion flag the kernel stores into pinned host memory.  0 = set; otherwise an error: the kernel ended
+// without storing it, or it has not stored it within two minutes (HNSW_GPU_POLL_LIMIT_S; a walk is under a
+// millisecond: the device is hung, and polling for ever would hang the caller with it).
+static int poll_limit_s()
+{
+	const char *e = getenv("HNSW_GPU_POLL_LIMIT_S");
+	return e && atoi(e) > 0 ? atoi(e) : 120;
+}
+
+static int poll_done_flag(const volatile uint32_t *flag, const char *what)
+{
+	uint64_t spins = 0;
+	struct timespec t0;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	while (*flag == 0)
+	{
+		__builtin_ia32_pause();
+		if ((++spins & 0xFFFF) == 0)
+		{
+			if (hipStreamQuery(nullptr) != hipErrorNotReady)
+			{
+				HIPCHK(hipStreamSynchronize(nullptr));                  // the kernel is gone: either it has just stored the flag, or it died
+				if (*flag == 0) return fail(HNSW_GPU_ERR_INTERNAL, "search kernel ended without completing %s", what);
+				break;
+			}
+			struct timespec t1;
+			clock_gettime(CLOCK_MONOTONIC, &t1);
+			if (t1.tv_sec - t0.tv_sec > poll_limit_s())
+			{
+				// ask the launch to end (every wave looks at the abort word between queries and every 256 hops), so that the
+				// device is usable again even though this call fails
+				(void) hnsw_gpu_abort_all();
+				return fail(HNSW_GPU_ERR_INTERNAL, "search kernel did not complete %s within %d s (abort requested)", what, poll_limit_s());
+			}
+		}
+	}
+	__atomic_thread_fence(__ATOMIC_ACQUIRE);
+	return HNSW_GPU_OK;
 }
 
 extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries, size_t nq, size_t ef,
@@ -936,19 +1112,9 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 		if (rc) return rc;
 		for (size_t i = 0; i < nq; i++)
 		{
-			uint64_t spins = 0;
-			while (hf[i] == 0)
-			{
-				__builtin_ia32_pause();
-				if ((++spins & 0xFFFF) == 0 && hipStreamQuery(nullptr) != hipErrorNotReady)
-				{
-					// the kernel is gone: either it has just stored the flag, or it died
-					HIPCHK(hipStreamSynchronize(nullptr));
-					if (hf[i] == 0) return fail(HNSW_GPU_ERR_INTERNAL, "search kernel ended without completing query %zu", i);
-				}
-			}
+			rc = poll_done_flag(hf + i, "a query");
+			if (rc) return rc;
 		}
-		__atomic_thread_fence(__ATOMIC_ACQUIRE);
 		memcpy(labels, hl, nq * ef * 8);
 		if (dists) memcpy(dists, hd, nq * ef * 4);
 		memcpy(counts, hc, nq * 4);
@@ -1063,18 +1229,11 @@ extern "C" int hnsw_gpu_search_trace_end(hnsw_gpu_index *ix, label_t *labels, di
 	const uint64_t *hl = (const uint64_t *) (h + t.qb); const float *hd = (const float *) (h + t.qb + t.lb);
 	const uint32_t *hc = (const uint32_t *) (h + t.qb + t.lb + t.db), *hs = (const uint32_t *) (h + t.qb + t.lb + t.db + t.cb);
 	const volatile uint32_t *hf = (const volatile uint32_t *) (h + t.qb + t.lb + t.db + t.cb + t.sb + t.pb);
-	uint64_t spins = 0;
-	while (hf[0] == 0)
 	{
-		__builtin_ia32_pause();
-		if ((++spins & 0xFFFF) == 0 && hipStreamQuery(nullptr) != hipErrorNotReady)
-		{
-			HIPCHK(hipStreamSynchronize(nullptr));
-			if (hf[0] == 0) { ix->trace_active = false; return fail(HNSW_GPU_ERR_INTERNAL, "search kernel ended without completing the query"); }
-		}
+		const int prc = poll_done_flag(hf, "the traced query");
+		ix->trace_active = false;
+		if (prc) return prc;
 	}
-	__atomic_thread_fence(__ATOMIC_ACQUIRE);
-	ix->trace_active = false;
 	if (ix->trace_base) { const uint32_t *hi = (const uint32_t *) hl; for (size_t i = 0; i < ef; i++) labels[i] = hi[i]; }
 	else memcpy(labels, hl, ef * 8);
 	if (dists) memcpy(dists, hd, ef * 4);
@@ -1132,6 +1291,24 @@ extern "C" int hnsw_gpu_team_counters(hnsw_gpu_index *ix, uint32_t *out8)
 	HIPCHK(hipSetDevice(ix->device));
 	HIPCHK(hipDeviceSynchronize());
 	HIPCHK(hipMemcpy(out8, ix->ws.team_dbg, 64, hipMemcpyDeviceToHost));
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_index_abort(hnsw_gpu_index *ix)
+{
+	// no ix->mu here: the thread that holds it may be the one waiting for the launch this call is meant to end
+	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
+	std::lock_guard<std::mutex> g(g_ws_mu);
+	return abort_ws_locked(&ix->ws) ? HNSW_GPU_OK : fail(HNSW_GPU_ERR_INTERNAL, "the workspace has no abort word");
+}
+
+extern "C" int hnsw_gpu_index_health(hnsw_gpu_index *ix, uint32_t *out8)
+{
+	if (!ix || !out8) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	std::lock_guard<std::recursive_mutex> g(ix->mu);
+	HIPCHK(hipSetDevice(ix->device));
+	HIPCHK(hipMemcpy(out8, ix->ws.health, 32, hipMemcpyDeviceToHost));
+	out8[0] = __atomic_load_n(ix->ws.abort_host, __ATOMIC_SEQ_CST);
 	return HNSW_GPU_OK;
 }
 
@@ -2029,6 +2206,61 @@ extern "C" int hnsw_gpu_gather_roof(hnsw_gpu_index *ix, int loads_per_lane, int 
 	if (rc) return rc;
 	const double bytes = (double) blocks * 4.0 * iters * loads_per_lane * 64.0 * 16.0;
 	*gbps = (float) (bytes / best / 1e6);
+	return HNSW_GPU_OK;
+}
+
+// Replay roof (device_roof.h): the rows a traced launch scored, gathered again by `slots` resident waves in the same query
+// order with nothing in between.  d_stats = that launch's stats array ({evals, hops} per query).  *ms = best of 3 timed
+// repetitions (after one warm-up), *bytes = row bytes one repetition reads.
+extern "C" int hnsw_gpu_replay_roof(hnsw_gpu_index *ix, const idx_t *d_evals, size_t evals_cap, const uint32_t *d_stats, size_t nq,
+									unsigned slots, int loads_per_lane, float *ms, double *bytes)
+{
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
+	if (!ix || !d_evals || !d_stats || !ms) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	if (ix->n == 0 || nq == 0 || slots < 4 || evals_cap == 0) return fail(HNSW_GPU_ERR_ARG, "need rows, queries and at least 4 slots");
+	HIPCHK(hipSetDevice(ix->device));
+	const uint32_t row_f4 = ix->stride / 4;
+	const uint32_t blocks = slots / 4;
+	float *out = (float *) ix->misc + 8;
+	uint32_t *ticket = ix->misc + 12;
+	hipEvent_t e0, e1;
+	HIPCHK(hipEventCreate(&e0));
+	HIPCHK(hipEventCreate(&e1));
+	float best = 1e30f;
+	int rc = HNSW_GPU_OK;
+	for (int rep = 0; rep < 4 && rc == HNSW_GPU_OK; rep++)
+	{
+		(void) hipMemsetAsync(ticket, 0, 4, nullptr);
+		(void) hipEventRecord(e0, nullptr);
+		const float4 *base = (const float4 *) ix->vec;
+		switch (loads_per_lane)
+		{
+#define ROOF(T) case T: hipLaunchKernelGGL(replay_roof_kernel<T>, dim3(blocks), dim3(256), 0, nullptr, base, row_f4, d_evals, (uint32_t) evals_cap, d_stats, (uint32_t) nq, ticket, out); break
+			ROOF(8); ROOF(16); ROOF(24);
+#undef ROOF
+			default: rc = fail(HNSW_GPU_ERR_ARG, "loads_per_lane must be 8, 16 or 24");
+		}
+		if (rc) break;
+		(void) hipEventRecord(e1, nullptr);
+		if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(HNSW_GPU_ERR_HIP, "replay roof kernel failed"); break; }
+		float t = 0.f;
+		(void) hipEventElapsedTime(&t, e0, e1);
+		if (rep > 0 && t < best) best = t;            // first repetition warms up
+	}
+	(void) hipEventDestroy(e0);
+	(void) hipEventDestroy(e1);
+	if (rc) return rc;
+	*ms = best;
+	if (bytes)
+	{
+		// rows actually in the trace: sum over queries of min(evals, cap)
+		std::vector<uint32_t> st(2 * nq);
+		HIPCHK(hipMemcpy(st.data(), d_stats, 2 * nq * 4, hipMemcpyDeviceToHost));
+		double rows = 0;
+		for (size_t i = 0; i < nq; i++) rows += (double) std::min<size_t>(st[2 * i], evals_cap);
+		*bytes = rows * ix->stride * 4.0;
+	}
 	return HNSW_GPU_OK;
 }
 

@@ -29,17 +29,23 @@ def sift_like(n: int, dim: int = 128, k: int = 256, seed: int = 42, stream: int 
 
 
 def gmm_torch(n: int, dim: int, k: int = 1000, sigma: float = 0.3, seed: int = 42, stream: int = 0,
-              device="cuda", chunk: int = 1 << 18):
-    """Device generator for the full-size configs (1M x 768 = 3 GB is produced in HBM)."""
+              device="cuda", chunk: int = 1 << 18, distinct_clusters: bool = False):
+    """Device generator for the full-size configs (1M x 768 = 3 GB is produced in HBM).
+    distinct_clusters: point i comes from a cluster of its own (a random permutation of the k clusters; needs n <= k) —
+    queries that share no home cluster."""
     import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed * 1000003 + 0xC0)
     centres = torch.randn((k, dim), generator=g, device=device, dtype=torch.float32)
     g.manual_seed(seed * 1000003 + 1 + stream)
     out = torch.empty((n, dim), device=device, dtype=torch.float32)
+    perm = None
+    if distinct_clusters:
+        assert n <= k, "distinct_clusters needs at least as many clusters as points"
+        perm = torch.randperm(k, generator=g, device=device)
     for i in range(0, n, chunk):
         m = min(chunk, n - i)
-        which = torch.randint(0, k, (m,), generator=g, device=device)
+        which = perm[i:i + m] if perm is not None else torch.randint(0, k, (m,), generator=g, device=device)
         out[i:i + m] = centres[which] + sigma * torch.randn((m, dim), generator=g, device=device,
                                                             dtype=torch.float32)
     return out

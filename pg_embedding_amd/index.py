@@ -264,6 +264,41 @@ class GpuIndex:
         check(self.L.hnsw_gpu_gather_roof(self._h, loads_per_lane, waves_per_cu, iters, C.byref(v)), "hnsw_gpu_gather_roof")
         return float(v.value)
 
+    def search_traced_torch(self, queries, ef: int, evals_cap: int = 4096):
+        """hnsw_gpu_search_traced_dev: search_torch(..., stats=True) plus out["evals"] (nq x evals_cap int32: the rows each walk
+        scored, in order; out["stats"][:, 0] of them are valid) and out["times"] (nq x 2 int64: 100 MHz device clock at the
+        start of the query and at the end of its walk).  Measurement only."""
+        torch = _torch()
+        nq = queries.shape[0]
+        dev = queries.device
+        out = {"labels": torch.empty((nq, ef), dtype=torch.int64, device=dev), "dists": torch.empty((nq, ef), dtype=torch.float32, device=dev),
+               "counts": torch.empty((nq,), dtype=torch.int32, device=dev), "stats": torch.empty((nq, 2), dtype=torch.int32, device=dev),
+               "evals": torch.empty((nq, evals_cap), dtype=torch.int32, device=dev), "times": torch.zeros((nq, 2), dtype=torch.int64, device=dev)}
+        s = torch.cuda.current_stream(dev).cuda_stream
+        check(self.L.hnsw_gpu_search_traced_dev(self._h, queries.data_ptr(), nq, ef, out["labels"].data_ptr(), out["dists"].data_ptr(),
+                                                out["counts"].data_ptr(), out["stats"].data_ptr(), out["evals"].data_ptr(), evals_cap,
+                                                out["times"].data_ptr(), s), "hnsw_gpu_search_traced_dev")
+        return out
+
+    def replay_roof(self, traced: dict, slots: int, loads_per_lane: int = 24):
+        """(ms, bytes) of hnsw_gpu_replay_roof over the trace of a search_traced_torch launch."""
+        ms, by = C.c_float(0), C.c_double(0)
+        ev = traced["evals"]
+        check(self.L.hnsw_gpu_replay_roof(self._h, ev.data_ptr(), ev.shape[1], traced["stats"].data_ptr(), ev.shape[0], slots, loads_per_lane,
+                                          C.byref(ms), C.byref(by)), "hnsw_gpu_replay_roof")
+        return float(ms.value), float(by.value)
+
+    def health(self) -> dict:
+        """Health words of the default search workspace (include/hnsw_gpu.h, hnsw_gpu_index_health): all zero in a healthy life."""
+        v = (C.c_uint32 * 8)()
+        check(self.L.hnsw_gpu_index_health(self._h, v), "hnsw_gpu_index_health")
+        return {"abort_pending": int(v[0]), "slice_timeouts": int(v[1]), "package_timeouts": int(v[2]), "aborted_waves": int(v[3]),
+                "slices_delivered": int(v[4])}
+
+    def abort(self) -> None:
+        """Ask the search launches of this mirror that are in flight to end (callable from any thread)."""
+        check(self.L.hnsw_gpu_index_abort(self._h), "hnsw_gpu_index_abort")
+
     def last_search_slots(self) -> int:
         v = C.c_uint32(0)
         check(self.L.hnsw_gpu_last_search_slots(self._h, C.byref(v)), "hnsw_gpu_last_search_slots")

@@ -1,6 +1,7 @@
 """Experiment: ef in (256, 512] — beam form with 16 set registers vs the generic LDS form (same index)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pg_embedding_amd import watchdog; watchdog.arm()      # --timeout SECONDS (default 900): a hung device run costs one case, not the round
 import numpy as np, torch
 import pg_embedding_amd as pg
 from pg_embedding_amd.datasets import gmm_torch

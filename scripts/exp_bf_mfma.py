@@ -1,6 +1,7 @@
 """Experiment: BASELINE config 5 — 1M x 1536 cosine, Q=1024 batched, scoring as an f32 MFMA GEMM."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pg_embedding_amd import watchdog; watchdog.arm()      # --timeout SECONDS (default 900): a hung device run costs one case, not the round
 import numpy as np, torch
 import pg_embedding_amd as pg
 from pg_embedding_amd._lib import gpu_lib

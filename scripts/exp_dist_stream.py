@@ -1,6 +1,7 @@
 """Roofline of the batched distance kernel alone (hnsw_dist_func over many rows): 1M x dim rows streamed once."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pg_embedding_amd import watchdog; watchdog.arm()      # --timeout SECONDS (default 900): a hung device run costs one case, not the round
 import torch
 import pg_embedding_amd as pg
 from pg_embedding_amd._lib import gpu_lib, check

@@ -1,6 +1,7 @@
 """Experiment: search throughput vs batch size and resident blocks per CU (one build)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pg_embedding_amd import watchdog; watchdog.arm()      # --timeout SECONDS (default 900): a hung device run costs one case, not the round
 import numpy as np, torch
 import pg_embedding_amd as pg
 from pg_embedding_amd.datasets import gmm_torch

@@ -3,6 +3,7 @@ usage: exp_team.py <dim> <m> [metric] [sift]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pg_embedding_amd import watchdog; watchdog.arm()      # --timeout SECONDS (default 900): a hung device run costs one case, not the round
 import numpy as np
 import torch
 import pg_embedding_amd as pg

@@ -1,5 +1,15 @@
 """Turn the FETCH_SIZE / WRITE_SIZE PMC passes of scripts/profile_bench.sh into profiles/traffic.json."""
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_digest():
+    h = hashlib.sha256()
+    for f in ("device_dist.h", "device_search.h"):
+        with open(os.path.join(ROOT, "pg_embedding_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
 
 def last_mean(d, counter, last=3, pat="hnsw_search"):
     vals = []
@@ -23,9 +33,11 @@ wl["metric"] = "l2" if ", l2," in cfg["workload"] else ("cosine" if ", cosine," 
 print(json.dumps({
     "run": os.path.basename(os.path.normpath(out)),
     "kernel": line["roofline"].get("kernel"),
+    "kernel_source_digest": kernel_source_digest(),
     "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), last 3 dispatches of hnsw_search_kernel of bench.py",
     "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
     "correction": "gfx950: FETCH_SIZE tallies 64 B per 128-B request for wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM section)",
     "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024,
     "alg_bytes_per_launch": line["roofline"]["alg_bytes_per_launch"],
+    "kernel_ms_per_launch_of_that_run": line["roofline"]["kernel_ms_per_launch"],
     "workload": wl}, indent=1))

@@ -7,6 +7,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
+from pg_embedding_amd import watchdog; watchdog.arm()      # --timeout SECONDS (default 900): a hung device run costs one case, not the round
 import numpy as np                                            # noqa: E402
 from pg_embedding_amd._lib import shim_lib                    # noqa: E402
 from pg_embedding_amd.server import ServerProcess, client_lib  # noqa: E402

@@ -2,6 +2,7 @@
 1M-row index is the part of the hop that waits for HBM; the rest is the dependent instruction chain."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from pg_embedding_amd import watchdog; watchdog.arm()      # --timeout SECONDS (default 900): a hung device run costs one case, not the round
 import numpy as np, torch
 import pg_embedding_amd as pg
 from pg_embedding_amd.datasets import gmm_torch

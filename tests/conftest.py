@@ -15,17 +15,29 @@ def pytest_configure(config):
     oracle.build_oracle()
 
 
+# The library's own kernel watchdog (include/hnsw_gpu.h): a search launch that has been running for two minutes is asked to
+# end through its workspace's abort word, so a hung kernel ends by itself and its test FAILS (wrong or missing answers)
+# instead of keeping the device until somebody's limit kills the process.  Read once, at the library's first workspace.
+os.environ.setdefault("HNSW_GPU_WATCHDOG_S", "120")
+
+
 def pytest_collection_modifyitems(config, items):
-    """A device test that never returns (a kernel that waits for something that cannot happen keeps its caller polling)
-    must end the run with a failure, not hang it: pytest-timeout's watchdog thread ends the process after 15 minutes in
-    one test (the slowest full-size test takes about one)."""
+    """A device test that never returns must end the run with a failure, not hang it: pytest-timeout's watchdog thread
+    ends the process after 10 minutes in one test (the slowest full-size test takes about one).  The device tier does
+    not run without it: a missing plugin is a collection error, not a silent no-op."""
+    gpu_items = [it for it in items if it.get_closest_marker("gpu")]
+    if not gpu_items:
+        return
     try:
         import pytest_timeout  # noqa: F401
-    except Exception:
-        return
-    for it in items:
-        if it.get_closest_marker("gpu") and not it.get_closest_marker("timeout"):
-            it.add_marker(pytest.mark.timeout(900, method="thread"))
+    except Exception as e:
+        deselected_all = config.getoption("-m") and "not gpu" in config.getoption("-m")
+        if deselected_all:
+            return                                            # the CPU tier collects them only to deselect them
+        raise pytest.UsageError(f"the device tests need the pytest-timeout plugin (a hung kernel must fail, not hang): {e}")
+    for it in gpu_items:
+        if not it.get_closest_marker("timeout"):
+            it.add_marker(pytest.mark.timeout(600, method="thread"))
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -312,6 +312,7 @@ namespace pgemb { alignas(16) static unsigned char smem[SIMT_LDS_BYTES]; }
 #define __builtin_amdgcn_sched_barrier(x) ((void) 0)
 #define __builtin_amdgcn_s_sleep(x) sched_yield()
 #define __builtin_amdgcn_s_memtime() ((uint64_t) __rdtsc())
+#define __builtin_amdgcn_s_memrealtime() ((uint64_t) (__rdtsc() >> 5))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) (simt::die("MFMA is not modelled"), (c))
 
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1

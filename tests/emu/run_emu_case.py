@@ -21,7 +21,7 @@ import pg_embedding_amd as pg                              # noqa: E402
 import util as U                                           # noqa: E402
 from pg_embedding_amd.datasets import gmm                  # noqa: E402
 
-KEYS = ("HNSW_GPU_TEAM", "HNSW_GPU_TEAM_WPB", "HNSW_GPU_MAX_BLOCKS", "HNSW_GPU_NARROW5", "HNSW_GPU_HASH_ENTRIES", "HNSW_GPU_BEAM",
+KEYS = ("HNSW_GPU_TEAM", "HNSW_GPU_TEAM_WPB", "HNSW_GPU_MAX_BLOCKS", "HNSW_GPU_NARROW5", "HNSW_GPU_HASH_ENTRIES", "HNSW_GPU_BEAM",      # (HNSW_GPU_TEAM_SPEC: as the caller of this script set it)
         "HNSW_GPU_BEAM16", "HNSW_GPU_FORCE_LDS_HEAPS", "SIMT_EMU_CUS", "SIMT_EMU_JITTER", "SIMT_EMU_JITTER_US", "SIMT_EMU_SEED")
 
 
@@ -85,7 +85,64 @@ def second_walk():
         for rep in range(2):
             setenv(dict(env, SIMT_EMU_SEED=str(rep)))
             bad += wrong(ix.search(Q, ef), want, 32)
-        out.append({"env": env, "kernel": ix.last_search_kernel(), "walks": 64, "wrong": bad, "blocks_x_waves": ix.last_search_slots()})
+        out.append({"env": env, "kernel": ix.last_search_kernel(), "walks": 64, "wrong": bad, "blocks_x_waves": ix.last_search_slots(), "health": ix.health()})
+    return out
+
+
+def abort():
+    """the host's abort word: a launch that is asked to end does end (every wave leaves at its next look), says so in the
+    health words, and the next launch on the same workspace is exact again (the bitmaps the aborted waves left are re-zeroed)"""
+    import threading
+    n, dim, m, ef = 3000, 96, 16, 48
+    port, X = U.build_port(n, dim, m, 40, pg.DIST_L2, k=10, seed=3)
+    out = []
+    for env in ({"HNSW_GPU_TEAM": "1"}, {"HNSW_GPU_TEAM": "0", "HNSW_GPU_HASH_ENTRIES": "0"}, {"HNSW_GPU_BEAM": "0"}, {"HNSW_GPU_FORCE_LDS_HEAPS": "1"}):
+        setenv(dict(env, SIMT_EMU_CUS="2"))
+        ix = U.mirror(port, pg.DIST_L2, efs=ef)
+        Q = gmm(4000, dim, k=10, seed=9)                       # minutes of emulated work if nobody stops it
+        t = threading.Timer(1.0, lambda: ix.abort())
+        t0 = time.time()
+        t.start()
+        ix.search(Q, ef)
+        took = time.time() - t0
+        h = ix.health()
+        Q2 = gmm(12, dim, k=10, seed=10)
+        want = port.search_many(Q2, ef, nthreads=4)
+        bad = wrong(ix.search(Q2, ef), want, 12)
+        out.append({"env": env, "kernel": ix.last_search_kernel(), "seconds_until_the_launch_ended": round(took, 2), "health_after_abort": h,
+                    "health_after_next": ix.health(), "wrong_after": bad})
+        ix.close()
+    return out
+
+
+def traced():
+    """the evaluation trace of a launch (measurement entry point of bench.py's replay roof) == the rows the walk must score,
+    restated from its pop sequence and the link lists; and the replay kernel runs over it"""
+    import ctypes as C
+    out = []
+    n, dim, m, ef, cap = 1500, 40, 8, 48, 512
+    port, X = U.build_port(n, dim, m, 40, pg.DIST_L2, k=10, seed=13)
+    Q = gmm(6, dim, k=10, seed=14)
+    for env in ({"HNSW_GPU_TEAM": "0"}, {"HNSW_GPU_TEAM": "1"}, {"HNSW_GPU_BEAM": "0"}, {"HNSW_GPU_FORCE_LDS_HEAPS": "1"}):
+        setenv(env)
+        ix = U.mirror(port, pg.DIST_L2, efs=ef)
+        nq = len(Q)
+        lab = np.empty((nq, ef), np.uint64); dst = np.empty((nq, ef), np.float32); cnt = np.empty(nq, np.uint32)
+        st = np.zeros((nq, 2), np.uint32); ev = np.full((nq, cap), 0xFFFFFFFF, np.uint32); tm = np.zeros((nq, 2), np.uint64)
+        Qc = np.ascontiguousarray(Q, np.float32)
+        rc = ix.L.hnsw_gpu_search_traced_dev(ix._h, Qc.ctypes.data, nq, ef, lab.ctypes.data, dst.ctypes.data, cnt.ctypes.data, st.ctypes.data,
+                                             ev.ctypes.data, cap, tm.ctypes.data, None)       # (emulated device memory IS host memory)
+        assert rc == 0, rc
+        bad = 0
+        for i in range(nq):
+            _, _, pops, nev = ix.search_trace(Q[i], ef)
+            want = U.evals_from_pops(port.raw(), ix.meta, n, ix.meta.enterpoint_node, pops)
+            bad += 0 if (st[i, 0] == len(want) == nev and (ev[i, :len(want)] == want).all() and tm[i, 1] >= tm[i, 0] > 0) else 1
+        ms, by = C.c_float(0), C.c_double(0)
+        rc = ix.L.hnsw_gpu_replay_roof(ix._h, ev.ctypes.data, cap, st.ctypes.data, nq, 8, 8, C.byref(ms), C.byref(by))
+        out.append({"env": env, "kernel": ix.last_search_kernel(), "wrong": bad, "replay_rc": rc, "replay_bytes": by.value,
+                    "want_bytes": float(st[:, 0].sum()) * dim * 4})
+        ix.close()
     return out
 
 
@@ -141,4 +198,4 @@ def others():
 
 
 if __name__ == "__main__":
-    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others}[sys.argv[1]]()))
+    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced}[sys.argv[1]]()))

@@ -2,6 +2,7 @@
 the kernel time inside it, and the reference's own CPU code on the same graph."""
 import os, sys, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from pg_embedding_amd import watchdog; watchdog.arm()      # --timeout SECONDS (default 900): a hung device run costs one case, not the round
 import numpy as np, torch
 import oracle, pg_embedding_amd as pg
 from pg_embedding_amd._lib import gpu_lib

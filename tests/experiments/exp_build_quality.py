@@ -1,6 +1,7 @@
 """Experiment: batched device build vs serial (reference-order) build — degree, E_q, recall."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from pg_embedding_amd import watchdog; watchdog.arm()      # --timeout SECONDS (default 900): a hung device run costs one case, not the round
 import numpy as np, torch
 import oracle, pg_embedding_amd as pg
 from pg_embedding_amd.datasets import gmm_torch, recall_at_k

@@ -3,6 +3,7 @@ then timing on a 200k x 128 index (HNSW_GPU_LDS_SET_MIN_WAVES picks the form: 1 
 fits, 1000 = always HBM)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from pg_embedding_amd import watchdog; watchdog.arm()      # --timeout SECONDS (default 900): a hung device run costs one case, not the round
 import numpy as np, torch
 import oracle, pg_embedding_amd as pg
 from pg_embedding_amd.datasets import gmm, gmm_torch

@@ -3,6 +3,7 @@ by the multi-threaded CPU oracle on the exported bytes; covers the hash-set spil
 overflow handling, every shape of the row loader, ef up to 512 (LDS form) and vacuum flags."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from pg_embedding_amd import watchdog; watchdog.arm()      # --timeout SECONDS (default 900): a hung device run costs one case, not the round
 import numpy as np, torch
 import oracle, pg_embedding_amd as pg
 from pg_embedding_amd.datasets import gmm_torch

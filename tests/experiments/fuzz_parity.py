@@ -5,6 +5,7 @@ the first mismatch.   usage: fuzz_parity.py <cases> [seed]"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from pg_embedding_amd import watchdog; watchdog.arm()      # --timeout SECONDS (default 900): a hung device run costs one case, not the round
 import numpy as np
 import oracle
 import pg_embedding_amd as pg

@@ -10,6 +10,7 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
+from pg_embedding_amd import watchdog; watchdog.arm()      # --timeout SECONDS (default 900): a hung device run costs one case, not the round
 import server_util as SU                                   # noqa: E402
 
 n, dim, m, efc, nscan = (int(x) for x in (sys.argv[1:6] + ["20000", "128", "16", "64", "200"][len(sys.argv) - 1:]))

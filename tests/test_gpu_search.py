@@ -546,3 +546,35 @@ def test_nan_distances_do_not_hang_or_crash():
     cnt = raw[:, :4].copy().view(np.uint32).ravel()
     assert cnt.max() <= 12
     ix.close()
+
+
+@pytest.mark.parametrize("env", [{}, {"HNSW_GPU_TEAM": "0"}, {"HNSW_GPU_BEAM": "0"}, {"HNSW_GPU_FORCE_LDS_HEAPS": "1"}])
+def test_evaluation_trace_is_the_walk_and_replay_reads_its_bytes(env, monkeypatch):
+    """Measurement entry points of bench.py's replay roof (include/hnsw_gpu.h): the traced rows of every query are exactly what its
+    walk must score (entry point, then the unvisited links of every popped element, in order: restated from the pop sequence and
+    the element image), the per-query clock stamps are ordered, and the replay gathers exactly the traced bytes."""
+    import torch
+    from util import evals_from_pops
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n, dim, m, ef = 8000, 200, 16, 100
+    port, X = build_port(n, dim, m, 48, pg.DIST_L2, seed=31)
+    Q = gmm(300, dim, k=50, seed=31, stream=1)
+    ix = mirror(port, pg.DIST_L2)
+    tr = ix.search_traced_torch(torch.from_numpy(Q).cuda(), ef, evals_cap=2048)
+    torch.cuda.synchronize()
+    slots = ix.last_search_slots()
+    want = port.search_many(Q, ef, nthreads=8)
+    st = tr["stats"].cpu().numpy().astype(np.uint32)
+    assert (tr["labels"].cpu().numpy().view(np.uint64) == want["labels"]).all()
+    assert (st[:, 0] == want["evals"]).all() and (st[:, 1] == want["hops"]).all()
+    ev = tr["evals"].cpu().numpy().view(np.uint32)
+    tm = tr["times"].cpu().numpy()
+    assert (tm[:, 1] >= tm[:, 0]).all() and (tm[:, 0] > 0).all()
+    for i in range(0, 300, 23):
+        _, _, pops, nev = ix.search_trace(Q[i], ef)
+        w = evals_from_pops(port.raw(), ix.meta, n, ix.meta.enterpoint_node, pops)
+        assert nev == len(w) == st[i, 0] and (ev[i, :len(w)] == w).all(), i
+    ms, by = ix.replay_roof(tr, slots, 8)
+    assert ms > 0 and by == float(st[:, 0].sum()) * ix.meta.dim * 4
+    ix.close()

@@ -1,0 +1,166 @@
+"""Team form under the schedules the ordinary suites never produce, on the device, every answer compared bit
+for bit with the port oracle:
+
+  * a wave that walks SEVERAL queries while its siblings help — a launch squeezed into a few blocks (HNSW_GPU_MAX_BLOCKS), so
+    that every wave with queries takes many of them through the ticket counter with helpers attached; neighbouring queries of one
+    cluster follow each other, so that a package or a slice scored against the previous query would be for elements the next walk
+    pops too (the helper-bit clear at the start of a walk, the slice-job protocol);
+  * the batching server's shape: one big launch on stream A, back-to-back launches of 1-64 queries on streams B and C through
+    search contexts — the small launches' blocks start late and one after the other, behind the big one;
+  * the host's abort word on a real launch.
+
+Each test is bounded to about a minute and runs under the suite's watchdogs (tests/conftest.py): every inter-wave wait in the
+kernels is bounded, so a protocol mistake shows up as a wrong answer or a health counter here, not as a hang."""
+import os
+import time
+
+import numpy as np
+import pytest
+
+import pg_embedding_amd as pg
+from pg_embedding_amd.datasets import gmm
+from util import bits, build_port, mirror
+
+pytestmark = pytest.mark.gpu
+
+TEAM_KEYS = ("HNSW_GPU_TEAM", "HNSW_GPU_TEAM_WPB", "HNSW_GPU_MAX_BLOCKS", "HNSW_GPU_TEAM_SPEC")
+
+
+def _setenv(monkeypatch, env):
+    for k in TEAM_KEYS:
+        monkeypatch.delenv(k, raising=False)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+
+
+def _same(out, want, nq, what):
+    lab = out["labels"].cpu().numpy().view(np.uint64)
+    assert (lab == want["labels"][:nq]).all(), ("labels", what, int((lab != want["labels"][:nq]).any(axis=1).sum()))
+    assert (bits(out["dists"].cpu().numpy()) == bits(want["dists"][:nq])).all(), ("distance bits", what)
+    assert (out["counts"].cpu().numpy() == want["counts"][:nq]).all(), ("counts", what)
+    if out.get("stats") is not None:
+        st = out["stats"].cpu().numpy().astype(np.uint32)
+        assert (st[:, 0] == want["evals"][:nq]).all() and (st[:, 1] == want["hops"][:nq]).all(), ("E_q / H_q", what)
+
+
+@pytest.mark.timeout(240, method="thread")
+@pytest.mark.parametrize("dim,m,func,n", [(768, 16, pg.DIST_L2, 10000), (96, 16, pg.DIST_L2, 12000), (768, 32, pg.DIST_COSINE, 6000)])
+def test_a_wave_that_walks_many_queries_with_helpers_attached(dim, m, func, n, monkeypatch):
+    import torch
+    rng = np.random.default_rng(11 + dim + func)
+    port, X = build_port(n, dim, m, 64, func, k=40, seed=900 + dim + func)
+    ix = mirror(port, func, efs=128)
+    t_end = time.time() + 20.0                                 # per configuration; the oracle's share is outside the budget
+    cases = 0
+    delivered = 0
+    for r in range(200):
+        if time.time() > t_end and r >= 6:
+            break
+        # queries = slightly moved copies of a few rows, one after the other: consecutive walks cross the same elements
+        nq = int(rng.choice([8, 24, 64, 200]))
+        base = X[rng.integers(0, n, size=max(1, nq // 8))]
+        Q = (np.repeat(base, 8, axis=0)[:nq] + 0.01 * rng.standard_normal((nq, dim))).astype(np.float32)
+        ef = int(rng.choice([40, 128]))
+        want = port.search_many(Q, ef, nthreads=8)
+        dQ = torch.from_numpy(Q).cuda()
+        for blocks, wpb, spec in (("1", "8", "5"), ("2", "8", "0"), ("3", "4", "2"), ("1", "2", "0"), ("2", "8", "8")):
+            _setenv(monkeypatch, {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": wpb, "HNSW_GPU_MAX_BLOCKS": blocks, "HNSW_GPU_TEAM_SPEC": spec})
+            out = ix.search_torch(dQ, ef, stats=True)
+            torch.cuda.synchronize()
+            assert "true>" in ix.last_search_kernel()
+            _same(out, want, nq, (dim, r, nq, ef, blocks, wpb, spec))
+            cases += 1
+    h = ix.health()
+    delivered = h["slices_delivered"]
+    print(f"\n[team stress {dim}d func {func}] {cases} launches exact; health {h}")
+    assert h["aborted_waves"] == 0 and h["abort_pending"] == 0, h
+    assert delivered > 0, h                                    # the slice mechanism did run
+    assert h["slice_timeouts"] == 0, h                         # ... and no helper was ever late on an otherwise idle device
+    ix.close()
+
+
+@pytest.mark.timeout(300, method="thread")
+def test_small_launches_on_two_streams_beside_a_big_one(monkeypatch):
+    """The server's shape (csrc/server_main.cpp): 40 000 queries on stream A, meanwhile launches of 1-64 queries back to back on
+    streams B and C through search contexts.  The small launches' blocks become resident one by one as the big launch's waves
+    retire, so their waves take several queries each with helpers attached and detached at odd moments."""
+    import torch
+    _setenv(monkeypatch, {})
+    dim, m, func, n, ef = 768, 16, pg.DIST_L2, 16000, 128
+    port, X = build_port(n, dim, m, 64, func, k=60, seed=4242)
+    ix = mirror(port, func, efs=ef)
+    uniq = 2048
+    Qu = gmm(uniq, dim, k=60, seed=4242, stream=1)
+    want = port.search_many(Qu, ef, nthreads=8)
+    reps = 20
+    big = torch.from_numpy(np.tile(Qu, (reps, 1))).cuda()                      # 40 960 queries
+    dQu = torch.from_numpy(Qu).cuda()
+    sA, sB, sC = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    cB, cC = pg.SearchContext(ix), pg.SearchContext(ix)
+
+    def outs(nq):
+        return {"labels": torch.empty((nq, ef), dtype=torch.int64, device="cuda"), "dists": torch.empty((nq, ef), dtype=torch.float32, device="cuda"),
+                "counts": torch.empty((nq,), dtype=torch.int32, device="cuda"), "stats": torch.empty((nq, 2), dtype=torch.int32, device="cuda")}
+
+    rng = np.random.default_rng(5)
+    small_checked = 0
+    t_end = time.time() + 30.0
+    for rnd in range(40):
+        if time.time() > t_end and rnd >= 3:
+            break
+        torch.cuda.synchronize()
+        with torch.cuda.stream(sA):
+            obig = ix.search_torch(big, ef, stats=True)
+        pend = []
+        for k in range(24):                                    # back to back, no waiting in between
+            for ctx, st in ((cB, sB), (cC, sC)):
+                nq = int(rng.choice([1, 1, 2, 3, 8, 17, 64]))
+                o = int(rng.integers(0, uniq - nq + 1))
+                q = dQu[o:o + nq]
+                out = outs(nq)
+                ctx.search_torch(q, ef, out, stream=st)
+                pend.append((o, nq, out))
+        torch.cuda.synchronize()
+        for o, nq, out in pend:
+            sub = {k: v[o:o + nq] for k, v in want.items()}
+            _same(out, sub, nq, ("small", rnd, o, nq))
+            small_checked += nq
+        lab = obig["labels"].cpu().numpy().view(np.uint64).reshape(reps, uniq, ef)
+        assert (lab == want["labels"][None]).all(), ("big launch", rnd)
+        assert (bits(obig["dists"].cpu().numpy()).reshape(reps, uniq, ef) == bits(want["dists"])[None]).all()
+    h = ix.health()
+    print(f"\n[two-stream stress] {small_checked} small-launch answers + {rnd + 1} x 40 960 big-launch answers exact; health of the default workspace {h}")
+    assert small_checked > 0 and h["aborted_waves"] == 0
+    cB.close(); cC.close(); ix.close()
+
+
+@pytest.mark.timeout(120, method="thread")
+@pytest.mark.parametrize("env", [{}, {"HNSW_GPU_TEAM": "1"}, {"HNSW_GPU_BEAM": "0"}, {"HNSW_GPU_FORCE_LDS_HEAPS": "1"}])
+def test_a_launch_that_is_asked_to_end_does_end(env, monkeypatch):
+    """hnsw_gpu_index_abort while a long launch runs: it ends early (its waves count themselves in the health words), and the next
+    launch on the same workspace — whose bitmaps the aborted waves left dirty — equals the oracle."""
+    import torch
+    _setenv(monkeypatch, env)
+    dim, m, func, n, ef = 64, 16, pg.DIST_L2, 20000, 100
+    port, X = build_port(n, dim, m, 64, func, k=40, seed=77)
+    ix = mirror(port, func, efs=ef)
+    Q = torch.from_numpy(gmm(1 << 16, dim, k=40, seed=77, stream=1)).cuda().repeat(32, 1)       # 2 M queries: a second or so of work
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    with torch.cuda.stream(side):
+        ix.search_torch(Q, ef)
+    time.sleep(0.05)
+    ix.abort()
+    side.synchronize()
+    took = time.time() - t0
+    h = ix.health()
+    print(f"\n[abort {env}] kernel {ix.last_search_kernel()}: launch ended {took * 1e3:.0f} ms after it began; health {h}")
+    assert h["aborted_waves"] > 0 and h["abort_pending"] == 1, h
+    Q2 = gmm(300, dim, k=40, seed=78, stream=2)
+    want = port.search_many(Q2, ef, nthreads=8)
+    out = ix.search_torch(torch.from_numpy(Q2).cuda(), ef, stats=True)
+    torch.cuda.synchronize()
+    _same(out, want, 300, "after the abort")
+    assert ix.health()["abort_pending"] == 0
+    ix.close()

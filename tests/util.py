@@ -77,3 +77,22 @@ def classify_against_reference(port, Q, ef, ref_labels, nthreads=8):
                                      ((1, "stop"), (2, "accept"), (3, "pop_order"), (4, "evict"), (5, "output_order"))},
     }
     return got
+
+
+def evals_from_pops(raw, meta, n, entry, pops):
+    """The rows a walk scores, in order, restated from its pop sequence and the element image (hnswalg.cpp:55-97): the entry
+    point, then for every popped element its links in order that were not visited before.  What the kernels' evaluation trace
+    (hnsw_gpu_search_traced_dev) must equal."""
+    esz = int(meta.size_data_per_element)
+    img = np.frombuffer(np.ascontiguousarray(raw)[: n * esz], np.uint8).reshape(n, esz)
+    links = img[:, : (int(meta.maxM) + 1) * 4].copy().view(np.uint32)        # [count | links]
+    seen = {int(entry)}
+    out = [int(entry)]
+    for p in pops:
+        cnt = int(links[p, 0])
+        for t in links[p, 1:1 + cnt]:
+            t = int(t)
+            if t not in seen:
+                seen.add(t)
+                out.append(t)
+    return np.asarray(out, np.uint32)
