@@ -194,7 +194,10 @@ def trace_roof(ix, Q, ef):
     slots = ix.last_search_slots()
     row_bytes = int(ix.meta.dim + 3) // 4 * 16
     best = None
+    lpr = (row_bytes // 16 + 15) // 16                        # 16-byte loads per lane per row
     for lpl in (24, 16, 8):
+        if lpl % lpr and lpr % lpl:
+            continue                                          # would read partial rows: not a replay of this trace
         ms, by = ix.replay_roof(tr, slots, lpl)
         if best is None or ms < best[0]:
             best = (ms, by, lpl)
@@ -399,11 +402,15 @@ def main():
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     rec_t = torch.tensor([recall], dtype=torch.float64, device=dev)
     per_rank = [elapsed]
+    per_rank_kms = [kms]
+    per_rank_bytes = [bytes_launch]
     if use_dist:
-        mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        mine = torch.tensor([elapsed, kms, bytes_launch], dtype=torch.float64, device=dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
-        per_rank = [float(t.item()) for t in every]
+        per_rank = [float(t[0].item()) for t in every]
+        per_rank_kms = [float(t[1].item()) for t in every]
+        per_rank_bytes = [float(t[2].item()) for t in every]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(rec_t, op=dist.ReduceOp.MIN)
     elapsed = float(tmax.item())
@@ -435,7 +442,10 @@ def main():
         },
         "ranks": {"world_size_reported_by_backend": world, "backend": backend or "none (single process)",
                   "self_launched": os.environ.get("PGEMB_BENCH_SELF_LAUNCHED") == "1",
-                  "queries_per_s_per_rank": [args.nq * args.steps / t for t in per_rank]},
+                  "queries_per_s_per_rank": [args.nq * args.steps / t for t in per_rank],
+                  # every rank's own dominant-kernel figures (its own queries, its own HIP events): the 1 -> N curve rank by rank
+                  "kernel_ms_per_launch_per_rank": per_rank_kms,
+                  "roofline_frac_per_rank": [b / (k * 1e-3) / 1e9 / HBM_PEAK_GBS for b, k in zip(per_rank_bytes, per_rank_kms)]},
         "recall_at_10": float(rec_t.item()),
         "results_stable_across_steps": same,
         "evals_per_query": float(E.mean()),
@@ -737,6 +747,7 @@ def main_sharded(args):
     for _ in range(args.warmup):
         sh.search(Q, args.ef)
     barrier()
+    sh.record_timing = True
     ex0 = sh.exchanges
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -745,6 +756,14 @@ def main_sharded(args):
     elapsed = time.perf_counter() - t0
     exchanges = sh.exchanges - ex0
     local_ms = sh.index.last_search_ms()
+    steps_ms = sh.timings_ms()                       # per step on THIS rank: local search / pack + all-gather / merge
+    mine = torch.tensor([[float(np.mean([t[k] for t in steps_ms])) for k in range(3)]], dtype=torch.float64, device=dev)
+    every = [torch.zeros_like(mine) for _ in range(world)]
+    if use_dist:
+        dist.all_gather(every, mine)
+    else:
+        every = [mine]
+    per_rank_steps = [[float(x) for x in t.flatten().tolist()] for t in every]
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if use_dist:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -765,6 +784,9 @@ def main_sharded(args):
                       "self_launched": os.environ.get("PGEMB_BENCH_SELF_LAUNCHED") == "1"},
             "exchange": {"collectives_per_step": exchanges / max(args.steps, 1), "bytes_per_rank": block_bytes(nq, args.ef)},
             "local_search_kernel_ms": local_ms,
+            # mean over the timed steps, device events on each rank's search stream: where a step's time goes, rank by rank
+            "step_breakdown_ms_per_rank": [{"local_search_ms": r[0], "pack_and_exchange_ms": r[1], "merge_ms": r[2]} for r in per_rank_steps],
+            "step_breakdown_ms_rank0_per_step": [{"local_search_ms": a, "pack_and_exchange_ms": b, "merge_ms": c} for a, b, c in steps_ms],
             "recall_at_10": rec,
             "build_seconds": t_build, "merged_results_sorted_and_full": ok}))
     if use_dist:

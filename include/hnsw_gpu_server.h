@@ -58,8 +58,10 @@ enum
 	/* op            request                                              response                         */
 	HGS_OP_HELLO       = 1,  /* a0 = HGS_VERSION                               a0 = version, a1 = devices     */
 	HGS_OP_LOOKUP      = 2,  /* key                                            a0 = count, a1 = 1 present/0 absent, gen = current,
-	                                                                              payload = u64 content version (0 = absent): a
-	                                                                              server-wide sequence number, new at every change */
+	                                                                              payload = u64 content version: a server-wide
+	                                                                              sequence number, new at every change; for an
+	                                                                              absent key the "absent" version, new at every
+	                                                                              removal of a mirror (DROP, eviction) */
 	HGS_OP_UPLOAD      = 3,  /* key, gen, a0 = n, a1 = 0 or 1 + the content version of the LOOKUP this snapshot was walked
 	                            after, payload = HnswMetadata, fd = memfd holding n element images (embedding.c:222-228);
 	                            replaces the key's mirror — unless a1 is set and the mirror has changed since (an insert's

@@ -266,8 +266,18 @@ struct Shape2x4  { static constexpr int KB = 2,  RPG = 4, MIN_WAVES = 4; };   //
 struct Shape2x2  { static constexpr int KB = 2,  RPG = 2, MIN_WAVES = 5; };   // dim <= 128, the hot beam form: 96 VGPRs, 5 waves/SIMD
 struct Shape4x2  { static constexpr int KB = 4,  RPG = 2, MIN_WAVES = 4; };   // dim <= 256
 struct Shape8x2  { static constexpr int KB = 8,  RPG = 2, MIN_WAVES = 2; };   // dim <= 512
+// (experiment builds: -DHNSW_W3_12X1 / -DHNSW_W3_12X2 cap that shape's kernels at 168 VGPRs = 3 waves/SIMD; the host side
+// then wants HNSW_GPU_WIDE_WAVES=12 and HNSW_GPU_TEAM_WPB=6 or 4)
+#ifdef HNSW_W3_12X1
+struct Shape12x1 { static constexpr int KB = 12, RPG = 1, MIN_WAVES = 3; };
+#else
 struct Shape12x1 { static constexpr int KB = 12, RPG = 1, MIN_WAVES = 2; };   // larger (768 = one batch)
+#endif
+#ifdef HNSW_W3_12X2
+struct Shape12x2 { static constexpr int KB = 12, RPG = 2, MIN_WAVES = 3; };
+#else
 struct Shape12x2 { static constexpr int KB = 12, RPG = 2, MIN_WAVES = 2; };   // same, 8 rows per round trip
+#endif
 
 __host__ __device__ inline int shape_index(uint32_t kiters)
 {

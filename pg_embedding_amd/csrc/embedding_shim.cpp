@@ -170,16 +170,22 @@ static bool hnsw_search_impl(HnswMetadata *meta, const coord_t *point, size_t *n
 			fprintf(stderr, "pg_embedding_amd: no HIP device visible; the GPU hot path has no CPU fallback\n");
 			return false;
 		}
-		label_t *cbuf = (label_t *) malloc(ef * sizeof(label_t));   // caller frees (embedding.c:327)
+		// The walk runs host callbacks (hnsw_begin_read) that may leave by longjmp (elog(ERROR)): nothing malloc'd is held
+		// across it — the results land in a per-thread buffer (reclaimed by the next call, like the walk's other buffers) and
+		// the caller's array is allocated after the walk, as the reference does (hnswalg.cpp:262).
+		static thread_local std::vector<label_t> tl_res;
+		try { if (tl_res.size() < ef) tl_res.resize(ef); } catch (...) { return false; }
 		uint32_t cnt = 0;
-		if (cbuf && shimcache::search(meta, point, ef, cbuf, &cnt, dev))
+		if (shimcache::search(meta, point, ef, tl_res.data(), &cnt, dev))
 		{
+			label_t *cbuf = (label_t *) malloc((cnt ? cnt : 1) * sizeof(label_t));   // caller frees (embedding.c:327)
+			if (!cbuf) return false;
+			memcpy(cbuf, tl_res.data(), (size_t) cnt * sizeof(label_t));
 			*n_results = cnt;
 			*results = cbuf;
 			return true;
 		}
 		fprintf(stderr, "pg_embedding_amd: hnsw_search failed: %s\n", hnsw_gpu_last_error());
-		free(cbuf);
 		return false;
 	}
 	if (!ix)

@@ -774,7 +774,7 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	if (rreg)
 	{
 		// [query | hash set (overlaid by the emit step's tie scratch) | newid | newdist]
-		const size_t fixed = off + 64 * 4 + 128 * 4;
+		const size_t fixed = off + 64 * 4 + 128 * 4 + (team_wanted ? sizeof(TeamCtl) : 0);   // (+ the wave's control block behind the regions)
 		// Rows of >= 1.25 KiB make the traversal HBM-bound, and there the LDS set pays (no L2
 		// atomics, ~10 % less HBM traffic; measured 5.4 -> 7.5 TB/s at 768 dims) at 8 waves per CU.
 		// Narrow rows are latency-bound and want 16-20 waves per CU: the beam form gives them a bucketed set of
@@ -783,7 +783,8 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		// (rows of up to 128 floats in the beam form with ef <= 128, L2 / Manhattan, launches that will not run as
 		// teams: 5 waves/SIMD with the 8-rows-per-pass shape — measured +6-10 % over 4 waves, profiles/r2m_*)
 		const bool wide = ix->stride > 320;
-		const size_t want_waves = wide ? 8 : (narrow5 ? 20 : 16);
+		size_t want_waves = wide ? 8 : (narrow5 ? 20 : 16);
+		if (const char *ww = getenv("HNSW_GPU_WIDE_WAVES")) if (wide && atoi(ww) >= 4) want_waves = (size_t) atoi(ww);   // (experiment builds at 3 waves/SIMD)
 		uint32_t hcap = wide ? 4096 : (rreg < 0 ? 2048 : 0);
 		const char *henv = getenv("HNSW_GPU_HASH_ENTRIES");
 		if (henv) hcap = (uint32_t) atoi(henv);
@@ -878,10 +879,12 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 			a.tm_off_dc = (uint32_t) o_dc; a.tm_dccap = (uint32_t) dccap;
 			{
 				// helpers of rank < tm_spec prepare packages ahead of the walk; the others score slices of its many-row hops
-				// (device_search.h, banner at TeamCtl).  HNSW_GPU_TEAM_SPEC overrides (8 = every helper speculates, no job is
-				// ever posted).
+				// (device_search.h, banner at TeamCtl).  Measured at 1M rows (profiles/r3a_slice_helpers.txt): 768 dims, 5 of
+				// 7 helpers speculating: one query 0.470 -> 0.438 ms, 16 queries -3.4 %, 256 -4.1 %, 1024 -3.4 %, 10 000 -0.5 %,
+				// 40 000 -0.2 %; 3: 0.452; 0 (nobody speculates): 0.618.  128 dims: a hop rarely has more rows than one pass of 16,
+				// slices lose 1-2 %, so narrow rows let every helper speculate.  HNSW_GPU_TEAM_SPEC overrides (8 = all speculate).
 				const char *senv = getenv("HNSW_GPU_TEAM_SPEC");
-				a.tm_spec = senv ? (uint32_t) std::max(0, atoi(senv)) : 5u;
+				a.tm_spec = senv ? (uint32_t) std::max(0, atoi(senv)) : (ix->stride > 320 ? 5u : 8u);
 			}
 			int maxlds = 64 * 1024;
 			(void) hipDeviceGetAttribute(&maxlds, hipDeviceAttributeMaxSharedMemoryPerBlock, ix->device);
@@ -2213,7 +2216,7 @@ extern "C" int hnsw_gpu_gather_roof(hnsw_gpu_index *ix, int loads_per_lane, int 
 // order with nothing in between.  d_stats = that launch's stats array ({evals, hops} per query).  *ms = best of 3 timed
 // repetitions (after one warm-up), *bytes = row bytes one repetition reads.
 extern "C" int hnsw_gpu_replay_roof(hnsw_gpu_index *ix, const idx_t *d_evals, size_t evals_cap, const uint32_t *d_stats, size_t nq,
-									unsigned slots, int loads_per_lane, float *ms, double *bytes)
+									unsigned slots, int loads_per_lane, float *ms, double *bytes, uint64_t *word_sum)
 {
 	std::unique_lock<std::recursive_mutex> lock_;
 	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
@@ -2221,9 +2224,15 @@ extern "C" int hnsw_gpu_replay_roof(hnsw_gpu_index *ix, const idx_t *d_evals, si
 	if (ix->n == 0 || nq == 0 || slots < 4 || evals_cap == 0) return fail(HNSW_GPU_ERR_ARG, "need rows, queries and at least 4 slots");
 	HIPCHK(hipSetDevice(ix->device));
 	const uint32_t row_f4 = ix->stride / 4;
+	{
+		const uint32_t lpr = (row_f4 + 15) / 16;
+		if (loads_per_lane <= 0 || ((uint32_t) loads_per_lane % lpr != 0 && lpr % (uint32_t) loads_per_lane != 0))
+			return fail(HNSW_GPU_ERR_ARG, "loads_per_lane %d does not tile a row of %u loads per lane", loads_per_lane, lpr);
+	}
 	const uint32_t blocks = slots / 4;
 	float *out = (float *) ix->misc + 8;
 	uint32_t *ticket = ix->misc + 12;
+	unsigned long long *d_check = (unsigned long long *) (ix->misc + 14);
 	hipEvent_t e0, e1;
 	HIPCHK(hipEventCreate(&e0));
 	HIPCHK(hipEventCreate(&e1));
@@ -2231,12 +2240,13 @@ extern "C" int hnsw_gpu_replay_roof(hnsw_gpu_index *ix, const idx_t *d_evals, si
 	int rc = HNSW_GPU_OK;
 	for (int rep = 0; rep < 4 && rc == HNSW_GPU_OK; rep++)
 	{
-		(void) hipMemsetAsync(ticket, 0, 4, nullptr);
+		(void) hipMemsetAsync(ticket, 0, 16, nullptr);           // ticket + the (test-only) word sum behind it
 		(void) hipEventRecord(e0, nullptr);
 		const float4 *base = (const float4 *) ix->vec;
 		switch (loads_per_lane)
 		{
-#define ROOF(T) case T: hipLaunchKernelGGL(replay_roof_kernel<T>, dim3(blocks), dim3(256), 0, nullptr, base, row_f4, d_evals, (uint32_t) evals_cap, d_stats, (uint32_t) nq, ticket, out); break
+#define ROOF(T) case T: if (word_sum) hipLaunchKernelGGL((replay_roof_kernel<T, true>), dim3(blocks), dim3(256), 0, nullptr, base, row_f4, d_evals, (uint32_t) evals_cap, d_stats, (uint32_t) nq, ticket, out, d_check); \
+				else hipLaunchKernelGGL((replay_roof_kernel<T, false>), dim3(blocks), dim3(256), 0, nullptr, base, row_f4, d_evals, (uint32_t) evals_cap, d_stats, (uint32_t) nq, ticket, out, d_check); break
 			ROOF(8); ROOF(16); ROOF(24);
 #undef ROOF
 			default: rc = fail(HNSW_GPU_ERR_ARG, "loads_per_lane must be 8, 16 or 24");
@@ -2252,6 +2262,7 @@ extern "C" int hnsw_gpu_replay_roof(hnsw_gpu_index *ix, const idx_t *d_evals, si
 	(void) hipEventDestroy(e1);
 	if (rc) return rc;
 	*ms = best;
+	if (word_sum) HIPCHK(hipMemcpy(word_sum, d_check, 8, hipMemcpyDeviceToHost));   // of the last repetition
 	if (bytes)
 	{
 		// rows actually in the trace: sum over queries of min(evals, cap)
@@ -2274,11 +2285,14 @@ struct hnsw_gpu_sharded
 	std::vector<hnsw_gpu_index *> shards;
 	int home = 0;                                   // device of shard 0: queries arrive and results leave there
 	std::vector<hipStream_t> streams;               // one per shard, on the shard's device
+	std::vector<SearchWs *> ws;                     // ... and a search workspace of its own per shard: a direct search on a shard
+	                                                // (its default workspace) and a sharded call never share tickets or bitmaps
 	std::vector<hipEvent_t> done;
 	std::vector<bool> direct;                       // the shard's device writes home memory directly
 	std::vector<float *> q_local; std::vector<size_t> q_cap;          // query copy on a remote shard's device
 	std::vector<char *> out_local; std::vector<size_t> out_cap;       // result block when not `direct`
 	hipEvent_t ready = nullptr;
+	hipEvent_t merged = nullptr; bool merged_set = false;             // end of the previous call's merge: `gather` may be rewritten after it
 	char *gather = nullptr; size_t gather_bytes = 0;                  // home: nshards result blocks
 	char *io = nullptr; size_t io_bytes = 0;                          // home: staging of the host-pointer form
 	hipStream_t home_stream = nullptr;
@@ -2291,12 +2305,14 @@ extern "C" void hnsw_gpu_sharded_destroy(hnsw_gpu_sharded *s)
 	{
 		(void) hipSetDevice(s->shards[i]->device);
 		if (i < s->streams.size() && s->streams[i]) (void) hipStreamDestroy(s->streams[i]);
+		if (i < s->ws.size() && s->ws[i]) { ws_free(s->ws[i]); delete s->ws[i]; }
 		if (i < s->done.size() && s->done[i]) (void) hipEventDestroy(s->done[i]);
 		if (i < s->q_local.size() && s->q_local[i]) (void) hipFree(s->q_local[i]);
 		if (i < s->out_local.size() && s->out_local[i]) (void) hipFree(s->out_local[i]);
 	}
 	(void) hipSetDevice(s->home);
 	if (s->ready) (void) hipEventDestroy(s->ready);
+	if (s->merged) (void) hipEventDestroy(s->merged);
 	if (s->gather) (void) hipFree(s->gather);
 	if (s->io) (void) hipFree(s->io);
 	if (s->home_stream) (void) hipStreamDestroy(s->home_stream);
@@ -2317,6 +2333,7 @@ extern "C" int hnsw_gpu_sharded_create(hnsw_gpu_index *const *shards, size_t nsh
 	s->shards.assign(shards, shards + nshards);
 	s->home = shards[0]->device;
 	s->streams.assign(nshards, nullptr); s->done.assign(nshards, nullptr); s->direct.assign(nshards, false);
+	s->ws.assign(nshards, nullptr);
 	s->q_local.assign(nshards, nullptr); s->q_cap.assign(nshards, 0);
 	s->out_local.assign(nshards, nullptr); s->out_cap.assign(nshards, 0);
 	hipError_t e = hipSuccess;
@@ -2326,6 +2343,8 @@ extern "C" int hnsw_gpu_sharded_create(hnsw_gpu_index *const *shards, size_t nsh
 		if ((e = hipSetDevice(dev)) != hipSuccess) break;
 		if ((e = hipStreamCreateWithFlags(&s->streams[i], hipStreamNonBlocking)) != hipSuccess) break;
 		if ((e = hipEventCreateWithFlags(&s->done[i], hipEventDisableTiming)) != hipSuccess) break;
+		s->ws[i] = new (std::nothrow) SearchWs();
+		if (!s->ws[i] || ws_init(s->ws[i]) != HNSW_GPU_OK) { e = hipErrorOutOfMemory; break; }
 		if (dev == s->home) s->direct[i] = true;
 		else
 		{
@@ -2340,6 +2359,7 @@ extern "C" int hnsw_gpu_sharded_create(hnsw_gpu_index *const *shards, size_t nsh
 	}
 	if (e == hipSuccess) e = hipSetDevice(s->home);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ready, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreateWithFlags(&s->merged, hipEventDisableTiming);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->home_stream, hipStreamNonBlocking);
 	if (e != hipSuccess)
 	{
@@ -2383,6 +2403,9 @@ extern "C" int hnsw_gpu_sharded_search_dev(hnsw_gpu_sharded *s, const coord_t *d
 		hnsw_gpu_index *ix = s->shards[i];
 		HIPCHK(hipSetDevice(ix->device));
 		HIPCHK(hipStreamWaitEvent(s->streams[i], s->ready, 0));
+		// a call on ANOTHER user stream than the previous one: its shard kernels must not overwrite `gather` (and the
+		// shards' result blocks) while the previous call's merge still reads it
+		if (s->merged_set) HIPCHK(hipStreamWaitEvent(s->streams[i], s->merged, 0));
 		const float *q = d_queries;
 		if (ix->device != s->home)                  // the shard reads its queries from its own HBM
 		{
@@ -2400,7 +2423,7 @@ extern "C" int hnsw_gpu_sharded_search_dev(hnsw_gpu_sharded *s, const coord_t *d
 		}
 		// per-shard searchKnn (hnswalg.cpp:234-252); with peer access the kernel's result stores land in the
 		// home device's memory directly — no copy step, no collective
-		rc = launch_search(ix, &ix->ws, q, dim, nq, ef, 0, (uint64_t *) blk, nullptr, (float *) (blk + o_d), (uint32_t *) (blk + o_c),
+		rc = launch_search(ix, s->ws[i], q, dim, nq, ef, 0, (uint64_t *) blk, nullptr, (float *) (blk + o_d), (uint32_t *) (blk + o_c),
 						   nullptr, s->streams[i]);
 		if (rc) return rc;
 		if (!s->direct[i])
@@ -2409,8 +2432,13 @@ extern "C" int hnsw_gpu_sharded_search_dev(hnsw_gpu_sharded *s, const coord_t *d
 	}
 	HIPCHK(hipSetDevice(s->home));
 	for (size_t i = 0; i < ns; i++) HIPCHK(hipStreamWaitEvent(stream, s->done[i], 0));
-	return hnsw_gpu_merge_topk_strided_dev(s->home, (const label_t *) s->gather, block / 8, (const dist_t *) (s->gather + o_d), block / 4,
-										   ns, nq, ef, d_labels, d_dists, d_counts, stream);
+	rc = hnsw_gpu_merge_topk_strided_dev(s->home, (const label_t *) s->gather, block / 8, (const dist_t *) (s->gather + o_d), block / 4,
+										 ns, nq, ef, d_labels, d_dists, d_counts, stream);
+	if (rc) return rc;
+	HIPCHK(hipSetDevice(s->home));
+	HIPCHK(hipEventRecord(s->merged, stream));
+	s->merged_set = true;
+	return HNSW_GPU_OK;
 }
 
 extern "C" int hnsw_gpu_sharded_search(hnsw_gpu_sharded *s, const coord_t *queries, size_t nq, size_t ef,

@@ -59,8 +59,9 @@ inline long copy_reachable(HnswMetadata *meta, Grow grow)
 		}
 		if ((size_t) idx >= slots)
 		{
+			// (doubling while small, then in steps of a quarter: the image of a large index must not cost twice its size)
 			size_t want = slots ? slots : 256;
-			while (want <= (size_t) idx) want *= 2;
+			while (want <= (size_t) idx) want += want < (1u << 16) ? want : want / 4;
 			base = grow(want * esz);
 			if (!base) { hnsw_end_read(meta); return -1; }
 			for (size_t s = slots; s < want; s++)

@@ -96,6 +96,14 @@ void logf(const char *fmt, ...)
 
 // ----------------------------------------------------------------------------- mirrors
 static std::atomic<uint64_t> g_vseq{0};          // content versions: never repeat within a server's life
+// "Absent" has a version too: the value LOOKUP reports for a key without a mirror, new at every removal of ANY mirror
+// (DROP — also of a key that had none —, eviction, an upload that dropped its predecessor and then failed).  Without
+// it "no mirror" at LOOKUP and "no mirror" at UPLOAD looked the same (0 == 0) across a VACUUM that flipped flags in
+// place and dropped the mirror in between — and the guarded upload of a snapshot walked before the VACUUM was taken,
+// with its stale flags and an unchanged generation.  One server-wide epoch is conservative (any removal makes the
+// guarded uploads in flight for absent keys walk again), never wrong.
+static std::atomic<uint64_t> g_absent_ver{0};
+static void note_removed() { g_absent_ver.store(++g_vseq); }
 
 struct Entry
 {
@@ -194,6 +202,7 @@ bool evict_one(uint64_t keep)
 		if (victim) g_map.erase(victim->key);
 	}
 	if (!victim) return false;
+	note_removed();
 	logf("evicting mirror %llx (%zu elements) to make room", (unsigned long long) victim->key, victim->count.load());
 	g_cnt.evictions++;
 	return true;        // freed when `victim` goes out of scope here
@@ -600,7 +609,7 @@ void do_upload(CReq &r)
 	auto guard_ok = [&r]() {
 		if (r.h.a1 == 0) return true;
 		EntryP cur = find_entry(r.h.key);
-		return (cur ? cur->version.load() : 0) == r.h.a1 - 1;
+		return (cur ? cur->version.load() : g_absent_ver.load()) == r.h.a1 - 1;
 	};
 	if (!guard_ok())
 	{
@@ -626,7 +635,7 @@ void do_upload(CReq &r)
 				std::lock_guard<std::mutex> lk(g_map_mu);
 				had = g_map.erase(r.h.key) > 0;
 			}
-			if (had) continue;
+			if (had) { note_removed(); continue; }
 		}
 		if (!evict_one(r.h.key)) break;
 	}
@@ -773,6 +782,7 @@ void do_control(CReq &r)
 			auto it = g_map.find(r.h.key);
 			if (it != g_map.end()) { e = it->second; g_map.erase(it); }
 		}
+		note_removed();                                    // also when there was nothing to drop: the caller invalidated something
 		r.c->respond(r.h, e ? HGS_OK : HGS_ERR_NOKEY);
 		break;
 	}
@@ -918,7 +928,7 @@ bool handle_message(const ConnP &c, const hgs_hdr &h, const char *payload)
 	case HGS_OP_LOOKUP:
 	{
 		EntryP e = find_entry(h.key);
-		const uint64_t ver = e ? e->version.load() : 0;      // payload: the content version an UPLOAD may be guarded by
+		const uint64_t ver = e ? e->version.load() : g_absent_ver.load();   // payload: the content version an UPLOAD may be guarded by
 		if (e) c->respond(h, HGS_OK, e->count.load(), 1, &ver, sizeof(ver), nullptr, 0, e->gen.load());
 		else c->respond(h, HGS_OK, 0, 0, &ver, sizeof(ver));
 		return true;

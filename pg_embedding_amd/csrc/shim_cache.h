@@ -18,7 +18,13 @@
 // the device walk: about twice the reference's latency, instead of a full O(N) re-mirror per call.  The fast forms
 // remain the explicit attach (hnsw_gpu_shim_attach) and the server with the identity/generation patch.
 //
-// Host memory: the cache keeps the flat image the mirror was built from (N x element size) beside the mirror.
+// Memory: the cache keeps the flat image the mirror was built from (N x element size, host) beside the mirror (HBM), per
+// THREAD (= per Postgres backend), for up to 4 indexes.  That is the price of the unmodified glue and it does not scale
+// with connections: a host with many backends should run the server mode (one mirror per index for all of them,
+// INTEGRATION.md §2).  Bounds: PG_EMBEDDING_GPU_CACHE_MAX_MB (default 4096) per index — larger ones are mirrored for the
+// call that needs them and dropped again; entries idle for PG_EMBEDDING_GPU_CACHE_IDLE_S (default 300) are dropped at the
+// next call into the library; an allocation failure while (re-)mirroring drops every other cached entry of the thread and
+// tries once more before the call fails; an entry left half-patched by a longjmp is dropped at the next call.
 // PG_EMBEDDING_GPU_CACHE=0 switches the cache off (every call re-mirrors, the round-1 behaviour).
 // Not thread-shared: the table is thread_local (a Postgres backend is one thread; a threaded C host gets one cache
 // per thread), so no lock is ever held across a host callback — a callback may leave by longjmp (elog(ERROR)).
@@ -28,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <vector>
 
 #include "hnsw_gpu.h"
@@ -48,6 +55,7 @@ struct Entry
 	std::vector<uint32_t> stamp;       // 2*epoch = found identical in this validation, 2*epoch+1 = found different
 	uint32_t epoch = 0;
 	uint64_t last_use = 0;
+	time_t last_time = 0;              // wall seconds of the last use (idle expiry)
 	bool suspect = false;              // an insert was interrupted half-way (a callback left by longjmp)
 	bool ephemeral = false;            // larger than the cache may keep: used for this call only, then dropped
 };
@@ -66,7 +74,7 @@ inline bool enabled()
 inline size_t max_shadow_bytes()
 {
 	const char *e = getenv("PG_EMBEDDING_GPU_CACHE_MAX_MB");
-	const long long mb = e ? atoll(e) : 16384;
+	const long long mb = e ? atoll(e) : 4096;
 	return mb <= 0 ? 0 : (size_t) mb << 20;
 }
 
@@ -83,6 +91,34 @@ inline void drop(Entry *e)
 	t.erase(std::remove(t.begin(), t.end(), e), t.end());
 	if (e->ix) hnsw_gpu_index_destroy(e->ix);
 	delete e;
+}
+
+inline time_t now_s()
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec;
+}
+
+inline long idle_limit_s()
+{
+	const char *e = getenv("PG_EMBEDDING_GPU_CACHE_IDLE_S");
+	return e ? atol(e) : 300;
+}
+
+// Housekeeping at the start of every call: entries an interrupted insert left half-patched (they would never be picked
+// again, but kept their HBM and host memory until LRU eviction) and entries nobody has used for a while.
+inline void sweep()
+{
+	auto &t = table();
+	const time_t now = now_s();
+	const long lim = idle_limit_s();
+	for (size_t i = 0; i < t.size();)
+	{
+		Entry *e = t[i];
+		if (e->suspect || (lim > 0 && e->last_time && now - e->last_time > lim)) drop(e);      // (erases t[i])
+		else i++;
+	}
 }
 
 // Per-thread buffers that outlive a callback's longjmp (reclaimed by the next call).
@@ -112,7 +148,26 @@ inline Entry *resnapshot(HnswMetadata *meta, Entry *e, int device)
 	});
 	if (n < 0) return nullptr;
 	hnsw_gpu_index *ix = nullptr;
-	if (hnsw_gpu_index_create_from_flat(meta, wb.data(), (size_t) n, device, &ix) != HNSW_GPU_OK) return nullptr;
+	int rc = hnsw_gpu_index_create_from_flat(meta, wb.data(), (size_t) n, device, &ix);
+	if (rc == HNSW_GPU_ERR_NOMEM || rc == HNSW_GPU_ERR_HIP)
+	{
+		// out of HBM (or of pinned staging)?  this thread's own cache goes first: the mirror this call replaces, then every
+		// other entry — a query that can be answered after giving up the cache must not fail
+		if (e && e->ix) { hnsw_gpu_index_destroy(e->ix); e->ix = nullptr; }
+		auto &all = table();
+		for (size_t i = 0; i < all.size();)
+		{
+			if (all[i] != e) drop(all[i]);
+			else i++;
+		}
+		rc = hnsw_gpu_index_create_from_flat(meta, wb.data(), (size_t) n, device, &ix);
+	}
+	if (rc != HNSW_GPU_OK)
+	{
+		if (e && !e->ix) drop(e);                                  // its mirror went in the attempt above
+		std::vector<char>().swap(wb);
+		return nullptr;
+	}
 	auto &t = table();
 	if (!e)
 	{
@@ -131,12 +186,17 @@ inline Entry *resnapshot(HnswMetadata *meta, Entry *e, int device)
 	e->n = (size_t) n;
 	e->shadow.swap(wb);                                        // the walk's image becomes the shadow: no second copy of the index
 	e->shadow.resize((size_t) n * meta->size_data_per_element);
+	if (e->shadow.capacity() > e->shadow.size() + e->shadow.size() / 8)
+	{
+		try { e->shadow.shrink_to_fit(); } catch (...) {}           // (the walk's buffer grows in steps: give the slack back)
+	}
 	std::vector<char>().swap(wb);
 	e->stamp.assign((size_t) n, 0);
 	e->epoch = 0;
 	e->suspect = false;
 	e->ephemeral = e->shadow.size() > max_shadow_bytes();
 	e->last_use = ++clock_();
+	e->last_time = now_s();
 	stats().snapshots++;
 	return e;
 }
@@ -146,6 +206,7 @@ inline Entry *resnapshot(HnswMetadata *meta, Entry *e, int device)
 inline Entry *pick(HnswMetadata *meta, bool *empty)
 {
 	*empty = false;
+	sweep();
 	const size_t esz = meta->size_data_per_element;
 	idx_t *links = nullptr;
 	if (!hnsw_begin_read(meta, meta->enterpoint_node, &links, nullptr, nullptr)) { *empty = true; return nullptr; }
@@ -166,7 +227,7 @@ inline Entry *pick(HnswMetadata *meta, bool *empty)
 			hit = e;
 	}
 	hnsw_end_read(meta);
-	if (hit) hit->last_use = ++clock_();
+	if (hit) { hit->last_use = ++clock_(); hit->last_time = now_s(); }
 	return hit;
 }
 

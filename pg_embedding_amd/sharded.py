@@ -88,6 +88,8 @@ class ShardedIndex:
         self.local_search = local_search
         self.merge = merge
         self.exchanges = 0                     # collectives issued so far (one per search)
+        self.record_timing = False             # bench.py --mode sharded: stamp the three steps of every search
+        self._stamps = []                      # per search: 4 device events (or 4 host times for CPU tensors)
 
     @classmethod
     def build(cls, rows, global_first: int, meta, device: int = 0, max_batch: int = 0, ratio: int = 0):
@@ -104,7 +106,20 @@ class ShardedIndex:
     def search(self, queries, ef: int):
         """Every rank passes the SAME queries; every rank returns the merged result."""
         import torch
+
+        def stamp():
+            if not self.record_timing:
+                return None
+            if queries.is_cuda:
+                e = torch.cuda.Event(enable_timing=True)
+                e.record(torch.cuda.current_stream(queries.device))
+                return e
+            import time
+            return time.perf_counter()
+
+        t0 = stamp()
         labels, dists = self.local_search(queries, ef)
+        t1 = stamp()
         nq = labels.shape[0]
         mine = pack_block(labels, dists)
         if self.world == 1:
@@ -119,7 +134,23 @@ class ShardedIndex:
             else:
                 self.dist.all_gather_into_tensor(flat, mine, group=self.group)
             self.exchanges += 1
+        t2 = stamp()
         if self.merge_packed is not None:
-            return self.merge_packed(blocks, nq, ef)
-        lab, dst = unpack_blocks(blocks, nq, ef)
-        return self.merge(lab, dst, ef)
+            res = self.merge_packed(blocks, nq, ef)
+        else:
+            lab, dst = unpack_blocks(blocks, nq, ef)
+            res = self.merge(lab, dst, ef)
+        if self.record_timing:
+            self._stamps.append((t0, t1, t2, stamp()))
+        return res
+
+    def timings_ms(self):
+        """[(local_search_ms, pack_and_exchange_ms, merge_ms)] of the searches since record_timing was switched on (device
+        events on the search stream; call after a synchronize)."""
+        out = []
+        for t0, t1, t2, t3 in self._stamps:
+            if isinstance(t0, float):
+                out.append(((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3))
+            else:
+                out.append((t0.elapsed_time(t1), t1.elapsed_time(t2), t2.elapsed_time(t3)))
+        return out

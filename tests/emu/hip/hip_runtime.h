@@ -19,6 +19,9 @@
 #pragma once
 #include <pthread.h>
 #include <sched.h>
+#include <signal.h>
+#include <sys/mman.h>
+#include <unistd.h>
 #include <ucontext.h>
 #include <x86intrin.h>
 
@@ -31,6 +34,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -292,7 +296,7 @@ alignas(16) static unsigned char smem[SIMT_LDS_BYTES];
 namespace pgemb { alignas(16) static unsigned char smem[SIMT_LDS_BYTES]; }
 
 #define hipLaunchKernelGGL(kernel, grid, block, lds, stream, ...) \
-	simt::launch(dim3(grid), dim3(block), (size_t) (lds), [=]() { kernel(__VA_ARGS__); }, ::smem, pgemb::smem, SIMT_LDS_BYTES)
+	simt::launch_on((stream), dim3(grid), dim3(block), (size_t) (lds), [=]() { kernel(__VA_ARGS__); }, ::smem, pgemb::smem, SIMT_LDS_BYTES)
 
 // ---- intrinsics ------------------------------------------------------------------------------------------------------------
 #define __ballot(p) simt::ballot((bool) (p))
@@ -349,9 +353,11 @@ static inline float max(float a, float b) { return fmaxf(a, b); }
 
 // ---- runtime API: one "device", synchronous ----------------------------------------------------------------------------------
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorPeerAccessAlreadyEnabled = 704, hipErrorInvalidValue = 1 };
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorPeerAccessAlreadyEnabled = 704, hipErrorInvalidValue = 1,
+	   hipErrorInvalidResourceHandle = 400, hipErrorInvalidDevice = 101 };
+struct simt_stream { int dev; };
 typedef struct simt_stream *hipStream_t;
-struct simt_event { std::chrono::steady_clock::time_point t; };
+struct simt_event { std::chrono::steady_clock::time_point t; int dev = 0; };
 typedef simt_event *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
@@ -359,11 +365,72 @@ enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 enum hipDeviceAttribute_t { hipDeviceAttributeMaxSharedMemoryPerBlock = 1, hipDeviceAttributeMultiprocessorCount = 2 };
 struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcessorCount; size_t totalGlobalMem; };
 
+// ---- several emulated devices (SIMT_EMU_DEVICES=N > 1) ------------------------------------------------------------------------
+// What the host code of a multi-device path can get wrong is WHICH device something belongs to, and the emulator checks
+// exactly that: every hipMalloc belongs to the device that was current (own pages); a kernel launched on device d runs with
+// the memory of every other device inaccessible (PROT_NONE) unless d enabled peer access to it (SIMT_EMU_PEER=0: the
+// "hardware" has no peer access at all) — touching it ends the process with a message; a launch or an event record on a
+// stream of another device than the current one fails as HIP's does (hipErrorInvalidResourceHandle through hipGetLastError /
+// the return value); hipMemcpyPeerAsync checks that both pointers belong to the devices it is told.  One kernel runs at a
+// time (the protection is process-wide).  With one device none of this is active.
+namespace simt {
+struct DevAlloc { char *p; size_t bytes; int dev; };
+inline std::mutex &rt_mu() { static std::mutex m; return m; }
+inline std::vector<DevAlloc> &allocs() { static std::vector<DevAlloc> a; return a; }
+inline thread_local int cur_dev = 0;
+inline thread_local int last_error = 0;
+inline int ndev() { static const int n = [] { const char *e = getenv("SIMT_EMU_DEVICES"); const int v = e ? atoi(e) : 1; return v >= 1 && v <= 16 ? v : 1; }(); return n; }
+inline bool peer_hw() { static const bool p = [] { const char *e = getenv("SIMT_EMU_PEER"); return !(e && atoi(e) == 0); }(); return p; }
+inline bool (&peer_on())[16][16] { static bool t[16][16] = {}; return t; }
+inline std::atomic<int> &running_dev() { static std::atomic<int> d{-1}; return d; }
+inline int owner_of(const void *q)
+{
+	for (const DevAlloc &a : allocs()) if ((const char *) q >= a.p && (const char *) q < a.p + a.bytes) return a.dev;
+	return -1;
+}
+inline void segv_handler(int, siginfo_t *si, void *)
+{
+	char msg[256];
+	int own = -1;
+	for (const DevAlloc &a : allocs()) if ((char *) si->si_addr >= a.p && (char *) si->si_addr < a.p + a.bytes) own = a.dev;
+	const int n = snprintf(msg, sizeof(msg), "SIMT emulator: a kernel on device %d touched %p, memory of device %d, without peer access\n",
+						   running_dev().load(), si->si_addr, own);
+	if (n > 0) (void) !write(2, msg, (size_t) n);
+	_exit(86);
+}
+inline void protect_others(int dev, int prot)
+{
+	for (const DevAlloc &a : allocs())
+		if (a.dev != dev && !peer_on()[dev][a.dev]) mprotect(a.p, a.bytes, prot);
+}
+inline void launch_on(simt_stream *stream, dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body, unsigned char *lds0,
+					  unsigned char *lds1, size_t lds_cap)
+{
+	if (ndev() == 1) { launch(grid, block, lds_bytes, body, lds0, lds1, lds_cap); return; }
+	if (stream && stream->dev != cur_dev) { last_error = 400; return; }          // hipErrorInvalidResourceHandle: nothing runs
+	std::lock_guard<std::mutex> g(rt_mu());
+	static bool handler = false;
+	if (!handler)
+	{
+		struct sigaction sa;
+		memset(&sa, 0, sizeof(sa));
+		sa.sa_sigaction = segv_handler; sa.sa_flags = SA_SIGINFO;
+		sigaction(SIGSEGV, &sa, nullptr);
+		handler = true;
+	}
+	running_dev().store(cur_dev);
+	protect_others(cur_dev, PROT_NONE);
+	launch(grid, block, lds_bytes, body, lds0, lds1, lds_cap);
+	protect_others(cur_dev, PROT_READ | PROT_WRITE);
+	running_dev().store(-1);
+}
+}  // namespace simt
+
 static inline const char *hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : (e == hipErrorOutOfMemory ? "out of memory" : "error"); }
-static inline hipError_t hipGetLastError() { return hipSuccess; }
-static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-static inline hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
-static inline hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
+static inline hipError_t hipGetLastError() { const int e = simt::last_error; simt::last_error = 0; return e; }
+static inline hipError_t hipGetDeviceCount(int *n) { *n = simt::ndev(); return hipSuccess; }
+static inline hipError_t hipGetDevice(int *d) { *d = simt::cur_dev; return hipSuccess; }
+static inline hipError_t hipSetDevice(int d) { if (d < 0 || d >= simt::ndev()) return hipErrorInvalidDevice; simt::cur_dev = d; return hipSuccess; }
 static inline int simt_num_cu() { const char *e = getenv("SIMT_EMU_CUS"); const int n = e ? atoi(e) : 2; return n > 0 ? n : 2; }
 static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
 {
@@ -380,33 +447,77 @@ static inline hipError_t hipDeviceGetAttribute(int *v, int attr, int)
 	return hipSuccess;
 }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
-static inline hipError_t hipDeviceCanAccessPeer(int *can, int, int) { *can = 0; return hipSuccess; }
-static inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipSuccess; }
+static inline hipError_t hipDeviceCanAccessPeer(int *can, int dev, int peer) { *can = simt::ndev() > 1 && simt::peer_hw() && dev != peer; return hipSuccess; }
+static inline hipError_t hipDeviceEnablePeerAccess(int peer, unsigned)
+{
+	if (peer < 0 || peer >= simt::ndev() || peer == simt::cur_dev || !simt::peer_hw()) return hipErrorInvalidDevice;
+	std::lock_guard<std::mutex> g(simt::rt_mu());
+	if (simt::peer_on()[simt::cur_dev][peer]) return hipErrorPeerAccessAlreadyEnabled;
+	simt::peer_on()[simt::cur_dev][peer] = true;
+	return hipSuccess;
+}
 template <typename T> static inline hipError_t hipMalloc(T **p, size_t bytes)
 {
+	if (simt::ndev() > 1)                                   // own pages, owned by the current device
+	{
+		const size_t pg = 4096, len = ((bytes ? bytes : 1) + pg - 1) / pg * pg;
+		void *q = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+		if (q == MAP_FAILED) return hipErrorOutOfMemory;
+		std::lock_guard<std::mutex> g(simt::rt_mu());
+		simt::allocs().push_back({(char *) q, len, simt::cur_dev});
+		*p = (T *) q;
+		return hipSuccess;
+	}
 	void *q = nullptr;
 	if (posix_memalign(&q, 256, bytes ? bytes : 256)) return hipErrorOutOfMemory;
 	*p = (T *) q;
 	return hipSuccess;
 }
-static inline hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+static inline hipError_t hipFree(void *p)
+{
+	if (simt::ndev() > 1)
+	{
+		std::lock_guard<std::mutex> g(simt::rt_mu());
+		auto &a = simt::allocs();
+		for (size_t i = 0; i < a.size(); i++)
+			if (a[i].p == (char *) p) { munmap(a[i].p, a[i].bytes); a.erase(a.begin() + (long) i); return hipSuccess; }
+		return p ? hipErrorInvalidValue : hipSuccess;
+	}
+	free(p);
+	return hipSuccess;
+}
 static inline hipError_t hipHostMalloc(void **p, size_t bytes, unsigned) { return posix_memalign(p, 256, bytes ? bytes : 256) ? hipErrorOutOfMemory : hipSuccess; }
 static inline hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
-static inline hipError_t hipMemcpyPeerAsync(void *d, int, const void *s, int, size_t n, hipStream_t = nullptr) { memcpy(d, s, n); return hipSuccess; }
+static inline hipError_t hipMemcpyPeerAsync(void *d, int ddev, const void *s, int sdev, size_t n, hipStream_t = nullptr)
+{
+	if (simt::ndev() > 1)
+	{
+		std::lock_guard<std::mutex> g(simt::rt_mu());
+		const int od = simt::owner_of(d), os = simt::owner_of(s);
+		if ((od >= 0 && od != ddev) || (os >= 0 && os != sdev)) return hipErrorInvalidValue;    // a pointer that is not on the device it was said to be on
+	}
+	memcpy(d, s, n);
+	return hipSuccess;
+}
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
-static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t) malloc(8); return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t) malloc(sizeof(simt_stream)); (*s)->dev = simt::cur_dev; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreate(s); }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
-static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new simt_event(); return hipSuccess; }
+static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new simt_event(); (*e)->dev = simt::cur_dev; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 static inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t = nullptr) { e->t = std::chrono::steady_clock::now(); return hipSuccess; }
+static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr)
+{
+	if (simt::ndev() > 1 && e->dev != (s ? s->dev : simt::cur_dev)) return hipErrorInvalidResourceHandle;   // event and stream of different devices
+	e->t = std::chrono::steady_clock::now();
+	return hipSuccess;
+}
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)

@@ -138,11 +138,57 @@ def traced():
             _, _, pops, nev = ix.search_trace(Q[i], ef)
             want = U.evals_from_pops(port.raw(), ix.meta, n, ix.meta.enterpoint_node, pops)
             bad += 0 if (st[i, 0] == len(want) == nev and (ev[i, :len(want)] == want).all() and tm[i, 1] >= tm[i, 0] > 0) else 1
-        ms, by = C.c_float(0), C.c_double(0)
-        rc = ix.L.hnsw_gpu_replay_roof(ix._h, ev.ctypes.data, cap, st.ctypes.data, nq, 8, 8, C.byref(ms), C.byref(by))
+        ms, by, ws = C.c_float(0), C.c_double(0), C.c_uint64(0)
+        rc = ix.L.hnsw_gpu_replay_roof(ix._h, ev.ctypes.data, cap, st.ctypes.data, nq, 8, 8, C.byref(ms), C.byref(by), C.byref(ws))
+        words = X.view(np.uint32).astype(np.uint64).sum(axis=1)
+        want_sum = int(sum(int(words[ev[i, :st[i, 0]]].sum()) for i in range(nq)) % (1 << 64))
         out.append({"env": env, "kernel": ix.last_search_kernel(), "wrong": bad, "replay_rc": rc, "replay_bytes": by.value,
-                    "want_bytes": float(st[:, 0].sum()) * dim * 4})
+                    "want_bytes": float(st[:, 0].sum()) * dim * 4, "word_sum_ok": int(ws.value) == want_sum})
         ix.close()
+    return out
+
+
+def sharded():
+    """hnsw_gpu_sharded_create / _search[_dev] with the shards on SEVERAL emulated devices (SIMT_EMU_DEVICES, set by the caller
+    before the library loads): per-shard search on the shard's own device and stream, results into the merging device's buffer
+    through peer access or — SIMT_EMU_PEER=0 / HNSW_GPU_SHARDED_NO_PEER=1 — through a staged peer copy, one merge == oracle per
+    shard + CPU merge.  The emulator ends the process if a kernel touches another device's memory without peer access, and
+    fails a launch or event record on a stream of the wrong device."""
+    import ctypes as C
+    from pg_embedding_amd._lib import gpu_lib
+    ndev = gpu_lib().hnsw_gpu_device_count()
+    out = {"devices": ndev, "cases": []}
+    n, dim, m, efc, ef, nq = 1800, 24, 6, 32, 20, 24
+    X = gmm(n, dim, k=12, seed=41)
+    Q = gmm(nq, dim, k=12, seed=41, stream=1)
+    X[n - 5] = X[7]                                            # identical rows in different shards
+    meta = pg.make_meta(dim, m, efc, ef, pg.DIST_L2)
+    import oracle
+    for nshards, order in ((2, (0, 1)), (3, (0, 1, 2)), (3, (2, 0, 1)), (5, (1, 0, 2, 1, 0))):
+        if max(order) >= ndev:
+            continue
+        shards, per = [], []
+        for r in range(nshards):
+            lo, hi = n * r // nshards, n * (r + 1) // nshards
+            port = oracle.PortIndex(dim, m, efc, ef, pg.DIST_L2)
+            port.add(X[lo:hi], np.arange(lo, hi, dtype=np.uint64))
+            port.set_deleted(1)
+            per.append(port.search_many(Q, ef))
+            shards.append(pg.GpuIndex.from_flat(meta, port.raw(), hi - lo, device=order[r]))
+        sh = pg.LocalShardedIndex(shards)
+        bad = 0
+        for rep in range(2):                                   # second call: buffers and events are reused
+            ml, md, mc = sh.search(Q, ef)
+            for q in range(nq):
+                l = np.concatenate([p["labels"][q, :p["counts"][q]] for p in per])
+                d = np.concatenate([p["dists"][q, :p["counts"][q]] for p in per])
+                o = np.lexsort((l, d))[:ef]
+                ok = mc[q] == o.size and (ml[q, :o.size] == l[o]).all() and (U.bits(md[q, :o.size]) == U.bits(d[o])).all()
+                bad += 0 if ok else 1
+        out["cases"].append({"shards": nshards, "devices_of_shards": list(order), "wrong": bad})
+        sh.close()
+        for ix in shards:
+            ix.close()
     return out
 
 
@@ -198,4 +244,4 @@ def others():
 
 
 if __name__ == "__main__":
-    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced}[sys.argv[1]]()))
+    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced, "sharded": sharded}[sys.argv[1]]()))

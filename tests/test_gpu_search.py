@@ -575,6 +575,12 @@ def test_evaluation_trace_is_the_walk_and_replay_reads_its_bytes(env, monkeypatc
         _, _, pops, nev = ix.search_trace(Q[i], ef)
         w = evals_from_pops(port.raw(), ix.meta, n, ix.meta.enterpoint_node, pops)
         assert nev == len(w) == st[i, 0] and (ev[i, :len(w)] == w).all(), i
-    ms, by = ix.replay_roof(tr, slots, 8)
-    assert ms > 0 and by == float(st[:, 0].sum()) * ix.meta.dim * 4
+    # the replay reads exactly the traced rows, whole: bytes, and the (order-free) sum of the bit patterns of every word
+    words = X.view(np.uint32).astype(np.uint64).sum(axis=1)
+    want_sum = int(sum(int(words[ev[i, :st[i, 0]]].sum()) for i in range(300)) % (1 << 64))
+    for lpl in (8, 16):                                        # a row of 200 floats = 4 loads per lane: both tile it
+        ms, by, ws = ix.replay_roof(tr, slots, lpl, check=True)
+        assert ms > 0 and by == float(st[:, 0].sum()) * ix.meta.dim * 4 and ws == want_sum, (lpl, ws, want_sum)
+    with pytest.raises(Exception):
+        ix.replay_roof(tr, slots, 24)                          # 24 loads do not tile 4: refused, not a partial replay
     ix.close()

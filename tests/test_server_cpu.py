@@ -491,7 +491,7 @@ def test_a_snapshot_cannot_replace_a_mirror_that_changed_since_its_lookup(srv):
     hdr = struct.Struct("<IHhIIQQQQ")
     key = 77
 
-    def call(op, aux=0, gen=0, a0=0, a1=0, payload=b"", fd=None):
+    def call(op, aux=0, gen=0, a0=0, a1=0, payload=b"", fd=None, key=key):
         s = socket.socket(socket.AF_UNIX, socket.SOCK_STREAM)
         s.settimeout(10)
         s.connect(srv.socket_path)
@@ -510,13 +510,13 @@ def test_a_snapshot_cannot_replace_a_mirror_that_changed_since_its_lookup(srv):
         s.close()
         return r, buf[48:48 + r[3]]
 
-    def version():
-        r, p = call(2)
+    def version(key=key):
+        r, p = call(2, key=key)
         return struct.unpack("<Q", p)[0], r
 
-    def upload(gen, guard, count=n):
+    def upload(gen, guard, count=n, key=key):
         img = port.raw()[:count * meta.size_data_per_element].tobytes()
-        return call(3, gen=gen, a0=count, a1=guard, payload=bytes(meta), fd=_sealed_memfd(img))[0]
+        return call(3, gen=gen, a0=count, a1=guard, payload=bytes(meta), fd=_sealed_memfd(img), key=key)[0]
 
     v0, r = version()
     assert v0 == 0 and r[8] == 0                                    # absent
@@ -535,6 +535,22 @@ def test_a_snapshot_cannot_replace_a_mirror_that_changed_since_its_lookup(srv):
     assert upload(6, v2 + 1)[2] == 0                                # a walk that started after the change is taken
     assert c.lookup(key) == (True, 6, n)
     assert upload(7, 0)[2] == 0                                     # unguarded (a host that owns the key outright)
+    # "absent" is versioned too.  A scanner LOOKUPs a key that has no mirror and walks the index while
+    # a VACUUM flips flags in place; the VACUUM ends with a DROP (of a key that may have no mirror: NOKEY); the scanner's
+    # guarded UPLOAD of its pre-VACUUM snapshot must be refused although the key is absent before AND after.
+    k2 = 78
+    va, r = version(k2)
+    assert r[8] == 0                                                # absent
+    assert call(6, key=k2)[0][2] == HGS_ERR_NOKEY                    # DROP of a key without a mirror ...
+    vb, r = version(k2)
+    assert r[8] == 0 and vb != va                                   # ... still absent, but not the same "absent"
+    assert upload(5, va + 1, key=k2)[2] == HGS_ERR_STALE             # the snapshot walked before the DROP is refused
+    assert upload(5, vb + 1, key=k2)[2] == 0                         # one walked after it is taken
+    # the same when the mirror existed at neither end but in between (uploaded and dropped by others)
+    k3 = 79
+    vc, _ = version(k3)
+    assert upload(9, 0, key=k3)[2] == 0 and call(6, key=k3)[0][2] == 0
+    assert upload(9, vc + 1, key=k3)[2] == HGS_ERR_STALE
     # an insert lands on a mirror that already holds the new row as the walk's zero placeholder (the host had
     # stored it, still unlinked, when the snapshot was taken): BIND gives it its row, then links it
     new = gmm(1, dim, k=20, seed=72)[0]

@@ -64,7 +64,10 @@ def _worker(rank, world, port, n, dim, ef, tmp):
         return torch.from_numpy(lab.view(np.int64)), torch.from_numpy(r["dists"])
 
     sh = ShardedIndex(local_search=local_search, merge=numpy_merge)
+    sh.record_timing = True                       # what bench.py --mode sharded reports per step and per rank
     labels, dists, counts = sh.search(torch.from_numpy(Q), ef)
+    tm = sh.timings_ms()
+    assert len(tm) == 1 and len(tm[0]) == 3 and all(t >= 0 for t in tm[0]) and sh.exchanges == 1
     # every rank must hold the same merged answer
     ref = [torch.zeros_like(labels) for _ in range(world)]
     dist.all_gather(ref, labels)

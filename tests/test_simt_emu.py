@@ -124,4 +124,32 @@ def test_the_evaluation_trace_is_the_walk_and_the_replay_runs_over_it(emu_lib):
     the unvisited links of every popped element in order — and hnsw_gpu_replay_roof gathers exactly those bytes."""
     res = run_case("traced", emu_lib, timeout=600)
     for r in res:
-        assert r["wrong"] == 0 and r["replay_rc"] == 0 and r["replay_bytes"] == r["want_bytes"], r
+        assert r["wrong"] == 0 and r["replay_rc"] == 0 and r["replay_bytes"] == r["want_bytes"] and r["word_sum_ok"], r
+
+
+@pytest.mark.parametrize("env", [{"SIMT_EMU_DEVICES": "3"}, {"SIMT_EMU_DEVICES": "3", "SIMT_EMU_PEER": "0"},
+                                 {"SIMT_EMU_DEVICES": "2", "HNSW_GPU_SHARDED_NO_PEER": "1"}])
+def test_native_sharded_search_with_shards_on_several_emulated_devices(emu_lib, env):
+    """The multi-device host code of hnsw_gpu_sharded_create / _search[_dev] (per-device streams and events, peer enabling,
+    cross-device result stores or the staged peer copy, the merge on the home device) with the shards on two and three EMULATED
+    devices — the first 8-GPU run must not be its first run.  The emulator gives every device its own pages and ends the process
+    when a kernel touches another device's memory without peer access; launches and event records on a stream of the wrong
+    device fail as HIP's do.  Peer access on (direct stores), no peer hardware, and peer access declined by the environment."""
+    res = run_case("sharded", emu_lib, env, timeout=900)
+    assert res["devices"] == int(env["SIMT_EMU_DEVICES"]) and len(res["cases"]) >= 1
+    assert all(c["wrong"] == 0 for c in res["cases"]), res
+
+
+def test_the_emulator_notices_a_store_into_another_devices_memory():
+    """teeth of the test above: the same source with the peer enabling removed (but the direct-store path kept) must die on the
+    first cross-device store"""
+    def no_enable(name, txt):
+        if name == "hnsw_gpu.hip":
+            needle = "const hipError_t pe = hipDeviceEnablePeerAccess(s->home, 0);"
+            assert txt.count(needle) == 1
+            txt = txt.replace(needle, "const hipError_t pe = hipSuccess;")
+        return txt
+    lib = build_emu.build_tree(tag="nopeer", edit=no_enable)
+    r = subprocess.run([sys.executable, RUN, "sharded", lib], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, SIMT_EMU_DEVICES="2"))
+    assert r.returncode == 86 and "without peer access" in r.stderr, (r.returncode, r.stderr[-800:])
