@@ -195,15 +195,15 @@ def trace_roof(ix, Q, ef):
     row_bytes = int(ix.meta.dim + 3) // 4 * 16
     best = None
     lpr = (row_bytes // 16 + 15) // 16                        # 16-byte loads per lane per row
-    for lpl in (24, 16, 8):
-        if lpl % lpr and lpr % lpl:
-            continue                                          # would read partial rows: not a replay of this trace
-        ms, by = ix.replay_roof(tr, slots, lpl)
-        if best is None or ms < best[0]:
-            best = (ms, by, lpl)
-    rms, rbytes, rlpl = best
-    out = {"replay_ms": rms, "replay_row_bytes": rbytes, "replay_GBps": rbytes / rms / 1e6, "replay_loads_per_lane": rlpl,
-           "replay_slots": slots}
+    shapes = [(2, 2), (2, 4), (2, 8)] if lpr <= 2 else [(4, 2), (4, 4)] if lpr <= 4 else [(8, 2), (4, 4)] if lpr <= 8 else [(12, 2), (12, 1), (6, 4)]
+    for kb, rpg in shapes:                                    # a roof: the best of the search kernel's own shape and its neighbours ...
+        for rs in (slots, 2 * slots):                         # ... at the search's own occupancy and with twice as many waves
+            ms, by = ix.replay_roof(tr, rs, kb, rpg)
+            if best is None or ms < best[0]:
+                best = (ms, by, f"<{kb},{rpg}>", rs)
+    rms, rbytes, rlpl, rslots = best
+    out = {"replay_ms": rms, "replay_row_bytes": rbytes, "replay_GBps": rbytes / rms / 1e6, "replay_shape": rlpl,
+           "replay_slots": rslots, "search_slots": slots}
     # ---- reuse distances, on the device with torch (tens of millions of reads) ----
     j = torch.arange(cap, device=Q.device, dtype=torch.int64)[None, :]
     valid = j < E[:, None]

@@ -156,17 +156,18 @@ int hnsw_gpu_team_counters(hnsw_gpu_index *ix, uint32_t *out16);
  * the j-th row query i scored (j < d_stats[2 * i]; truncated at evals_cap), d_times[2 * i], [2 * i + 1] = the device's
  * constant-rate clock (100 MHz) at the start of query i and at the end of its walk (d_times may be NULL) — and the REPLAY ROOF
  * made from it: the rows of such a trace gathered again by `slots` resident waves (hnsw_gpu_last_search_slots of the traced
- * launch) in the same query order, with the search kernel's load shape (`loads_per_lane` 16-byte loads in flight per lane: 8,
- * 16 or 24; it must tile a row: a multiple or a divisor of its ceil(dim/64) loads per lane) and nothing in between.  *ms = best
- * of three repetitions, *bytes = row bytes one repetition reads; word_sum (NULL, or for tests): the sum mod 2^64 of the 32-bit
- * patterns of every word one repetition read for the trace — equal to the same sum over the traced rows of the table.  The search
- * kernel cannot beat the replay of its own trace: search time / replay time is the cost of the walk's dependent chain,
- * bytes / replay time what the memory system gives this access pattern (bench.py: roofline.replay). */
+ * launch, or more) in the same query order, with the search kernel's load shape <kb, rpg> (device_dist.h, score_rows: kb
+ * chunk-steps of rpg rows per 16-lane group = kb * rpg 16-byte loads in flight per lane; the search kernel's own shape is <2,2> /
+ * <2,4> up to 128 dims, <4,2> up to 256, <8,2> up to 512, <12,2> beyond) and nothing in between.  *ms = best of three repetitions,
+ * *bytes = row bytes one repetition reads; word_sum (NULL, or for tests): the sum mod 2^64 of the 32-bit patterns of every word
+ * one repetition read for the trace — equal to the same sum over the traced rows of the table.  The search kernel should not beat
+ * the best replay of its own trace: search time / replay time is the cost of the walk's dependent chain, bytes / replay time
+ * what the memory system gives this access pattern (bench.py: roofline.replay). */
 int hnsw_gpu_search_traced_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t ef,
                                label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
                                idx_t *d_evals, size_t evals_cap, uint64_t *d_times, void *stream);
 int hnsw_gpu_replay_roof(hnsw_gpu_index *ix, const idx_t *d_evals, size_t evals_cap, const uint32_t *d_stats, size_t nq,
-                         unsigned slots, int loads_per_lane, float *ms, double *bytes, uint64_t *word_sum);
+                         unsigned slots, int kb, int rpg, float *ms, double *bytes, uint64_t *word_sum);
 
 /* Health of the mirror's default search workspace (8 words).  out8[0] = 1 while an abort request is pending, [1] = slices a
  * team helper did not deliver in time and [2] = helper packages that stayed "claimed" past the bound (both were then

@@ -54,23 +54,27 @@ __global__ __launch_bounds__(256) void gather_roof_kernel(const float4 *__restri
 // pass k+1 do not depend on the data of pass k.  Same bytes, same temporal locality between the queries of a launch
 // (what the caches see is the same), no dependencies: search time / replay time is what the walk's dependent chain costs,
 // replay bytes / replay time is what the memory system gives this trace.  The search kernel cannot beat it.
-// T = 16-byte loads per lane in flight per pass (search kernel: KB * RPG: 24 at 768 dims).  A row is row_f4 float4 = lpr =
-// ceil(row_f4 / 16) loads per lane of its 16-lane group.  T >= lpr: the 4 groups of a wave take 4 * (T / lpr) whole rows per
-// pass; T < lpr: 4 rows per pass in lpr / T steps of T loads.  The host only picks T with T % lpr == 0 or lpr % T == 0, so
-// every load of a pass is a load the trace asks for (no padding traffic, no partial rows).
+// Load shape <KB, RPG> as in score_rows (device_dist.h): every 16-lane group owns RPG rows per pass and issues KB chunk-steps
+// of all of them before the first use = KB * RPG independent 16-byte loads per lane in flight (the search kernel's shape at
+// 768 dims: <12, 2>); a row of lpr = ceil(row_f4 / 16) loads per lane takes ceil(lpr / KB) steps.  No address arithmetic beyond
+// the search kernel's own: the replay must be limited by the memory system, not by integer divisions.
 // CHECK (tests only): also sums the bit patterns of every word the trace asks for (mod 2^64, order-free) into *check, so a test
 // can tell that the replay read exactly the traced rows, whole.
-template <int T, bool CHECK>
+constexpr uint32_t REPLAY_STAGE = 512;
+template <int KB, int RPG, bool CHECK>
 __global__ __launch_bounds__(256) void replay_roof_kernel(const float4 *__restrict__ base, uint32_t row_f4, const uint32_t *__restrict__ evals,
 														   uint32_t evals_cap, const uint32_t *__restrict__ nevals, uint32_t nq,
 														   uint32_t *ticket, float *out, unsigned long long *check)
 {
+	// row ids staged in LDS, REPLAY_STAGE at a time (the search kernel has its ids in LDS too: a pass must not wait for an id
+	// load before it can issue its row loads); dynamic LDS: 4 waves x REPLAY_STAGE x 4 bytes
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	constexpr uint32_t STAGE = REPLAY_STAGE;
 	unsigned long long bits = 0;
-	const uint32_t lane = threadIdx.x & 63;
+	const uint32_t lane = threadIdx.x & 63, wib = threadIdx.x >> 6;
 	const uint32_t g = lane >> 4, sub = lane & 15;
 	const uint32_t lpr = (row_f4 + 15) / 16;                 // loads per lane per row
-	const uint32_t kb = lpr < (uint32_t) T ? lpr : (uint32_t) T;   // chunk-steps of one row per pass
-	const uint32_t rpg = (uint32_t) T / kb;                  // rows per group per pass
+	uint32_t *ids = reinterpret_cast<uint32_t *>(smem) + (size_t) wib * STAGE;
 	float acc = 0.f;
 	for (;;)
 	{
@@ -78,27 +82,50 @@ __global__ __launch_bounds__(256) void replay_roof_kernel(const float4 *__restri
 		if (lane == 0) qi = atomicAdd(ticket, 1u);
 		qi = __builtin_amdgcn_readfirstlane(qi);
 		if (qi >= nq) break;
-		const uint32_t *ids = evals + (size_t) qi * evals_cap;
+		const uint32_t *gids = evals + (size_t) qi * evals_cap;
 		uint32_t ne = nevals[2 * (size_t) qi];               // (the search kernel's stats array: {evals, hops} per query)
 		ne = ne < evals_cap ? ne : evals_cap;
-		for (uint32_t r0 = 0; r0 < ne; r0 += 4 * rpg)
-			for (uint32_t k0 = 0; k0 < lpr; k0 += kb)
+		for (uint32_t s0 = 0; s0 < ne; s0 += STAGE)
+		{
+			const uint32_t ns = ne - s0 < STAGE ? ne - s0 : STAGE;
+			__builtin_amdgcn_wave_barrier();
+			for (uint32_t i = lane; i < ns; i += 64) ids[i] = gids[s0 + i];
+			__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			for (uint32_t r0 = 0; r0 < ns; r0 += 4 * RPG)
 			{
-				float4 v[T];
+				const float4 *rp[RPG];
+				bool rin[RPG];
 #pragma unroll
-				for (int t = 0; t < T; t++)
+				for (int rr = 0; rr < RPG; rr++)
 				{
-					const uint32_t rr = (uint32_t) t / kb, c = (k0 + (uint32_t) t % kb) * 16 + sub;
-					uint32_t r = r0 + rr * 4 + g;
-					r = r < ne ? r : ne - 1;                 // (the last pass of a query re-reads its last row where the search kernel narrows the pass)
-					const uint32_t row = ids[r];
-					v[t] = base[(size_t) row * row_f4 + (c < row_f4 ? c : row_f4 - 1)];
-					if (CHECK && r0 + rr * 4 + g < ne && c < row_f4)
-						bits += (unsigned long long) __float_as_uint(v[t].x) + __float_as_uint(v[t].y) + __float_as_uint(v[t].z) + __float_as_uint(v[t].w);
+					const uint32_t r = r0 + (uint32_t) rr * 4 + g;
+					rin[rr] = r < ns;                        // (a partial last pass re-reads its last row where the search kernel narrows the pass)
+					rp[rr] = base + (size_t) ids[rin[rr] ? r : ns - 1] * row_f4;
 				}
+				for (uint32_t k0 = 0; k0 < lpr; k0 += KB)
+				{
+					float4 x[RPG][KB];
 #pragma unroll
-				for (int t = 0; t < T; t++) acc += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+					for (int u = 0; u < KB; u++)
+					{
+						const uint32_t c = (k0 + (uint32_t) u) * 16 + sub;
+						const uint32_t cc = c < row_f4 ? c : row_f4 - 1;
+#pragma unroll
+						for (int rr = 0; rr < RPG; rr++)
+						{
+							x[rr][u] = rp[rr][cc];
+							if (CHECK && rin[rr] && c < row_f4)
+								bits += (unsigned long long) __float_as_uint(x[rr][u].x) + __float_as_uint(x[rr][u].y) + __float_as_uint(x[rr][u].z) + __float_as_uint(x[rr][u].w);
+						}
+					}
+#pragma unroll
+					for (int u = 0; u < KB; u++)
+#pragma unroll
+						for (int rr = 0; rr < RPG; rr++) acc += (x[rr][u].x + x[rr][u].y) + (x[rr][u].z + x[rr][u].w);
+				}
 			}
+		}
 	}
 	if (acc == 12345.678f) out[0] = acc;    // keeps the loads alive
 	if (CHECK) atomicAdd(check, bits);

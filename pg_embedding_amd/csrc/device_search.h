@@ -1275,7 +1275,8 @@ struct TeamCtl
 	uint32_t job;          // main: a scoring job for its slice helpers: view << 15 | helper mask << 7 | rows ...
 	uint32_t jobseq;       // ... and its number (written after `job`, read before and after it: a helper never pairs one
 	                       //     job's number with another job's description)
-	uint32_t done;         // helper: number of the last job whose slice I finished (my sums are in `slice`)
+	uint32_t done;         // helper: the last job whose slice I finished (my sums are in `slice`): job number * 8 + the walking
+	                       //     wave it was for — a helper moves from walk to walk, and two walking waves' job numbers may coincide
 	uint32_t pad0, pad1, pad2;
 	float    slice[2 * SLICE_ROWS];     // helper: sums of my slice [0, SLICE_ROWS) and, cosine, |x|^2 behind them
 };
@@ -1291,7 +1292,10 @@ struct TeamCtl
 //   helper  sees jobseq change (it remembered the number from BEFORE its helper bit became visible, so a job that names
 //           it always looks new), reads job between two reads of jobseq, scores its slice into ITS OWN ctl[me].slice
 //           (never into the main's arrays: a helper that is late for a job the main gave up on writes where nobody
-//           reads), then stores ctl[me].done = that job's number.  A late `done` never equals a later job's number.
+//           reads), then stores ctl[me].done = that job's number * 8 + the main's wave number.  A late `done` never equals
+//           a later job's value, and — a helper moves from walk to walk, and the job numbers of two walking waves of a
+//           block may coincide — never another main's either (found on the device at Q = 1024 / 1536 dims, where helpers
+//           change walks all the time: profiles/r3d_c5_spec_mismatch.txt; it is also reset when a helper attaches).
 // (job word: the helper mask is the walking wave's own snapshot, so a helper that attaches meanwhile changes nobody's
 // slice; `view` = whose region holds the id list.)
 constexpr uint32_t SLICE_WAIT_POLLS = 20000;    // ~1 ms of polling: two orders of magnitude above a slice's round trip
@@ -1423,6 +1427,7 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 		// (read BEFORE my bit becomes visible: a job the walking wave posts from now on may name me, and must look new to me;
 		// reading it after the atomicOr could swallow a job posted in between — the walking wave would wait for me forever)
 		uint32_t last_job = __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[target].jobseq));
+		if (lane == 0) __hip_atomic_store(&ctl[wib].done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // nothing delivered to THIS walk yet
 		__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 		if (lane == 0) atomicOr(&ctl[target].helpers, 1u << wib);
 		unsigned char *mreg = smem + (size_t) target * a.wave_bytes;
@@ -1460,7 +1465,7 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 						auto by_id = [ids](uint32_t r) { return ids[r]; };
 						score_rows_fit<FUNC, SH::KB, SH::RPG, SLICE_ROWS>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_id, cnt, ctl[wib].slice, lane);
 						wave_sync();
-						if (lane == 0) __hip_atomic_store(&ctl[wib].done, js, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+						if (lane == 0) __hip_atomic_store(&ctl[wib].done, js * 8u + target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 					}
 					continue;
 				}
@@ -1854,11 +1859,12 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 								const uint32_t h = (uint32_t) __builtin_ctz(mm);
 								const uint32_t cnt = nscore - lo < PASS ? nscore - lo : PASS;
 								uint32_t polls = 0;
-								bool got = (uint32_t) __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[h].done)) == jobseq;
+								const uint32_t mine_done = jobseq * 8u + wib;        // this job of THIS walk, nobody else's
+								bool got = (uint32_t) __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[h].done)) == mine_done;
 								for (; !got && polls < SLICE_WAIT_POLLS; polls++)
 								{
 									__builtin_amdgcn_s_sleep(0);
-									got = (uint32_t) __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[h].done)) == jobseq;
+									got = (uint32_t) __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[h].done)) == mine_done;
 								}
 								wave_sync();
 								if (got)

@@ -2216,7 +2216,7 @@ extern "C" int hnsw_gpu_gather_roof(hnsw_gpu_index *ix, int loads_per_lane, int 
 // order with nothing in between.  d_stats = that launch's stats array ({evals, hops} per query).  *ms = best of 3 timed
 // repetitions (after one warm-up), *bytes = row bytes one repetition reads.
 extern "C" int hnsw_gpu_replay_roof(hnsw_gpu_index *ix, const idx_t *d_evals, size_t evals_cap, const uint32_t *d_stats, size_t nq,
-									unsigned slots, int loads_per_lane, float *ms, double *bytes, uint64_t *word_sum)
+									unsigned slots, int kb, int rpg, float *ms, double *bytes, uint64_t *word_sum)
 {
 	std::unique_lock<std::recursive_mutex> lock_;
 	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
@@ -2224,11 +2224,6 @@ extern "C" int hnsw_gpu_replay_roof(hnsw_gpu_index *ix, const idx_t *d_evals, si
 	if (ix->n == 0 || nq == 0 || slots < 4 || evals_cap == 0) return fail(HNSW_GPU_ERR_ARG, "need rows, queries and at least 4 slots");
 	HIPCHK(hipSetDevice(ix->device));
 	const uint32_t row_f4 = ix->stride / 4;
-	{
-		const uint32_t lpr = (row_f4 + 15) / 16;
-		if (loads_per_lane <= 0 || ((uint32_t) loads_per_lane % lpr != 0 && lpr % (uint32_t) loads_per_lane != 0))
-			return fail(HNSW_GPU_ERR_ARG, "loads_per_lane %d does not tile a row of %u loads per lane", loads_per_lane, lpr);
-	}
 	const uint32_t blocks = slots / 4;
 	float *out = (float *) ix->misc + 8;
 	uint32_t *ticket = ix->misc + 12;
@@ -2238,18 +2233,21 @@ extern "C" int hnsw_gpu_replay_roof(hnsw_gpu_index *ix, const idx_t *d_evals, si
 	HIPCHK(hipEventCreate(&e1));
 	float best = 1e30f;
 	int rc = HNSW_GPU_OK;
+	const int shape = kb * 100 + rpg;
 	for (int rep = 0; rep < 4 && rc == HNSW_GPU_OK; rep++)
 	{
 		(void) hipMemsetAsync(ticket, 0, 16, nullptr);           // ticket + the (test-only) word sum behind it
 		(void) hipEventRecord(e0, nullptr);
 		const float4 *base = (const float4 *) ix->vec;
-		switch (loads_per_lane)
+		switch (shape)
 		{
-#define ROOF(T) case T: if (word_sum) hipLaunchKernelGGL((replay_roof_kernel<T, true>), dim3(blocks), dim3(256), 0, nullptr, base, row_f4, d_evals, (uint32_t) evals_cap, d_stats, (uint32_t) nq, ticket, out, d_check); \
-				else hipLaunchKernelGGL((replay_roof_kernel<T, false>), dim3(blocks), dim3(256), 0, nullptr, base, row_f4, d_evals, (uint32_t) evals_cap, d_stats, (uint32_t) nq, ticket, out, d_check); break
-			ROOF(8); ROOF(16); ROOF(24);
+#define ROOF(K, R) case K * 100 + R: \
+				if (word_sum) hipLaunchKernelGGL((replay_roof_kernel<K, R, true>), dim3(blocks), dim3(256), 4 * REPLAY_STAGE * 4, nullptr, base, row_f4, d_evals, (uint32_t) evals_cap, d_stats, (uint32_t) nq, ticket, out, d_check); \
+				else hipLaunchKernelGGL((replay_roof_kernel<K, R, false>), dim3(blocks), dim3(256), 4 * REPLAY_STAGE * 4, nullptr, base, row_f4, d_evals, (uint32_t) evals_cap, d_stats, (uint32_t) nq, ticket, out, d_check); \
+				break
+			ROOF(2, 2); ROOF(2, 4); ROOF(2, 8); ROOF(4, 2); ROOF(4, 4); ROOF(8, 2); ROOF(12, 1); ROOF(12, 2); ROOF(6, 4);
 #undef ROOF
-			default: rc = fail(HNSW_GPU_ERR_ARG, "loads_per_lane must be 8, 16 or 24");
+			default: rc = fail(HNSW_GPU_ERR_ARG, "no replay shape <%d, %d> (have <2,2> <2,4> <2,8> <4,2> <4,4> <8,2> <6,4> <12,1> <12,2>)", kb, rpg);
 		}
 		if (rc) break;
 		(void) hipEventRecord(e1, nullptr);

@@ -280,14 +280,14 @@ class GpuIndex:
                                                 out["times"].data_ptr(), s), "hnsw_gpu_search_traced_dev")
         return out
 
-    def replay_roof(self, traced: dict, slots: int, loads_per_lane: int = 24, check: bool = False):
-        """(ms, bytes) of hnsw_gpu_replay_roof over the trace of a search_traced_torch launch; with check=True also the sum mod
-        2^64 of the bit patterns of every word the replay read for the trace (tests)."""
+    def replay_roof(self, traced: dict, slots: int, kb: int = 12, rpg: int = 2, word_sum: bool = False):
+        """(ms, bytes) of hnsw_gpu_replay_roof over the trace of a search_traced_torch launch with load shape <kb, rpg>; with
+        word_sum=True also the sum mod 2^64 of the bit patterns of every word the replay read for the trace (tests)."""
         ms, by, ws = C.c_float(0), C.c_double(0), C.c_uint64(0)
         ev = traced["evals"]
-        check(self.L.hnsw_gpu_replay_roof(self._h, ev.data_ptr(), ev.shape[1], traced["stats"].data_ptr(), ev.shape[0], slots, loads_per_lane,
-                                           C.byref(ms), C.byref(by), C.byref(ws) if check else None), "hnsw_gpu_replay_roof")
-        return (float(ms.value), float(by.value), int(ws.value)) if check else (float(ms.value), float(by.value))
+        check(self.L.hnsw_gpu_replay_roof(self._h, ev.data_ptr(), ev.shape[1], traced["stats"].data_ptr(), ev.shape[0], slots, kb, rpg,
+                                          C.byref(ms), C.byref(by), C.byref(ws) if word_sum else None), "hnsw_gpu_replay_roof")
+        return (float(ms.value), float(by.value), int(ws.value)) if word_sum else (float(ms.value), float(by.value))
 
     def health(self) -> dict:
         """Health words of the default search workspace (include/hnsw_gpu.h, hnsw_gpu_index_health): all zero in a healthy life."""

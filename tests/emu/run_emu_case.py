@@ -89,6 +89,29 @@ def second_walk():
     return out
 
 
+def moving_helpers():
+    """several walking waves per block whose helpers change walks (a wave whose walk is over helps a sibling that still walks),
+    few helpers per walk and all of them slice helpers (HNSW_GPU_TEAM_SPEC 0 / 2): a helper's completion word must not be taken
+    for another walking wave's job with the same number"""
+    n, dim, m, ef = 3000, 96, 16, 48
+    port, X = U.build_port(n, dim, m, 40, pg.DIST_L2, k=10, seed=3)
+    out = []
+    for nq in (6, 10, 14):
+        Q = gmm(nq, dim, k=10, seed=6 + nq)
+        want = port.search_many(Q, ef, nthreads=4)
+        for spec in ("0", "2"):
+            setenv({"HNSW_GPU_TEAM": "1", "SIMT_EMU_CUS": "2"})
+            os.environ["HNSW_GPU_TEAM_SPEC"] = spec
+            ix = U.mirror(port, pg.DIST_L2, efs=ef)
+            bad = 0
+            for rep in range(3):
+                bad += wrong(ix.search(Q, ef), want, nq)
+            out.append({"nq": nq, "spec": spec, "wrong": bad, "walks": 3 * nq, "health": ix.health(), "kernel": ix.last_search_kernel()})
+            ix.close()
+    os.environ.pop("HNSW_GPU_TEAM_SPEC", None)
+    return out
+
+
 def abort():
     """the host's abort word: a launch that is asked to end does end (every wave leaves at its next look), says so in the
     health words, and the next launch on the same workspace is exact again (the bitmaps the aborted waves left are re-zeroed)"""
@@ -139,7 +162,7 @@ def traced():
             want = U.evals_from_pops(port.raw(), ix.meta, n, ix.meta.enterpoint_node, pops)
             bad += 0 if (st[i, 0] == len(want) == nev and (ev[i, :len(want)] == want).all() and tm[i, 1] >= tm[i, 0] > 0) else 1
         ms, by, ws = C.c_float(0), C.c_double(0), C.c_uint64(0)
-        rc = ix.L.hnsw_gpu_replay_roof(ix._h, ev.ctypes.data, cap, st.ctypes.data, nq, 8, 8, C.byref(ms), C.byref(by), C.byref(ws))
+        rc = ix.L.hnsw_gpu_replay_roof(ix._h, ev.ctypes.data, cap, st.ctypes.data, nq, 8, 2, 4, C.byref(ms), C.byref(by), C.byref(ws))
         words = X.view(np.uint32).astype(np.uint64).sum(axis=1)
         want_sum = int(sum(int(words[ev[i, :st[i, 0]]].sum()) for i in range(nq)) % (1 << 64))
         out.append({"env": env, "kernel": ix.last_search_kernel(), "wrong": bad, "replay_rc": rc, "replay_bytes": by.value,
@@ -244,4 +267,4 @@ def others():
 
 
 if __name__ == "__main__":
-    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced, "sharded": sharded}[sys.argv[1]]()))
+    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced, "sharded": sharded, "moving_helpers": moving_helpers}[sys.argv[1]]()))

@@ -578,9 +578,9 @@ def test_evaluation_trace_is_the_walk_and_replay_reads_its_bytes(env, monkeypatc
     # the replay reads exactly the traced rows, whole: bytes, and the (order-free) sum of the bit patterns of every word
     words = X.view(np.uint32).astype(np.uint64).sum(axis=1)
     want_sum = int(sum(int(words[ev[i, :st[i, 0]]].sum()) for i in range(300)) % (1 << 64))
-    for lpl in (8, 16):                                        # a row of 200 floats = 4 loads per lane: both tile it
-        ms, by, ws = ix.replay_roof(tr, slots, lpl, check=True)
-        assert ms > 0 and by == float(st[:, 0].sum()) * ix.meta.dim * 4 and ws == want_sum, (lpl, ws, want_sum)
+    for kb, rpg in ((4, 2), (4, 4), (2, 4), (12, 1)):          # a row of 200 floats = 4 loads per lane: whole steps, half steps, padded steps
+        ms, by, ws = ix.replay_roof(tr, slots, kb, rpg, word_sum=True)
+        assert ms > 0 and by == float(st[:, 0].sum()) * ix.meta.dim * 4 and ws == want_sum, (kb, rpg, ws, want_sum)
     with pytest.raises(Exception):
-        ix.replay_roof(tr, slots, 24)                          # 24 loads do not tile 4: refused, not a partial replay
+        ix.replay_roof(tr, slots, 5, 3)                        # not a shape the replay has: refused
     ix.close()

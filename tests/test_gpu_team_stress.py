@@ -80,6 +80,42 @@ def test_a_wave_that_walks_many_queries_with_helpers_attached(dim, m, func, n, m
 
 
 @pytest.mark.timeout(300, method="thread")
+@pytest.mark.parametrize("dim,m,func,n", [(1536, 32, pg.DIST_COSINE, 5000), (768, 16, pg.DIST_L2, 10000)])
+def test_helpers_that_move_from_walk_to_walk_inside_a_block(dim, m, func, n, monkeypatch):
+    """Launches of a few hundred to a thousand queries: every block has several walking waves, and a wave whose walk is over helps
+    whichever sibling still walks — helpers change walks all the time, with few helpers per walk.  With HNSW_GPU_TEAM_SPEC 0 / 1 / 2
+    those few helpers take slices, so a helper's completion word meets walking waves whose job numbers coincide with the ones
+    it served before (the round-3 device finding at Q = 1024 / 1536 dims: profiles/r3d_c5_spec_mismatch.txt).  Every answer ==
+    the oracle's, for many launches."""
+    import torch
+    rng = np.random.default_rng(1234 + dim)
+    port, X = build_port(n, dim, m, 64, func, k=40, seed=4000 + dim)
+    ix = mirror(port, func, efs=128)
+    ef = 128
+    pool = gmm(4096, dim, k=40, seed=4000 + dim, stream=1)
+    want_all = port.search_many(pool, ef, nthreads=8)
+    dpool = torch.from_numpy(pool).cuda()
+    t_end = time.time() + 25.0
+    launches = 0
+    for r in range(400):
+        if time.time() > t_end and r >= 8:
+            break
+        nq = int(rng.choice([130, 300, 700, 1024, 1500]))
+        o = int(rng.integers(0, 4096 - nq + 1))
+        spec = str(rng.choice([0, 0, 1, 2, 2, 5]))
+        _setenv(monkeypatch, {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_SPEC": spec})
+        out = ix.search_torch(dpool[o:o + nq], ef, stats=True)
+        torch.cuda.synchronize()
+        sub = {k: v[o:o + nq] for k, v in want_all.items() if isinstance(v, np.ndarray)}
+        _same(out, sub, nq, (dim, r, nq, spec))
+        launches += 1
+    h = ix.health()
+    print(f"\n[moving helpers {dim}d func {func}] {launches} launches exact; health {h}")
+    assert h["slices_delivered"] > 0 and h["aborted_waves"] == 0, h
+    ix.close()
+
+
+@pytest.mark.timeout(300, method="thread")
 def test_small_launches_on_two_streams_beside_a_big_one(monkeypatch):
     """The server's shape (csrc/server_main.cpp): 40 000 queries on stream A, meanwhile launches of 1-64 queries back to back on
     streams B and C through search contexts.  The small launches' blocks become resident one by one as the big launch's waves

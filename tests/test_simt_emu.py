@@ -93,7 +93,7 @@ def test_a_helper_that_never_delivers_costs_time_not_answers():
     """Every inter-wave wait is bounded and falls back to the walking wave doing the work itself: the same source with the
     helpers' completion store removed (a protocol bug of the worst kind: every job is left waiting) still answers every
     query exactly as the oracle does, and the health words say what happened."""
-    DONE = "if (lane == 0) __hip_atomic_store(&ctl[wib].done, js, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);"
+    DONE = "if (lane == 0) __hip_atomic_store(&ctl[wib].done, js * 8u + target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);"
 
     def drop_done(name, txt):
         if name == "device_search.h":
@@ -153,3 +153,11 @@ def test_the_emulator_notices_a_store_into_another_devices_memory():
     r = subprocess.run([sys.executable, RUN, "sharded", lib], capture_output=True, text=True, timeout=900,
                        env=dict(os.environ, SIMT_EMU_DEVICES="2"))
     assert r.returncode == 86 and "without peer access" in r.stderr, (r.returncode, r.stderr[-800:])
+
+
+def test_helpers_that_change_walks_inside_a_block(emu_lib):
+    """several walking waves per block, slice helpers that move from a finished walk to a sibling's: exact (device counterpart
+    with thousands of launches: tests/test_gpu_team_stress.py::test_helpers_that_move_from_walk_to_walk_inside_a_block)"""
+    res = run_case("moving_helpers", emu_lib, timeout=900)
+    assert all(r["wrong"] == 0 and "true>" in r["kernel"] for r in res), res
+    assert sum(r["health"]["slices_delivered"] for r in res) > 50, res
