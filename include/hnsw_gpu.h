@@ -99,6 +99,14 @@ int hnsw_gpu_index_get_links(hnsw_gpu_index *ix, idx_t idx, idx_t *out);
  * changed (hnswalg.cpp:169-222), for the write-back of hnsw_bind_point.  `others` holds maxM * (maxM + 1) values. */
 int hnsw_gpu_index_get_link_lists(hnsw_gpu_index *ix, idx_t idx, idx_t *mine, idx_t *others);
 
+/* hnsw_bind_point's device side in ONE call (hnswalg.cpp:279-291, 225-232): element `idx` — which must be the mirror's current
+ * count — is appended (row + label) and linked exactly as the reference's serial insert links it (hnsw_gpu_index_link with
+ * max_batch = 1: graph bytes equal the reference's), and the changed link lists come back as hnsw_gpu_index_get_link_lists
+ * returns them: `mine` = [count | links] of the new element (maxM + 1 words), `others` = one such list per neighbour in mine's
+ * order.  No host wait between the steps: the row is read from and the lists are written to pinned host memory by the kernels
+ * themselves, and the calling core polls one completion flag. */
+int hnsw_gpu_index_insert_one(hnsw_gpu_index *ix, const coord_t *point, label_t label, idx_t idx, idx_t *mine, idx_t *others);
+
 size_t hnsw_gpu_index_count(const hnsw_gpu_index *ix);
 int    hnsw_gpu_index_device(const hnsw_gpu_index *ix);
 void   hnsw_gpu_index_destroy(hnsw_gpu_index *ix);

@@ -39,6 +39,9 @@ struct BuildArgs
 	const uint32_t *nseg;
 	uint32_t *ticket;
 	uint32_t wave_bytes;                // LDS per wave
+	uint32_t single;                    // count == 1 (the reference's serial insert): the selected neighbours are distinct targets, so the
+	uint32_t *seg_out;                  // pairs need no sort — select_links_kernel writes one segment per pair (seg_out, nseg_out) and ends
+	uint32_t *nseg_out;                 // the pair array itself; reverse_links_kernel then reads `pairs` as its sorted input
 };
 
 // Copy one padded row into the LDS query image (zero tail up to qpad_floats).
@@ -178,6 +181,15 @@ __global__ __launch_bounds__(256) void select_links_kernel(const BuildArgs a)
 	base = __builtin_amdgcn_readfirstlane(base);
 	for (uint32_t j = lane; j < nsel; j += 64)
 		a.pairs[base + j] = ((uint64_t) (uint32_t) keyB[j] << 32) | p;
+	if (a.single)                                       // one new element: every pair is a segment of its own, in link order (:183)
+	{
+		for (uint32_t j = lane; j < nsel; j += 64) a.seg_out[j] = j;
+		if (lane == 0)
+		{
+			*a.nseg_out = nsel;
+			if (nsel < a.pair_slots) a.pairs[nsel] = ~0ull;     // end of the pair array
+		}
+	}
 }
 
 // Step 3 helper: mark the first pair of every target.

@@ -92,6 +92,8 @@ struct SearchArgs
 	uint64_t *set_scratch;      // generic form with its sets in HBM: per-slot area, set_stride keys apart
 	uint32_t out_stride;        // result slots per query in the output arrays (the caller's ef; a.ef may be clamped to n)
 	size_t set_stride;
+	uint32_t wide_p, wide_ch, wide_nr, wide_nc;   // wide-beam form (device_search_wide.h): result slots (a power of two >= ef), keys per
+	                            // chunk, chunks of the result / candidate array (their extremes live in LDS at off_res / off_cand)
 	int mode;                   // 0 = hnsw_search semantics, 1 = searchBaseLayer only
 	// team form (beam kernel, TEAM = true; banner "Team form" further down)
 	uint32_t team_mains;        // waves of a block that take queries (wib < team_mains); the others start as helpers

@@ -240,7 +240,9 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 		return false;
 	}
 	static thread_local idx_t mine[4097];
+	static thread_local std::vector<idx_t> others;            // the neighbours' lists, all fetched in one launch
 	bool ok = false;
+	bool fused = false;                                  // append + link + gather went as one call (hnsw_gpu_index_insert_one)
 	shimcache::Entry *ce = nullptr;                      // cached mirror (unmodified glue): its shadow follows the insert
 	do
 	{
@@ -279,7 +281,10 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 				if (!hnsw_begin_read(meta, idx, nullptr, nullptr, &label)) break;
 				hnsw_end_read(meta);
 				if (hnsw_gpu_index_reserve(ix, (size_t) idx + 1 + (size_t) idx / 2) != HNSW_GPU_OK) break;
-				if (hnsw_gpu_index_append(ix, point, &label, 1) != HNSW_GPU_OK) break;
+				// the row, its links and the changed lists in one call: nothing waits on the host between the steps
+				others.resize(maxM * (maxM + 1));
+				if (hnsw_gpu_index_insert_one(ix, point, label, idx, mine, others.data()) != HNSW_GPU_OK) break;
+				fused = true;
 				if (ce && !shimcache::shadow_append(meta, ce, (size_t) idx + 1, idx, point, label)) break;
 			}
 			else if (have != (size_t) idx + 1)
@@ -290,10 +295,12 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 			}
 		}
 		if (idx == 0) { ok = true; break; }
-		if (hnsw_gpu_index_link(ix, idx, 1, 1, 0, nullptr) != HNSW_GPU_OK) break;
-		static thread_local std::vector<idx_t> others;            // the neighbours' lists, all fetched in one launch
-		others.resize(maxM * (maxM + 1));
-		if (hnsw_gpu_index_get_link_lists(ix, idx, mine, others.data()) != HNSW_GPU_OK) break;
+		if (!fused)                                          // the mirror already held the row (an attached mirror the host appended to)
+		{
+			if (hnsw_gpu_index_link(ix, idx, 1, 1, 0, nullptr) != HNSW_GPU_OK) break;
+			others.resize(maxM * (maxM + 1));
+			if (hnsw_gpu_index_get_link_lists(ix, idx, mine, others.data()) != HNSW_GPU_OK) break;
+		}
 		for (uint32_t j = 0; j < mine[0]; j++)               // neighbours first, like hnswalg.cpp:183-222 ...
 		{
 			const idx_t *other = others.data() + (size_t) j * (maxM + 1);

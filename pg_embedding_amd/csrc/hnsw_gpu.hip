@@ -17,6 +17,7 @@
 #include "hnsw_gpu.h"
 #include "device_dist.h"
 #include "device_search.h"
+#include "device_search_wide.h"
 #include "device_build.h"
 #include "device_bf_mfma.h"
 #include "device_roof.h"
@@ -643,6 +644,13 @@ static search_kernel_t pick_search_kernel_f(int func, bool team)
 			default:       return hnsw_search_kernel_beam<F_MANHATTAN, SH, U, false>;
 		}
 	}
+	if (RREG == 3)          // wide-beam form (any ef), device_search_wide.h
+		switch (func)
+		{
+			case F_L2:     return hnsw_search_kernel_wide<F_L2, SH>;
+			case F_COSINE: return hnsw_search_kernel_wide<F_COSINE, SH>;
+			default:       return hnsw_search_kernel_wide<F_MANHATTAN, SH>;
+		}
 	if (RREG == 1)          // generic form, sets in HBM
 		switch (func)
 		{
@@ -657,7 +665,7 @@ static search_kernel_t pick_search_kernel_f(int func, bool team)
 			case F_COSINE: return hnsw_search_kernel_lds<F_COSINE, SH, false>;
 			default:       return hnsw_search_kernel_lds<F_MANHATTAN, SH, false>;
 		}
-	constexpr int R = RREG <= 1 ? 2 : RREG;
+	constexpr int R = (RREG <= 1 || RREG == 3) ? 2 : RREG;
 	switch (func)
 	{
 		case F_L2:     return hnsw_search_kernel_reg<F_L2, SH, R>;
@@ -678,6 +686,7 @@ static search_kernel_t pick_search_kernel_s(int func, int rreg, bool team)
 		case -8: return pick_search_kernel_f<SH, -8>(func, team);
 		case -16: return pick_search_kernel_f<SH, -16>(func, team);
 		case 1:  return pick_search_kernel_f<SH, 1>(func, false);
+		case 3:  return pick_search_kernel_f<SH, 3>(func, false);
 		default: return pick_search_kernel_f<SH, 0>(func, false);
 	}
 }
@@ -705,7 +714,9 @@ static search_kernel_t pick_search_kernel(int func, uint32_t kiters, int rreg, b
 static const size_t LDS_PER_CU = 160 * 1024;
 static const size_t VIS_BUDGET_BYTES = (size_t) 24 << 30;     // cap on bitmap workspace
 static const size_t SET_BUDGET_BYTES = (size_t) 8 << 30;      // cap on the HBM result/candidate areas (generic form)
-static const size_t MAX_EF = 65536;                           // effective beam (after clamping to the index size)
+// (no cap on the effective beam: beyond WIDE_EF_MIN the wide-beam form keeps both sets with a second level of chunk extremes,
+// device_search_wide.h; what bounds a beam is the per-slot scratch, 24 bytes per result slot, under SET_BUDGET_BYTES)
+static const size_t WIDE_EF_MIN = 2048;
 
 static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries, size_t q_stride, size_t nq, size_t ef, int mode,
 						 uint64_t *d_labels, uint32_t *d_idx, float *d_dists, uint32_t *d_counts,
@@ -724,8 +735,6 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	// as far as it likes; the output arrays keep the caller's ef as their row stride.
 	const size_t out_stride = ef;
 	ef = std::min(ef, std::max<size_t>(ix->n, 1));
-	if (ef > MAX_EF)
-		return fail(HNSW_GPU_ERR_ARG, "ef %zu with %zu elements: beams above %zu are not supported", out_stride, ix->n, MAX_EF);
 	HIPCHK(hipSetDevice(ix->device));
 
 	SearchArgs a;
@@ -755,8 +764,11 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	const char *force = getenv("HNSW_GPU_FORCE_LDS_HEAPS");
 	const bool use_beam = !(beam && atoi(beam) == 0) && ix->cap < 0x80000000ull;
 	const bool beam16 = use_beam && ef > 256 && ef <= 512 && (b16 ? atoi(b16) > 0 : shape_index(a.kiters) >= 2);
+	const char *wmin = getenv("HNSW_GPU_WIDE_EF_MIN");
+	const size_t wide_min = wmin ? (size_t) atoll(wmin) : WIDE_EF_MIN;
 	int rreg;
-	if (force && atoi(force) > 0) rreg = 0;
+	if (ef > wide_min) rreg = 3;
+	else if (force && atoi(force) > 0) rreg = 0;
 	else if (use_beam && (ef <= 256 || beam16)) rreg = ef <= 64 ? -2 : (ef <= 128 ? -4 : (ef <= 256 ? -8 : -16));
 	else rreg = ef <= 128 ? 2 : (ef <= 256 ? 4 : 0);
 	const size_t ucap = rreg < 0 ? (size_t) 64 * (size_t) -rreg : 0;      // beam form: slots of the accepted set
@@ -771,7 +783,23 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	const bool narrow5 = shape_index(a.kiters) == 0 && (rreg == -2 || rreg == -4) && (int) ix->meta.dist_func != F_COSINE &&
 						 !team_wanted && !(n5 && atoi(n5) == 0);
 	size_t off = (size_t) a.qpad_floats * 4;
-	if (rreg)
+	if (rreg == 3)
+	{
+		// wide-beam form: both sets in the slot's HBM area [res: P | cand: 2P], P = the power of two >= ef (the output sort is a
+		// bitonic network); per-chunk extremes in LDS: chunks of >= 1024 keys, at most 1024 chunks of candidates
+		size_t P = 2;
+		while (P < ef) P <<= 1;
+		size_t ch = 1024;
+		while ((2 * ef + ch - 1) / ch > 1024) ch <<= 1;
+		a.wide_p = (uint32_t) P; a.wide_ch = (uint32_t) ch;
+		a.wide_nr = (uint32_t) ((ef + ch - 1) / ch); a.wide_nc = (uint32_t) ((2 * ef + ch - 1) / ch);
+		a.set_stride = 3 * P;
+		a.off_res = (uint32_t) off;  off += round_up((size_t) a.wide_nr * 8, 16);
+		a.off_cand = (uint32_t) off; off += round_up((size_t) a.wide_nc * 8, 16);
+		if (3 * P * 8 > SET_BUDGET_BYTES)
+			return fail(HNSW_GPU_ERR_NOMEM, "ef %zu needs %zu bytes of scratch per query slot (more than the %zu-byte budget)", ef, 3 * P * 8, SET_BUDGET_BYTES);
+	}
+	else if (rreg)
 	{
 		// [query | hash set (overlaid by the emit step's tie scratch) | newid | newdist]
 		const size_t fixed = off + 64 * 4 + 128 * 4 + (team_wanted ? sizeof(TeamCtl) : 0);   // (+ the wave's control block behind the regions)
@@ -904,6 +932,7 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		const char *shp = (shape_index(a.kiters) == 3 && getenv("HNSW_GPU_SHAPE_12X1")) ? "Shape12x1" : shapes[shape_index(a.kiters)];
 		if (narrow5 && !team) shp = "Shape2x2";
 		if (rreg < 0) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_beam<%d, pgemb::%s, %d, %s>", (int) ix->meta.dist_func, shp, -rreg, team ? "true" : "false");
+		else if (rreg == 3) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_wide<%d, pgemb::%s>", (int) ix->meta.dist_func, shp);
 		else if (rreg >= 2) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_reg<%d, pgemb::%s, %d>", (int) ix->meta.dist_func, shp, rreg);
 		else snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_lds<%d, pgemb::%s, %s>", (int) ix->meta.dist_func, shp, rreg == 1 ? "true" : "false");
 	}
@@ -931,7 +960,7 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	// workspace: one bitmap + log per resident wave
 	const size_t words = std::max<size_t>(1, (ix->cap + 31) / 32);   // by capacity: stable while the index grows
 	size_t max_slots = std::max<size_t>(wpb, VIS_BUDGET_BYTES / (words * 4));
-	if (rreg == 1) max_slots = std::max<size_t>(wpb, std::min(max_slots, SET_BUDGET_BYTES / (a.set_stride * 8)));
+	if (rreg == 1 || rreg == 3) max_slots = std::max<size_t>(wpb, std::min(max_slots, SET_BUDGET_BYTES / (a.set_stride * 8)));
 	if (blocks * wpb > max_slots) blocks = std::max<size_t>(1, max_slots / wpb);
 	const size_t slots = blocks * wpb;
 	const uint32_t logcap = 8192;
@@ -964,7 +993,7 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		w->beam_keys = slots * ucap;
 	}
 	a.beam_scratch = w->beam;
-	if (rreg == 1)
+	if (rreg == 1 || rreg == 3)
 	{
 		const size_t keys = slots * a.set_stride;
 		if (keys > w->set_keys)
@@ -1880,21 +1909,27 @@ extern "C" int hnsw_gpu_index_link(hnsw_gpu_index *ix, size_t first, size_t coun
 	{
 		const size_t b = std::min({end - linked, max_batch, std::max<size_t>(1, linked / ratio)});
 		const size_t bslots = b * M;
+		const bool single = b == 1;                     // the reference's serial insert: no sort, no segment marking (device_build.h)
 		HIPCHK(hipMemsetAsync(ctr, 0, 16, stream));
-		HIPCHK(hipMemsetAsync(pairs, 0xFF, bslots * 8, stream));
+		if (!single) HIPCHK(hipMemsetAsync(pairs, 0xFF, bslots * 8, stream));
 		// 1. searchBaseLayer(ef = efConstruction) for every new element (hnswalg.cpp:229)
 		int rc = launch_search(ix, &ix->ws, ix->vec + linked * ix->stride, ix->stride, b, efc, 1, nullptr, cand_idx, cand_dist,
 							   cand_cnt, nullptr, stream);
 		if (rc) return rc;
 		// 2. choose links, emit reverse pairs
 		a.first = (uint32_t) linked; a.count = (uint32_t) b; a.pair_slots = (uint32_t) bslots;
+		a.single = single ? 1u : 0u; a.seg_out = seg; a.nseg_out = ctr + 1;
+		a.sorted_pairs = single ? pairs : sorted;
 		hipLaunchKernelGGL(ksel, dim3((uint32_t) ((b + wpb - 1) / wpb)), dim3(wpb * 64), lds, stream, a);
 		// 3. reverse edges grouped by target
-		size_t tb = ix->bld_tmp_bytes;
-		if (pgemb_sort_u64(B + o_tmp, &tb, pairs, sorted, (int) bslots, stream) != 0)
-			return fail(HNSW_GPU_ERR_HIP, "radix sort failed");
-		hipLaunchKernelGGL(mark_segments_kernel, dim3((uint32_t) ((bslots + 255) / 256)), dim3(256), 0, stream, sorted,
-						   (uint32_t) bslots, seg, ctr + 1);
+		if (!single)
+		{
+			size_t tb = ix->bld_tmp_bytes;
+			if (pgemb_sort_u64(B + o_tmp, &tb, pairs, sorted, (int) bslots, stream) != 0)
+				return fail(HNSW_GPU_ERR_HIP, "radix sort failed");
+			hipLaunchKernelGGL(mark_segments_kernel, dim3((uint32_t) ((bslots + 255) / 256)), dim3(256), 0, stream, sorted,
+							   (uint32_t) bslots, seg, ctr + 1);
+		}
 		const uint32_t rblocks = (uint32_t) std::min<size_t>((bslots + wpb - 1) / wpb, (size_t) ix->num_cu * 4);
 		hipLaunchKernelGGL(krev, dim3(rblocks), dim3(wpb * 64), lds, stream, a);
 		HIPCHK(hipGetLastError());
@@ -2005,6 +2040,74 @@ extern "C" int hnsw_gpu_index_get_link_lists(hnsw_gpu_index *ix, idx_t idx, idx_
 	size_t k = 0;
 	for (size_t s = 0; s < maxM && k < mine[0]; s++)
 		if (h[s] != LINK_NONE) { compact(h + (1 + s) * ls, others + k * (maxM + 1)); k++; }
+	return HNSW_GPU_OK;
+}
+
+__global__ __launch_bounds__(64) void store_flag_kernel(uint32_t *flag)
+{
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: the gathered lists are in host memory before the flag
+	if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// hnsw_bind_point's device side in ONE host call (hnswalg.cpp:279-291, 225-232): element `idx` (= the mirror's current count)
+// is appended and linked exactly as the reference's serial insert links it, and the changed link lists — its own and one per
+// selected neighbour — come back compacted ([count | links], maxM + 1 words each) for the host's write-back.  Everything is
+// enqueued on the default stream without a host wait in between: the row and its label are read by the append kernel straight
+// from pinned host memory, the gathered lists are written straight into it, and a one-thread kernel behind them stores a
+// completion flag that the calling core polls (no copy engine, no interrupt wake-up: the few-queries mechanics of
+// hnsw_gpu_search_batch).  Round 2 made this call as append (2 blocking copies + sync) + link (2 memsets, search, select, a
+// hipCUB radix sort, segment marking, reverse) + get_link_lists (launch + sync): 0.85-1.5 ms per row against the reference's
+// 0.06-0.12 ms; a single row needs no sort (its neighbours are distinct targets) and no waits.
+extern "C" int hnsw_gpu_index_insert_one(hnsw_gpu_index *ix, const coord_t *point, label_t label, idx_t idx, idx_t *mine, idx_t *others)
+{
+	std::unique_lock<std::recursive_mutex> lock_;
+	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
+	if (!ix || !point || !mine || !others) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	if ((size_t) idx != ix->n) return fail(HNSW_GPU_ERR_ARG, "insert_one(%u): the mirror holds %zu elements", (unsigned) idx, ix->n);
+	if (ix->n + 1 > ix->cap) return fail(HNSW_GPU_ERR_ARG, "insert exceeds capacity (%zu)", ix->cap);
+	HIPCHK(hipSetDevice(ix->device));
+	if (ix->trace_active) { HIPCHK(hipStreamSynchronize(nullptr)); ix->trace_active = false; }   // an abandoned trace still writes the staging
+	const size_t dim = ix->meta.dim, maxM = ix->meta.maxM, ls = ix->lstride;
+	const size_t o_lab = round_up(dim * 4, 8), o_lists = round_up(o_lab + 8, 256), o_flag = o_lists + round_up((maxM + 1) * ls * 4, 256);
+	const size_t need = o_flag + 256;
+	if (ix->pin_bytes < need)
+	{
+		if (ix->pin) (void) hipHostFree(ix->pin);
+		ix->pin = nullptr; ix->pin_bytes = 0;
+		HIPCHK(hipHostMalloc((void **) &ix->pin, std::max<size_t>(need, 64 << 10), hipHostMallocDefault));
+		ix->pin_bytes = std::max<size_t>(need, 64 << 10);
+	}
+	char *h = ix->pin;
+	memcpy(h, point, dim * 4);
+	memcpy(h + o_lab, &label, 8);
+	volatile uint32_t *flag = (volatile uint32_t *) (h + o_flag);
+	*flag = 0;
+	int rc = hnsw_gpu_index_append_dev(ix, (const coord_t *) h, (const label_t *) (h + o_lab), 1, nullptr);
+	if (rc) return rc;
+	uint32_t *lists = (uint32_t *) (h + o_lists);
+	if (idx > 0)                                             // element 0 is never bound (hnswalg.cpp:228)
+	{
+		rc = hnsw_gpu_index_link(ix, idx, 1, 1, 0, nullptr);
+		if (rc) return rc;
+	}
+	hipLaunchKernelGGL(gather_link_lists_kernel, dim3((uint32_t) maxM + 1), dim3(64), 0, 0, ix->links, (uint32_t) ls, (uint32_t) idx,
+					   (uint32_t) ix->n, lists);
+	hipLaunchKernelGGL(store_flag_kernel, dim3(1), dim3(64), 0, 0, (uint32_t *) (h + o_flag));
+	HIPCHK(hipGetLastError());
+	rc = poll_done_flag(flag, "an insert");
+	if (rc) return rc;
+	auto compact = [&](const uint32_t *row, idx_t *out)
+	{
+		uint32_t cnt = 0;
+		for (size_t j = 0; j < maxM; j++)
+			if (row[j] != LINK_NONE) out[1 + cnt++] = row[j];
+		out[0] = cnt;
+		for (size_t j = cnt; j < maxM; j++) out[1 + j] = 0;
+	};
+	compact(lists, mine);
+	size_t k = 0;
+	for (size_t s2 = 0; s2 < maxM && k < mine[0]; s2++)
+		if (lists[s2] != LINK_NONE) { compact(lists + (1 + s2) * ls, others + k * (maxM + 1)); k++; }
 	return HNSW_GPU_OK;
 }
 

@@ -146,6 +146,15 @@ int hnsw_gpu_index_get_link_lists(hnsw_gpu_index *ix, idx_t idx, idx_t *mine, id
 	return rc;
 }
 
+int hnsw_gpu_index_insert_one(hnsw_gpu_index *ix, const coord_t *point, label_t label, idx_t idx, idx_t *mine, idx_t *others)
+{
+	if ((size_t) idx != port_count(ix->p)) return HNSW_GPU_ERR_ARG;
+	int rc = hnsw_gpu_index_append(ix, point, &label, 1);
+	if (rc == HNSW_GPU_OK && idx > 0) rc = hnsw_gpu_index_link(ix, idx, 1, 1, 0, NULL);
+	if (rc == HNSW_GPU_OK) rc = hnsw_gpu_index_get_link_lists(ix, idx, mine, others);
+	return rc;
+}
+
 int hnsw_gpu_index_export_flat(hnsw_gpu_index *ix, void *elements)
 {
 	memcpy(elements, port_data(ix->p), port_count(ix->p) * port_elem_size(ix->p));

@@ -112,6 +112,43 @@ def moving_helpers():
     return out
 
 
+def wide():
+    """the wide-beam form (device_search_wide.h) forced on every beam (HNSW_GPU_WIDE_EF_MIN=0): small beams with ties, beams of
+    hundreds, the index size and beyond, vacuumed rows, the walk's pop sequence — all == the oracle"""
+    import oracle
+    out = []
+    setenv({})
+    os.environ["HNSW_GPU_WIDE_EF_MIN"] = "0"
+    for dim, m, func, n, efs in ((24, 8, pg.DIST_L2, 900, (1, 40, 899, 5000)), (40, 6, pg.DIST_COSINE, 600, (64, 700)), (6, 8, pg.DIST_L2, 1500, (64, 256))):
+        if dim == 6:
+            rng = np.random.default_rng(11)
+            X = rng.integers(0, 2, size=(n, dim)).astype(np.float32)          # ties: 7 distinct distances
+            port = oracle.PortIndex(dim, m, 40, 64, func)
+            port.add(X)
+            Q = rng.integers(0, 2, size=(8, dim)).astype(np.float32)
+        else:
+            port, X = U.build_port(n, dim, m, 40, func, k=10, seed=dim)
+            Q = gmm(8, dim, k=10, seed=dim + 1)
+        for d in (3, 77, 200):
+            port.set_deleted(d, True)
+        for ef in efs:
+            ix = U.mirror(port, func, efs=min(ef, 64))
+            want = port.search_many(Q, ef, nthreads=4)
+            l, d, c = ix.search(Q, ef)
+            bad = 0
+            for q in range(len(Q)):
+                k = want["counts"][q]
+                ok = c[q] == k and (l[q][:k] == want["labels"][q][:k]).all() and (U.bits(d[q][:k]) == U.bits(want["dists"][q][:k])).all()
+                bad += 0 if ok else 1
+            gl, gd, gp, ge = ix.search_trace(Q[0], ef)
+            wl, wd, wp, we = port.search_trace(Q[0], ef)
+            tr = int(not (len(gp) == len(wp) and (gp == wp).all() and ge == we))
+            out.append({"dim": dim, "func": int(func), "ef": ef, "kernel": ix.last_search_kernel(), "wrong": bad, "trace_wrong": tr})
+            ix.close()
+    os.environ.pop("HNSW_GPU_WIDE_EF_MIN", None)
+    return out
+
+
 def abort():
     """the host's abort word: a launch that is asked to end does end (every wave leaves at its next look), says so in the
     health words, and the next launch on the same workspace is exact again (the bitmaps the aborted waves left are re-zeroed)"""
@@ -267,4 +304,4 @@ def others():
 
 
 if __name__ == "__main__":
-    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced, "sharded": sharded, "moving_helpers": moving_helpers}[sys.argv[1]]()))
+    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced, "sharded": sharded, "moving_helpers": moving_helpers, "wide": wide}[sys.argv[1]]()))

@@ -584,3 +584,55 @@ def test_evaluation_trace_is_the_walk_and_replay_reads_its_bytes(env, monkeypatc
     with pytest.raises(Exception):
         ix.replay_roof(tr, slots, 5, 3)                        # not a shape the replay has: refused
     ix.close()
+
+
+@pytest.mark.parametrize("func", FUNCS)
+def test_wide_beams_equal_the_oracle(func, monkeypatch):
+    """Beams of thousands up to the whole index and beyond (device_search_wide.h: the two sets with chunk extremes, candidate
+    compaction, bitonic output sort): ids, distance bits, E_q, H_q == the oracle's, vacuumed rows dropped, and a beam wider than the
+    index is the beam of the index size.  What the scan's efSearch doubling (embedding.c:329-343) reaches on a large index."""
+    import torch
+    n, dim, m = 30000, 32, 8
+    port, X = build_port(n, dim, m, 32, func, k=60, seed=910 + func)
+    for d in (5, 1234, 20000):
+        port.set_deleted(d, True)
+    Q = gmm(6, dim, k=60, seed=911, stream=1)
+    ix = mirror(port, func)
+    dQ = torch.from_numpy(Q).cuda()
+    for ef in (2100, 9000, 29999, 30000, 100000):
+        out = ix.search_torch(dQ, ef, stats=True)
+        torch.cuda.synchronize()
+        assert "kernel_wide" in ix.last_search_kernel()
+        want = port.search_many(Q, ef, nthreads=6)
+        cnt = out["counts"].cpu().numpy()
+        assert (cnt == want["counts"]).all(), (ef, cnt, want["counts"])
+        lab, dst = out["labels"].cpu().numpy().view(np.uint64), out["dists"].cpu().numpy()
+        for q in range(6):
+            k = cnt[q]
+            assert (lab[q, :k] == want["labels"][q, :k]).all() and (bits(dst[q, :k]) == bits(want["dists"][q, :k])).all(), (ef, q)
+            assert (lab[q, k:] == pg.NO_LABEL).all()
+        st = out["stats"].cpu().numpy().astype(np.uint32)
+        assert (st[:, 0] == want["evals"]).all() and (st[:, 1] == want["hops"]).all()
+    assert cnt.max() >= n - 500                                 # the last beam returned everything the entry point reaches, minus the vacuumed rows
+    ix.close()
+
+
+@pytest.mark.parametrize("ef", [1, 7, 64, 300])
+def test_wide_beam_form_at_small_beams_and_many_queries(ef, monkeypatch):
+    """the same form forced on small beams (HNSW_GPU_WIDE_EF_MIN=0) over many queries and equal distances (0/1 vectors: the
+    bound is shared by hundreds of elements, so evictions, the candidate compaction and the (dist, label) output order all meet ties)"""
+    monkeypatch.setenv("HNSW_GPU_WIDE_EF_MIN", "0")
+    rng = np.random.default_rng(12)
+    X = rng.integers(0, 2, size=(4000, 7)).astype(np.float32)
+    Q = rng.integers(0, 2, size=(300, 7)).astype(np.float32)
+    port = oracle.PortIndex(7, 8, 40, 64, pg.DIST_L2)
+    port.add(X)
+    port.set_deleted(17, True)
+    ix = mirror(port, pg.DIST_L2)
+    assert_same_as_oracle(ix, port, Q, ef)
+    assert "kernel_wide" in ix.last_search_kernel()
+    # the walk itself (searchBaseLayer only): pops and element numbers
+    gl, gd, gp, ge = ix.search_trace(Q[0], ef, base=True)
+    wl, wd, wp, we = port.search_trace(Q[0], ef, base=True)
+    assert (gp == wp).all() and ge == we and (gl == wl).all() and (bits(gd) == bits(wd)).all()
+    ix.close()

@@ -161,3 +161,9 @@ def test_helpers_that_change_walks_inside_a_block(emu_lib):
     res = run_case("moving_helpers", emu_lib, timeout=900)
     assert all(r["wrong"] == 0 and "true>" in r["kernel"] for r in res), res
     assert sum(r["health"]["slices_delivered"] for r in res) > 50, res
+
+
+def test_wide_beam_form_equals_the_oracle(emu_lib):
+    """device_search_wide.h on the CPU: every beam from 1 to beyond the index size, ties, vacuumed rows, the pop sequence"""
+    res = run_case("wide", emu_lib, timeout=900)
+    assert all(r["wrong"] == 0 and r["trace_wrong"] == 0 and "kernel_wide" in r["kernel"] for r in res), res
