@@ -77,16 +77,17 @@ def test_the_same_without_the_helper_bit_clear_is_reported(capsys):
         print("\n[simt emulator] without the helper-bit clear: " + "; ".join(f"{r['wrong']} of {r['walks']} answers wrong" for r in res))
 
 
-@pytest.mark.parametrize("spec", ["5", "0", "8"])
+@pytest.mark.parametrize("spec", ["5", "0"])
 def test_slice_helpers_and_hop_wide_append_are_exact_and_complete(emu_lib, spec):
     """Helpers scoring slices of the walking wave's many-row hops (device_search.h, banner at TeamCtl) and the one-step append
-    below ef: the many-walks schedule equals the oracle with five of seven helpers speculating (the default), with none (all of
-    them take slices) and with all (no job is ever posted); slices ARE delivered (the mechanism is in use) and none times out."""
+    below ef: the many-walks schedule equals the oracle with five of seven helpers speculating (the default) and with none (all of
+    them take slices; "all speculate" is what test_a_wave_that_walks_many_queries_… and the forms test run with fewer helpers);
+    slices ARE delivered (the mechanism is in use) and none times out."""
     res = run_case("second_walk", emu_lib, {"HNSW_GPU_TEAM_SPEC": spec}, timeout=600)
     assert all(r["wrong"] == 0 for r in res), res
     h = res[-1]["health"]                                  # totals of the mirror's life
     assert h["slice_timeouts"] == 0 and h["aborted_waves"] == 0, h
-    assert (h["slices_delivered"] > 100) == (spec != "8"), h
+    assert h["slices_delivered"] > 100, h
 
 
 def test_a_helper_that_never_delivers_costs_time_not_answers():
