@@ -883,6 +883,24 @@ def cpu_baseline(args, ix, Q, gpu_labels, gpu_dists, func):
         dk, dm = p["div_kind"], p["div_margin"]
         gd = gpu_dists[:nt].cpu().numpy()
         unexplained = (~same) & (dk == 0)
+        # ... and directly: the same launch in the debug arithmetic that reproduces the summation order of THIS oracle/_ref build
+        # (HNSW_GPU_REF_ORDER=1, csrc/device_dist.h score_rows_ref: L2 with dims % 16 == 0, Manhattan with dims % 4 == 0) must
+        # return the compiled reference's id list for EVERY query of the sample — no classification needed
+        ordered = None
+        if (func == 0 and args.dim % 16 == 0) or (func == 2 and args.dim % 4 == 0):
+            import torch
+            os.environ["HNSW_GPU_REF_ORDER"] = "1"
+            try:
+                if args.ef <= 128:
+                    oo = ix.search_torch(Q[:nt].contiguous(), args.ef)
+                    torch.cuda.synchronize()
+                    olab = oo["labels"].cpu().numpy().view(np.uint64)
+                    osame = (rt["labels"] == olab).all(axis=1)
+                    ordered = {"queries": nt, "queries_with_the_references_id_list": int(osame.sum()), "kernel": ix.last_search_kernel(),
+                               "note": "debug arithmetic in the reference build's own summation order; never the timed path"}
+            finally:
+                os.environ.pop("HNSW_GPU_REF_ORDER", None)
+        res["reference_order_mode"] = ordered
         res["parity_vs_reference"] = {
             "queries": nt,
             "device_equals_oracle_bit_exact": bool((p["labels"] == glab).all() and

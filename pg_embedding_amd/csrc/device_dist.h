@@ -24,6 +24,11 @@
 namespace pgemb {
 
 enum : int { F_L2 = 0, F_COSINE = 1, F_MANHATTAN = 2 };   // embedding.h:22-26
+// Debug-only arithmetic (HNSW_GPU_REF_ORDER=1, score_rows_ref below): the summation order of oracle/_ref's OWN build of
+// distfunc.c (gcc -Ofast, read off its disassembly), so that the device's id lists can be compared with the compiled
+// reference's query by query instead of through the canonical-order oracle.  Never the default: that order belongs to one
+// compiler's output.
+enum : int { F_L2_REF = 3, F_MANHATTAN_REF = 4 };
 
 // Compiler-level ordering point for cross-lane LDS hand-offs inside ONE wavefront
 // (LDS operations of a wave execute in order; this only stops the compiler from
@@ -110,7 +115,7 @@ __device__ __forceinline__ void acc_step(RowAcc &s, const float4 &q, const float
 template <int FUNC>
 __device__ __forceinline__ float finish_dist(float s0, float s1, float qnorm)
 {
-	if (FUNC == F_L2)
+	if (FUNC == F_L2 || FUNC == F_L2_REF)
 		return __builtin_sqrtf(s0);
 	if (FUNC == F_COSINE)
 	{
@@ -152,11 +157,65 @@ __device__ __forceinline__ float query_norm(const float4 *q4, uint32_t nchunks, 
 // to cover a whole row per trip when it fits: 768 dims = <12,1>, 128 dims = <2,4>.
 constexpr uint32_t OUT2 = 64;      // offset of the second sum (cosine |x|^2) in a score_rows output array
 
+// The reference build's own order (debug mode, F_L2_REF / F_MANHATTAN_REF), as oracle/_ref/distfunc.o computes it:
+//   l2_dist_impl_avx2 (distfunc.c:28-65, dims % 16 == 0): eight accumulators, acc_j += (d0_j^2 + d1_j^2) per 16 elements with
+//     d0 = x[16k + j] - y[16k + j], d1 = x[16k + 8 + j] - y[16k + 8 + j] (two multiplies, one add, one add: no FMA), then
+//     ((t0 + t1) + (t2 + t3)) + ((t6 + t7) + (t4 + t5)), sqrtf;
+//   manhattan_dist_impl (distfunc.c:147-155, auto-vectorised, dims % 4 == 0): four accumulators acc_j += |x[4k + j] - y[4k + j]|,
+//     then (a0 + a2) + (a1 + a3).
+// One lane per accumulator (8 / 4 lanes per row), strided scalar loads — it exists to be compared, not timed.
+template <int FUNC, typename RowId>
+__device__ __forceinline__ void score_rows_ref(const float *__restrict__ vec, size_t stride, const float *qf, uint32_t n,
+											   RowId rowid, uint32_t nrows, float *out, int lane)
+{
+	if (FUNC == F_L2_REF)
+	{
+		const uint32_t j = lane & 7, g = lane >> 3;
+		for (uint32_t base = 0; base < nrows; base += 8)
+		{
+			const uint32_t r = base + g;
+			const bool v = r < nrows;
+			const float *row = vec + (size_t) rowid(v ? r : nrows - 1) * stride;
+			float acc = 0.f;
+			for (uint32_t k = 0; k + 16 <= n; k += 16)
+			{
+				const float d0 = qf[k + j] - row[k + j], d1 = qf[k + 8 + j] - row[k + 8 + j];
+				const float m0 = d0 * d0, m1 = d1 * d1;
+				acc = acc + (m0 + m1);
+			}
+			acc = acc + dpp_move<0xB1>(acc);      // t0+t1 | t2+t3 | t4+t5 | t6+t7
+			acc = acc + dpp_move<0x4E>(acc);      // (t0+t1)+(t2+t3) | (t4+t5)+(t6+t7) (= (t6+t7)+(t4+t5) bit for bit)
+			acc = acc + dpp_move<0x141>(acc);     // the two halves of the eight lanes
+			if (j == 0 && v) out[r] = acc;
+		}
+	}
+	else
+	{
+		const uint32_t j = lane & 3, g = lane >> 2;
+		for (uint32_t base = 0; base < nrows; base += 16)
+		{
+			const uint32_t r = base + g;
+			const bool v = r < nrows;
+			const float *row = vec + (size_t) rowid(v ? r : nrows - 1) * stride;
+			float acc = 0.f;
+			for (uint32_t k = 0; k + 4 <= n; k += 4) acc = acc + __builtin_fabsf(qf[k + j] - row[k + j]);
+			acc = acc + dpp_move<0x4E>(acc);      // a0+a2 | a1+a3
+			acc = acc + dpp_move<0xB1>(acc);      // (a0+a2)+(a1+a3)
+			if (j == 0 && v) out[r] = acc;
+		}
+	}
+}
+
 template <int FUNC, int KB, int RPG, uint32_t O2 = OUT2, typename RowId>
 __device__ __forceinline__ void score_rows(const float *__restrict__ vec, size_t stride,
 										   const float4 *q4, uint32_t nchunks, uint32_t kiters,
 										   RowId rowid, uint32_t nrows, float *out, int lane)
 {
+	if (FUNC == F_L2_REF || FUNC == F_MANHATTAN_REF)
+	{
+		score_rows_ref<FUNC>(vec, stride, reinterpret_cast<const float *>(q4), nchunks * 4, rowid, nrows, out, lane);
+		return;
+	}
 	const uint32_t g = lane >> 4, sub = lane & 15;
 	const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 	// Every load below is UNCONDITIONAL: rows past the end re-read the last valid row and

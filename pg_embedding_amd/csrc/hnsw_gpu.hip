@@ -641,6 +641,8 @@ static search_kernel_t pick_search_kernel_f(int func, bool team)
 		{
 			case F_L2:     return hnsw_search_kernel_beam<F_L2, SH, U, false>;
 			case F_COSINE: return hnsw_search_kernel_beam<F_COSINE, SH, U, false>;
+			case F_L2_REF:        if (U == 4) return hnsw_search_kernel_beam<F_L2_REF, SH, 4, false>; return nullptr;          // (debug arithmetic:
+			case F_MANHATTAN_REF: if (U == 4) return hnsw_search_kernel_beam<F_MANHATTAN_REF, SH, 4, false>; return nullptr;   //  one set size only)
 			default:       return hnsw_search_kernel_beam<F_MANHATTAN, SH, U, false>;
 		}
 	}
@@ -766,8 +768,23 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	const bool beam16 = use_beam && ef > 256 && ef <= 512 && (b16 ? atoi(b16) > 0 : shape_index(a.kiters) >= 2);
 	const char *wmin = getenv("HNSW_GPU_WIDE_EF_MIN");
 	const size_t wide_min = wmin ? (size_t) atoll(wmin) : WIDE_EF_MIN;
+	// Debug arithmetic (device_dist.h, F_L2_REF / F_MANHATTAN_REF): the summation order of oracle/_ref's own build, for a query-by-query
+	// comparison of id lists with the compiled reference.  One kernel set only: beam form, 4 set registers, one wave per query.
+	int func_code = (int) ix->meta.dist_func;
+	bool reforder = false;
+	if (const char *ro = getenv("HNSW_GPU_REF_ORDER"))
+		if (atoi(ro) > 0)
+		{
+			const bool ok = ef <= 128 && ix->cap < 0x80000000ull &&
+							((func_code == F_L2 && ix->meta.dim % 16 == 0) || (func_code == F_MANHATTAN && ix->meta.dim % 4 == 0));
+			if (!ok)
+				return fail(HNSW_GPU_ERR_ARG, "HNSW_GPU_REF_ORDER: only L2 with dims %% 16 == 0 or Manhattan with dims %% 4 == 0, ef <= 128");
+			reforder = true;
+			func_code = func_code == F_L2 ? F_L2_REF : F_MANHATTAN_REF;
+		}
 	int rreg;
-	if (ef > wide_min) rreg = 3;
+	if (reforder) rreg = -4;
+	else if (ef > wide_min) rreg = 3;
 	else if (force && atoi(force) > 0) rreg = 0;
 	else if (use_beam && (ef <= 256 || beam16)) rreg = ef <= 64 ? -2 : (ef <= 128 ? -4 : (ef <= 256 ? -8 : -16));
 	else rreg = ef <= 128 ? 2 : (ef <= 256 ? 4 : 0);
@@ -777,11 +794,11 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	const int treq = tenv ? atoi(tenv) : -1;
 	const char *tmax = getenv("HNSW_GPU_TEAM_MAX_NQ");
 	const size_t auto_nq = tmax ? (size_t) atoll(tmax) : (size_t) ix->num_cu;
-	const bool team_wanted = rreg < 0 && treq != 0 && (treq > 0 || ix->stride > 320 || nq <= auto_nq);
+	const bool team_wanted = rreg < 0 && !reforder && treq != 0 && (treq > 0 || ix->stride > 320 || nq <= auto_nq);
 	// narrow rows, hot form: beam kernel with <= 4 set registers, one sum per row (L2 / Manhattan), not a team
 	const char *n5 = getenv("HNSW_GPU_NARROW5");
 	const bool narrow5 = shape_index(a.kiters) == 0 && (rreg == -2 || rreg == -4) && (int) ix->meta.dist_func != F_COSINE &&
-						 !team_wanted && !(n5 && atoi(n5) == 0);
+						 !team_wanted && !reforder && !(n5 && atoi(n5) == 0);
 	size_t off = (size_t) a.qpad_floats * 4;
 	if (rreg == 3)
 	{
@@ -926,12 +943,13 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	if (!team) { wpb = 4; while (wpb > 1 && (size_t) wpb * a.wave_bytes > 64 * 1024) wpb >>= 1; }
 	a.off_ctl = (uint32_t) ((size_t) wpb * a.wave_bytes);
 	const size_t lds = (size_t) wpb * a.wave_bytes + (team ? wpb * sizeof(TeamCtl) : 0);
-	search_kernel_t kern = pick_search_kernel((int) ix->meta.dist_func, a.kiters, rreg, team, narrow5);
+	search_kernel_t kern = pick_search_kernel(func_code, a.kiters, rreg, team, narrow5);
+	if (!kern) return fail(HNSW_GPU_ERR_INTERNAL, "no kernel for this configuration");
 	{
 		static const char *const shapes[4] = { "Shape2x4", "Shape4x2", "Shape8x2", "Shape12x2" };
 		const char *shp = (shape_index(a.kiters) == 3 && getenv("HNSW_GPU_SHAPE_12X1")) ? "Shape12x1" : shapes[shape_index(a.kiters)];
 		if (narrow5 && !team) shp = "Shape2x2";
-		if (rreg < 0) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_beam<%d, pgemb::%s, %d, %s>", (int) ix->meta.dist_func, shp, -rreg, team ? "true" : "false");
+		if (rreg < 0) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_beam<%d, pgemb::%s, %d, %s>", func_code, shp, -rreg, team ? "true" : "false");
 		else if (rreg == 3) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_wide<%d, pgemb::%s>", (int) ix->meta.dist_func, shp);
 		else if (rreg >= 2) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_reg<%d, pgemb::%s, %d>", (int) ix->meta.dist_func, shp, rreg);
 		else snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_lds<%d, pgemb::%s, %s>", (int) ix->meta.dist_func, shp, rreg == 1 ? "true" : "false");

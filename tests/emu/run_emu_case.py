@@ -149,6 +149,58 @@ def wide():
     return out
 
 
+def reforder():
+    """debug arithmetic HNSW_GPU_REF_ORDER=1 (device_dist.h, score_rows_ref): the summation order of oracle/_ref's own build of
+    distfunc.c.  With it the kernels' id lists AND distance bits equal the compiled reference's for every query — not through
+    the canonical-order oracle, directly.  (Skipped when this host's _ref build sums in another order: checked first on
+    plain pairs against a numpy statement of the order.)"""
+    import oracle
+    if not oracle.have_ref():
+        return {"skipped": "no oracle/_ref here"}
+    out = []
+    for func, dim, n in ((pg.DIST_L2, 128, 2500), (pg.DIST_L2, 48, 1500), (pg.DIST_MANHATTAN, 36, 1500)):
+        X = gmm(n, dim, k=20, seed=dim)
+        Q = gmm(24, dim, k=20, seed=dim + 1)
+        ref = oracle.RefIndex(dim, 8, 32, 64, func, capacity=n)
+        ref.add(X)
+        # the order itself, in numpy float32, against the reference's own hnsw_dist_func on this host
+        def np_dist(q, x):
+            q = q.astype(np.float32); x = x.astype(np.float32)
+            if func == pg.DIST_L2:
+                acc = np.zeros(8, np.float32)
+                for k in range(0, dim, 16):
+                    d0, d1 = q[k:k + 8] - x[k:k + 8], q[k + 8:k + 16] - x[k + 8:k + 16]
+                    acc = acc + (d0 * d0 + d1 * d1)
+                r = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[6] + acc[7]) + (acc[4] + acc[5]))
+                return np.sqrt(np.float32(r))
+            acc = np.zeros(4, np.float32)
+            for k in range(0, dim, 4):
+                acc = acc + np.abs(q[k:k + 4] - x[k:k + 4])
+            return (acc[0] + acc[2]) + (acc[1] + acc[3])
+        same_order = all(U.bits(np.float32(oracle.ref_dist(func, Q[i % 24], X[i * 7 % n]))) == U.bits(np.float32(np_dist(Q[i % 24], X[i * 7 % n]))) for i in range(200))
+        if not same_order:
+            out.append({"func": int(func), "dim": dim, "skipped": "this host's _ref build sums in another order"})
+            continue
+        setenv({})
+        os.environ["HNSW_GPU_REF_ORDER"] = "1"
+        meta = pg.make_meta(dim, 8, 32, 64, func)
+        ix = pg.GpuIndex.from_flat(meta, ref.raw(), n)
+        bad = 0
+        for ef in (10, 64, 128):
+            want = ref.search_many(Q, ef)
+            l, d, c = ix.search(Q, ef)
+            for q in range(len(Q)):
+                k = want["counts"][q]
+                ok = c[q] == k and (l[q][:k] == want["labels"][q][:k]).all()
+                # (hnsw_search returns no distances: the reference's own hnsw_dist_func for the rows it returned)
+                ok = ok and (U.bits(d[q][:k]) == U.bits(oracle.ref_dist_many(func, Q[q], X[want["labels"][q][:k].astype(np.int64)]))).all()
+                bad += 0 if ok else 1
+        out.append({"func": int(func), "dim": dim, "kernel": ix.last_search_kernel(), "wrong_vs_the_compiled_reference": bad, "queries": 3 * len(Q)})
+        ix.close()
+        os.environ.pop("HNSW_GPU_REF_ORDER", None)
+    return out
+
+
 def abort():
     """the host's abort word: a launch that is asked to end does end (every wave leaves at its next look), says so in the
     health words, and the next launch on the same workspace is exact again (the bitmaps the aborted waves left are re-zeroed)"""
@@ -304,4 +356,4 @@ def others():
 
 
 if __name__ == "__main__":
-    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced, "sharded": sharded, "moving_helpers": moving_helpers, "wide": wide}[sys.argv[1]]()))
+    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced, "sharded": sharded, "moving_helpers": moving_helpers, "wide": wide, "reforder": reforder}[sys.argv[1]]()))

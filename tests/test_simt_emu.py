@@ -168,3 +168,16 @@ def test_wide_beam_form_equals_the_oracle(emu_lib):
     """device_search_wide.h on the CPU: every beam from 1 to beyond the index size, ties, vacuumed rows, the pop sequence"""
     res = run_case("wide", emu_lib, timeout=900)
     assert all(r["wrong"] == 0 and r["trace_wrong"] == 0 and "kernel_wide" in r["kernel"] for r in res), res
+
+
+def test_reference_order_arithmetic_returns_the_compiled_references_ids(emu_lib):
+    """HNSW_GPU_REF_ORDER=1 (debug): distances summed in the order of oracle/_ref's own build of distfunc.c — the kernels' id lists
+    and distance bits then equal the COMPILED REFERENCE's for every query, with no canonical-order oracle in between."""
+    res = run_case("reforder", emu_lib, timeout=900)
+    if isinstance(res, dict):
+        pytest.skip(res["skipped"])
+    ran = [r for r in res if "skipped" not in r]
+    if not ran:
+        pytest.skip("this host's _ref build sums in another order than the one score_rows_ref restates")
+    assert all(r["wrong_vs_the_compiled_reference"] == 0 and "kernel_beam<3" in r["kernel"] or "kernel_beam<4" in r["kernel"] for r in ran), res
+    assert all(r["wrong_vs_the_compiled_reference"] == 0 for r in ran), res
