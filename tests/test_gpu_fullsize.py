@@ -141,3 +141,32 @@ def test_device_equals_oracle_and_every_reference_mismatch_is_a_flipped_near_tie
         again = pg.GpuIndex.from_flat(ix.meta, raw, N)
         assert (again.export_flat() == raw).all()
         again.close()
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="needs oracle/_ref (the compiled reference)")
+def test_reference_order_mode_equals_the_compiled_reference_for_every_query(cfg, monkeypatch):
+    """At full size, DIRECTLY against the reference binary: with HNSW_GPU_REF_ORDER=1 (debug arithmetic in the summation order of
+    oracle/_ref's own build of distfunc.c, csrc/device_dist.h score_rows_ref) the id list of EVERY query equals the compiled
+    reference's — no oracle in between, nothing to classify.  L2 configurations (M, C2); cosine has no such mode."""
+    import torch
+    if cfg["func"] != pg.DIST_L2:
+        pytest.skip("reference-order arithmetic exists for L2 and Manhattan")
+    ix, ef, dim, m, efc, func, nq = cfg["ix"], cfg["ef"], cfg["dim"], cfg["m"], cfg["efc"], cfg["func"], cfg["nq"]
+    Q = cfg["Q"][:nq].contiguous()
+    Qh = Q.cpu().numpy()
+    raw = ix.export_flat()
+    ref = oracle.RefIndex(dim, m, efc, ef, func, capacity=N)
+    ref.load_raw(raw, N)
+    r = ref.search_many(Qh, ef, nthreads=THREADS)
+    monkeypatch.setenv("HNSW_GPU_REF_ORDER", "1")
+    out = ix.search_torch(Q, ef)
+    torch.cuda.synchronize()
+    assert "kernel_beam<3" in ix.last_search_kernel()
+    lab = out["labels"].cpu().numpy().view(np.uint64)
+    dst = out["dists"].cpu().numpy()
+    X0 = cfg["X"][torch.from_numpy(lab[0].astype(np.int64)).cuda()].cpu().numpy()
+    if not (bits(dst[0]) == bits(oracle.ref_dist_many(func, Qh[0], X0))).all():
+        pytest.skip("this host's oracle/_ref build sums in another order than the one score_rows_ref restates")
+    same = (lab == r["labels"]).all(axis=1)
+    print(f"\n[{cfg['name']}] reference-order mode: {int(same.sum())} of {nq} id lists equal the compiled reference's")
+    assert same.all()
