@@ -108,6 +108,9 @@ int hnsw_gpu_index_get_link_lists(hnsw_gpu_index *ix, idx_t idx, idx_t *mine, id
 int hnsw_gpu_index_insert_one(hnsw_gpu_index *ix, const coord_t *point, label_t label, idx_t idx, idx_t *mine, idx_t *others);
 
 size_t hnsw_gpu_index_count(const hnsw_gpu_index *ix);
+/* Elements the mirror has room for (hnsw_gpu_index_reserve grows it: a reallocation and a copy of the whole mirror, so a caller that
+ * appends row by row asks for room geometrically and only when this says it must). */
+size_t hnsw_gpu_index_capacity(const hnsw_gpu_index *ix);
 int    hnsw_gpu_index_device(const hnsw_gpu_index *ix);
 void   hnsw_gpu_index_destroy(hnsw_gpu_index *ix);
 

@@ -35,6 +35,10 @@ int hnsw_gpu_shim_detach(HnswMetadata *meta);
  * The cache belongs to the calling thread (a Postgres backend is one): at most four indexes, least recently used first out;
  * a host that ends threads calls hnsw_gpu_shim_cache_clear() on them first, or their mirrors stay allocated. */
 void hnsw_gpu_shim_cache_stats(uint64_t out[8]);
+/* Where this thread's hnsw_bind_point calls spent their time, cumulative nanoseconds: out[0] the validated cache's preparation
+ * (pick + traced validation walk + host-side comparison), [1] the device insert (hnsw_gpu_index_insert_one), [2] the write-back
+ * through hnsw_begin_write, [3] everything else, [4] = number of calls. */
+void hnsw_gpu_shim_insert_times(uint64_t out[5]);
 void hnsw_gpu_shim_cache_clear(void);
 
 #ifdef __cplusplus

@@ -497,6 +497,7 @@ static void run(char *line)
 
 /* the in-process drop-in library's cache counters, when that is what is linked underneath (include/hnsw_gpu_shim.h) */
 extern void hnsw_gpu_shim_cache_stats(uint64_t out[8]) __attribute__((weak));
+extern void hnsw_gpu_shim_insert_times(uint64_t out[5]) __attribute__((weak));
 
 int main(void)
 {
@@ -541,6 +542,14 @@ int main(void)
 				"fallbacks %llu elements_read %llu\n", (unsigned long long) c[0], (unsigned long long) c[1], (unsigned long long) c[2],
 				(unsigned long long) c[3], (unsigned long long) c[4], (unsigned long long) c[5], (unsigned long long) c[6],
 				(unsigned long long) c[7]);
+		if (hnsw_gpu_shim_insert_times)
+		{
+			uint64_t t[5];
+			hnsw_gpu_shim_insert_times(t);
+			if (t[4])
+				fprintf(stderr, "shim inserts: %llu calls, per call us: prepare (validation walk) %.1f, device insert %.1f, write-back %.1f, other %.1f\n",
+						(unsigned long long) t[4], t[0] / 1e3 / t[4], t[1] / 1e3 / t[4], t[2] / 1e3 / t[4], t[3] / 1e3 / t[4]);
+		}
 	}
 	return 0;
 }

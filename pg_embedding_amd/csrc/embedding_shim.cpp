@@ -26,6 +26,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <new>
 #include <unordered_map>
@@ -221,8 +222,21 @@ static bool hnsw_search_impl(HnswMetadata *meta, const coord_t *point, size_t *n
 // to the host through hnsw_begin_write/hnsw_end_write (one write pin at a time,
 // embedding.c:780-781).  With an attached mirror that already holds elements [0, idx) only the
 // new element is uploaded; otherwise the index is mirrored first.
+// Where an insert's time goes (cumulative ns per thread; hnsw_gpu_shim_insert_times): the validated cache's preparation (pick + the
+// traced validation walk with the host-side comparison), the device insert (hnsw_gpu_index_insert_one or link + gather), the
+// write-back through hnsw_begin_write, and everything else (label read, reserve, shadow upkeep).
+static thread_local uint64_t t_ins[5] = {0, 0, 0, 0, 0};     // prepare, device, write-back, other, calls
+static inline uint64_t now_ns()
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return (uint64_t) ts.tv_sec * 1000000000ull + (uint64_t) ts.tv_nsec;
+}
+
 static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t idx)
 {
+	const uint64_t t_enter = now_ns();
+	uint64_t t_prep = 0, t_dev = 0, t_wb = 0;
 	if (!meta || !point) return false;
 	hnsw_gpu_index *ix = nullptr;
 	bool own = false;
@@ -250,7 +264,9 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 		{
 			const int dev = pick_device();
 			if (dev < 0) { fprintf(stderr, "pg_embedding_amd: no HIP device visible; the GPU hot path has no CPU fallback\n"); break; }
+			const uint64_t tp = now_ns();
 			ce = shimcache::prepare_insert(meta, point, idx, dev);   // every element the insert will read == the host's
+			t_prep = now_ns() - tp;
 			if (!ce) break;
 			ix = ce->ix;
 			ce->suspect = true;                          // until the write-back below has completed
@@ -265,7 +281,8 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 			if (have < (size_t) idx)                     // element numbers skipped a page-tail hole (embedding.c:229,693)
 			{                                            // or the tail was not reachable: dead placeholders
 				const size_t gap = (size_t) idx - have;
-				if (hnsw_gpu_index_reserve(ix, (size_t) idx + 1 + (size_t) idx / 2) != HNSW_GPU_OK) break;
+				if ((size_t) idx + 1 > hnsw_gpu_index_capacity(ix) &&          // (grow by half, and only when the row does not fit: a reserve
+					hnsw_gpu_index_reserve(ix, (size_t) idx + 1 + (size_t) idx / 2) != HNSW_GPU_OK) break;   //  is a copy of the whole mirror — round 2 asked for it at every insert)
 				coord_t *zeros = (coord_t *) calloc(gap * meta->dim, sizeof(coord_t));
 				label_t *dead = (label_t *) malloc(gap * sizeof(label_t));
 				bool fine = zeros && dead;
@@ -280,10 +297,13 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 				label_t label = 0;
 				if (!hnsw_begin_read(meta, idx, nullptr, nullptr, &label)) break;
 				hnsw_end_read(meta);
-				if (hnsw_gpu_index_reserve(ix, (size_t) idx + 1 + (size_t) idx / 2) != HNSW_GPU_OK) break;
+				if ((size_t) idx + 1 > hnsw_gpu_index_capacity(ix) &&          // (grow by half, and only when the row does not fit: a reserve
+					hnsw_gpu_index_reserve(ix, (size_t) idx + 1 + (size_t) idx / 2) != HNSW_GPU_OK) break;   //  is a copy of the whole mirror — round 2 asked for it at every insert)
 				// the row, its links and the changed lists in one call: nothing waits on the host between the steps
 				others.resize(maxM * (maxM + 1));
+				const uint64_t td = now_ns();
 				if (hnsw_gpu_index_insert_one(ix, point, label, idx, mine, others.data()) != HNSW_GPU_OK) break;
+				t_dev = now_ns() - td;
 				fused = true;
 				if (ce && !shimcache::shadow_append(meta, ce, (size_t) idx + 1, idx, point, label)) break;
 			}
@@ -301,6 +321,7 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 			others.resize(maxM * (maxM + 1));
 			if (hnsw_gpu_index_get_link_lists(ix, idx, mine, others.data()) != HNSW_GPU_OK) break;
 		}
+		const uint64_t tw = now_ns();
 		for (uint32_t j = 0; j < mine[0]; j++)               // neighbours first, like hnswalg.cpp:183-222 ...
 		{
 			const idx_t *other = others.data() + (size_t) j * (maxM + 1);
@@ -317,6 +338,7 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 			hnsw_end_write(meta);
 			if (ce) shimcache::shadow_set_links(meta, ce, idx, mine);
 		}
+		t_wb = now_ns() - tw;
 		ok = true;
 	} while (0);
 	if (ce)
@@ -327,6 +349,10 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 	if (!ok)
 		fprintf(stderr, "pg_embedding_amd: hnsw_bind_point(%u) failed: %s\n", (unsigned) idx, hnsw_gpu_last_error());
 	if (own && ix) hnsw_gpu_index_destroy(ix);
+	{
+		const uint64_t total = now_ns() - t_enter;
+		t_ins[0] += t_prep; t_ins[1] += t_dev; t_ins[2] += t_wb; t_ins[3] += total - t_prep - t_dev - t_wb; t_ins[4]++;
+	}
 	return ok;
 }
 
@@ -340,6 +366,10 @@ extern "C" void hnsw_gpu_shim_cache_stats(uint64_t out[8])
 	const shimcache::Stats &s = shimcache::stats();
 	out[0] = s.snapshots; out[1] = s.searches; out[2] = s.search_rounds; out[3] = s.inserts; out[4] = s.insert_rounds;
 	out[5] = s.patched; out[6] = s.fallbacks; out[7] = s.elements_read;
+}
+extern "C" void hnsw_gpu_shim_insert_times(uint64_t out[5])
+{
+	for (int i = 0; i < 5; i++) out[i] = t_ins[i];
 }
 extern "C" void hnsw_gpu_shim_cache_clear(void)
 {

@@ -319,6 +319,7 @@ extern "C" void hnsw_gpu_index_destroy(hnsw_gpu_index *ix)
 }
 
 extern "C" size_t hnsw_gpu_index_count(const hnsw_gpu_index *ix) { return ix ? ix->n : 0; }
+extern "C" size_t hnsw_gpu_index_capacity(const hnsw_gpu_index *ix) { return ix ? ix->cap : 0; }
 extern "C" int    hnsw_gpu_index_device(const hnsw_gpu_index *ix) { return ix ? ix->device : -1; }
 
 // ------------------------------------------------------------------------------------

@@ -702,6 +702,8 @@ void do_bind(CReq &r)
 	if (r.payload.size() != dim * 4) { r.c->respond(r.h, HGS_ERR_PROTOCOL); return; }
 	const coord_t *point = (const coord_t *) r.payload.data();
 	std::vector<uint32_t> out;
+	std::vector<idx_t> mine(maxM + 1), others(maxM * (maxM + 1));
+	bool fused = false;
 	int rc = HNSW_GPU_OK;
 	{
 		WriteLock wl(e.get());
@@ -714,15 +716,18 @@ void do_bind(CReq &r)
 			const size_t gap = (size_t) idx - have;
 			std::vector<coord_t> zeros(gap * dim, 0.f);
 			std::vector<label_t> dead(gap, (label_t) 1 << HNSW_LABEL_DELETED_BIT);
-			rc = hnsw_gpu_index_reserve(e->ix, (size_t) idx + 1 + (size_t) idx / 2);
+			// (room is asked for geometrically and only when needed: a reserve reallocates and copies the whole mirror)
+			if ((size_t) idx + 1 > hnsw_gpu_index_capacity(e->ix)) rc = hnsw_gpu_index_reserve(e->ix, (size_t) idx + 1 + (size_t) idx / 2);
 			if (rc == HNSW_GPU_OK) rc = hnsw_gpu_index_append(e->ix, zeros.data(), dead.data(), gap);
 			have = (size_t) idx;
 		}
 		if (rc == HNSW_GPU_OK && have == (size_t) idx)
 		{
+			// the row, its links and the changed lists in one call with no host wait between the steps (hnsw_gpu_index_insert_one)
 			label_t label = (label_t) r.h.a0;
-			rc = hnsw_gpu_index_reserve(e->ix, (size_t) idx + 1 + (size_t) idx / 2);
-			if (rc == HNSW_GPU_OK) rc = hnsw_gpu_index_append(e->ix, point, &label, 1);
+			if ((size_t) idx + 1 > hnsw_gpu_index_capacity(e->ix)) rc = hnsw_gpu_index_reserve(e->ix, (size_t) idx + 1 + (size_t) idx / 2);
+			if (rc == HNSW_GPU_OK) rc = hnsw_gpu_index_insert_one(e->ix, point, label, idx, mine.data(), others.data());
+			fused = rc == HNSW_GPU_OK;
 		}
 		else if (rc == HNSW_GPU_OK && have == (size_t) idx + 1)
 		{
@@ -739,14 +744,15 @@ void do_bind(CReq &r)
 		out.push_back(0);
 		if (rc == HNSW_GPU_OK && idx != 0)       // bindPoint: nothing to do for the first element, hnswalg.cpp:228
 		{
-			std::vector<idx_t> mine(maxM + 1), other(maxM + 1);
-			rc = hnsw_gpu_index_link(e->ix, idx, 1, 1, 0, nullptr);
-			if (rc == HNSW_GPU_OK) rc = hnsw_gpu_index_get_links(e->ix, idx, mine.data());
+			if (!fused)                           // the mirror already held the row: link it, then one launch for all changed lists
+			{
+				rc = hnsw_gpu_index_link(e->ix, idx, 1, 1, 0, nullptr);
+				if (rc == HNSW_GPU_OK) rc = hnsw_gpu_index_get_link_lists(e->ix, idx, mine.data(), others.data());
+			}
 			for (uint32_t j = 0; rc == HNSW_GPU_OK && j < mine[0]; j++)
 			{
-				rc = hnsw_gpu_index_get_links(e->ix, mine[1 + j], other.data());
 				out.push_back(mine[1 + j]);
-				out.insert(out.end(), other.begin(), other.end());
+				out.insert(out.end(), others.begin() + (size_t) j * (maxM + 1), others.begin() + (size_t) (j + 1) * (maxM + 1));
 				out[0]++;
 			}
 			out.push_back(idx);

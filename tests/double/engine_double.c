@@ -102,6 +102,7 @@ int hnsw_gpu_index_update_from_flat(hnsw_gpu_index *ix, const void *elements, si
 }
 
 int hnsw_gpu_index_reserve(hnsw_gpu_index *ix, size_t capacity) { (void) ix; (void) capacity; return HNSW_GPU_OK; }
+size_t hnsw_gpu_index_capacity(const hnsw_gpu_index *ix) { (void) ix; return (size_t) 1 << 40; }
 
 int hnsw_gpu_index_append(hnsw_gpu_index *ix, const coord_t *vectors, const label_t *labels, size_t n)
 {

@@ -29,8 +29,8 @@ def run(exe, rows, scans, env=None):
     assert r.returncode == 0, r.stderr[-2000:]
     build = float(re.search(r"Time: ([0-9.]+) ms  create_index", r.stderr).group(1)) / 1e3
     sel = sorted(float(x) for x in re.findall(r"Time: ([0-9.]+) ms  select", r.stderr))
-    stats = [ln for ln in r.stderr.splitlines() if ln.startswith("shim cache")]
-    return r.stdout, build, (sel[len(sel) // 2] if sel else 0.0), (stats[0] if stats else "")
+    stats = [ln for ln in r.stderr.splitlines() if ln.startswith("shim cache") or ln.startswith("shim inserts")]
+    return r.stdout, build, (sel[len(sel) // 2] if sel else 0.0), " | ".join(stats)
 
 
 gpu = SU.build_pg_regress(os.environ.get("PGEMB_GLUE_VARIANT", "gpu"))      # "shimdouble": the CPU engine double (dry run)
