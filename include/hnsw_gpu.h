@@ -106,6 +106,11 @@ int hnsw_gpu_index_get_link_lists(hnsw_gpu_index *ix, idx_t idx, idx_t *mine, id
  * order.  No host wait between the steps: the row is read from and the lists are written to pinned host memory by the kernels
  * themselves, and the calling core polls one completion flag. */
 int hnsw_gpu_index_insert_one(hnsw_gpu_index *ix, const coord_t *point, label_t label, idx_t idx, idx_t *mine, idx_t *others);
+/* The same for a caller that has just walked for `point` on this mirror (hnsw_gpu_search_trace in base mode with ef =
+ * efConstruction): cand_idx / cand_dist = that walk's result, element numbers and distances ascending by (dist, idx), ncand of them.
+ * The insert's own search would return exactly this list (same query, same graph: the new row is not linked yet), so it is not run. */
+int hnsw_gpu_index_insert_candidates(hnsw_gpu_index *ix, const coord_t *point, label_t label, idx_t idx, const idx_t *cand_idx,
+                                     const dist_t *cand_dist, uint32_t ncand, idx_t *mine, idx_t *others);
 
 size_t hnsw_gpu_index_count(const hnsw_gpu_index *ix);
 /* Elements the mirror has room for (hnsw_gpu_index_reserve grows it: a reallocation and a copy of the whole mirror, so a caller that

@@ -302,7 +302,13 @@ static bool hnsw_bind_point_impl(HnswMetadata *meta, const coord_t *point, idx_t
 				// the row, its links and the changed lists in one call: nothing waits on the host between the steps
 				others.resize(maxM * (maxM + 1));
 				const uint64_t td = now_ns();
-				if (hnsw_gpu_index_insert_one(ix, point, label, idx, mine, others.data()) != HNSW_GPU_OK) break;
+				const shimcache::InsertWalk &iw = shimcache::insert_walk();
+				// (under the validated cache the walk for this point has just been done, to CHECK the mirror: its result is the
+				// insert's candidate list — the same query on the same graph — so the device does not walk a second time)
+				const int irc = (ce && iw.valid && !getenv("PG_EMBEDDING_GPU_INSERT_REWALK"))
+					? hnsw_gpu_index_insert_candidates(ix, point, label, idx, iw.idx.data(), iw.dist.data(), iw.cnt, mine, others.data())
+					: hnsw_gpu_index_insert_one(ix, point, label, idx, mine, others.data());
+				if (irc != HNSW_GPU_OK) break;
 				t_dev = now_ns() - td;
 				fused = true;
 				if (ce && !shimcache::shadow_append(meta, ce, (size_t) idx + 1, idx, point, label)) break;

@@ -1850,14 +1850,18 @@ extern "C" int pgemb_sort_u64(void *tmp, size_t *tmp_bytes, const uint64_t *in, 
 
 typedef void (*build_kernel_t)(const BuildArgs);
 
-extern "C" int hnsw_gpu_index_link(hnsw_gpu_index *ix, size_t first, size_t count, size_t max_batch, size_t ratio,
-								   void *stream_)
+// ext_*: the candidates of ONE new element (count == 1) as a search already produced them — ascending by (dist, idx), the order
+// searchBaseLayer's results leave hnsw_gpu_search_base* in — in memory the device can read (pinned host memory will do): the link
+// step then runs without a search of its own (hnsw_gpu_index_insert_candidates).
+static int link_range(hnsw_gpu_index *ix, size_t first, size_t count, size_t max_batch, size_t ratio, void *stream_,
+					  const uint32_t *ext_idx, const float *ext_dist, const uint32_t *ext_cnt)
 {
 	std::unique_lock<std::recursive_mutex> lock_;
 	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
 	if (first + count > ix->n) return fail(HNSW_GPU_ERR_ARG, "elements [%zu, %zu) are not stored (count %zu)", first, first + count, ix->n);
 	if (count == 0) return HNSW_GPU_OK;
+	if (ext_idx && (count != 1 || !ext_dist || !ext_cnt)) return fail(HNSW_GPU_ERR_ARG, "external candidates are for one element");
 	if (max_batch == 0) max_batch = 4096;
 	if (ratio == 0) ratio = 8;
 	const size_t efc = ix->meta.efConstruction, M = ix->meta.M, maxM = ix->meta.maxM;
@@ -1931,10 +1935,18 @@ extern "C" int hnsw_gpu_index_link(hnsw_gpu_index *ix, size_t first, size_t coun
 		const bool single = b == 1;                     // the reference's serial insert: no sort, no segment marking (device_build.h)
 		HIPCHK(hipMemsetAsync(ctr, 0, 16, stream));
 		if (!single) HIPCHK(hipMemsetAsync(pairs, 0xFF, bslots * 8, stream));
-		// 1. searchBaseLayer(ef = efConstruction) for every new element (hnswalg.cpp:229)
-		int rc = launch_search(ix, &ix->ws, ix->vec + linked * ix->stride, ix->stride, b, efc, 1, nullptr, cand_idx, cand_dist,
-							   cand_cnt, nullptr, stream);
-		if (rc) return rc;
+		// 1. searchBaseLayer(ef = efConstruction) for every new element (hnswalg.cpp:229) — unless the caller brought its result
+		if (ext_idx)
+		{
+			a.cand_idx = ext_idx; a.cand_dist = ext_dist; a.cand_cnt = ext_cnt;
+		}
+		else
+		{
+			a.cand_idx = cand_idx; a.cand_dist = cand_dist; a.cand_cnt = cand_cnt;
+			int rc = launch_search(ix, &ix->ws, ix->vec + linked * ix->stride, ix->stride, b, efc, 1, nullptr, cand_idx, cand_dist,
+								   cand_cnt, nullptr, stream);
+			if (rc) return rc;
+		}
 		// 2. choose links, emit reverse pairs
 		a.first = (uint32_t) linked; a.count = (uint32_t) b; a.pair_slots = (uint32_t) bslots;
 		a.single = single ? 1u : 0u; a.seg_out = seg; a.nseg_out = ctr + 1;
@@ -1955,6 +1967,12 @@ extern "C" int hnsw_gpu_index_link(hnsw_gpu_index *ix, size_t first, size_t coun
 		linked += b;
 	}
 	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_index_link(hnsw_gpu_index *ix, size_t first, size_t count, size_t max_batch, size_t ratio,
+								   void *stream_)
+{
+	return link_range(ix, first, count, max_batch, ratio, stream_, nullptr, nullptr, nullptr);
 }
 
 // ------------------------------------------------------------------------------------
@@ -2077,18 +2095,22 @@ __global__ __launch_bounds__(64) void store_flag_kernel(uint32_t *flag)
 // hnsw_gpu_search_batch).  Round 2 made this call as append (2 blocking copies + sync) + link (2 memsets, search, select, a
 // hipCUB radix sort, segment marking, reverse) + get_link_lists (launch + sync): 0.85-1.5 ms per row against the reference's
 // 0.06-0.12 ms; a single row needs no sort (its neighbours are distinct targets) and no waits.
-extern "C" int hnsw_gpu_index_insert_one(hnsw_gpu_index *ix, const coord_t *point, label_t label, idx_t idx, idx_t *mine, idx_t *others)
+static int insert_impl(hnsw_gpu_index *ix, const coord_t *point, label_t label, idx_t idx, const idx_t *cand_idx, const dist_t *cand_dist,
+					   uint32_t ncand, idx_t *mine, idx_t *others)
 {
 	std::unique_lock<std::recursive_mutex> lock_;
 	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix || !point || !mine || !others) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	if (cand_idx && (!cand_dist || ncand > ix->meta.efConstruction)) return fail(HNSW_GPU_ERR_ARG, "bad candidate list");
 	if ((size_t) idx != ix->n) return fail(HNSW_GPU_ERR_ARG, "insert_one(%u): the mirror holds %zu elements", (unsigned) idx, ix->n);
 	if (ix->n + 1 > ix->cap) return fail(HNSW_GPU_ERR_ARG, "insert exceeds capacity (%zu)", ix->cap);
 	HIPCHK(hipSetDevice(ix->device));
 	if (ix->trace_active) { HIPCHK(hipStreamSynchronize(nullptr)); ix->trace_active = false; }   // an abandoned trace still writes the staging
 	const size_t dim = ix->meta.dim, maxM = ix->meta.maxM, ls = ix->lstride;
+	const size_t efc_ = ix->meta.efConstruction;
 	const size_t o_lab = round_up(dim * 4, 8), o_lists = round_up(o_lab + 8, 256), o_flag = o_lists + round_up((maxM + 1) * ls * 4, 256);
-	const size_t need = o_flag + 256;
+	const size_t o_ci = o_flag + 256, o_cd = o_ci + round_up(efc_ * 4, 256), o_cc = o_cd + round_up(efc_ * 4, 256);
+	const size_t need = o_cc + 256;
 	if (ix->pin_bytes < need)
 	{
 		if (ix->pin) (void) hipHostFree(ix->pin);
@@ -2106,7 +2128,15 @@ extern "C" int hnsw_gpu_index_insert_one(hnsw_gpu_index *ix, const coord_t *poin
 	uint32_t *lists = (uint32_t *) (h + o_lists);
 	if (idx > 0)                                             // element 0 is never bound (hnswalg.cpp:228)
 	{
-		rc = hnsw_gpu_index_link(ix, idx, 1, 1, 0, nullptr);
+		if (cand_idx)                                        // the walk has been done (and validated) already: its result, from pinned memory
+		{
+			memcpy(h + o_ci, cand_idx, (size_t) ncand * 4);
+			memcpy(h + o_cd, cand_dist, (size_t) ncand * 4);
+			*(uint32_t *) (h + o_cc) = ncand;
+			rc = link_range(ix, idx, 1, 1, 0, nullptr, (const uint32_t *) (h + o_ci), (const float *) (h + o_cd), (const uint32_t *) (h + o_cc));
+		}
+		else
+			rc = link_range(ix, idx, 1, 1, 0, nullptr, nullptr, nullptr, nullptr);
 		if (rc) return rc;
 	}
 	hipLaunchKernelGGL(gather_link_lists_kernel, dim3((uint32_t) maxM + 1), dim3(64), 0, 0, ix->links, (uint32_t) ls, (uint32_t) idx,
@@ -2128,6 +2158,21 @@ extern "C" int hnsw_gpu_index_insert_one(hnsw_gpu_index *ix, const coord_t *poin
 	for (size_t s2 = 0; s2 < maxM && k < mine[0]; s2++)
 		if (lists[s2] != LINK_NONE) { compact(lists + (1 + s2) * ls, others + k * (maxM + 1)); k++; }
 	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_index_insert_one(hnsw_gpu_index *ix, const coord_t *point, label_t label, idx_t idx, idx_t *mine, idx_t *others)
+{
+	return insert_impl(ix, point, label, idx, nullptr, nullptr, 0, mine, others);
+}
+
+// The same with the candidate list given: what searchBaseLayer(point, ef = efConstruction) returned on THIS mirror a moment ago
+// (hnsw_gpu_search_trace in base mode: element numbers and distances ascending by (dist, idx)) — a caller that has just walked for
+// the point (the validated cache of the unmodified glue walks to CHECK the mirror, shim_cache.h) does not pay for the walk twice.
+extern "C" int hnsw_gpu_index_insert_candidates(hnsw_gpu_index *ix, const coord_t *point, label_t label, idx_t idx, const idx_t *cand_idx,
+												const dist_t *cand_dist, uint32_t ncand, idx_t *mine, idx_t *others)
+{
+	if (!cand_idx || !cand_dist) return fail(HNSW_GPU_ERR_ARG, "NULL candidate list");
+	return insert_impl(ix, point, label, idx, cand_idx, cand_dist, ncand, mine, others);
 }
 
 // Refresh part of the mirror from the host: element images of [first, first+count) replace what

@@ -285,7 +285,7 @@ struct Validator
 // One traced walk on the mirror, validated while it runs.  `extra_results`: the results are expanded too (inserts).
 // Returns the number of differing elements (0 = the answer in labels/count is the host's), -1 = re-mirror, -2 = failure.
 inline long traced_walk(HnswMetadata *meta, Entry *e, const coord_t *point, size_t ef, int base, label_t *labels, uint32_t *count,
-						std::vector<uint32_t> &pops, size_t cap, bool expand_results)
+						std::vector<uint32_t> &pops, size_t cap, bool expand_results, dist_t *dists = nullptr)
 {
 	if (hnsw_gpu_search_trace_begin(e->ix, point, ef, base, cap) != HNSW_GPU_OK) return -2;
 	Validator v(meta, e);                                       // (host callbacks from here on: no library lock is held)
@@ -301,7 +301,7 @@ inline long traced_walk(HnswMetadata *meta, Entry *e, const coord_t *point, size
 		if (got == 0) __builtin_ia32_pause();
 	}
 	uint32_t npops = 0;
-	if (hnsw_gpu_search_trace_end(e->ix, labels, nullptr, count, &npops, nullptr) != HNSW_GPU_OK) return -2;
+	if (hnsw_gpu_search_trace_end(e->ix, labels, dists, count, &npops, nullptr) != HNSW_GPU_OK) return -2;
 	if (npops > cap || have != npops) return -1;                // a walk too long to validate
 	if (expand_results)
 	{
@@ -410,9 +410,17 @@ inline bool search(HnswMetadata *meta, const coord_t *point, size_t ef, label_t 
 // mutuallyConnectNewElement / getNeighborsByHeuristic (hnswalg.cpp:117-222) — the link lists of the selected
 // neighbours and the vectors of THEIR link targets; the selected neighbours are among the search's results, so the
 // results are expanded like pops.  Returns null on failure.
+// What the validation walk of prepare_insert found: searchBaseLayer(point, ef = efConstruction) on the mirror, element numbers and
+// distances ascending by (dist, idx) — exactly what the insert's own search would return a moment later (same query, same graph:
+// the new row is not linked yet), so the device insert takes it instead of walking again (hnsw_gpu_index_insert_candidates).
+// valid only when prepare_insert returned through a clean validation (not after a re-mirror: no walk ran then).
+struct InsertWalk { bool valid = false; uint32_t cnt = 0; std::vector<idx_t> idx; std::vector<dist_t> dist; };
+inline InsertWalk &insert_walk() { static thread_local InsertWalk w; return w; }
+
 inline Entry *prepare_insert(HnswMetadata *meta, const coord_t *point, idx_t idx, int device)
 {
 	bool empty = false;
+	insert_walk().valid = false;
 	Entry *e = pick(meta, &empty);
 	stats().inserts++;
 	if (empty) return nullptr;                                  // (idx 0 never gets here; an index without entry point cannot take idx > 0)
@@ -423,14 +431,23 @@ inline Entry *prepare_insert(HnswMetadata *meta, const coord_t *point, idx_t idx
 	if (pops.size() < POPS_CAP + efc + 64) pops.resize(POPS_CAP + efc + 64);
 	static thread_local std::vector<label_t> res;
 	res.resize(efc);
+	InsertWalk &iw = insert_walk();
+	iw.dist.resize(efc);
+	iw.idx.resize(efc);
 	for (int round = 0; round < 12; round++)
 	{
 		uint32_t cnt = 0;
 		stats().insert_rounds++;
-		const long diff = traced_walk(meta, e, point, efc, 1, res.data(), &cnt, pops, POPS_CAP, true);
+		const long diff = traced_walk(meta, e, point, efc, 1, res.data(), &cnt, pops, POPS_CAP, true, iw.dist.data());
 		if (diff == -2) return nullptr;
 		if (diff < 0) break;
-		if (diff == 0) return e;
+		if (diff == 0)
+		{
+			for (uint32_t i = 0; i < cnt; i++) iw.idx[i] = (idx_t) res[i];
+			iw.cnt = cnt;
+			iw.valid = true;
+			return e;
+		}
 		if ((size_t) diff > 64 + e->n / 4) break;
 		if (!apply_patches(meta, e)) break;
 	}

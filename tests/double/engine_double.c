@@ -156,6 +156,13 @@ int hnsw_gpu_index_insert_one(hnsw_gpu_index *ix, const coord_t *point, label_t 
 	return rc;
 }
 
+int hnsw_gpu_index_insert_candidates(hnsw_gpu_index *ix, const coord_t *point, label_t label, idx_t idx, const idx_t *cand_idx,
+									 const dist_t *cand_dist, uint32_t ncand, idx_t *mine, idx_t *others)
+{
+	(void) cand_idx; (void) cand_dist; (void) ncand;     /* the double walks itself: same graph either way */
+	return hnsw_gpu_index_insert_one(ix, point, label, idx, mine, others);
+}
+
 int hnsw_gpu_index_export_flat(hnsw_gpu_index *ix, void *elements)
 {
 	memcpy(elements, port_data(ix->p), port_count(ix->p) * port_elem_size(ix->p));
