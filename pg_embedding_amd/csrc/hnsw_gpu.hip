@@ -2032,16 +2032,35 @@ extern "C" int hnsw_gpu_index_get_links(hnsw_gpu_index *ix, idx_t idx, idx_t *ou
 // The link list of one element and the lists of all its neighbours in one launch + one wait: what an insert changed
 // (hnswalg.cpp:169-222: the new element's list and a reverse link in each neighbour's), for the write-back of
 // hnsw_bind_point.  Rows land in the mirror's pinned staging; block 0 = the element, block 1+j = its j-th link slot.
+// done_ctr / flag (hnsw_gpu_index_insert_*): the block that finishes LAST stores the completion flag behind a system-scope release —
+// the lists of every block are in host memory before the flag, and no extra launch is needed for it.
 __global__ __launch_bounds__(64) void gather_link_lists_kernel(const uint32_t *__restrict__ links, uint32_t lstride, uint32_t idx,
-															   uint32_t n, uint32_t *__restrict__ out)
+															   uint32_t n, uint32_t *__restrict__ out, uint32_t *done_ctr, uint32_t *flag)
 {
 	uint32_t src = idx;
+	bool have = true;
 	if (blockIdx.x > 0)
 	{
 		src = links[(size_t) idx * lstride + (blockIdx.x - 1)];
-		if (src == LINK_NONE || src >= n) { for (uint32_t j = threadIdx.x; j < lstride; j += 64) out[(size_t) blockIdx.x * lstride + j] = LINK_NONE; return; }
+		have = src != LINK_NONE && src < n;
 	}
-	for (uint32_t j = threadIdx.x; j < lstride; j += 64) out[(size_t) blockIdx.x * lstride + j] = links[(size_t) src * lstride + j];
+	for (uint32_t j = threadIdx.x; j < lstride; j += 64)
+		out[(size_t) blockIdx.x * lstride + j] = have ? links[(size_t) src * lstride + j] : LINK_NONE;
+	if (flag)
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // system scope: this block's rows
+		uint32_t last = 0;
+		if (threadIdx.x == 0) last = atomicAdd(done_ctr, 1u) == gridDim.x - 1 ? 1u : 0u;
+		if (__builtin_amdgcn_readfirstlane(last))
+		{
+			__builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");    // every other block's release happened before its increment
+			if (threadIdx.x == 0)
+			{
+				atomicExch(done_ctr, 0u);                     // ready for the next insert: no memset between calls
+				__hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
+		}
+	}
 }
 
 extern "C" int hnsw_gpu_index_get_link_lists(hnsw_gpu_index *ix, idx_t idx, idx_t *mine, idx_t *others)
@@ -2061,7 +2080,7 @@ extern "C" int hnsw_gpu_index_get_link_lists(hnsw_gpu_index *ix, idx_t idx, idx_
 	}
 	uint32_t *h = (uint32_t *) ix->pin;
 	hipLaunchKernelGGL(gather_link_lists_kernel, dim3((uint32_t) maxM + 1), dim3(64), 0, 0, ix->links, (uint32_t) ls, (uint32_t) idx,
-					   (uint32_t) ix->n, h);
+					   (uint32_t) ix->n, h, (uint32_t *) nullptr, (uint32_t *) nullptr);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipStreamSynchronize(nullptr));
 	auto compact = [&](const uint32_t *row, idx_t *out)
@@ -2078,12 +2097,6 @@ extern "C" int hnsw_gpu_index_get_link_lists(hnsw_gpu_index *ix, idx_t idx, idx_
 	for (size_t s = 0; s < maxM && k < mine[0]; s++)
 		if (h[s] != LINK_NONE) { compact(h + (1 + s) * ls, others + k * (maxM + 1)); k++; }
 	return HNSW_GPU_OK;
-}
-
-__global__ __launch_bounds__(64) void store_flag_kernel(uint32_t *flag)
-{
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope: the gathered lists are in host memory before the flag
-	if (threadIdx.x == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // hnsw_bind_point's device side in ONE host call (hnswalg.cpp:279-291, 225-232): element `idx` (= the mirror's current count)
@@ -2139,9 +2152,9 @@ static int insert_impl(hnsw_gpu_index *ix, const coord_t *point, label_t label, 
 			rc = link_range(ix, idx, 1, 1, 0, nullptr, nullptr, nullptr, nullptr);
 		if (rc) return rc;
 	}
+	// (the gather's last block stores the flag; its block counter is word 3 of the mirror's misc words: zero at creation, reset by that block)
 	hipLaunchKernelGGL(gather_link_lists_kernel, dim3((uint32_t) maxM + 1), dim3(64), 0, 0, ix->links, (uint32_t) ls, (uint32_t) idx,
-					   (uint32_t) ix->n, lists);
-	hipLaunchKernelGGL(store_flag_kernel, dim3(1), dim3(64), 0, 0, (uint32_t *) (h + o_flag));
+					   (uint32_t) ix->n, lists, ix->misc + 3, (uint32_t *) (h + o_flag));
 	HIPCHK(hipGetLastError());
 	rc = poll_done_flag(flag, "an insert");
 	if (rc) return rc;

@@ -336,6 +336,7 @@ template <typename T> static inline T atomicCAS(T *p, T expect, T v)
 	return expect;
 }
 static inline uint32_t atomicAdd(uint32_t *p, int v) { return __atomic_fetch_add(p, (uint32_t) v, __ATOMIC_SEQ_CST); }
+static inline uint32_t atomicExch(uint32_t *p, uint32_t v) { return __atomic_exchange_n(p, v, __ATOMIC_SEQ_CST); }
 
 static inline float __int_as_float(int v) { float f; memcpy(&f, &v, 4); return f; }
 static inline int __float_as_int(float f) { int v; memcpy(&v, &f, 4); return v; }
