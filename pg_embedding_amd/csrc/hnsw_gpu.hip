@@ -95,8 +95,9 @@ struct SearchWs
 // the library's own watchdog: HNSW_GPU_WATCHDOG_S=<seconds>) can reach it without the mirror's lock —
 // the thread that owns the lock is the one that is stuck.
 // ------------------------------------------------------------------------------------
-static std::mutex g_ws_mu;
-static std::vector<SearchWs *> g_ws_all;
+// (never destroyed: the watchdog thread is detached and may still be looking at them while the process exits)
+static std::mutex &g_ws_mu = *new std::mutex;
+static std::vector<SearchWs *> &g_ws_all = *new std::vector<SearchWs *>;
 static bool g_watchdog_started = false;
 
 static int64_t now_ms()
@@ -996,6 +997,8 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	if (__atomic_load_n(&w->abort_sent, __ATOMIC_SEQ_CST))
 	{
 		// the previous launch of this workspace was asked to end early: its waves left their bitmaps as they were
+		fprintf(stderr, "pg_embedding_amd: the previous search launch of this workspace (%s) was asked to end early (abort word): its outputs "
+				"are undefined; the workspace is re-zeroed\n", w->kname);
 		HIPCHK(hipStreamSynchronize(stream));
 		if (stream) HIPCHK(hipStreamSynchronize(nullptr));
 		if (w->vis) HIPCHK(hipMemset(w->vis, 0, w->vis_slots * w->vis_words * 4));

@@ -200,3 +200,36 @@ def test_a_launch_that_is_asked_to_end_does_end(env, monkeypatch):
     _same(out, want, 300, "after the abort")
     assert ix.health()["abort_pending"] == 0
     ix.close()
+
+
+@pytest.mark.timeout(180, method="thread")
+def test_the_librarys_own_watchdog_ends_a_launch_that_runs_too_long():
+    """HNSW_GPU_WATCHDOG_S (read once, at the library's first workspace — hence a process of its own): a search launch that has been
+    running longer than that is asked to end by a library thread, says so on stderr, and counts the waves that left."""
+    import subprocess
+    import sys
+    code = r'''
+import os, sys, time
+sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
+import numpy as np, torch
+import pg_embedding_amd as pg
+from pg_embedding_amd.datasets import gmm
+from util import build_port, mirror
+port, X = build_port(20000, 64, 16, 64, pg.DIST_L2, k=40, seed=77)
+ix = mirror(port, pg.DIST_L2, efs=100)
+Q = torch.from_numpy(gmm(1 << 16, 64, k=40, seed=77, stream=1)).cuda().repeat(320, 1)      # 21 M queries: several seconds of work
+torch.cuda.synchronize()
+t0 = time.time()
+ix.search_torch(Q, 100)
+torch.cuda.synchronize()
+print("ENDED_AFTER_S", round(time.time() - t0, 2), "HEALTH", ix.health())
+'''
+    env = dict(os.environ, HNSW_GPU_WATCHDOG_S="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=170, env=env,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("ENDED_AFTER_S")][0]
+    secs = float(line.split()[1])
+    print("\n[library watchdog] " + line)
+    assert "hnsw_gpu watchdog" in r.stderr and "aborting it" in r.stderr, r.stderr[-1500:]
+    assert "'aborted_waves': 0" not in line and secs < 3.5, line
