@@ -217,14 +217,14 @@ from pg_embedding_amd.datasets import gmm
 from util import build_port, mirror
 port, X = build_port(20000, 64, 16, 64, pg.DIST_L2, k=40, seed=77)
 ix = mirror(port, pg.DIST_L2, efs=100)
-Q = torch.from_numpy(gmm(1 << 16, 64, k=40, seed=77, stream=1)).cuda().repeat(320, 1)      # 21 M queries: several seconds of work
+Q = torch.from_numpy(gmm(1 << 16, 64, k=40, seed=77, stream=1)).cuda().repeat(32, 1)       # 2 M queries on 16 blocks (HNSW_GPU_MAX_BLOCKS): tens of seconds of work
 torch.cuda.synchronize()
 t0 = time.time()
 ix.search_torch(Q, 100)
 torch.cuda.synchronize()
 print("ENDED_AFTER_S", round(time.time() - t0, 2), "HEALTH", ix.health())
 '''
-    env = dict(os.environ, HNSW_GPU_WATCHDOG_S="1")
+    env = dict(os.environ, HNSW_GPU_WATCHDOG_S="1", HNSW_GPU_MAX_BLOCKS="16")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=170, env=env,
                        cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert r.returncode == 0, r.stderr[-2000:]
