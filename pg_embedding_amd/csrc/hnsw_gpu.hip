@@ -971,6 +971,10 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		blocks = std::min<size_t>(nq, (size_t) per_cu * ix->num_cu);
 		a.team_mains = (uint32_t) std::min<size_t>(wpb, (nq + blocks - 1) / blocks);
 	}
+	// (experiment knob: walking waves per block of a team launch — the others help from the start; scripts/exp_spec_ab.py)
+	if (team)
+		if (const char *tm = getenv("HNSW_GPU_TEAM_MAINS"))
+			if (atoi(tm) > 0) a.team_mains = std::min<uint32_t>(a.team_mains, (uint32_t) atoi(tm));
 	// (test knob: fewer blocks than the launch would get, so that the waves with queries take SEVERAL each through the
 	// ticket counter while their siblings help — the schedule of a small launch whose other blocks start late,
 	// tests/experiments/team_second_walk_stress.py)
