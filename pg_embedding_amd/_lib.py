@@ -108,6 +108,9 @@ def gpu_lib():
     L.hnsw_gpu_last_search_slots.argtypes = [vp, _u32p]
     L.hnsw_gpu_index_health.argtypes = [vp, _u32p]
     L.hnsw_gpu_index_insert_one.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp]
+    L.hnsw_gpu_index_insert_candidates.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint32, vp, vp]
+    L.hnsw_gpu_index_capacity.restype = sz
+    L.hnsw_gpu_index_capacity.argtypes = [vp]
     L.hnsw_gpu_search_traced_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp, sz, vp, vp]
     L.hnsw_gpu_replay_roof.argtypes = [vp, vp, sz, vp, sz, C.c_uint, i32, i32, _f32p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.hnsw_gpu_index_abort.argtypes = [vp]

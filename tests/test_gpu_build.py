@@ -124,3 +124,44 @@ def test_mfma_exhaustive_scorer_equals_canonical_scan(func, n, dim, nq, k):
     assert (i0 == i1).all()
     assert (d0.view(torch.int32) == d1.view(torch.int32)).all()
     ix.close()
+
+
+@pytest.mark.parametrize("func,dim,m,efc", [(pg.DIST_L2, 24, 6, 40), (pg.DIST_COSINE, 100, 16, 64)])
+def test_insert_one_and_insert_candidates_build_the_oracles_graph(func, dim, m, efc):
+    """hnsw_gpu_index_insert_one (append + serial link + changed lists in one call) and hnsw_gpu_index_insert_candidates (the same
+    with the candidate list taken from a traced walk instead of a second search): row by row they build the graph the oracle's
+    serial inserts build, byte for byte, and the lists they return are the lists the mirror holds."""
+    import ctypes as C
+    n = 700
+    X = gmm(n, dim, k=20, seed=5 + dim)
+    labels = np.arange(n, dtype=np.uint64) * 3 + 1
+    port = oracle.PortIndex(dim, m, efc, 64, func)
+    port.add(X, labels)
+    meta = pg.make_meta(dim, m, efc, 64, func)
+    maxM = int(meta.maxM)
+    for use_candidates in (False, True):
+        ix = pg.GpuIndex.empty(meta, n)
+        mine = (C.c_uint32 * (maxM + 1))()
+        others = (C.c_uint32 * (maxM * (maxM + 1)))()
+        for i in range(n):
+            p = np.ascontiguousarray(X[i])
+            if use_candidates and i > 0:
+                # what the validated cache does: a traced base-layer walk for the point on the mirror as it is, then the insert off its result
+                ci, cd, pops, nev = ix.search_trace(p, efc, base=True)
+                ci32 = np.ascontiguousarray(ci.astype(np.uint32))
+                cd32 = np.ascontiguousarray(cd, dtype=np.float32)
+                rc = ix.L.hnsw_gpu_index_insert_candidates(ix._h, p.ctypes.data, int(labels[i]), i, ci32.ctypes.data, cd32.ctypes.data,
+                                                           len(ci32), mine, others)
+            else:
+                rc = ix.L.hnsw_gpu_index_insert_one(ix._h, p.ctypes.data, int(labels[i]), i, mine, others)
+            assert rc == 0, (i, use_candidates)
+            if i in (1, 50, n - 1):                              # the returned lists == the mirror's lists
+                got = ix.export_flat().reshape(i + 1, -1)[:, :(maxM + 1) * 4].copy().view(np.uint32)
+                assert (np.frombuffer(mine, np.uint32) [:1 + mine[0]] == got[i, :1 + mine[0]]).all()
+                for j in range(mine[0]):
+                    o = np.frombuffer(others, np.uint32)[j * (maxM + 1):(j + 1) * (maxM + 1)]
+                    assert (o[:1 + o[0]] == got[mine[1 + j], :1 + o[0]]).all()
+        got = ix.export_flat().reshape(n, -1)
+        want = live_image(port.raw(), meta, n)
+        assert (got == want).all(), f"use_candidates={use_candidates}: {(got != want).any(axis=1).sum()} elements differ"
+        ix.close()
