@@ -53,10 +53,10 @@ def forms():
         n, nq = (1200, 12) if dim < 700 else (500, 6)
         port, X = U.build_port(n, dim, m, 40, func, k=10, seed=dim)
         Q = gmm(nq, dim, k=10, seed=dim + 1)
-        for ef in efs:
+        for k, ef in enumerate(efs):
             ix = U.mirror(port, func, efs=ef)
             want = port.search_many(Q, ef, nthreads=4)
-            for env in variants:
+            for env in (variants if k == 0 else variants[::3]):      # (a configuration's second beam width: every third variant)
                 setenv(env)
                 t0 = time.time()
                 got = ix.search(Q, ef)
@@ -78,14 +78,16 @@ def second_walk():
     Q = (np.repeat(base, 8, axis=0) + 0.01 * rng.standard_normal((32, dim))).astype(np.float32)
     want = port.search_many(Q, ef, nthreads=4)
     out = []
-    for env in ({"HNSW_GPU_TEAM": "1", "HNSW_GPU_MAX_BLOCKS": "1", "SIMT_EMU_CUS": "256"},
-                {"HNSW_GPU_TEAM": "1", "HNSW_GPU_MAX_BLOCKS": "1", "SIMT_EMU_CUS": "256", "SIMT_EMU_JITTER": "500", "SIMT_EMU_JITTER_US": "3000"},
-                {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "4", "HNSW_GPU_MAX_BLOCKS": "2", "SIMT_EMU_CUS": "256"}):
+    envs = ({"HNSW_GPU_TEAM": "1", "HNSW_GPU_MAX_BLOCKS": "1", "SIMT_EMU_CUS": "256"},
+            {"HNSW_GPU_TEAM": "1", "HNSW_GPU_MAX_BLOCKS": "1", "SIMT_EMU_CUS": "256", "SIMT_EMU_JITTER": "500", "SIMT_EMU_JITTER_US": "3000"},
+            {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "4", "HNSW_GPU_MAX_BLOCKS": "2", "SIMT_EMU_CUS": "256"})
+    quick = bool(os.environ.get("EMU_SECOND_WALK_QUICK"))      # (the report-only and teeth variants: one schedule with, one without jitter, once)
+    for env in (envs[:2] if quick else envs):
         bad = 0
-        for rep in range(2):
+        for rep in range(1 if quick else 2):
             setenv(dict(env, SIMT_EMU_SEED=str(rep)))
             bad += wrong(ix.search(Q, ef), want, 32)
-        out.append({"env": env, "kernel": ix.last_search_kernel(), "walks": 64, "wrong": bad, "blocks_x_waves": ix.last_search_slots(), "health": ix.health()})
+        out.append({"env": env, "kernel": ix.last_search_kernel(), "walks": 32 if quick else 64, "wrong": bad, "blocks_x_waves": ix.last_search_slots(), "health": ix.health()})
     return out
 
 

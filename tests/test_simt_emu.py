@@ -55,14 +55,9 @@ def test_the_other_kernels_behind_the_c_abi(emu_lib):
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
 
 
-def test_a_wave_that_walks_many_queries_with_helpers_attached(emu_lib):
-    """one wave, 32 neighbouring queries, seven helpers (with and without schedule jitter; two waves with three helpers each)"""
-    res = run_case("second_walk", emu_lib)
-    assert all(r["wrong"] == 0 and "true>" in r["kernel"] for r in res), res
-
-
-def test_the_same_without_the_helper_bit_clear_is_reported(capsys):
-    """The schedule above is what the clear at the start of a walk (device_search.h) is for: without that one line a good part
+def test_many_walks_without_the_helper_bit_clear_is_reported(capsys):
+    """One wave, 32 neighbouring queries one after the other, seven helpers attached (the schedule of
+    test_slice_helpers_and_hop_wide_append_are_exact_and_complete) is what the clear at the start of a walk (device_search.h) is for: without that one line a good part
     of the answers is wrong.  Reported, not asserted — it is a race, and a test must not depend on losing one."""
     CLEAR = "if (TEAM) __hip_atomic_store(&ctl[wib].helpers, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);"
 
@@ -72,15 +67,16 @@ def test_the_same_without_the_helper_bit_clear_is_reported(capsys):
             txt = txt.replace(CLEAR, ";")
         return txt
     lib = build_emu.build_tree(tag="noclear", edit=drop_clear)
-    res = run_case("second_walk", lib, {"HNSW_GPU_TEAM_SPEC": "8"})
+    res = run_case("second_walk", lib, {"HNSW_GPU_TEAM_SPEC": "8", "EMU_SECOND_WALK_QUICK": "1"})
     with capsys.disabled():
         print("\n[simt emulator] without the helper-bit clear: " + "; ".join(f"{r['wrong']} of {r['walks']} answers wrong" for r in res))
 
 
 @pytest.mark.parametrize("spec", ["5", "0"])
 def test_slice_helpers_and_hop_wide_append_are_exact_and_complete(emu_lib, spec):
-    """Helpers scoring slices of the walking wave's many-row hops (device_search.h, banner at TeamCtl) and the one-step append
-    below ef: the many-walks schedule equals the oracle with five of seven helpers speculating (the default) and with none (all of
+    """A wave that walks MANY queries with helpers attached — one wave, 32 neighbouring queries, seven helpers, with and without
+    schedule jitter; two waves with three helpers each — with helpers scoring slices of its many-row hops (device_search.h, banner
+    at TeamCtl) and the one-step append below ef: the many-walks schedule equals the oracle with five of seven helpers speculating (the default) and with none (all of
     them take slices; "all speculate" is what test_a_wave_that_walks_many_queries_… and the forms test run with fewer helpers);
     slices ARE delivered (the mechanism is in use) and none times out."""
     res = run_case("second_walk", emu_lib, {"HNSW_GPU_TEAM_SPEC": spec}, timeout=600)
@@ -104,10 +100,10 @@ def test_a_helper_that_never_delivers_costs_time_not_answers():
             txt = txt.replace("constexpr uint32_t SLICE_WAIT_POLLS = 20000;", "constexpr uint32_t SLICE_WAIT_POLLS = 50;")   # (emulated polls are slow)
         return txt
     lib = build_emu.build_tree(tag="nodone", edit=drop_done)
-    res = run_case("second_walk", lib, {"HNSW_GPU_TEAM_SPEC": "0"}, timeout=900)
+    res = run_case("second_walk", lib, {"HNSW_GPU_TEAM_SPEC": "0", "EMU_SECOND_WALK_QUICK": "1"}, timeout=900)
     assert all(r["wrong"] == 0 for r in res), res
     h = res[-1]["health"]
-    assert h["slice_timeouts"] > 100 and h["slices_delivered"] == 0, h
+    assert h["slice_timeouts"] > 50 and h["slices_delivered"] == 0, h
 
 
 def test_a_launch_that_is_asked_to_end_does_end(emu_lib):
