@@ -154,7 +154,7 @@ __device__ __forceinline__ float query_norm(const float4 *q4, uint32_t nchunks, 
 // issues KB chunk-steps of ALL its rows before the first use, i.e. KB*RPG independent
 // 16-byte loads per lane (KB*RPG KiB per wave) are in flight per memory round trip.  The
 // traversal is a chain of dependent round trips, so the shape is picked per dimensionality
-// to cover a whole row per trip when it fits: 768 dims = <12,2>, 128 dims = <2,4> / <2,2>, 1536 dims = <24,1> (small launches).
+// to cover a whole row per trip when it fits: 768 dims = <12,1>, 128 dims = <2,4>.
 constexpr uint32_t OUT2 = 64;      // offset of the second sum (cosine |x|^2) in a score_rows output array
 
 // The reference build's own order (debug mode, F_L2_REF / F_MANHATTAN_REF), as oracle/_ref/distfunc.o computes it:
@@ -325,12 +325,18 @@ struct Shape2x4  { static constexpr int KB = 2,  RPG = 4, MIN_WAVES = 4; };   //
 struct Shape2x2  { static constexpr int KB = 2,  RPG = 2, MIN_WAVES = 5; };   // dim <= 128, the hot beam form: 96 VGPRs, 5 waves/SIMD
 struct Shape4x2  { static constexpr int KB = 4,  RPG = 2, MIN_WAVES = 4; };   // dim <= 256
 struct Shape8x2  { static constexpr int KB = 8,  RPG = 2, MIN_WAVES = 2; };   // dim <= 512
-struct Shape12x2 { static constexpr int KB = 12, RPG = 2, MIN_WAVES = 2; };   // larger (768 = one batch): 8 rows per round trip
-// Rows of more than 768 floats need two <12,2> batches — two dependent-issue round trips — per pass of 8 rows.  <24,1> covers 24
-// chunk-steps = 1536 floats of ONE row per group in one batch: 4 rows per pass, one round trip.  Same bytes in flight (24 loads per
-// lane), same per-row summation order (it does not depend on the batch shape); fewer round trips per hop for a walk that is a chain
-// of round trips — small launches of very wide rows (BASELINE config C5: 1536 dims, Q = 1024) — and narrower slices for slice helpers.
-struct Shape24x1 { static constexpr int KB = 24, RPG = 1, MIN_WAVES = 2; };
+// (experiment builds: -DHNSW_W3_12X1 / -DHNSW_W3_12X2 cap that shape's kernels at 168 VGPRs = 3 waves/SIMD; the host side
+// then wants HNSW_GPU_WIDE_WAVES=12 and HNSW_GPU_TEAM_WPB=6 or 4)
+#ifdef HNSW_W3_12X1
+struct Shape12x1 { static constexpr int KB = 12, RPG = 1, MIN_WAVES = 3; };
+#else
+struct Shape12x1 { static constexpr int KB = 12, RPG = 1, MIN_WAVES = 2; };   // larger (768 = one batch)
+#endif
+#ifdef HNSW_W3_12X2
+struct Shape12x2 { static constexpr int KB = 12, RPG = 2, MIN_WAVES = 3; };
+#else
+struct Shape12x2 { static constexpr int KB = 12, RPG = 2, MIN_WAVES = 2; };   // same, 8 rows per round trip
+#endif
 
 __host__ __device__ inline int shape_index(uint32_t kiters)
 {

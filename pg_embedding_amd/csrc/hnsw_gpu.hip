@@ -695,7 +695,7 @@ static search_kernel_t pick_search_kernel_s(int func, int rreg, bool team)
 	}
 }
 
-static search_kernel_t pick_search_kernel(int func, uint32_t kiters, int rreg, bool team, bool narrow5, bool shape24)
+static search_kernel_t pick_search_kernel(int func, uint32_t kiters, int rreg, bool team, bool narrow5)
 {
 	switch (shape_index(kiters))
 	{
@@ -710,7 +710,7 @@ static search_kernel_t pick_search_kernel(int func, uint32_t kiters, int rreg, b
 		case 1:  return pick_search_kernel_s<Shape4x2>(func, rreg, team);
 		case 2:  return pick_search_kernel_s<Shape8x2>(func, rreg, team);
 		default:
-			if (shape24) return pick_search_kernel_s<Shape24x1>(func, rreg, team);
+			if (getenv("HNSW_GPU_SHAPE_12X1")) return pick_search_kernel_s<Shape12x1>(func, rreg, team);
 			return pick_search_kernel_s<Shape12x2>(func, rreg, team);
 	}
 }
@@ -754,11 +754,7 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	if (a.n > 0 && a.entry >= a.n) return fail(HNSW_GPU_ERR_ARG, "enterpoint_node %u >= count %u", a.entry, a.n);
 
 	// LDS carve per wave
-	// rows of more than 768 floats in launches of at most 8 queries per CU (a walk there is a chain of round trips, not a share of the
-	// memory system): whole rows per load batch, device_dist.h Shape24x1.  HNSW_GPU_SHAPE_24X1=0/1 forces it off/on.
-	const char *s24 = getenv("HNSW_GPU_SHAPE_24X1");
-	const bool shape24 = a.kiters > 12 && (s24 ? atoi(s24) > 0 : nq <= (size_t) 8 * ix->num_cu);
-	a.qpad_floats = (uint32_t) round_up(a.kiters, shape24 ? 24u : shape_kb(shape_index(a.kiters))) * 64;
+	a.qpad_floats = (uint32_t) round_up(a.kiters, shape_kb(shape_index(a.kiters))) * 64;
 	// Form of the accepted-set bookkeeping (rreg):
 	//   beam form (one accepted set in registers, acceptance by counting): default up to ef = 256, and up
 	//     to ef = 512 for rows wider than 256 floats — those run at 2 waves/SIMD anyway, so 16 set registers
@@ -949,11 +945,11 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	if (!team) { wpb = 4; while (wpb > 1 && (size_t) wpb * a.wave_bytes > 64 * 1024) wpb >>= 1; }
 	a.off_ctl = (uint32_t) ((size_t) wpb * a.wave_bytes);
 	const size_t lds = (size_t) wpb * a.wave_bytes + (team ? wpb * sizeof(TeamCtl) : 0);
-	search_kernel_t kern = pick_search_kernel(func_code, a.kiters, rreg, team, narrow5, shape24);
+	search_kernel_t kern = pick_search_kernel(func_code, a.kiters, rreg, team, narrow5);
 	if (!kern) return fail(HNSW_GPU_ERR_INTERNAL, "no kernel for this configuration");
 	{
 		static const char *const shapes[4] = { "Shape2x4", "Shape4x2", "Shape8x2", "Shape12x2" };
-		const char *shp = shape24 ? "Shape24x1" : shapes[shape_index(a.kiters)];
+		const char *shp = (shape_index(a.kiters) == 3 && getenv("HNSW_GPU_SHAPE_12X1")) ? "Shape12x1" : shapes[shape_index(a.kiters)];
 		if (narrow5 && !team) shp = "Shape2x2";
 		if (rreg < 0) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_beam<%d, pgemb::%s, %d, %s>", func_code, shp, -rreg, team ? "true" : "false");
 		else if (rreg == 3) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_wide<%d, pgemb::%s>", (int) ix->meta.dist_func, shp);

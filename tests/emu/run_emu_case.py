@@ -21,7 +21,7 @@ import pg_embedding_amd as pg                              # noqa: E402
 import util as U                                           # noqa: E402
 from pg_embedding_amd.datasets import gmm                  # noqa: E402
 
-KEYS = ("HNSW_GPU_TEAM", "HNSW_GPU_TEAM_WPB", "HNSW_GPU_MAX_BLOCKS", "HNSW_GPU_NARROW5", "HNSW_GPU_HASH_ENTRIES", "HNSW_GPU_BEAM", "HNSW_GPU_SHAPE_24X1",      # (HNSW_GPU_TEAM_SPEC: as the caller of this script set it)
+KEYS = ("HNSW_GPU_TEAM", "HNSW_GPU_TEAM_WPB", "HNSW_GPU_MAX_BLOCKS", "HNSW_GPU_NARROW5", "HNSW_GPU_HASH_ENTRIES", "HNSW_GPU_BEAM",      # (HNSW_GPU_TEAM_SPEC: as the caller of this script set it)
         "HNSW_GPU_BEAM16", "HNSW_GPU_FORCE_LDS_HEAPS", "SIMT_EMU_CUS", "SIMT_EMU_JITTER", "SIMT_EMU_JITTER_US", "SIMT_EMU_SEED")
 
 
@@ -46,21 +46,17 @@ def forms():
     variants = [{}, {"HNSW_GPU_TEAM": "0"}, {"HNSW_GPU_TEAM": "0", "HNSW_GPU_NARROW5": "0"}, {"HNSW_GPU_TEAM": "1"},
                 {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "4"}, {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "2", "HNSW_GPU_HASH_ENTRIES": "512"},
                 {"HNSW_GPU_HASH_ENTRIES": "0"}, {"HNSW_GPU_BEAM": "0"}, {"HNSW_GPU_FORCE_LDS_HEAPS": "1"}, {"HNSW_GPU_TEAM": "1", "SIMT_EMU_CUS": "64"}]
-    cfgs = ((32, 8, pg.DIST_L2, (10, 100)), (100, 16, pg.DIST_COSINE, (40,)), (200, 8, pg.DIST_MANHATTAN, (40, 300)), (768, 16, pg.DIST_L2, (64,)),
-            (1000, 8, pg.DIST_COSINE, (40,)))          # > 768 floats: the <24,1> whole-row batches (padded here), small launches
+    cfgs = ((32, 8, pg.DIST_L2, (10, 100)), (100, 16, pg.DIST_COSINE, (40,)), (200, 8, pg.DIST_MANHATTAN, (40, 300)), (768, 16, pg.DIST_L2, (64,)))
     if os.environ.get("EMU_FORMS_QUICK"):
         cfgs = (cfgs[1], cfgs[3])
     for dim, m, func, efs in cfgs:
-        n, nq = (1200, 12) if dim < 700 else ((500, 6) if dim < 900 else (300, 4))
+        n, nq = (1200, 12) if dim < 700 else (500, 6)
         port, X = U.build_port(n, dim, m, 40, func, k=10, seed=dim)
         Q = gmm(nq, dim, k=10, seed=dim + 1)
         for k, ef in enumerate(efs):
             ix = U.mirror(port, func, efs=ef)
             want = port.search_many(Q, ef, nthreads=4)
-            vs = variants if k == 0 else variants[::3]               # (a configuration's second beam width: every third variant)
-            if dim > 900:
-                vs = [{}, {"HNSW_GPU_TEAM": "0"}, {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "4"}, {"HNSW_GPU_SHAPE_24X1": "0"}, {"HNSW_GPU_FORCE_LDS_HEAPS": "1"}]
-            for env in vs:
+            for env in (variants if k == 0 else variants[::3]):      # (a configuration's second beam width: every third variant)
                 setenv(env)
                 t0 = time.time()
                 got = ix.search(Q, ef)

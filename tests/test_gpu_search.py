@@ -329,6 +329,7 @@ def test_many_queries_reuse_slots():
     {"HNSW_GPU_HASH_ENTRIES": "512"},        # tiny LDS visited set: most ids spill to the HBM bitmap
     {"HNSW_GPU_HASH_ENTRIES": "0"},          # bitmap only
     {"HNSW_GPU_FORCE_LDS_HEAPS": "1"},       # generic kernel (sorted arrays in LDS) at small ef
+    {"HNSW_GPU_SHAPE_12X1": "1"},
     {"HNSW_GPU_BEAM": "0"},                  # two-set register form instead of the beam form
     {"HNSW_GPU_BEAM": "0", "HNSW_GPU_HASH_ENTRIES": "512"},
     {"HNSW_GPU_BEAM16": "0"},                # ef in (256, 512]: LDS form instead of 16 set registers
@@ -671,36 +672,4 @@ def test_reference_order_mode_returns_the_compiled_references_id_lists(func, dim
         assert same.all(), f"{int((~same).sum())} of {nq} id lists differ from the compiled reference's"
         for q in range(0, nq, 97):
             assert (bits(dst[q, :cnt[q]]) == bits(oracle.ref_dist_many(func, Q[q], X[lab[q, :cnt[q]].astype(np.int64)]))).all()
-    ix.close()
-
-
-@pytest.mark.parametrize("func", FUNCS)
-@pytest.mark.parametrize("dim", [1536, 1000, 2000])
-def test_whole_row_batches_for_very_wide_rows(func, dim, monkeypatch):
-    """Rows of more than 768 floats in small launches use the <24,1> load shape (device_dist.h, Shape24x1: 24 chunk-steps of one row
-    per group in one batch — a 1536-float row in one round trip instead of two); 1000 floats = a padded batch, 2000 = a batch and a
-    tail.  One-wave and team form, the default choice (small launch) and forced on a launch above the threshold; forced off gives the
-    same bytes: the summation order of a row does not depend on the batch shape."""
-    import torch
-    n = 2500
-    port, X = build_port(n, dim, 12, 40, func, k=30, seed=dim + func)
-    Q = gmm(300, dim, k=30, seed=dim + func, stream=1)
-    ix = mirror(port, func)
-    want = port.search_many(Q, 64, nthreads=8)
-    dQ = torch.from_numpy(Q).cuda()
-    seen = set()
-    for env in ({}, {"HNSW_GPU_TEAM": "0"}, {"HNSW_GPU_SHAPE_24X1": "0"}, {"HNSW_GPU_SHAPE_24X1": "1", "HNSW_GPU_TEAM": "0"}):
-        for k in ("HNSW_GPU_TEAM", "HNSW_GPU_SHAPE_24X1"):
-            monkeypatch.delenv(k, raising=False)
-        for k, v in env.items():
-            monkeypatch.setenv(k, v)
-        for nq in (1, 37, 300):
-            out = ix.search_torch(dQ[:nq].contiguous(), 64, stats=True)
-            torch.cuda.synchronize()
-            seen.add(ix.last_search_kernel().split("pgemb::")[2].split(",")[0])
-            assert (out["labels"].cpu().numpy().view(np.uint64) == want["labels"][:nq]).all(), (env, nq)
-            assert (bits(out["dists"].cpu().numpy()) == bits(want["dists"][:nq])).all(), (env, nq)
-            st = out["stats"].cpu().numpy().astype(np.uint32)
-            assert (st[:, 0] == want["evals"][:nq]).all() and (st[:, 1] == want["hops"][:nq]).all()
-    assert seen == {"Shape24x1", "Shape12x2"}, seen
     ix.close()
