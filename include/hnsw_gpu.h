@@ -111,6 +111,12 @@ int hnsw_gpu_index_insert_one(hnsw_gpu_index *ix, const coord_t *point, label_t 
  * The insert's own search would return exactly this list (same query, same graph: the new row is not linked yet), so it is not run. */
 int hnsw_gpu_index_insert_candidates(hnsw_gpu_index *ix, const coord_t *point, label_t label, idx_t idx, const idx_t *cand_idx,
                                      const dist_t *cand_dist, uint32_t ncand, idx_t *mine, idx_t *others);
+/* Both run as two launches built for latency (csrc/device_insert.h: every distance getNeighborsByHeuristic can ask for — the lower
+ * triangle of the candidates' pair matrix — is scored by all wavefronts at once, the chain of hnswalg.cpp:130-150 then runs out of LDS;
+ * one block per reverse link) when the pair matrix of max(efConstruction, maxM + 1) candidates fits a CU's LDS, and through the
+ * general builder (hnsw_gpu_index_link with max_batch = 1) otherwise or with HNSW_GPU_INSERT_FUSED=0.  Same graph bytes either way.
+ * out[0] / out[1] = inserts of this process that took the first / the second path. */
+void hnsw_gpu_insert_path_counts(uint64_t out[2]);
 
 size_t hnsw_gpu_index_count(const hnsw_gpu_index *ix);
 /* Elements the mirror has room for (hnsw_gpu_index_reserve grows it: a reallocation and a copy of the whole mirror, so a caller that

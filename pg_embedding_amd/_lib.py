@@ -109,6 +109,8 @@ def gpu_lib():
     L.hnsw_gpu_index_health.argtypes = [vp, _u32p]
     L.hnsw_gpu_index_insert_one.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp]
     L.hnsw_gpu_index_insert_candidates.argtypes = [vp, vp, C.c_uint64, C.c_uint32, vp, vp, C.c_uint32, vp, vp]
+    L.hnsw_gpu_insert_path_counts.argtypes = [vp]
+    L.hnsw_gpu_insert_path_counts.restype = None
     L.hnsw_gpu_index_capacity.restype = sz
     L.hnsw_gpu_index_capacity.argtypes = [vp]
     L.hnsw_gpu_search_traced_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp, sz, vp, vp]

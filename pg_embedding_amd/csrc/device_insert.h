@@ -1,0 +1,300 @@
+// device_insert.h — the reference's serial insert of ONE element (hnswalg.cpp:225-232, 155-223, 117-153) as two launches
+// built for LATENCY (hnsw_gpu_index_insert_one / _insert_candidates; the batched builder of device_build.h is built for
+// throughput and stays as it is).
+//
+// Where a serial insert's time went (profiles/r3h_serial_insert.txt): getNeighborsByHeuristic is a chain — candidate k is
+// compared with the neighbours chosen before it (hnswalg.cpp:137-148), so one wavefront walking the candidates pays a row
+// fetch and up to M/4 scoring passes per candidate, 64 candidates in a row, and each of the <= M neighbours whose list is
+// full repeats that over maxM + 1 candidates.  But the only data-dependent part of the chain is WHICH earlier candidates
+// were chosen: every distance it can ask for is dist(candidate k, candidate j) with j < k in pop order.  So:
+//   step 1  insert_select_kernel   G blocks: every wavefront takes candidates k and scores ALL earlier candidates against
+//           them (the strict lower triangle of the pair matrix, ncand * (ncand - 1) / 2 distances, 16 rows per pass);
+//           the block that finishes last runs the chain out of LDS — one compare + ballot per candidate — and writes the
+//           new element's link list and the list of targets.  Block 0 also stores the row (the append).
+//   step 2  insert_reverse_kernel  one block per target (hnswalg.cpp:183-222): room in the list -> append; full -> the
+//           same triangle over {new, old links} around the target, chain by wave 0.  Each block writes its target's list
+//           into the mirror AND into the caller's pinned staging; the block that finishes last stores the completion flag.
+// The values are the ones device_build.h computes (same staged "query", same rows, per-row summation order independent of
+// the pass shape), so the graph stays byte-identical to the oracle's: tests/test_gpu_build.py, tests/emu (insert scenario).
+#pragma once
+#include "device_build.h"
+
+namespace pgemb {
+
+struct InsertArgs
+{
+	BuildArgs b;                  // vec, links, dims, M, maxM, lstride, efc, cand_* (one element), first = the new element
+	const float    *src_row;      // the point, dim floats (pinned host memory); NULL = the row is stored already
+	const uint64_t *src_label;
+	uint64_t *labels;
+	uint32_t *targets;            // step 1 -> step 2: the chosen neighbours in link order
+	uint32_t *ntargets;
+	float    *dmat;               // step 1: pair matrix in device memory, side x side
+	uint32_t *lists_out;          // [(maxM + 1)][lstride]: row 0 = the new element's list, row 1 + j = the list of link slot j
+	uint32_t *done1, *done2;      // block counters (zero between calls: the last block resets them)
+	uint32_t *flag;               // completion flag in pinned host memory
+	uint32_t nw;                  // wavefronts per block
+	uint32_t side;                // row length of the pair matrix
+	uint32_t cap;                 // key array length
+	uint32_t bind;                // 0 = element 0: stored, never bound (hnswalg.cpp:228)
+};
+
+constexpr int INS_KB = 4, INS_RPG = 4;       // 16 rows per scoring pass, 4 chunk-steps per load batch
+
+// Block-shared part of the LDS carve; the per-wave parts (query image, 2 x 64 sums) follow it.
+struct InsertLds
+{
+	uint64_t *pop, *keyA, *keyB;  // [cap] each: pop order | scratch | sorted output
+	uint32_t *selpos;             // [cap]: chosen candidates as positions in pop order
+	uint32_t *cur;                // [maxM + 2]: cur[0] = incoming, cur[1..] = the target's links
+	uint32_t *sh;                 // [4] block-shared words
+	float    *D;                  // [side * side]
+	float    *qf;                 // this wave's query image
+	float    *tmpd;               // this wave's 2 x 64 sums
+};
+
+__device__ __forceinline__ InsertLds insert_carve(const InsertArgs &a, unsigned char *smem, uint32_t wib)
+{
+	InsertLds L;
+	L.pop = reinterpret_cast<uint64_t *>(smem);
+	L.keyA = L.pop + a.cap;
+	L.keyB = L.keyA + a.cap;
+	L.selpos = reinterpret_cast<uint32_t *>(L.keyB + a.cap);
+	L.cur = L.selpos + a.cap;
+	L.sh = L.cur + ((a.b.maxM + 2 + 3) & ~3u);
+	L.D = reinterpret_cast<float *>(L.sh + 4);
+	float *waves = L.D + (size_t) a.side * a.side;
+	L.qf = waves + (size_t) wib * (a.b.qpad_floats + 128);
+	L.tmpd = L.qf + a.b.qpad_floats;
+	return L;
+}
+
+// Strict lower triangle of the pair matrix: D[k * side + j] = dist(candidate k staged as the query, row of candidate j) for
+// j < k, candidates in pop order (pop[i] = ord(dist) << 32 | ~idx).  Candidate k costs ceil(k / 16) passes, so wavefront w
+// of W takes k = w, w + W, ... from BOTH ends (k and ncand - 1 - k) and every wavefront ends with about the same number.
+template <int FUNC>
+__device__ __forceinline__ void pair_triangle(const BuildArgs &a, const uint64_t *pop, uint32_t ncand, float *D, uint32_t side,
+											  float *qf, float *tmpd, uint32_t w, uint32_t W, int lane)
+{
+	const float4 *q4 = reinterpret_cast<const float4 *>(qf);
+	for (uint32_t h = w; 2 * h < ncand; h += W)
+		for (uint32_t end = 0; end < 2; end++)
+		{
+			const uint32_t k = end ? ncand - 1 - h : h;
+			if (end && k == h) break;                       // the middle one once
+			if (k == 0) continue;                           // nothing before the first
+			stage_row(qf, a.vec + (size_t) (~(uint32_t) pop[k]) * a.stride, a.stride, a.qpad_floats, lane);
+			float qnorm = 0.f;
+			if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
+			for (uint32_t b = 0; b < k; b += 64)
+			{
+				const uint32_t nb = k - b < 64 ? k - b : 64;
+				auto by_pos = [pop, b](uint32_t r) { return ~(uint32_t) pop[b + r]; };
+				score_rows_fit<FUNC, INS_KB, INS_RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_pos, nb, tmpd, lane);
+				wave_sync();
+				const float d = finish_dist<FUNC>(tmpd[lane], tmpd[OUT2 + lane], qnorm);
+				if ((uint32_t) lane < nb) D[(size_t) k * side + b + lane] = d;
+				wave_sync();
+			}
+		}
+}
+
+// The chain of getNeighborsByHeuristic (hnswalg.cpp:130-150) over the finished triangle; one wavefront.  Leaves the chosen
+// candidates in keyA as ord(dist) << 32 | idx and returns how many.
+__device__ __forceinline__ uint32_t chain_select(const uint64_t *pop, uint32_t ncand, uint32_t NN, const float *D, uint32_t side,
+												 uint32_t *selpos, uint64_t *keyA, int lane)
+{
+	uint32_t nsel = 0;
+	for (uint32_t k = 0; k < ncand && nsel < NN; k++)               // :130-132
+	{
+		const uint64_t key = pop[k];
+		const float dist_to_query = unord_f32((uint32_t) (key >> 32));
+		bool closer = false;
+		for (uint32_t b = 0; b < nsel; b += 64)                      // :137-148
+		{
+			const uint32_t i = b + lane;
+			if (i < nsel) closer |= D[(size_t) k * side + selpos[i]] < dist_to_query;
+		}
+		if (__ballot(closer) == 0)                                   // :149
+		{
+			if (lane == 0)
+			{
+				selpos[nsel] = k;
+				keyA[nsel] = (key & 0xFFFFFFFF00000000ull) | (uint32_t) ~(uint32_t) key;
+			}
+			nsel++;
+			wave_sync();
+		}
+	}
+	return nsel;
+}
+
+// Block counter: true in every thread of the block that arrives last.  Everything the block wrote is released first (at
+// `system` scope when the data is for the host), and the last block acquires what the others wrote.
+template <bool SYSTEM>
+__device__ __forceinline__ bool last_block(uint32_t *ctr, uint32_t *sh_word)
+{
+	if (SYSTEM) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+	else        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+	__syncthreads();
+	if (threadIdx.x == 0) *sh_word = atomicAdd(ctr, 1u) == gridDim.x - 1 ? 1u : 0u;
+	__syncthreads();
+	const bool last = *sh_word != 0;
+	if (last)
+	{
+		if (SYSTEM) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "");
+		else        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+	}
+	return last;
+}
+
+// Step 1.
+template <int FUNC>
+__global__ __launch_bounds__(512) void insert_select_kernel(const InsertArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = threadIdx.x & 63;
+	const uint32_t wib = threadIdx.x >> 6;
+	const InsertLds L = insert_carve(a, smem, wib);
+	const uint32_t p = a.b.first;
+
+	if (a.src_row && blockIdx.x == 0)                              // the append: padded row and label (links: below, by the last block)
+	{
+		for (uint32_t c = threadIdx.x; c < a.b.stride; c += blockDim.x)
+			const_cast<float *>(a.b.vec)[(size_t) p * a.b.stride + c] = (c < a.b.dim) ? a.src_row[c] : 0.f;
+		if (threadIdx.x == 0) a.labels[p] = a.src_label ? *a.src_label : (uint64_t) p;
+	}
+
+	const uint32_t ncand = a.bind ? a.b.cand_cnt[0] : 0;
+	const bool chain = ncand >= a.b.M;                              // hnswalg.cpp:119-120: fewer than M candidates are all kept
+	if (wib == 0)                                                   // candidates into pop order of the (-dist, idx) heap (:125-128)
+	{
+		for (uint32_t i = lane; i < ncand; i += 64)
+			L.keyA[i] = ((uint64_t) ord_f32(a.b.cand_dist[i]) << 32) | (uint32_t) ~a.b.cand_idx[i];
+		wave_sync();
+		rank_sort(L.keyA, L.pop, ncand, false, lane);
+	}
+	__syncthreads();
+	if (chain)
+		pair_triangle<FUNC>(a.b, L.pop, ncand, a.dmat, a.side, L.qf, L.tmpd, blockIdx.x * a.nw + wib, gridDim.x * a.nw, lane);
+	if (!last_block<false>(a.done1, L.sh)) return;
+
+	if (chain)                                                      // the triangle into LDS: the chain reads it ~ncand * nsel times
+	{
+		for (uint32_t i = threadIdx.x; i < ncand * a.side; i += blockDim.x)
+			if (i % a.side < i / a.side) L.D[i] = a.dmat[i];
+	}
+	__syncthreads();
+	if (wib == 0)
+	{
+		uint32_t nsel;
+		if (chain)
+			nsel = chain_select(L.pop, ncand, a.b.M, L.D, a.side, L.selpos, L.keyA, lane);
+		else
+		{
+			for (uint32_t i = lane; i < ncand; i += 64)
+				L.keyA[i] = (L.pop[i] & 0xFFFFFFFF00000000ull) | (uint32_t) ~(uint32_t) L.pop[i];
+			nsel = ncand;
+			wave_sync();
+		}
+		// own link list = chosen, farthest first ((dist, idx) max-heap pops, hnswalg.cpp:164-181); one target per link (:183)
+		rank_sort(L.keyA, L.keyB, nsel, true, lane);
+		uint32_t *mine = a.b.links + (size_t) p * a.b.lstride;
+		for (uint32_t j = lane; j < a.b.lstride; j += 64)
+			mine[j] = (j < nsel) ? (uint32_t) L.keyB[j] : LINK_NONE;
+		for (uint32_t j = lane; j < nsel; j += 64) a.targets[j] = (uint32_t) L.keyB[j];
+		if (lane == 0)
+		{
+			*a.ntargets = nsel;
+			atomicExch(a.done1, 0u);                                // ready for the next insert
+		}
+	}
+}
+
+// Step 2: block s = target s (blocks past the number of targets only count themselves done).
+template <int FUNC>
+__global__ __launch_bounds__(512) void insert_reverse_kernel(const InsertArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	const int lane = threadIdx.x & 63;
+	const uint32_t wib = threadIdx.x >> 6;
+	const InsertLds L = insert_carve(a, smem, wib);
+	const float4 *q4 = reinterpret_cast<const float4 *>(L.qf);
+	const uint32_t p = a.b.first, s = blockIdx.x;
+	const uint32_t nt = *a.ntargets;
+
+	if (s == 0)                                                     // the new element's own list, as step 1 left it in the mirror
+		for (uint32_t j = threadIdx.x; j < a.b.lstride; j += blockDim.x)
+			a.lists_out[j] = a.b.links[(size_t) p * a.b.lstride + j];
+	if (s < nt)
+	{
+		const uint32_t t = a.targets[s];
+		uint32_t *list = a.b.links + (size_t) t * a.b.lstride;
+		if (wib == 0)
+		{
+			// load + compact the current list (an imported image may have holes)
+			uint32_t cnt = 0;
+			for (uint32_t j0 = 0; j0 < a.b.lstride; j0 += 64)
+			{
+				const uint32_t j = j0 + lane;
+				const uint32_t v = (j < a.b.lstride) ? list[j] : LINK_NONE;
+				const uint64_t m = __ballot(v != LINK_NONE);
+				if (v != LINK_NONE) L.cur[1 + cnt + lane_rank(m)] = v;
+				cnt += (uint32_t) __builtin_popcountll(m);
+			}
+			wave_sync();
+			if (cnt < a.b.maxM)                                      // hnswalg.cpp:194-196
+			{
+				if (lane == 0) { L.cur[1 + cnt] = p; L.sh[1] = cnt + 1; L.sh[2] = 0; }
+			}
+			else                                                    // :197-220: re-select maxM of {new, old links} around t
+			{
+				if (lane == 0) { L.cur[0] = p; L.sh[1] = cnt; L.sh[2] = 1; }
+				stage_row(L.qf, a.b.vec + (size_t) t * a.b.stride, a.b.stride, a.b.qpad_floats, lane);
+				float qnorm = 0.f;
+				if (FUNC == F_COSINE) qnorm = query_norm(q4, a.b.nchunks, a.b.kiters, lane);
+				for (uint32_t b = 0; b <= cnt; b += 64)
+				{
+					const uint32_t nb = cnt + 1 - b < 64 ? cnt + 1 - b : 64;
+					const uint32_t *cc = L.cur;
+					auto by_id = [cc, b](uint32_t r) { return cc[b + r]; };
+					score_rows_fit<FUNC, INS_KB, INS_RPG>(a.b.vec, a.b.stride, q4, a.b.nchunks, a.b.kiters, by_id, nb, L.tmpd, lane);
+					wave_sync();
+					const float dl = finish_dist<FUNC>(L.tmpd[lane], L.tmpd[OUT2 + lane], qnorm);
+					if ((uint32_t) lane < nb) L.keyA[b + lane] = ((uint64_t) ord_f32(dl) << 32) | (uint32_t) ~L.cur[b + lane];
+					wave_sync();
+				}
+				rank_sort(L.keyA, L.pop, cnt + 1, false, lane);      // pop order of (-dist, idx)
+			}
+		}
+		__syncthreads();
+		uint32_t cnt = L.sh[1];
+		if (L.sh[2])                                                // block-uniform
+		{
+			pair_triangle<FUNC>(a.b, L.pop, cnt + 1, L.D, a.side, L.qf, L.tmpd, wib, a.nw, lane);
+			__syncthreads();
+			if (wib == 0)
+			{
+				const uint32_t nsel = chain_select(L.pop, cnt + 1, a.b.maxM, L.D, a.side, L.selpos, L.keyA, lane);
+				rank_sort(L.keyA, L.keyB, nsel, true, lane);         // :214-219: farthest first
+				for (uint32_t j = lane; j < nsel; j += 64) L.cur[1 + j] = (uint32_t) L.keyB[j];
+				cnt = nsel;
+				wave_sync();
+			}
+		}
+		if (wib == 0)
+			for (uint32_t j = lane; j < a.b.lstride; j += 64)
+			{
+				const uint32_t v = (j < cnt) ? L.cur[1 + j] : LINK_NONE;
+				list[j] = v;
+				a.lists_out[(size_t) (1 + s) * a.b.lstride + j] = v;
+			}
+	}
+	if (last_block<true>(a.done2, L.sh) && threadIdx.x == 0)
+	{
+		atomicExch(a.done2, 0u);
+		__hip_atomic_store(a.flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+	}
+}
+
+}  // namespace pgemb

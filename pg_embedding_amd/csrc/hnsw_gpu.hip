@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -19,6 +20,7 @@
 #include "device_search.h"
 #include "device_search_wide.h"
 #include "device_build.h"
+#include "device_insert.h"
 #include "device_bf_mfma.h"
 #include "device_roof.h"
 
@@ -233,6 +235,8 @@ struct hnsw_gpu_index
 	bool trace_active = false; size_t trace_ef = 0, trace_cap = 0, trace_seen = 0; int trace_base = 0;
 	// builder scratch (hnsw_gpu_index_link)
 	void *bld = nullptr; size_t bld_batch = 0; size_t bld_tmp_bytes = 0;
+	// single-insert scratch (device_insert.h): candidates of the insert's own walk | targets | pair matrix
+	void *ins = nullptr; size_t ins_bytes = 0;
 	// exhaustive MFMA scorer: |row|^2 cache + scratch
 	float *xnorm = nullptr; size_t xnorm_n = 0, xnorm_cap = 0;
 	void *bf = nullptr; size_t bf_bytes = 0;
@@ -312,6 +316,7 @@ extern "C" void hnsw_gpu_index_destroy(hnsw_gpu_index *ix)
 	if (ix->scratch) (void) hipFree(ix->scratch);
 	if (ix->pin) (void) hipHostFree(ix->pin);
 	if (ix->bld) (void) hipFree(ix->bld);
+	if (ix->ins) (void) hipFree(ix->ins);
 	if (ix->xnorm) (void) hipFree(ix->xnorm);
 	if (ix->bf) (void) hipFree(ix->bf);
 	if (ix->bf_e0) (void) hipEventDestroy(ix->bf_e0);
@@ -2106,6 +2111,80 @@ extern "C" int hnsw_gpu_index_get_link_lists(hnsw_gpu_index *ix, idx_t idx, idx_
 	return HNSW_GPU_OK;
 }
 
+// Gathered link rows (row 0 = the element, row 1 + s = the element in its link slot s) -> the compacted [count | links] lists of
+// the element and of each neighbour, in the order of the compacted list.
+static void compact_lists(const uint32_t *lists, size_t maxM, size_t ls, idx_t *mine, idx_t *others)
+{
+	auto compact = [&](const uint32_t *row, idx_t *out)
+	{
+		uint32_t cnt = 0;
+		for (size_t j = 0; j < maxM; j++)
+			if (row[j] != LINK_NONE) out[1 + cnt++] = row[j];
+		out[0] = cnt;
+		for (size_t j = cnt; j < maxM; j++) out[1 + j] = 0;
+	};
+	compact(lists, mine);
+	size_t k = 0;
+	for (size_t s2 = 0; s2 < maxM && k < mine[0]; s2++)
+		if (lists[s2] != LINK_NONE) { compact(lists + (1 + s2) * ls, others + k * (maxM + 1)); k++; }
+}
+
+typedef void (*insert_kernel_t)(const InsertArgs);
+
+static std::atomic<uint64_t> g_inserts_two_launch{0}, g_inserts_general{0};
+extern "C" void hnsw_gpu_insert_path_counts(uint64_t out[2])
+{
+	if (!out) return;
+	out[0] = g_inserts_two_launch.load();
+	out[1] = g_inserts_general.load();
+}
+
+static bool insert_fused_wanted()
+{
+	const char *e = getenv("HNSW_GPU_INSERT_FUSED");         // 0: the four-launch path of round 3's first half (A/B runs, tests of both)
+	return !(e && e[0] == '0');
+}
+
+// The two-launch insert's shape for this mirror: *lds = 0 when its block-shared arrays (the pair matrix above all: side^2
+// floats, side = max(efConstruction, maxM + 1)) do not fit a CU's LDS even with one wavefront per block — the caller then
+// takes the general builder path.  Device scratch (ix->ins): candidates of the insert's own walk | targets | pair matrix.
+static int plan_insert(hnsw_gpu_index *ix, InsertArgs *a, size_t *lds)
+{
+	*lds = 0;
+	memset(a, 0, sizeof(*a));
+	const size_t efc = ix->meta.efConstruction, M = ix->meta.M, maxM = ix->meta.maxM;
+	if (efc == 0 || M == 0 || M > maxM) return fail(HNSW_GPU_ERR_ARG, "bad efConstruction/M");
+	BuildArgs &b = a->b;
+	b.vec = ix->vec; b.links = ix->links;
+	b.dim = (uint32_t) ix->meta.dim; b.stride = ix->stride; b.nchunks = ix->stride / 4; b.kiters = (b.nchunks + 15) / 16;
+	b.qpad_floats = (uint32_t) round_up(b.kiters, INS_KB) * 64;
+	b.maxM = (uint32_t) maxM; b.M = (uint32_t) M; b.lstride = ix->lstride; b.efc = (uint32_t) efc;
+	const size_t side = round_up(std::max(efc, maxM + 1), 4);
+	const size_t cap = round_up(std::max<size_t>(side, 64), 8);
+	const size_t shared = cap * (8 * 3 + 4) + round_up(maxM + 2, 4) * 4 + 16 + side * side * 4;
+	const size_t per_wave = ((size_t) b.qpad_floats + 128) * 4;
+	size_t nw = 8;
+	while (nw > 1 && shared + nw * per_wave > LDS_PER_CU - 1024) nw >>= 1;
+	if (shared + nw * per_wave > LDS_PER_CU - 1024) return HNSW_GPU_OK;
+	a->nw = (uint32_t) nw; a->side = (uint32_t) side; a->cap = (uint32_t) cap;
+	const size_t o_ci = 0, o_cd = o_ci + round_up(efc * 4, 256), o_cc = o_cd + round_up(efc * 4, 256);
+	const size_t o_tg = o_cc + 256, o_dm = o_tg + round_up(M * 4, 256), total = o_dm + side * side * 4;
+	if (ix->ins_bytes < total)
+	{
+		if (ix->ins) (void) hipFree(ix->ins);
+		ix->ins = nullptr; ix->ins_bytes = 0;
+		HIPCHK(hipMalloc(&ix->ins, total));
+		ix->ins_bytes = total;
+	}
+	char *S = (char *) ix->ins;
+	b.cand_idx = (const uint32_t *) (S + o_ci); b.cand_dist = (const float *) (S + o_cd); b.cand_cnt = (const uint32_t *) (S + o_cc);
+	a->targets = (uint32_t *) (S + o_tg); a->dmat = (float *) (S + o_dm);
+	a->labels = ix->labels;
+	a->ntargets = ix->misc + 5; a->done1 = ix->misc + 4; a->done2 = ix->misc + 3;
+	*lds = shared + nw * per_wave;
+	return HNSW_GPU_OK;
+}
+
 // hnsw_bind_point's device side in ONE host call (hnswalg.cpp:279-291, 225-232): element `idx` (= the mirror's current count)
 // is appended and linked exactly as the reference's serial insert links it, and the changed link lists — its own and one per
 // selected neighbour — come back compacted ([count | links], maxM + 1 words each) for the host's write-back.  Everything is
@@ -2143,9 +2222,63 @@ static int insert_impl(hnsw_gpu_index *ix, const coord_t *point, label_t label, 
 	memcpy(h + o_lab, &label, 8);
 	volatile uint32_t *flag = (volatile uint32_t *) (h + o_flag);
 	*flag = 0;
-	int rc = hnsw_gpu_index_append_dev(ix, (const coord_t *) h, (const label_t *) (h + o_lab), 1, nullptr);
-	if (rc) return rc;
 	uint32_t *lists = (uint32_t *) (h + o_lists);
+	int rc;
+	InsertArgs ia;
+	size_t ilds = 0;
+	if (insert_fused_wanted() && plan_insert(ix, &ia, &ilds) == HNSW_GPU_OK && ilds)
+	{
+		// two launches (device_insert.h): [append +] pair triangle + chain | one block per target + the flag
+		insert_kernel_t ksel, krev;
+		switch ((int) ix->meta.dist_func)
+		{
+			case F_L2:     ksel = insert_select_kernel<F_L2>;        krev = insert_reverse_kernel<F_L2>; break;
+			case F_COSINE: ksel = insert_select_kernel<F_COSINE>;    krev = insert_reverse_kernel<F_COSINE>; break;
+			default:       ksel = insert_select_kernel<F_MANHATTAN>; krev = insert_reverse_kernel<F_MANHATTAN>; break;
+		}
+		if (ilds > 48 * 1024)
+		{
+			HIPCHK(hipFuncSetAttribute((const void *) ksel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ilds));
+			HIPCHK(hipFuncSetAttribute((const void *) krev, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ilds));
+		}
+		ia.b.first = (uint32_t) idx; ia.b.count = 1;
+		ia.bind = idx > 0 ? 1u : 0u;
+		ia.lists_out = lists; ia.flag = (uint32_t *) (h + o_flag);
+		if (cand_idx || idx == 0)                            // the walk has been done (and validated) already: the kernel reads its result, the row and the label from pinned memory
+		{
+			if (cand_idx)
+			{
+				memcpy(h + o_ci, cand_idx, (size_t) ncand * 4);
+				memcpy(h + o_cd, cand_dist, (size_t) ncand * 4);
+			}
+			*(uint32_t *) (h + o_cc) = ncand;
+			ia.b.cand_idx = (const uint32_t *) (h + o_ci); ia.b.cand_dist = (const float *) (h + o_cd); ia.b.cand_cnt = (const uint32_t *) (h + o_cc);
+			ia.src_row = (const float *) h; ia.src_label = (const uint64_t *) (h + o_lab);
+			ix->n += 1;                                      // stored by step 1's block 0
+		}
+		else                                                 // searchBaseLayer(ef = efConstruction) of the insert itself (hnswalg.cpp:229): the row has to be stored first
+		{
+			rc = hnsw_gpu_index_append_dev(ix, (const coord_t *) h, (const label_t *) (h + o_lab), 1, nullptr);
+			if (rc) return rc;
+			rc = launch_search(ix, &ix->ws, ix->vec + (size_t) idx * ix->stride, ix->stride, 1, efc_, 1, nullptr, (uint32_t *) ia.b.cand_idx,
+							   (float *) ia.b.cand_dist, (uint32_t *) ia.b.cand_cnt, nullptr, nullptr);
+			if (rc) return rc;
+			ia.src_row = nullptr; ia.src_label = nullptr;
+		}
+		// (a wavefront takes candidates from both ends of the pop order: efConstruction / 2 wavefronts have work)
+		const uint32_t g1 = (uint32_t) std::max<size_t>(1, ((efc_ + 1) / 2 + ia.nw - 1) / ia.nw);
+		hipLaunchKernelGGL(ksel, dim3(g1), dim3(ia.nw * 64), ilds, 0, ia);
+		hipLaunchKernelGGL(krev, dim3((uint32_t) ix->meta.M), dim3(ia.nw * 64), ilds, 0, ia);
+		HIPCHK(hipGetLastError());
+		rc = poll_done_flag(flag, "an insert");
+		if (rc) return rc;
+		compact_lists(lists, maxM, ls, mine, others);
+		g_inserts_two_launch++;
+		return HNSW_GPU_OK;
+	}
+	g_inserts_general++;
+	rc = hnsw_gpu_index_append_dev(ix, (const coord_t *) h, (const label_t *) (h + o_lab), 1, nullptr);
+	if (rc) return rc;
 	if (idx > 0)                                             // element 0 is never bound (hnswalg.cpp:228)
 	{
 		if (cand_idx)                                        // the walk has been done (and validated) already: its result, from pinned memory
@@ -2165,18 +2298,7 @@ static int insert_impl(hnsw_gpu_index *ix, const coord_t *point, label_t label, 
 	HIPCHK(hipGetLastError());
 	rc = poll_done_flag(flag, "an insert");
 	if (rc) return rc;
-	auto compact = [&](const uint32_t *row, idx_t *out)
-	{
-		uint32_t cnt = 0;
-		for (size_t j = 0; j < maxM; j++)
-			if (row[j] != LINK_NONE) out[1 + cnt++] = row[j];
-		out[0] = cnt;
-		for (size_t j = cnt; j < maxM; j++) out[1 + j] = 0;
-	};
-	compact(lists, mine);
-	size_t k = 0;
-	for (size_t s2 = 0; s2 < maxM && k < mine[0]; s2++)
-		if (lists[s2] != LINK_NONE) { compact(lists + (1 + s2) * ls, others + k * (maxM + 1)); k++; }
+	compact_lists(lists, maxM, ls, mine, others);
 	return HNSW_GPU_OK;
 }
 

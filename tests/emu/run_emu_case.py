@@ -22,7 +22,7 @@ import util as U                                           # noqa: E402
 from pg_embedding_amd.datasets import gmm                  # noqa: E402
 
 KEYS = ("HNSW_GPU_TEAM", "HNSW_GPU_TEAM_WPB", "HNSW_GPU_MAX_BLOCKS", "HNSW_GPU_NARROW5", "HNSW_GPU_HASH_ENTRIES", "HNSW_GPU_BEAM",      # (HNSW_GPU_TEAM_SPEC: as the caller of this script set it)
-        "HNSW_GPU_BEAM16", "HNSW_GPU_FORCE_LDS_HEAPS", "SIMT_EMU_CUS", "SIMT_EMU_JITTER", "SIMT_EMU_JITTER_US", "SIMT_EMU_SEED")
+        "HNSW_GPU_BEAM16", "HNSW_GPU_FORCE_LDS_HEAPS", "SIMT_EMU_CUS", "SIMT_EMU_JITTER", "SIMT_EMU_JITTER_US", "SIMT_EMU_SEED", "HNSW_GPU_INSERT_FUSED")
 
 
 def setenv(env):
@@ -357,5 +357,63 @@ def others():
     return out
 
 
+def insert():
+    """the serial insert in one call (device_insert.h: pair triangle + chain, one block per target): hnsw_gpu_index_insert_one and
+    hnsw_gpu_index_insert_candidates row by row == the oracle's graph bytes, and the lists they return == the mirror's; the four-launch
+    builder path (HNSW_GPU_INSERT_FUSED=0) gives the same bytes"""
+    import ctypes as C
+    import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_build import live_image
+    out = {}
+    quick = os.environ.get("EMU_INSERT_QUICK") == "1"
+    shake = {k: os.environ[k] for k in ("SIMT_EMU_JITTER", "SIMT_EMU_JITTER_US", "SIMT_EMU_SEED") if k in os.environ}   # the caller's schedule shaking stays on
+    cases = ((pg.DIST_L2, 12, 4, 36, 150), (pg.DIST_COSINE, 9, 1, 5, 90), (pg.DIST_MANHATTAN, 20, 3, 40, 110))
+    for func, dim, m, efc, n in (cases[:1] if quick else cases):
+        X = gmm(n, dim, k=10, seed=dim + 1)
+        X[40:44] = X[20:24]                                  # equal distances: ties by element number
+        labels = np.arange(n, dtype=np.uint64) * 5 + 2
+        port = oracle.PortIndex(dim, m, efc, 64, func)
+        port.add(X, labels)
+        meta = pg.make_meta(dim, m, efc, 64, func)
+        maxM = int(meta.maxM)
+        want = live_image(port.raw(), meta, n)
+        for mode, fused in (("one", "1"), ("candidates", "1"), ("one", "0")):
+            if quick and mode == "one" and fused == "0":
+                continue
+            setenv(dict(shake, HNSW_GPU_INSERT_FUSED=fused))
+            ix = pg.GpuIndex.empty(meta, n)
+            mine = (C.c_uint32 * (maxM + 1))()
+            others = (C.c_uint32 * (maxM * (maxM + 1)))()
+            bad_lists = 0
+            for i in range(n):
+                p = np.ascontiguousarray(X[i])
+                if mode == "candidates" and i > 0:
+                    ci, cd, pops, nev = ix.search_trace(p, efc, base=True)
+                    ci32 = np.ascontiguousarray(ci.astype(np.uint32))
+                    cd32 = np.ascontiguousarray(cd, dtype=np.float32)
+                    rc = ix.L.hnsw_gpu_index_insert_candidates(ix._h, p.ctypes.data, int(labels[i]), i, ci32.ctypes.data, cd32.ctypes.data,
+                                                               len(ci32), mine, others)
+                else:
+                    rc = ix.L.hnsw_gpu_index_insert_one(ix._h, p.ctypes.data, int(labels[i]), i, mine, others)
+                if rc != 0:
+                    out[f"rc_{func}_{mode}_{fused}"] = [i, rc]
+                    break
+                if i in (1, n // 2, n - 1):
+                    got = ix.export_flat().reshape(i + 1, -1)[:, :(maxM + 1) * 4].copy().view(np.uint32)
+                    bad_lists += int(not (np.frombuffer(mine, np.uint32)[:1 + mine[0]] == got[i, :1 + mine[0]]).all())
+                    for j in range(mine[0]):
+                        o = np.frombuffer(others, np.uint32)[j * (maxM + 1):(j + 1) * (maxM + 1)]
+                        bad_lists += int(not (o[:1 + o[0]] == got[mine[1 + j], :1 + o[0]]).all())
+            got = ix.export_flat().reshape(n, -1)
+            out[f"insert_{func}_{mode}_fused{fused}"] = int((got != want).any(axis=1).sum()) + bad_lists
+            ix.close()
+    setenv({})
+    paths = (C.c_uint64 * 2)()
+    pg._lib.gpu_lib().hnsw_gpu_insert_path_counts(paths)
+    out["two_launch_inserts"], out["general_inserts"] = int(paths[0]), int(paths[1])
+    return out
+
+
 if __name__ == "__main__":
-    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced, "sharded": sharded, "moving_helpers": moving_helpers, "wide": wide, "reforder": reforder}[sys.argv[1]]()))
+    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced, "sharded": sharded, "moving_helpers": moving_helpers, "wide": wide, "reforder": reforder, "insert": insert}[sys.argv[1]]()))

@@ -14,6 +14,7 @@ import pg_embedding_amd as pg
 from pg_embedding_amd._lib import check
 from pg_embedding_amd.datasets import gmm
 
+sync = torch.cuda.synchronize if torch.cuda.is_available() else (lambda: None)      # (the emulated library needs none)
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 dim = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 m, efc, extra = 16, 64, 2000
@@ -22,7 +23,7 @@ meta = pg.make_meta(dim, m, efc, 64, pg.DIST_L2)
 ix = pg.GpuIndex.empty(meta, n + extra + 16)
 ix.append(X[:n])
 ix.link(0, n)
-torch.cuda.synchronize()
+sync()
 L, h = ix.L, ix._h
 maxM = int(meta.maxM)
 mine = (C.c_uint32 * (maxM + 1))()
@@ -33,17 +34,39 @@ def med(ts):
     return float(np.median(ts)) * 1e3
 
 
-# 1. the fused call
-ts = []
-for i in range(extra // 2):
-    p = np.ascontiguousarray(X[n + i])
-    t0 = time.perf_counter()
-    check(L.hnsw_gpu_index_insert_one(h, p.ctypes.data, n + i, n + i, mine, others), "insert_one")
-    ts.append(time.perf_counter() - t0)
-print(f"{n} x {dim} m={m} efc={efc}: hnsw_gpu_index_insert_one          median {med(ts):.3f} ms  (p10 {np.percentile(ts, 10) * 1e3:.3f}, p90 {np.percentile(ts, 90) * 1e3:.3f})", flush=True)
+# 1. the one-call inserts: two launches built for latency (device_insert.h) against the general builder path (HNSW_GPU_INSERT_FUSED=0),
+#    with the insert's own walk (insert_one) and with the walk's result handed over (insert_candidates: what the shim does)
+nxt = n
+for fused in ("1", "0"):
+    os.environ["HNSW_GPU_INSERT_FUSED"] = fused
+    what = "two launches (device_insert.h)" if fused == "1" else "general builder path        "
+    ts = []
+    for i in range(extra // 8):
+        p = np.ascontiguousarray(X[nxt])
+        t0 = time.perf_counter()
+        check(L.hnsw_gpu_index_insert_one(h, p.ctypes.data, nxt, nxt, mine, others), "insert_one")
+        ts.append(time.perf_counter() - t0)
+        nxt += 1
+    print(f"{n} x {dim} m={m} efc={efc}: hnsw_gpu_index_insert_one,        {what}: median {med(ts):.3f} ms  (p10 {np.percentile(ts, 10) * 1e3:.3f}, p90 {np.percentile(ts, 90) * 1e3:.3f})", flush=True)
+    ts, tw = [], []
+    for i in range(extra // 8):
+        p = np.ascontiguousarray(X[nxt])
+        t0 = time.perf_counter()
+        ci, cd, pops, nev = ix.search_trace(p, efc, base=True)
+        t1 = time.perf_counter()
+        ci32 = np.ascontiguousarray(ci.astype(np.uint32)); cd32 = np.ascontiguousarray(cd, dtype=np.float32)
+        t2 = time.perf_counter()
+        check(L.hnsw_gpu_index_insert_candidates(h, p.ctypes.data, nxt, nxt, ci32.ctypes.data, cd32.ctypes.data, len(ci32), mine, others), "insert_candidates")
+        ts.append(time.perf_counter() - t2); tw.append(t1 - t0)
+        nxt += 1
+    print(f"{n} x {dim} m={m} efc={efc}: hnsw_gpu_index_insert_candidates, {what}: median {med(ts):.3f} ms  (p10 {np.percentile(ts, 10) * 1e3:.3f}, p90 {np.percentile(ts, 90) * 1e3:.3f}) behind a traced walk of {med(tw):.3f} ms", flush=True)
+os.environ.pop("HNSW_GPU_INSERT_FUSED")
+paths = (C.c_uint64 * 2)()
+L.hnsw_gpu_insert_path_counts(paths)
+print(f"   inserts by path: two launches {paths[0]}, general {paths[1]}", flush=True)
 # 2. the round-2 sequence: append (blocking copies) + link + get_link_lists
 ts, ta, tl, tg = [], [], [], []
-base = n + extra // 2
+base = nxt
 for i in range(extra // 2):
     p = np.ascontiguousarray(X[base + i])
     lab = np.asarray([base + i], np.uint64)
@@ -51,7 +74,7 @@ for i in range(extra // 2):
     check(L.hnsw_gpu_index_append(h, p.ctypes.data, lab.ctypes.data, 1), "append")
     t1 = time.perf_counter()
     check(L.hnsw_gpu_index_link(h, base + i, 1, 1, 0, None), "link")
-    torch.cuda.synchronize()
+    sync()
     t2 = time.perf_counter()
     check(L.hnsw_gpu_index_get_link_lists(h, base + i, mine, others), "get_link_lists")
     t3 = time.perf_counter()

@@ -126,13 +126,23 @@ def test_mfma_exhaustive_scorer_equals_canonical_scan(func, n, dim, nq, k):
     ix.close()
 
 
-@pytest.mark.parametrize("func,dim,m,efc", [(pg.DIST_L2, 24, 6, 40), (pg.DIST_COSINE, 100, 16, 64)])
-def test_insert_one_and_insert_candidates_build_the_oracles_graph(func, dim, m, efc):
+def insert_paths():
+    import ctypes as C
+    paths = (C.c_uint64 * 2)()
+    pg._lib.gpu_lib().hnsw_gpu_insert_path_counts(paths)
+    return int(paths[0]), int(paths[1])
+
+
+@pytest.mark.parametrize("func,dim,m,efc,fused", [(pg.DIST_L2, 24, 6, 40, "1"), (pg.DIST_COSINE, 100, 16, 64, "1"), (pg.DIST_MANHATTAN, 33, 5, 24, "1"),
+                                                 (pg.DIST_L2, 24, 6, 40, "0"), (pg.DIST_L2, 16, 4, 230, "1")])
+def test_insert_one_and_insert_candidates_build_the_oracles_graph(func, dim, m, efc, fused, monkeypatch):
     """hnsw_gpu_index_insert_one (append + serial link + changed lists in one call) and hnsw_gpu_index_insert_candidates (the same
     with the candidate list taken from a traced walk instead of a second search): row by row they build the graph the oracle's
     serial inserts build, byte for byte, and the lists they return are the lists the mirror holds."""
     import ctypes as C
-    n = 700
+    monkeypatch.setenv("HNSW_GPU_INSERT_FUSED", fused)
+    before = insert_paths()
+    n = 700 if efc < 200 else 400
     X = gmm(n, dim, k=20, seed=5 + dim)
     labels = np.arange(n, dtype=np.uint64) * 3 + 1
     port = oracle.PortIndex(dim, m, efc, 64, func)
@@ -165,3 +175,8 @@ def test_insert_one_and_insert_candidates_build_the_oracles_graph(func, dim, m, 
         want = live_image(port.raw(), meta, n)
         assert (got == want).all(), f"use_candidates={use_candidates}: {(got != want).any(axis=1).sum()} elements differ"
         ix.close()
+    # which path ran: two launches built for latency (device_insert.h) unless switched off or the pair matrix of
+    # max(efConstruction, maxM + 1) = 230 candidates does not fit a CU's LDS — then the general builder, same bytes
+    after = insert_paths()
+    two, general = after[0] - before[0], after[1] - before[1]
+    assert (two, general) == ((2 * n, 0) if fused == "1" and efc < 200 else (0, 2 * n)), (two, general)

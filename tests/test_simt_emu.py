@@ -55,6 +55,17 @@ def test_the_other_kernels_behind_the_c_abi(emu_lib):
     assert r.returncode == 0 and " passed" in r.stdout, (r.stdout[-1500:], r.stderr[-500:])
 
 
+def test_the_two_launch_insert_builds_the_oracles_graph(emu_lib):
+    """device_insert.h (pair triangle by all wavefronts of several blocks, chain by the last block, one block per target): row by row
+    through hnsw_gpu_index_insert_one and hnsw_gpu_index_insert_candidates the graph bytes and the returned lists are the oracle's.
+    (All three functions, the general builder path beside it and a shaken schedule: tests/emu/run_emu_case.py insert with
+    SIMT_EMU_JITTER=1, minutes — run when device_insert.h changes.)"""
+    res = run_case("insert", emu_lib, env={"EMU_INSERT_QUICK": "1"})
+    two, general = res.pop("two_launch_inserts"), res.pop("general_inserts")
+    assert res and all(v == 0 for v in res.values()), res
+    assert two == 300 and general == 0, (two, general)
+
+
 def test_many_walks_without_the_helper_bit_clear_is_reported(capsys):
     """One wave, 32 neighbouring queries one after the other, seven helpers attached (the schedule of
     test_slice_helpers_and_hop_wide_append_are_exact_and_complete) is what the clear at the start of a walk (device_search.h) is for: without that one line a good part
