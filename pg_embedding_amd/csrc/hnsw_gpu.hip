@@ -2236,10 +2236,13 @@ static int insert_impl(hnsw_gpu_index *ix, const coord_t *point, label_t label, 
 			case F_COSINE: ksel = insert_select_kernel<F_COSINE>;    krev = insert_reverse_kernel<F_COSINE>; break;
 			default:       ksel = insert_select_kernel<F_MANHATTAN>; krev = insert_reverse_kernel<F_MANHATTAN>; break;
 		}
-		if (ilds > 48 * 1024)
+		static std::atomic<size_t> lds_allowed[3][8];          // per function and device: the attribute is set when a larger carve comes along, not per insert
+		std::atomic<size_t> &allowed = lds_allowed[std::min(std::max((int) ix->meta.dist_func, 0), 2)][ix->device & 7];
+		if (ilds > 48 * 1024 && (ilds > allowed.load() || ix->device > 7))
 		{
 			HIPCHK(hipFuncSetAttribute((const void *) ksel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ilds));
 			HIPCHK(hipFuncSetAttribute((const void *) krev, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ilds));
+			allowed.store(ilds);
 		}
 		ia.b.first = (uint32_t) idx; ia.b.count = 1;
 		ia.bind = idx > 0 ? 1u : 0u;
