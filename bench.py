@@ -500,6 +500,7 @@ def main():
     # ---- the other BASELINE configs and the stress datasets of SURVEY.md §8(d), same kernels, N=1 only (extras, not `value`)
     if rank == 0 and world == 1 and not args.no_side_configs:
         result["other_configs"] = side_configs(args, dev, local)
+        result["serial_insert"] = serial_insert(args, dev)
     if rank == 0:
         print(json.dumps(result))
     if use_dist:
@@ -660,6 +661,52 @@ def side_configs(args, dev, local):
                     "with nothing in between (frac_of_replay <= 1 by construction), hbm_lower_bound_GBps the reads no cache can hold "
                     "over the kernel's time; roofline.hbm_only is the cache-hostile table of the headline shape")
     return res
+
+
+def serial_insert(args, dev):
+    """The other side of the boundary (SURVEY.md §8 'next' row: hnsw_bind_point): one row at a time into a 20 000-row mirror of the
+    headline shape — hnsw_gpu_index_insert_one (append + the insert's own walk + link + the changed lists back, one call) and
+    hnsw_gpu_index_insert_candidates behind a traced walk (what the validated cache of the unmodified glue runs per insert).
+    Wall-clock medians of the calls on this host core; not part of `value`."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    import pg_embedding_amd as pg
+    from pg_embedding_amd._lib import check
+    from pg_embedding_amd.datasets import gmm_torch
+    n, extra = 20000, 400
+    X = gmm_torch(n + extra, args.dim, k=100, sigma=0.3, seed=7, stream=0, device=dev).cpu().numpy()
+    meta = pg.make_meta(args.dim, args.m, 64, 64, pg.DIST_L2)
+    ix = pg.GpuIndex.empty(meta, n + extra)
+    ix.append(X[:n])
+    ix.link(0, n)
+    torch.cuda.synchronize()
+    maxM = int(meta.maxM)
+    mine = (C.c_uint32 * (maxM + 1))()
+    others = (C.c_uint32 * (maxM * (maxM + 1)))()
+    t_one, t_cand, t_walk = [], [], []
+    for i in range(extra):
+        p = np.ascontiguousarray(X[n + i])
+        if i < extra // 2:
+            t0 = time.perf_counter()
+            check(ix.L.hnsw_gpu_index_insert_one(ix._h, p.ctypes.data, n + i, n + i, mine, others), "insert_one")
+            t_one.append(time.perf_counter() - t0)
+        else:
+            t0 = time.perf_counter()
+            ci, cd, pops, nev = ix.search_trace(p, 64, base=True)
+            t1 = time.perf_counter()
+            ci32 = np.ascontiguousarray(ci.astype(np.uint32)); cd32 = np.ascontiguousarray(cd, dtype=np.float32)
+            t2 = time.perf_counter()
+            check(ix.L.hnsw_gpu_index_insert_candidates(ix._h, p.ctypes.data, n + i, n + i, ci32.ctypes.data, cd32.ctypes.data, len(ci32), mine, others),
+                  "insert_candidates")
+            t_cand.append(time.perf_counter() - t2); t_walk.append(t1 - t0)
+    paths = (C.c_uint64 * 2)()
+    ix.L.hnsw_gpu_insert_path_counts(paths)
+    ix.close()
+    ms = lambda ts: float(np.median(ts)) * 1e3
+    return {"mirror": f"{n}x{args.dim} l2 m={args.m} efconstruction=64 (device build)", "rows_inserted": extra,
+            "insert_one_ms_median": ms(t_one), "insert_candidates_ms_median": ms(t_cand), "traced_walk_ef64_ms_median": ms(t_walk),
+            "two_launch_inserts": int(paths[0]), "general_path_inserts": int(paths[1])}
 
 
 def hostile(args, dev, local, func):
