@@ -124,6 +124,37 @@ class GpuIndex:
         155-223, 117-153).  max_batch=1 == the reference's serial inserts, bit for bit."""
         check(self.L.hnsw_gpu_index_link(self._h, first, count, max_batch, ratio, stream), "hnsw_gpu_index_link")
 
+    def reserve(self, capacity: int) -> None:
+        """Room for `capacity` elements (a reallocation and a copy of the mirror when it has to grow)."""
+        check(self.L.hnsw_gpu_index_reserve(self._h, int(capacity)), "hnsw_gpu_index_reserve")
+
+    def insert_one(self, point: np.ndarray, label: int, candidates=None):
+        """hnsw_bind_point's device side in one call (hnswalg.cpp:279-291, 225-232): the row becomes element `count` and is linked
+        exactly as the reference's serial insert links it.  candidates = (element numbers, distances) of a base-mode walk with
+        ef = efConstruction made for this point on this mirror (search_trace(..., base=True)): the insert then runs off that list
+        (hnsw_gpu_index_insert_candidates).  Returns (mine, others): the new element's links and, per link, that neighbour's links."""
+        p = np.ascontiguousarray(point, dtype=np.float32).reshape(self.meta.dim)
+        maxM = int(self.meta.maxM)
+        mine = np.zeros(maxM + 1, np.uint32)
+        others = np.zeros(maxM * (maxM + 1), np.uint32)
+        idx = self.count
+        if candidates is None:
+            check(self.L.hnsw_gpu_index_insert_one(self._h, p.ctypes.data, int(label), idx, mine.ctypes.data, others.ctypes.data),
+                  "hnsw_gpu_index_insert_one")
+        else:
+            ci = np.ascontiguousarray(candidates[0], dtype=np.uint32)
+            cd = np.ascontiguousarray(candidates[1], dtype=np.float32)
+            check(self.L.hnsw_gpu_index_insert_candidates(self._h, p.ctypes.data, int(label), idx, ci.ctypes.data, cd.ctypes.data, len(ci),
+                                                          mine.ctypes.data, others.ctypes.data), "hnsw_gpu_index_insert_candidates")
+        k = int(mine[0])
+        return mine[1:1 + k].copy(), [others[j * (maxM + 1) + 1:j * (maxM + 1) + 1 + int(others[j * (maxM + 1)])].copy() for j in range(k)]
+
+    def insert_path_counts(self):
+        """(inserts of this process through the two launches of csrc/device_insert.h, through the general builder path)"""
+        out = (C.c_uint64 * 2)()
+        self.L.hnsw_gpu_insert_path_counts(out)
+        return int(out[0]), int(out[1])
+
     def update_from_flat(self, elements: np.ndarray, first: int, count: int) -> None:
         """Replace / add elements [first, first+count) from host element images."""
         elements = np.ascontiguousarray(elements, dtype=np.uint8)
