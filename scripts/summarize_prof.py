@@ -33,7 +33,7 @@ def main():
     if ks:
         print("| kernel | calls | total ns | avg ns | % |")
         print("|---|---|---|---|---|")
-        for r in sorted(ks, key=lambda r: -float(r["TotalDurationNs"]))[:10]:
+        for r in sorted(ks, key=lambda r: -float(r["TotalDurationNs"]))[:16]:
             print(f"| {r['Name'][:72]} | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {float(r['Percentage']):.2f} |")
     kt = rows(d, "*kernel_trace.csv")
     if kt:

@@ -134,7 +134,9 @@ def insert_paths():
 
 
 @pytest.mark.parametrize("func,dim,m,efc,fused", [(pg.DIST_L2, 24, 6, 40, "1"), (pg.DIST_COSINE, 100, 16, 64, "1"), (pg.DIST_MANHATTAN, 33, 5, 24, "1"),
-                                                 (pg.DIST_L2, 24, 6, 40, "0"), (pg.DIST_L2, 16, 4, 230, "1")])
+                                                 (pg.DIST_L2, 24, 6, 40, "0"), (pg.DIST_L2, 16, 4, 230, "1"),
+                                                 # lists longer than a wavefront (maxM = 80), the largest pair matrix that fits (188), rows whose block needs > 48 KiB of LDS
+                                                 (pg.DIST_L2, 8, 40, 100, "1"), (pg.DIST_COSINE, 8, 4, 188, "1"), (pg.DIST_L2, 1536, 3, 12, "1")])
 def test_insert_one_and_insert_candidates_build_the_oracles_graph(func, dim, m, efc, fused, monkeypatch):
     """hnsw_gpu_index_insert_one (append + serial link + changed lists in one call) and hnsw_gpu_index_insert_candidates (the same
     with the candidate list taken from a traced walk instead of a second search): row by row they build the graph the oracle's
@@ -142,7 +144,7 @@ def test_insert_one_and_insert_candidates_build_the_oracles_graph(func, dim, m, 
     import ctypes as C
     monkeypatch.setenv("HNSW_GPU_INSERT_FUSED", fused)
     before = insert_paths()
-    n = 700 if efc < 200 else 400
+    n = 700 if efc < 100 and dim < 1000 else 400
     X = gmm(n, dim, k=20, seed=5 + dim)
     labels = np.arange(n, dtype=np.uint64) * 3 + 1
     port = oracle.PortIndex(dim, m, efc, 64, func)
