@@ -6,16 +6,20 @@
 // compared with the neighbours chosen before it (hnswalg.cpp:137-148), so one wavefront walking the candidates pays a row
 // fetch and up to M/4 scoring passes per candidate, 64 candidates in a row, and each of the <= M neighbours whose list is
 // full repeats that over maxM + 1 candidates.  But the only data-dependent part of the chain is WHICH earlier candidates
-// were chosen: every distance it can ask for is dist(candidate k, candidate j) with j < k in pop order.  So:
-//   step 1  insert_select_kernel   G blocks: every wavefront takes candidates k and scores ALL earlier candidates against
-//           them (the strict lower triangle of the pair matrix, ncand * (ncand - 1) / 2 distances, 16 rows per pass);
-//           the block that finishes last runs the chain out of LDS — one compare + ballot per candidate — and writes the
-//           new element's link list and the list of targets.  Block 0 also stores the row (the append).
-//   step 2  insert_reverse_kernel  one block per target (hnswalg.cpp:183-222): room in the list -> append; full -> the
-//           same triangle over {new, old links} around the target, chain by wave 0.  Each block writes its target's list
-//           into the mirror AND into the caller's pinned staging; the block that finishes last stores the completion flag.
-// The values are the ones device_build.h computes (same staged "query", same rows, per-row summation order independent of
-// the pass shape), so the graph stays byte-identical to the oracle's: tests/test_gpu_build.py, tests/emu (insert scenario).
+// were chosen: every comparison it can ask for is  dist(candidate k, candidate j) < dist(candidate k, query)  with j < k in
+// pop order — one BIT per pair.  So:
+//   step 1  insert_select_kernel   the strict lower triangle of that bit matrix is cut into units of (candidate k, 16 earlier
+//           candidates) and every wavefront of the grid takes one: stage row k, score 16 rows, one ballot, 16 bits stored.
+//           Two memory round trips, whatever efConstruction is.  The block that finishes last gathers the bits into LDS
+//           (candidates x candidates / 8 bytes) and runs the chain on them: "does row k's mask meet the chosen set" is one
+//           AND per 64 candidates, the next row's mask is already on its way while this one is tested.  It writes the new
+//           element's link list and the list of targets.  Block 0 also stores the row (the append).
+//   step 2  insert_reverse_kernel  one block per target (hnswalg.cpp:183-222): room in the list -> append; full -> the same
+//           units over {new, old links} around the target across the block's wavefronts, chain by wave 0.  Each block
+//           writes its target's list into the mirror AND into the caller's pinned staging; the block that finishes last
+//           stores the completion flag.
+// The distances are the ones device_build.h computes (same staged "query", same rows, per-row summation order independent
+// of the pass shape), so the graph stays byte-identical to the oracle's: tests/test_gpu_build.py, tests/emu (insert scenario).
 #pragma once
 #include "device_build.h"
 
@@ -29,26 +33,27 @@ struct InsertArgs
 	uint64_t *labels;
 	uint32_t *targets;            // step 1 -> step 2: the chosen neighbours in link order
 	uint32_t *ntargets;
-	float    *dmat;               // step 1: pair matrix in device memory, side x side
+	uint16_t *bits;               // step 1: the bit matrix in device memory, [side][side / 16] pieces of 16 bits
 	uint32_t *lists_out;          // [(maxM + 1)][lstride]: row 0 = the new element's list, row 1 + j = the list of link slot j
 	uint32_t *done1, *done2;      // block counters (zero between calls: the last block resets them)
 	uint32_t *flag;               // completion flag in pinned host memory
 	uint32_t nw;                  // wavefronts per block
-	uint32_t side;                // row length of the pair matrix
+	uint32_t side;                // candidates the bit matrix has room for (a multiple of 64)
 	uint32_t cap;                 // key array length
 	uint32_t bind;                // 0 = element 0: stored, never bound (hnswalg.cpp:228)
+	uint32_t ncand_p1;            // 1 + the number of candidates when the host knows it (no read over the bus for it), else 0
 };
 
-constexpr int INS_KB = 4, INS_RPG = 4;       // 16 rows per scoring pass, 4 chunk-steps per load batch
+constexpr int INS_KB = 4, INS_RPG = 4;       // one scoring pass = 16 rows = one unit, 4 chunk-steps per load batch
+constexpr uint32_t INS_MAX_SIDE = 512;      // the chain keeps the chosen set as one 64-bit word per lane-of-eight
 
 // Block-shared part of the LDS carve; the per-wave parts (query image, 2 x 64 sums) follow it.
 struct InsertLds
 {
 	uint64_t *pop, *keyA, *keyB;  // [cap] each: pop order | scratch | sorted output
-	uint32_t *selpos;             // [cap]: chosen candidates as positions in pop order
 	uint32_t *cur;                // [maxM + 2]: cur[0] = incoming, cur[1..] = the target's links
 	uint32_t *sh;                 // [4] block-shared words
-	float    *D;                  // [side * side]
+	uint64_t *m64;                // [side][side / 64]: bit j of row k = candidate j is closer to candidate k than the query is
 	float    *qf;                 // this wave's query image
 	float    *tmpd;               // this wave's 2 x 64 sums
 };
@@ -59,73 +64,96 @@ __device__ __forceinline__ InsertLds insert_carve(const InsertArgs &a, unsigned 
 	L.pop = reinterpret_cast<uint64_t *>(smem);
 	L.keyA = L.pop + a.cap;
 	L.keyB = L.keyA + a.cap;
-	L.selpos = reinterpret_cast<uint32_t *>(L.keyB + a.cap);
-	L.cur = L.selpos + a.cap;
+	L.m64 = L.keyB + a.cap;
+	L.cur = reinterpret_cast<uint32_t *>(L.m64 + (size_t) a.side * (a.side / 64));
 	L.sh = L.cur + ((a.b.maxM + 2 + 3) & ~3u);
-	L.D = reinterpret_cast<float *>(L.sh + 4);
-	float *waves = L.D + (size_t) a.side * a.side;
+	float *waves = reinterpret_cast<float *>(L.sh + 4);
 	L.qf = waves + (size_t) wib * (a.b.qpad_floats + 128);
 	L.tmpd = L.qf + a.b.qpad_floats;
 	return L;
 }
 
-// Strict lower triangle of the pair matrix: D[k * side + j] = dist(candidate k staged as the query, row of candidate j) for
-// j < k, candidates in pop order (pop[i] = ord(dist) << 32 | ~idx).  Candidate k costs ceil(k / 16) passes, so wavefront w
-// of W takes k = w, w + W, ... from BOTH ends (k and ncand - 1 - k) and every wavefront ends with about the same number.
-template <int FUNC>
-__device__ __forceinline__ void pair_triangle(const BuildArgs &a, const uint64_t *pop, uint32_t ncand, float *D, uint32_t side,
-											  float *qf, float *tmpd, uint32_t w, uint32_t W, int lane)
+// rank_sort of device_build.h across a block: wavefront w ranks keys w*64.., (w + W)*64.. .  Callers put a block barrier behind it.
+__device__ __forceinline__ void rank_sort_block(const uint64_t *in, uint64_t *out, uint32_t n, bool descending, uint32_t w, uint32_t W, int lane)
 {
-	const float4 *q4 = reinterpret_cast<const float4 *>(qf);
-	for (uint32_t h = w; 2 * h < ncand; h += W)
-		for (uint32_t end = 0; end < 2; end++)
+	for (uint32_t b = w * 64; b < n; b += W * 64)
+	{
+		const uint32_t i = b + lane;
+		if (i < n)
 		{
-			const uint32_t k = end ? ncand - 1 - h : h;
-			if (end && k == h) break;                       // the middle one once
-			if (k == 0) continue;                           // nothing before the first
-			stage_row(qf, a.vec + (size_t) (~(uint32_t) pop[k]) * a.stride, a.stride, a.qpad_floats, lane);
-			float qnorm = 0.f;
-			if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
-			for (uint32_t b = 0; b < k; b += 64)
-			{
-				const uint32_t nb = k - b < 64 ? k - b : 64;
-				auto by_pos = [pop, b](uint32_t r) { return ~(uint32_t) pop[b + r]; };
-				score_rows_fit<FUNC, INS_KB, INS_RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_pos, nb, tmpd, lane);
-				wave_sync();
-				const float d = finish_dist<FUNC>(tmpd[lane], tmpd[OUT2 + lane], qnorm);
-				if ((uint32_t) lane < nb) D[(size_t) k * side + b + lane] = d;
-				wave_sync();
-			}
+			const uint64_t k = in[i];
+			uint32_t r = 0;
+			for (uint32_t j = 0; j < n; j++) r += (descending ? in[j] > k : in[j] < k) ? 1u : 0u;
+			out[r] = k;
 		}
+	}
 }
 
-// The chain of getNeighborsByHeuristic (hnswalg.cpp:130-150) over the finished triangle; one wavefront.  Leaves the chosen
-// candidates in keyA as ord(dist) << 32 | idx and returns how many.
-__device__ __forceinline__ uint32_t chain_select(const uint64_t *pop, uint32_t ncand, uint32_t NN, const float *D, uint32_t side,
-												 uint32_t *selpos, uint64_t *keyA, int lane)
+// Unit u of the triangle -> (candidate k >= 1, group g of 16 earlier candidates, 16 * g < k).  Candidates 16i+1 .. 16i+16 have
+// i + 1 groups each, so band i holds 16 (i + 1) units and 8 i (i + 1) units lie before it.
+__device__ __forceinline__ void unit_of(uint32_t u, uint32_t &k, uint32_t &g)
+{
+	uint32_t i = 0;
+	while (8u * (i + 1u) * (i + 2u) <= u) i++;
+	const uint32_t r = u - 8u * i * (i + 1u);
+	k = 16u * i + 1u + r / (i + 1u);
+	g = r % (i + 1u);
+}
+__host__ __device__ __forceinline__ uint32_t units_for(uint32_t ncand)      // units that cover candidates 1 .. ncand - 1 (whole bands)
+{
+	const uint32_t bands = ncand > 1 ? (ncand - 1 + 15) / 16 : 0;
+	return 8u * bands * (bands + 1u);
+}
+
+// One unit: bits[k][g] = for the 16 candidates j = 16g .. 16g + 15 (j < k, pop order): dist(candidate k staged as the query,
+// row of candidate j) < dist(candidate k, the insert's query) — hnswalg.cpp:141-146 for every pair the chain can ask about.
+template <int FUNC, typename Bits>
+__device__ __forceinline__ void triangle_unit(const BuildArgs &a, const uint64_t *pop, uint32_t k, uint32_t g, Bits *bits, uint32_t pieces,
+											  float *qf, float *tmpd, int lane)
+{
+	const float4 *q4 = reinterpret_cast<const float4 *>(qf);
+	const uint64_t key = pop[k];
+	const float dist_to_query = unord_f32((uint32_t) (key >> 32));
+	stage_row(qf, a.vec + (size_t) (~(uint32_t) key) * a.stride, a.stride, a.qpad_floats, lane);
+	float qnorm = 0.f;
+	if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
+	const uint32_t b = 16u * g;
+	const uint32_t nb = k - b < 16u ? k - b : 16u;
+	auto by_pos = [pop, b](uint32_t r) { return ~(uint32_t) pop[b + r]; };
+	score_rows_fit<FUNC, INS_KB, INS_RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, by_pos, nb, tmpd, lane);
+	wave_sync();
+	const float d = finish_dist<FUNC>(tmpd[lane], tmpd[OUT2 + lane], qnorm);
+	const uint64_t m = __ballot((uint32_t) lane < nb && d < dist_to_query);
+	if (lane == 0) bits[(size_t) k * pieces + g] = (Bits) m;
+	wave_sync();
+}
+
+// The chain of getNeighborsByHeuristic (hnswalg.cpp:130-150) over the finished bit matrix; one wavefront.  Lane w < W keeps
+// word w of the chosen set; row k + 1's words are loaded before row k is decided (the loads do not depend on the decisions).
+// Leaves the chosen candidates in keyA as ord(dist) << 32 | idx and returns how many.
+__device__ __forceinline__ uint32_t chain_select(const uint64_t *pop, uint32_t ncand, uint32_t NN, const uint64_t *m64, uint32_t W,
+												 uint64_t *keyA, int lane)
 {
 	uint32_t nsel = 0;
+	uint64_t chosen = 0;
+	const bool mine = (uint32_t) lane < W;
+	uint64_t row = (mine && ncand) ? m64[lane] : 0ull;
 	for (uint32_t k = 0; k < ncand && nsel < NN; k++)               // :130-132
 	{
-		const uint64_t key = pop[k];
-		const float dist_to_query = unord_f32((uint32_t) (key >> 32));
-		bool closer = false;
-		for (uint32_t b = 0; b < nsel; b += 64)                      // :137-148
+		const uint64_t nxt = (mine && k + 1 < ncand) ? m64[(size_t) (k + 1) * W + lane] : 0ull;
+		if (__ballot((row & chosen) != 0ull) == 0)                   // :137-149: nobody chosen so far is closer to it than the query
 		{
-			const uint32_t i = b + lane;
-			if (i < nsel) closer |= D[(size_t) k * side + selpos[i]] < dist_to_query;
-		}
-		if (__ballot(closer) == 0)                                   // :149
-		{
+			if ((uint32_t) lane == (k >> 6)) chosen |= 1ull << (k & 63);
 			if (lane == 0)
 			{
-				selpos[nsel] = k;
+				const uint64_t key = pop[k];
 				keyA[nsel] = (key & 0xFFFFFFFF00000000ull) | (uint32_t) ~(uint32_t) key;
 			}
 			nsel++;
-			wave_sync();
 		}
+		row = nxt;
 	}
+	wave_sync();
 	return nsel;
 }
 
@@ -157,6 +185,7 @@ __global__ __launch_bounds__(512) void insert_select_kernel(const InsertArgs a)
 	const uint32_t wib = threadIdx.x >> 6;
 	const InsertLds L = insert_carve(a, smem, wib);
 	const uint32_t p = a.b.first;
+	const uint32_t W = a.side / 64, pieces = a.side / 16;
 
 	if (a.src_row && blockIdx.x == 0)                              // the append: padded row and label (links: below, by the last block)
 	{
@@ -165,31 +194,38 @@ __global__ __launch_bounds__(512) void insert_select_kernel(const InsertArgs a)
 		if (threadIdx.x == 0) a.labels[p] = a.src_label ? *a.src_label : (uint64_t) p;
 	}
 
-	const uint32_t ncand = a.bind ? a.b.cand_cnt[0] : 0;
+	const uint32_t ncand = !a.bind ? 0u : (a.ncand_p1 ? a.ncand_p1 - 1u : a.b.cand_cnt[0]);
 	const bool chain = ncand >= a.b.M;                              // hnswalg.cpp:119-120: fewer than M candidates are all kept
-	if (wib == 0)                                                   // candidates into pop order of the (-dist, idx) heap (:125-128)
-	{
-		for (uint32_t i = lane; i < ncand; i += 64)
-			L.keyA[i] = ((uint64_t) ord_f32(a.b.cand_dist[i]) << 32) | (uint32_t) ~a.b.cand_idx[i];
-		wave_sync();
-		rank_sort(L.keyA, L.pop, ncand, false, lane);
-	}
+	// candidates into pop order of the (-dist, idx) heap (:125-128) — every block for itself: it names the rows of its units
+	for (uint32_t i = threadIdx.x; i < ncand; i += blockDim.x)
+		L.keyA[i] = ((uint64_t) ord_f32(a.b.cand_dist[i]) << 32) | (uint32_t) ~a.b.cand_idx[i];
+	__syncthreads();
+	rank_sort_block(L.keyA, L.pop, ncand, false, wib, a.nw, lane);
 	__syncthreads();
 	if (chain)
-		pair_triangle<FUNC>(a.b, L.pop, ncand, a.dmat, a.side, L.qf, L.tmpd, blockIdx.x * a.nw + wib, gridDim.x * a.nw, lane);
+		for (uint32_t u = blockIdx.x * a.nw + wib; u < units_for(ncand); u += gridDim.x * a.nw)
+		{
+			uint32_t k, g;
+			unit_of(u, k, g);
+			if (k < ncand) triangle_unit<FUNC>(a.b, L.pop, k, g, a.bits, pieces, L.qf, L.tmpd, lane);
+		}
 	if (!last_block<false>(a.done1, L.sh)) return;
 
-	if (chain)                                                      // the triangle into LDS: the chain reads it ~ncand * nsel times
+	if (chain)                                                      // the bits into LDS, 16 at a time; what no unit wrote (j >= k) is zero
 	{
-		for (uint32_t i = threadIdx.x; i < ncand * a.side; i += blockDim.x)
-			if (i % a.side < i / a.side) L.D[i] = a.dmat[i];
+		uint16_t *m16 = reinterpret_cast<uint16_t *>(L.m64);
+		for (uint32_t i = threadIdx.x; i < ncand * pieces; i += blockDim.x)
+		{
+			const uint32_t k = i / pieces, g = i % pieces;
+			m16[i] = 16u * g < k ? a.bits[i] : (uint16_t) 0;
+		}
 	}
 	__syncthreads();
 	if (wib == 0)
 	{
 		uint32_t nsel;
 		if (chain)
-			nsel = chain_select(L.pop, ncand, a.b.M, L.D, a.side, L.selpos, L.keyA, lane);
+			nsel = chain_select(L.pop, ncand, a.b.M, L.m64, W, L.keyA, lane);
 		else
 		{
 			for (uint32_t i = lane; i < ncand; i += 64)
@@ -222,6 +258,7 @@ __global__ __launch_bounds__(512) void insert_reverse_kernel(const InsertArgs a)
 	const float4 *q4 = reinterpret_cast<const float4 *>(L.qf);
 	const uint32_t p = a.b.first, s = blockIdx.x;
 	const uint32_t nt = *a.ntargets;
+	const uint32_t W = a.side / 64, pieces = a.side / 16;
 
 	if (s == 0)                                                     // the new element's own list, as step 1 left it in the mirror
 		for (uint32_t j = threadIdx.x; j < a.b.lstride; j += blockDim.x)
@@ -264,18 +301,27 @@ __global__ __launch_bounds__(512) void insert_reverse_kernel(const InsertArgs a)
 					if ((uint32_t) lane < nb) L.keyA[b + lane] = ((uint64_t) ord_f32(dl) << 32) | (uint32_t) ~L.cur[b + lane];
 					wave_sync();
 				}
-				rank_sort(L.keyA, L.pop, cnt + 1, false, lane);      // pop order of (-dist, idx)
 			}
 		}
 		__syncthreads();
 		uint32_t cnt = L.sh[1];
 		if (L.sh[2])                                                // block-uniform
 		{
-			pair_triangle<FUNC>(a.b, L.pop, cnt + 1, L.D, a.side, L.qf, L.tmpd, wib, a.nw, lane);
+			const uint32_t ncand = cnt + 1;
+			rank_sort_block(L.keyA, L.pop, ncand, false, wib, a.nw, lane);      // pop order of (-dist, idx)
+			for (uint32_t i = threadIdx.x; i < ncand * W; i += blockDim.x) L.m64[i] = 0ull;
+			__syncthreads();
+			uint16_t *m16 = reinterpret_cast<uint16_t *>(L.m64);
+			for (uint32_t u = wib; u < units_for(ncand); u += a.nw)
+			{
+				uint32_t k, g;
+				unit_of(u, k, g);
+				if (k < ncand) triangle_unit<FUNC>(a.b, L.pop, k, g, m16, pieces, L.qf, L.tmpd, lane);
+			}
 			__syncthreads();
 			if (wib == 0)
 			{
-				const uint32_t nsel = chain_select(L.pop, cnt + 1, a.b.maxM, L.D, a.side, L.selpos, L.keyA, lane);
+				const uint32_t nsel = chain_select(L.pop, ncand, a.b.maxM, L.m64, W, L.keyA, lane);
 				rank_sort(L.keyA, L.keyB, nsel, true, lane);         // :214-219: farthest first
 				for (uint32_t j = lane; j < nsel; j += 64) L.cur[1 + j] = (uint32_t) L.keyB[j];
 				cnt = nsel;

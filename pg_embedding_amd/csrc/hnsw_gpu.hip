@@ -2145,9 +2145,9 @@ static bool insert_fused_wanted()
 	return !(e && e[0] == '0');
 }
 
-// The two-launch insert's shape for this mirror: *lds = 0 when its block-shared arrays (the pair matrix above all: side^2
-// floats, side = max(efConstruction, maxM + 1)) do not fit a CU's LDS even with one wavefront per block — the caller then
-// takes the general builder path.  Device scratch (ix->ins): candidates of the insert's own walk | targets | pair matrix.
+// The two-launch insert's shape for this mirror: *lds = 0 when max(efConstruction, maxM + 1) candidates are more than the chain
+// of device_insert.h keeps in one wavefront's registers (INS_MAX_SIDE) or a block does not fit a CU's LDS — the caller then takes
+// the general builder path.  Device scratch (ix->ins): candidates of the insert's own walk | targets | bit matrix.
 static int plan_insert(hnsw_gpu_index *ix, InsertArgs *a, size_t *lds)
 {
 	*lds = 0;
@@ -2159,16 +2159,17 @@ static int plan_insert(hnsw_gpu_index *ix, InsertArgs *a, size_t *lds)
 	b.dim = (uint32_t) ix->meta.dim; b.stride = ix->stride; b.nchunks = ix->stride / 4; b.kiters = (b.nchunks + 15) / 16;
 	b.qpad_floats = (uint32_t) round_up(b.kiters, INS_KB) * 64;
 	b.maxM = (uint32_t) maxM; b.M = (uint32_t) M; b.lstride = ix->lstride; b.efc = (uint32_t) efc;
-	const size_t side = round_up(std::max(efc, maxM + 1), 4);
-	const size_t cap = round_up(std::max<size_t>(side, 64), 8);
-	const size_t shared = cap * (8 * 3 + 4) + round_up(maxM + 2, 4) * 4 + 16 + side * side * 4;
+	const size_t side = round_up(std::max(efc, maxM + 1), 64);
+	if (side > INS_MAX_SIDE) return HNSW_GPU_OK;
+	const size_t cap = side;
+	const size_t shared = cap * 8 * 3 + side * (side / 64) * 8 + round_up(maxM + 2, 4) * 4 + 16;
 	const size_t per_wave = ((size_t) b.qpad_floats + 128) * 4;
 	size_t nw = 8;
 	while (nw > 1 && shared + nw * per_wave > LDS_PER_CU - 1024) nw >>= 1;
 	if (shared + nw * per_wave > LDS_PER_CU - 1024) return HNSW_GPU_OK;
 	a->nw = (uint32_t) nw; a->side = (uint32_t) side; a->cap = (uint32_t) cap;
 	const size_t o_ci = 0, o_cd = o_ci + round_up(efc * 4, 256), o_cc = o_cd + round_up(efc * 4, 256);
-	const size_t o_tg = o_cc + 256, o_dm = o_tg + round_up(M * 4, 256), total = o_dm + side * side * 4;
+	const size_t o_tg = o_cc + 256, o_bits = o_tg + round_up(M * 4, 256), total = o_bits + side * (side / 16) * 2;
 	if (ix->ins_bytes < total)
 	{
 		if (ix->ins) (void) hipFree(ix->ins);
@@ -2178,7 +2179,7 @@ static int plan_insert(hnsw_gpu_index *ix, InsertArgs *a, size_t *lds)
 	}
 	char *S = (char *) ix->ins;
 	b.cand_idx = (const uint32_t *) (S + o_ci); b.cand_dist = (const float *) (S + o_cd); b.cand_cnt = (const uint32_t *) (S + o_cc);
-	a->targets = (uint32_t *) (S + o_tg); a->dmat = (float *) (S + o_dm);
+	a->targets = (uint32_t *) (S + o_tg); a->bits = (uint16_t *) (S + o_bits);
 	a->labels = ix->labels;
 	a->ntargets = ix->misc + 5; a->done1 = ix->misc + 4; a->done2 = ix->misc + 3;
 	*lds = shared + nw * per_wave;
@@ -2255,6 +2256,7 @@ static int insert_impl(hnsw_gpu_index *ix, const coord_t *point, label_t label, 
 				memcpy(h + o_cd, cand_dist, (size_t) ncand * 4);
 			}
 			*(uint32_t *) (h + o_cc) = ncand;
+			ia.ncand_p1 = ncand + 1;                         // known here: the kernels do not fetch it over the bus
 			ia.b.cand_idx = (const uint32_t *) (h + o_ci); ia.b.cand_dist = (const float *) (h + o_cd); ia.b.cand_cnt = (const uint32_t *) (h + o_cc);
 			ia.src_row = (const float *) h; ia.src_label = (const uint64_t *) (h + o_lab);
 			ix->n += 1;                                      // stored by step 1's block 0
@@ -2268,8 +2270,8 @@ static int insert_impl(hnsw_gpu_index *ix, const coord_t *point, label_t label, 
 			if (rc) return rc;
 			ia.src_row = nullptr; ia.src_label = nullptr;
 		}
-		// (a wavefront takes candidates from both ends of the pop order: efConstruction / 2 wavefronts have work)
-		const uint32_t g1 = (uint32_t) std::max<size_t>(1, ((efc_ + 1) / 2 + ia.nw - 1) / ia.nw);
+		// (one wavefront per unit of the bit triangle: device_insert.h)
+		const uint32_t g1 = std::max<uint32_t>(1u, (units_for((uint32_t) efc_) + ia.nw - 1) / ia.nw);
 		hipLaunchKernelGGL(ksel, dim3(g1), dim3(ia.nw * 64), ilds, 0, ia);
 		hipLaunchKernelGGL(krev, dim3((uint32_t) ix->meta.M), dim3(ia.nw * 64), ilds, 0, ia);
 		HIPCHK(hipGetLastError());

@@ -134,9 +134,10 @@ def insert_paths():
 
 
 @pytest.mark.parametrize("func,dim,m,efc,fused", [(pg.DIST_L2, 24, 6, 40, "1"), (pg.DIST_COSINE, 100, 16, 64, "1"), (pg.DIST_MANHATTAN, 33, 5, 24, "1"),
-                                                 (pg.DIST_L2, 24, 6, 40, "0"), (pg.DIST_L2, 16, 4, 230, "1"),
-                                                 # lists longer than a wavefront (maxM = 80), the largest pair matrix that fits (188), rows whose block needs > 48 KiB of LDS
-                                                 (pg.DIST_L2, 8, 40, 100, "1"), (pg.DIST_COSINE, 8, 4, 188, "1"), (pg.DIST_L2, 1536, 3, 12, "1")])
+                                                 (pg.DIST_L2, 24, 6, 40, "0"), (pg.DIST_L2, 16, 4, 600, "1"),
+                                                 # lists longer than a wavefront (maxM = 80), bit matrices of 3 and 4 words per row, rows whose block needs > 48 KiB of LDS
+                                                 (pg.DIST_L2, 8, 40, 100, "1"), (pg.DIST_COSINE, 8, 4, 188, "1"), (pg.DIST_L2, 16, 4, 230, "1"),
+                                                 (pg.DIST_L2, 1536, 3, 12, "1")])
 def test_insert_one_and_insert_candidates_build_the_oracles_graph(func, dim, m, efc, fused, monkeypatch):
     """hnsw_gpu_index_insert_one (append + serial link + changed lists in one call) and hnsw_gpu_index_insert_candidates (the same
     with the candidate list taken from a traced walk instead of a second search): row by row they build the graph the oracle's
@@ -177,8 +178,8 @@ def test_insert_one_and_insert_candidates_build_the_oracles_graph(func, dim, m, 
         want = live_image(port.raw(), meta, n)
         assert (got == want).all(), f"use_candidates={use_candidates}: {(got != want).any(axis=1).sum()} elements differ"
         ix.close()
-    # which path ran: two launches built for latency (device_insert.h) unless switched off or the pair matrix of
-    # max(efConstruction, maxM + 1) = 230 candidates does not fit a CU's LDS — then the general builder, same bytes
+    # which path ran: two launches built for latency (device_insert.h) unless switched off or max(efConstruction, maxM + 1) = 600
+    # candidates are more than its chain keeps in one wavefront (512) — then the general builder, same bytes
     after = insert_paths()
     two, general = after[0] - before[0], after[1] - before[1]
-    assert (two, general) == ((2 * n, 0) if fused == "1" and efc < 200 else (0, 2 * n)), (two, general)
+    assert (two, general) == ((2 * n, 0) if fused == "1" and efc <= 512 else (0, 2 * n)), (two, general)
