@@ -218,6 +218,7 @@ inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, b
 	else if (ctrl == 0x142) s = row >= 1 ? (row - 1) * 16 + 15 : -1;
 	else if (ctrl == 0x143) s = row >= 2 ? 31 : -1;
 	else if (ctrl == 0x138) s = i - 1;
+	else if (ctrl == 0x130) s = i < 63 ? i + 1 : -1;
 	else die("DPP control not modelled");
 	if (s < 0 || !((w->gmask >> s) & 1)) return old;
 	return (int) (uint32_t) w->gather[s];
