@@ -2261,14 +2261,13 @@ static int insert_impl(hnsw_gpu_index *ix, const coord_t *point, label_t label, 
 			ia.src_row = (const float *) h; ia.src_label = (const uint64_t *) (h + o_lab);
 			ix->n += 1;                                      // stored by step 1's block 0
 		}
-		else                                                 // searchBaseLayer(ef = efConstruction) of the insert itself (hnswalg.cpp:229): the row has to be stored first
-		{
-			rc = hnsw_gpu_index_append_dev(ix, (const coord_t *) h, (const label_t *) (h + o_lab), 1, nullptr);
-			if (rc) return rc;
-			rc = launch_search(ix, &ix->ws, ix->vec + (size_t) idx * ix->stride, ix->stride, 1, efc_, 1, nullptr, (uint32_t *) ia.b.cand_idx,
+		else                                                 // searchBaseLayer(ef = efConstruction) of the insert itself (hnswalg.cpp:229), the point read as
+		{                                                    // the query straight from pinned memory over the idx elements stored so far; step 1 stores the row
+			rc = launch_search(ix, &ix->ws, (const float *) h, dim, 1, efc_, 1, nullptr, (uint32_t *) ia.b.cand_idx,
 							   (float *) ia.b.cand_dist, (uint32_t *) ia.b.cand_cnt, nullptr, nullptr);
 			if (rc) return rc;
-			ia.src_row = nullptr; ia.src_label = nullptr;
+			ia.src_row = (const float *) h; ia.src_label = (const uint64_t *) (h + o_lab);
+			ix->n += 1;
 		}
 		// (one wavefront per unit of the bit triangle: device_insert.h)
 		const uint32_t g1 = std::max<uint32_t>(1u, (units_for((uint32_t) efc_) + ia.nw - 1) / ia.nw);
