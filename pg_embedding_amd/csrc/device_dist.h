@@ -24,11 +24,11 @@
 namespace pgemb {
 
 enum : int { F_L2 = 0, F_COSINE = 1, F_MANHATTAN = 2 };   // embedding.h:22-26
-// Debug-only arithmetic (HNSW_GPU_REF_ORDER=1, score_rows_ref below): the summation order of oracle/_ref's OWN build of
+// Debug-only arithmetic (HNSW_GPU_REF_ORDER=1, score_rows_ref below; all three functions): the summation order of oracle/_ref's OWN build of
 // distfunc.c (gcc -Ofast, read off its disassembly), so that the device's id lists can be compared with the compiled
 // reference's query by query instead of through the canonical-order oracle.  Never the default: that order belongs to one
 // compiler's output.
-enum : int { F_L2_REF = 3, F_MANHATTAN_REF = 4 };
+enum : int { F_L2_REF = 3, F_MANHATTAN_REF = 4, F_COSINE_REF = 5 };
 
 // Compiler-level ordering point for cross-lane LDS hand-offs inside ONE wavefront
 // (LDS operations of a wave execute in order; this only stops the compiler from
@@ -117,7 +117,7 @@ __device__ __forceinline__ float finish_dist(float s0, float s1, float qnorm)
 {
 	if (FUNC == F_L2 || FUNC == F_L2_REF)
 		return __builtin_sqrtf(s0);
-	if (FUNC == F_COSINE)
+	if (FUNC == F_COSINE || FUNC == F_COSINE_REF)
 	{
 		const float prod = qnorm * s1;                                  // float product, distfunc.c:144
 		const double r = 1.0 - (double) s0 / __builtin_sqrt((double) prod);
@@ -162,12 +162,49 @@ constexpr uint32_t OUT2 = 64;      // offset of the second sum (cosine |x|^2) in
 //     d0 = x[16k + j] - y[16k + j], d1 = x[16k + 8 + j] - y[16k + 8 + j] (two multiplies, one add, one add: no FMA), then
 //     ((t0 + t1) + (t2 + t3)) + ((t6 + t7) + (t4 + t5)), sqrtf;
 //   manhattan_dist_impl (distfunc.c:147-155, auto-vectorised, dims % 4 == 0): four accumulators acc_j += |x[4k + j] - y[4k + j]|,
-//     then (a0 + a2) + (a1 + a3).
+//     then (a0 + a2) + (a1 + a3);
+//   cosine_dist_impl (distfunc.c:133-145, auto-vectorised, dims % 4 == 0): three sets of four accumulators, dot_j += x[4k + j] * y[4k + j]
+//     (mulps, addps: no FMA) and the two squared norms likewise, each reduced as (a0 + a2) + (a1 + a3); float product of the
+//     norms, double 1 - dot / sqrt(product) (finish_dist).
 // One lane per accumulator (8 / 4 lanes per row), strided scalar loads — it exists to be compared, not timed.
-template <int FUNC, typename RowId>
+__device__ __forceinline__ float query_norm_ref(const float *qf, uint32_t n, int lane)      // |q|^2 in cosine_dist_impl's order; every lane returns it
+{
+	const uint32_t j = lane & 3;
+	float acc = 0.f;
+	for (uint32_t k = 0; k + 4 <= n; k += 4) { const float m = qf[k + j] * qf[k + j]; acc = acc + m; }
+	acc = acc + dpp_move<0x4E>(acc);
+	acc = acc + dpp_move<0xB1>(acc);
+	return acc;
+}
+
+template <int FUNC, uint32_t O2, typename RowId>
 __device__ __forceinline__ void score_rows_ref(const float *__restrict__ vec, size_t stride, const float *qf, uint32_t n,
 											   RowId rowid, uint32_t nrows, float *out, int lane)
 {
+	if (FUNC == F_COSINE_REF)
+	{
+		const uint32_t j = lane & 3, g = lane >> 2;
+		for (uint32_t base = 0; base < nrows; base += 16)
+		{
+			const uint32_t r = base + g;
+			const bool v = r < nrows;
+			const float *row = vec + (size_t) rowid(v ? r : nrows - 1) * stride;
+			float dot = 0.f, nrm = 0.f;
+			for (uint32_t k = 0; k + 4 <= n; k += 4)
+			{
+				const float x = row[k + j];
+				const float m0 = qf[k + j] * x, m1 = x * x;
+				dot = dot + m0;
+				nrm = nrm + m1;
+			}
+			dot = dot + dpp_move<0x4E>(dot);      // a0+a2 | a1+a3
+			dot = dot + dpp_move<0xB1>(dot);      // (a0+a2)+(a1+a3)
+			nrm = nrm + dpp_move<0x4E>(nrm);
+			nrm = nrm + dpp_move<0xB1>(nrm);
+			if (j == 0 && v) { out[r] = dot; out[O2 + r] = nrm; }
+		}
+		return;
+	}
 	if (FUNC == F_L2_REF)
 	{
 		const uint32_t j = lane & 7, g = lane >> 3;
@@ -211,9 +248,9 @@ __device__ __forceinline__ void score_rows(const float *__restrict__ vec, size_t
 										   const float4 *q4, uint32_t nchunks, uint32_t kiters,
 										   RowId rowid, uint32_t nrows, float *out, int lane)
 {
-	if (FUNC == F_L2_REF || FUNC == F_MANHATTAN_REF)
+	if (FUNC == F_L2_REF || FUNC == F_MANHATTAN_REF || FUNC == F_COSINE_REF)
 	{
-		score_rows_ref<FUNC>(vec, stride, reinterpret_cast<const float *>(q4), nchunks * 4, rowid, nrows, out, lane);
+		score_rows_ref<FUNC, O2>(vec, stride, reinterpret_cast<const float *>(q4), nchunks * 4, rowid, nrows, out, lane);
 		return;
 	}
 	const uint32_t g = lane >> 4, sub = lane & 15;

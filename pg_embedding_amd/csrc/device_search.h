@@ -1626,6 +1626,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		wave_sync();
 		float qnorm = 0.f;
 		if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
+		if (FUNC == F_COSINE_REF) qnorm = query_norm_ref(qf, a.nchunks * 4, lane);
 
 		uint64_t uk[UREG];
 #pragma unroll

@@ -650,6 +650,7 @@ static search_kernel_t pick_search_kernel_f(int func, bool team)
 			case F_COSINE: return hnsw_search_kernel_beam<F_COSINE, SH, U, false>;
 			case F_L2_REF:        if (U == 4) return hnsw_search_kernel_beam<F_L2_REF, SH, 4, false>; return nullptr;          // (debug arithmetic:
 			case F_MANHATTAN_REF: if (U == 4) return hnsw_search_kernel_beam<F_MANHATTAN_REF, SH, 4, false>; return nullptr;   //  one set size only)
+			case F_COSINE_REF:    if (U == 4) return hnsw_search_kernel_beam<F_COSINE_REF, SH, 4, false>; return nullptr;
 			default:       return hnsw_search_kernel_beam<F_MANHATTAN, SH, U, false>;
 		}
 	}
@@ -775,7 +776,7 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	const bool beam16 = use_beam && ef > 256 && ef <= 512 && (b16 ? atoi(b16) > 0 : shape_index(a.kiters) >= 2);
 	const char *wmin = getenv("HNSW_GPU_WIDE_EF_MIN");
 	const size_t wide_min = wmin ? (size_t) atoll(wmin) : WIDE_EF_MIN;
-	// Debug arithmetic (device_dist.h, F_L2_REF / F_MANHATTAN_REF): the summation order of oracle/_ref's own build, for a query-by-query
+	// Debug arithmetic (device_dist.h, F_L2_REF / F_MANHATTAN_REF / F_COSINE_REF): the summation order of oracle/_ref's own build, for a query-by-query
 	// comparison of id lists with the compiled reference.  One kernel set only: beam form, 4 set registers, one wave per query.
 	int func_code = (int) ix->meta.dist_func;
 	bool reforder = false;
@@ -783,11 +784,11 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		if (atoi(ro) > 0)
 		{
 			const bool ok = ef <= 128 && ix->cap < 0x80000000ull &&
-							((func_code == F_L2 && ix->meta.dim % 16 == 0) || (func_code == F_MANHATTAN && ix->meta.dim % 4 == 0));
+							((func_code == F_L2 && ix->meta.dim % 16 == 0) || ((func_code == F_MANHATTAN || func_code == F_COSINE) && ix->meta.dim % 4 == 0));
 			if (!ok)
-				return fail(HNSW_GPU_ERR_ARG, "HNSW_GPU_REF_ORDER: only L2 with dims %% 16 == 0 or Manhattan with dims %% 4 == 0, ef <= 128");
+				return fail(HNSW_GPU_ERR_ARG, "HNSW_GPU_REF_ORDER: only L2 with dims %% 16 == 0 or cosine / Manhattan with dims %% 4 == 0, ef <= 128");
 			reforder = true;
-			func_code = func_code == F_L2 ? F_L2_REF : F_MANHATTAN_REF;
+			func_code = func_code == F_L2 ? F_L2_REF : (func_code == F_COSINE ? F_COSINE_REF : F_MANHATTAN_REF);
 		}
 	int rreg;
 	if (reforder) rreg = -4;

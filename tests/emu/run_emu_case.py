@@ -160,7 +160,7 @@ def reforder():
     if not oracle.have_ref():
         return {"skipped": "no oracle/_ref here"}
     out = []
-    for func, dim, n in ((pg.DIST_L2, 128, 2500), (pg.DIST_L2, 48, 1500), (pg.DIST_MANHATTAN, 36, 1500)):
+    for func, dim, n in ((pg.DIST_L2, 128, 2500), (pg.DIST_L2, 48, 1500), (pg.DIST_MANHATTAN, 36, 1500), (pg.DIST_COSINE, 44, 1500)):
         X = gmm(n, dim, k=20, seed=dim)
         Q = gmm(24, dim, k=20, seed=dim + 1)
         ref = oracle.RefIndex(dim, 8, 32, 64, func, capacity=n)
@@ -175,6 +175,14 @@ def reforder():
                     acc = acc + (d0 * d0 + d1 * d1)
                 r = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[6] + acc[7]) + (acc[4] + acc[5]))
                 return np.sqrt(np.float32(r))
+            if func == pg.DIST_COSINE:
+                dot, na, nb = np.zeros(4, np.float32), np.zeros(4, np.float32), np.zeros(4, np.float32)
+                for k in range(0, dim, 4):
+                    dot = dot + q[k:k + 4] * x[k:k + 4]
+                    na = na + q[k:k + 4] * q[k:k + 4]
+                    nb = nb + x[k:k + 4] * x[k:k + 4]
+                red = lambda a: (a[0] + a[2]) + (a[1] + a[3])
+                return np.float32(1.0 - np.float64(red(dot)) / np.sqrt(np.float64(np.float32(red(na) * red(nb)))))
             acc = np.zeros(4, np.float32)
             for k in range(0, dim, 4):
                 acc = acc + np.abs(q[k:k + 4] - x[k:k + 4])

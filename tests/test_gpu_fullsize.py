@@ -147,10 +147,8 @@ def test_device_equals_oracle_and_every_reference_mismatch_is_a_flipped_near_tie
 def test_reference_order_mode_equals_the_compiled_reference_for_every_query(cfg, monkeypatch):
     """At full size, DIRECTLY against the reference binary: with HNSW_GPU_REF_ORDER=1 (debug arithmetic in the summation order of
     oracle/_ref's own build of distfunc.c, csrc/device_dist.h score_rows_ref) the id list of EVERY query equals the compiled
-    reference's — no oracle in between, nothing to classify.  L2 configurations (M, C2); cosine has no such mode."""
+    reference's — no oracle in between, nothing to classify.  Every configuration (L2: M, C2; cosine: C3 ...)."""
     import torch
-    if cfg["func"] != pg.DIST_L2:
-        return                                             # (the cosine configurations: reference-order arithmetic exists for L2 and Manhattan only)
     ix, ef, dim, m, efc, func, nq = cfg["ix"], cfg["ef"], cfg["dim"], cfg["m"], cfg["efc"], cfg["func"], cfg["nq"]
     Q = cfg["Q"][:nq].contiguous()
     Qh = Q.cpu().numpy()
@@ -161,7 +159,7 @@ def test_reference_order_mode_equals_the_compiled_reference_for_every_query(cfg,
     monkeypatch.setenv("HNSW_GPU_REF_ORDER", "1")
     out = ix.search_torch(Q, ef)
     torch.cuda.synchronize()
-    assert "kernel_beam<3" in ix.last_search_kernel()
+    assert ("kernel_beam<3" if func == pg.DIST_L2 else "kernel_beam<5") in ix.last_search_kernel()
     lab = out["labels"].cpu().numpy().view(np.uint64)
     dst = out["dists"].cpu().numpy()
     X0 = cfg["X"][torch.from_numpy(lab[0].astype(np.int64)).cuda()].cpu().numpy()
