@@ -940,10 +940,10 @@ def cpu_baseline(args, ix, Q, gpu_labels, gpu_dists, func):
         gd = gpu_dists[:nt].cpu().numpy()
         unexplained = (~same) & (dk == 0)
         # ... and directly: the same launch in the debug arithmetic that reproduces the summation order of THIS oracle/_ref build
-        # (HNSW_GPU_REF_ORDER=1, csrc/device_dist.h score_rows_ref: L2 with dims % 16 == 0, Manhattan with dims % 4 == 0) must
+        # (HNSW_GPU_REF_ORDER=1, csrc/device_dist.h score_rows_ref: L2 with dims % 16 == 0, cosine / Manhattan with dims % 4 == 0) must
         # return the compiled reference's id list for EVERY query of the sample — no classification needed
         ordered = None
-        if (func == 0 and args.dim % 16 == 0) or (func == 2 and args.dim % 4 == 0):
+        if (func == 0 and args.dim % 16 == 0) or (func in (1, 2) and args.dim % 4 == 0):
             import torch
             os.environ["HNSW_GPU_REF_ORDER"] = "1"
             try:
