@@ -2273,6 +2273,11 @@ static int insert_impl(hnsw_gpu_index *ix, const coord_t *point, label_t label, 
 		// (one wavefront per unit of the bit triangle: device_insert.h)
 		const uint32_t g1 = std::max<uint32_t>(1u, (units_for((uint32_t) efc_) + ia.nw - 1) / ia.nw);
 		hipLaunchKernelGGL(ksel, dim3(g1), dim3(ia.nw * 64), ilds, 0, ia);
+		if (hipError_t le = hipGetLastError(); le != hipSuccess)
+		{
+			ix->n = idx;                                     // nothing was stored
+			return fail(HNSW_GPU_ERR_HIP, "insert step 1 did not launch: %s", hipGetErrorString(le));
+		}
 		hipLaunchKernelGGL(krev, dim3((uint32_t) ix->meta.M), dim3(ia.nw * 64), ilds, 0, ia);
 		HIPCHK(hipGetLastError());
 		rc = poll_done_flag(flag, "an insert");
