@@ -14,4 +14,4 @@ for tag in "$@"; do
   echo "## variant $tag: exp_cfg.py $ARGS" >> $OUT
   timeout 300 python $R/scripts/exp_cfg.py $ARGS >> $OUT 2>&1 || echo "variant $tag failed ($?)" >> $OUT
 done
-cat $OUT
+cat $OUT | tail -40
