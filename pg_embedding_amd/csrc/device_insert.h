@@ -37,7 +37,8 @@ struct InsertArgs
 	uint32_t *lists_out;          // [(maxM + 1)][lstride]: row 0 = the new element's list, row 1 + j = the list of link slot j
 	uint32_t *done1, *done2;      // block counters (zero between calls: the last block resets them)
 	uint32_t *flag;               // completion flag in pinned host memory
-	uint32_t nw;                  // wavefronts per block
+	uint32_t nw;                  // wavefronts per block, step 1
+	uint32_t nw2;                 // wavefronts per block, step 2 (one block per target: more wavefronts = fewer rounds of units)
 	uint32_t side;                // candidates the bit matrix has room for (a multiple of 64)
 	uint32_t cap;                 // key array length
 	uint32_t bind;                // 0 = element 0: stored, never bound (hnswalg.cpp:228)
@@ -248,8 +249,9 @@ __global__ __launch_bounds__(512) void insert_select_kernel(const InsertArgs a)
 }
 
 // Step 2: block s = target s (blocks past the number of targets only count themselves done).
+// (12 wavefronts: the scoring pass of 16 rows wants ~150-180 VGPRs, which a block of 16 wavefronts cannot have)
 template <int FUNC>
-__global__ __launch_bounds__(512) void insert_reverse_kernel(const InsertArgs a)
+__global__ __launch_bounds__(768) void insert_reverse_kernel(const InsertArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = threadIdx.x & 63;
@@ -279,28 +281,10 @@ __global__ __launch_bounds__(512) void insert_reverse_kernel(const InsertArgs a)
 				if (v != LINK_NONE) L.cur[1 + cnt + lane_rank(m)] = v;
 				cnt += (uint32_t) __builtin_popcountll(m);
 			}
-			wave_sync();
-			if (cnt < a.b.maxM)                                      // hnswalg.cpp:194-196
+			if (lane == 0)
 			{
-				if (lane == 0) { L.cur[1 + cnt] = p; L.sh[1] = cnt + 1; L.sh[2] = 0; }
-			}
-			else                                                    // :197-220: re-select maxM of {new, old links} around t
-			{
-				if (lane == 0) { L.cur[0] = p; L.sh[1] = cnt; L.sh[2] = 1; }
-				stage_row(L.qf, a.b.vec + (size_t) t * a.b.stride, a.b.stride, a.b.qpad_floats, lane);
-				float qnorm = 0.f;
-				if (FUNC == F_COSINE) qnorm = query_norm(q4, a.b.nchunks, a.b.kiters, lane);
-				for (uint32_t b = 0; b <= cnt; b += 64)
-				{
-					const uint32_t nb = cnt + 1 - b < 64 ? cnt + 1 - b : 64;
-					const uint32_t *cc = L.cur;
-					auto by_id = [cc, b](uint32_t r) { return cc[b + r]; };
-					score_rows_fit<FUNC, INS_KB, INS_RPG>(a.b.vec, a.b.stride, q4, a.b.nchunks, a.b.kiters, by_id, nb, L.tmpd, lane);
-					wave_sync();
-					const float dl = finish_dist<FUNC>(L.tmpd[lane], L.tmpd[OUT2 + lane], qnorm);
-					if ((uint32_t) lane < nb) L.keyA[b + lane] = ((uint64_t) ord_f32(dl) << 32) | (uint32_t) ~L.cur[b + lane];
-					wave_sync();
-				}
+				if (cnt < a.b.maxM) { L.cur[1 + cnt] = p; L.sh[1] = cnt + 1; L.sh[2] = 0; }      // hnswalg.cpp:194-196
+				else                { L.cur[0] = p;       L.sh[1] = cnt;     L.sh[2] = 1; }      // :197-220: re-select maxM of {new, old links} around t
 			}
 		}
 		__syncthreads();
@@ -308,11 +292,27 @@ __global__ __launch_bounds__(512) void insert_reverse_kernel(const InsertArgs a)
 		if (L.sh[2])                                                // block-uniform
 		{
 			const uint32_t ncand = cnt + 1;
-			rank_sort_block(L.keyA, L.pop, ncand, false, wib, a.nw, lane);      // pop order of (-dist, idx)
+			// distances of the candidates around t, 16 per wavefront (t staged by each wavefront that has a group)
+			for (uint32_t b = 16u * wib; b < ncand; b += 16u * a.nw2)
+			{
+				stage_row(L.qf, a.b.vec + (size_t) t * a.b.stride, a.b.stride, a.b.qpad_floats, lane);
+				float qnorm = 0.f;
+				if (FUNC == F_COSINE) qnorm = query_norm(q4, a.b.nchunks, a.b.kiters, lane);
+				const uint32_t nb = ncand - b < 16u ? ncand - b : 16u;
+				const uint32_t *cc = L.cur;
+				auto by_id = [cc, b](uint32_t r) { return cc[b + r]; };
+				score_rows_fit<FUNC, INS_KB, INS_RPG>(a.b.vec, a.b.stride, q4, a.b.nchunks, a.b.kiters, by_id, nb, L.tmpd, lane);
+				wave_sync();
+				const float dl = finish_dist<FUNC>(L.tmpd[lane], L.tmpd[OUT2 + lane], qnorm);
+				if ((uint32_t) lane < nb) L.keyA[b + lane] = ((uint64_t) ord_f32(dl) << 32) | (uint32_t) ~L.cur[b + lane];
+				wave_sync();
+			}
+			__syncthreads();
+			rank_sort_block(L.keyA, L.pop, ncand, false, wib, a.nw2, lane);     // pop order of (-dist, idx)
 			for (uint32_t i = threadIdx.x; i < ncand * W; i += blockDim.x) L.m64[i] = 0ull;
 			__syncthreads();
 			uint16_t *m16 = reinterpret_cast<uint16_t *>(L.m64);
-			for (uint32_t u = wib; u < units_for(ncand); u += a.nw)
+			for (uint32_t u = wib; u < units_for(ncand); u += a.nw2)
 			{
 				uint32_t k, g;
 				unit_of(u, k, g);

@@ -2168,7 +2168,10 @@ static int plan_insert(hnsw_gpu_index *ix, InsertArgs *a, size_t *lds)
 	size_t nw = 8;
 	while (nw > 1 && shared + nw * per_wave > LDS_PER_CU - 1024) nw >>= 1;
 	if (shared + nw * per_wave > LDS_PER_CU - 1024) return HNSW_GPU_OK;
-	a->nw = (uint32_t) nw; a->side = (uint32_t) side; a->cap = (uint32_t) cap;
+	size_t nw2 = 12;                                                                // step 2: up to 12 wavefronts around one target (device_insert.h)
+	while (nw2 > nw && shared + nw2 * per_wave > LDS_PER_CU - 1024) nw2 -= 4;
+	if (nw2 < nw) nw2 = nw;
+	a->nw = (uint32_t) nw; a->nw2 = (uint32_t) nw2; a->side = (uint32_t) side; a->cap = (uint32_t) cap;
 	const size_t o_ci = 0, o_cd = o_ci + round_up(efc * 4, 256), o_cc = o_cd + round_up(efc * 4, 256);
 	const size_t o_tg = o_cc + 256, o_bits = o_tg + round_up(M * 4, 256), total = o_bits + side * (side / 16) * 2;
 	if (ix->ins_bytes < total)
@@ -2183,7 +2186,7 @@ static int plan_insert(hnsw_gpu_index *ix, InsertArgs *a, size_t *lds)
 	a->targets = (uint32_t *) (S + o_tg); a->bits = (uint16_t *) (S + o_bits);
 	a->labels = ix->labels;
 	a->ntargets = ix->misc + 5; a->done1 = ix->misc + 4; a->done2 = ix->misc + 3;
-	*lds = shared + nw * per_wave;
+	*lds = shared + nw2 * per_wave;                                                 // (the larger of the two carves: one attribute for both kernels)
 	return HNSW_GPU_OK;
 }
 
@@ -2278,7 +2281,7 @@ static int insert_impl(hnsw_gpu_index *ix, const coord_t *point, label_t label, 
 			ix->n = idx;                                     // nothing was stored
 			return fail(HNSW_GPU_ERR_HIP, "insert step 1 did not launch: %s", hipGetErrorString(le));
 		}
-		hipLaunchKernelGGL(krev, dim3((uint32_t) ix->meta.M), dim3(ia.nw * 64), ilds, 0, ia);
+		hipLaunchKernelGGL(krev, dim3((uint32_t) ix->meta.M), dim3(ia.nw2 * 64), ilds, 0, ia);
 		HIPCHK(hipGetLastError());
 		rc = poll_done_flag(flag, "an insert");
 		if (rc) return rc;

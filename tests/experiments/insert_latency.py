@@ -1,6 +1,6 @@
 """Where a serial insert's time goes: hnsw_gpu_index_insert_one (append + serial link + gather, one polled wait)
 on an attached mirror, its pieces one by one, and a traced one-query walk with ef = efConstruction (what the validated cache of the
-unmodified glue runs in front of every insert).   python tests/experiments/insert_latency.py [rows=20000] [dims=128] [--timeout S]"""
+unmodified glue runs in front of every insert).   python tests/experiments/insert_latency.py [rows=20000] [dims=128] [serial] [--timeout S]"""
 import ctypes as C
 import os
 import sys
@@ -22,7 +22,10 @@ X = gmm(n + extra, dim, k=100, seed=5)
 meta = pg.make_meta(dim, m, efc, 64, pg.DIST_L2)
 ix = pg.GpuIndex.empty(meta, n + extra + 16)
 ix.append(X[:n])
-ix.link(0, n)
+serial_base = "serial" in sys.argv[3:]                     # the first n rows linked one by one (the reference's own graph: fuller lists) instead of in batches
+ix.link(0, n, max_batch=1) if serial_base else ix.link(0, n)
+if serial_base:
+    print(f"(base graph of {n} rows built by serial inserts)", flush=True)
 sync()
 L, h = ix.L, ix._h
 maxM = int(meta.maxM)
