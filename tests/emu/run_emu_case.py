@@ -376,7 +376,9 @@ def insert():
     out = {}
     quick = os.environ.get("EMU_INSERT_QUICK") == "1"
     shake = {k: os.environ[k] for k in ("SIMT_EMU_JITTER", "SIMT_EMU_JITTER_US", "SIMT_EMU_SEED") if k in os.environ}   # the caller's schedule shaking stays on
-    cases = ((pg.DIST_L2, 12, 4, 36, 150), (pg.DIST_COSINE, 9, 1, 5, 90), (pg.DIST_MANHATTAN, 20, 3, 40, 110))
+    cases = ((pg.DIST_L2, 12, 4, 36, 150), (pg.DIST_COSINE, 9, 1, 5, 90), (pg.DIST_MANHATTAN, 20, 3, 40, 110),
+             (pg.DIST_L2, 6, 40, 100, 130),            # lists longer than a wavefront (maxM = 80), two mask words per candidate
+             (pg.DIST_L2, 6, 4, 600, 100))             # more candidates than the chain keeps (512): the general builder path, same bytes
     for func, dim, m, efc, n in (cases[:1] if quick else cases):
         X = gmm(n, dim, k=10, seed=dim + 1)
         X[40:44] = X[20:24]                                  # equal distances: ties by element number
@@ -405,7 +407,7 @@ def insert():
                 else:
                     rc = ix.L.hnsw_gpu_index_insert_one(ix._h, p.ctypes.data, int(labels[i]), i, mine, others)
                 if rc != 0:
-                    out[f"rc_{func}_{mode}_{fused}"] = [i, rc]
+                    out[f"rc_f{func}_efc{efc}_{mode}_{fused}"] = [i, rc]
                     break
                 if i in (1, n // 2, n - 1):
                     got = ix.export_flat().reshape(i + 1, -1)[:, :(maxM + 1) * 4].copy().view(np.uint32)
@@ -414,7 +416,7 @@ def insert():
                         o = np.frombuffer(others, np.uint32)[j * (maxM + 1):(j + 1) * (maxM + 1)]
                         bad_lists += int(not (o[:1 + o[0]] == got[mine[1 + j], :1 + o[0]]).all())
             got = ix.export_flat().reshape(n, -1)
-            out[f"insert_{func}_{mode}_fused{fused}"] = int((got != want).any(axis=1).sum()) + bad_lists
+            out[f"insert_f{func}_d{dim}_m{m}_efc{efc}_{mode}_fused{fused}"] = int((got != want).any(axis=1).sum()) + bad_lists
             ix.close()
     setenv({})
     paths = (C.c_uint64 * 2)()
