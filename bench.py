@@ -36,7 +36,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 from pg_embedding_amd import watchdog                      # noqa: E402
-watchdog.arm(default_seconds=3000.0)                       # --timeout SECONDS: a hung launch ends the run with status 124, not never
+watchdog.arm(default_seconds=3000.0, env_sync=False)                    # --timeout SECONDS: a hung launch ends the run with status 124, not never
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 REL_TOL = 1e-5            # north-star tolerance (BASELINE.json)
@@ -894,6 +894,7 @@ def cpu_baseline(args, ix, Q, gpu_labels, gpu_dists, func):
     Checker/baseline only."""
     import numpy as np
     import oracle
+    import pg_embedding_amd as pg
 
     raw = ix.export_flat()
     kind = "reference" if oracle.have_ref() else "port"
@@ -945,7 +946,7 @@ def cpu_baseline(args, ix, Q, gpu_labels, gpu_dists, func):
         ordered = None
         if (func == 0 and args.dim % 16 == 0) or (func in (1, 2) and args.dim % 4 == 0):
             import torch
-            os.environ["HNSW_GPU_REF_ORDER"] = "1"
+            pg.config_set("HNSW_GPU_REF_ORDER", 1)          # (the library reads its environment once: a knob is changed by saying so)
             try:
                 if args.ef <= 128:
                     oo = ix.search_torch(Q[:nt].contiguous(), args.ef)
@@ -955,7 +956,7 @@ def cpu_baseline(args, ix, Q, gpu_labels, gpu_dists, func):
                     ordered = {"queries": nt, "queries_with_the_references_id_list": int(osame.sum()), "kernel": ix.last_search_kernel(),
                                "note": "debug arithmetic in the reference build's own summation order; never the timed path"}
             finally:
-                os.environ.pop("HNSW_GPU_REF_ORDER", None)
+                pg.config_set("HNSW_GPU_REF_ORDER", None)
         res["reference_order_mode"] = ordered
         res["parity_vs_reference"] = {
             "queries": nt,

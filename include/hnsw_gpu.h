@@ -190,25 +190,44 @@ int hnsw_gpu_search_traced_dev(hnsw_gpu_index *ix, const coord_t *d_queries, siz
                                idx_t *d_evals, size_t evals_cap, uint64_t *d_times, void *stream);
 int hnsw_gpu_replay_roof(hnsw_gpu_index *ix, const idx_t *d_evals, size_t evals_cap, const uint32_t *d_stats, size_t nq,
                          unsigned slots, int kb, int rpg, float *ms, double *bytes, uint64_t *word_sum);
+/* ... with every query's trace cut into `parts` (1..64) equal pieces that different waves gather: the roof of a launch of fewer
+ * queries than resident waves in which `parts` waves share the rows of one walk (parts = 1: the call above). */
+int hnsw_gpu_replay_roof_parts(hnsw_gpu_index *ix, const idx_t *d_evals, size_t evals_cap, const uint32_t *d_stats, size_t nq,
+                               unsigned slots, int kb, int rpg, unsigned parts, float *ms, double *bytes, uint64_t *word_sum);
 
 /* Health of the mirror's default search workspace (8 words).  out8[0] = 1 while an abort request is pending, [1] = slices a
  * team helper did not deliver in time and [2] = helper packages that stayed "claimed" past the bound (both were then
  * computed by the walking wave itself: results are unaffected, the counts say a protocol is slower than designed;
  * 0 in a healthy life), [3] = waves that left a launch because of an abort request, [4] = slices team helpers scored
- * for walking waves (says that mechanism is in use), [5..7] = 0 (totals since the mirror exists). */
+ * for walking waves (says that mechanism is in use), [5] = abort requests this workspace has received, [6..7] = 0 (totals since the mirror exists). */
 int hnsw_gpu_index_health(hnsw_gpu_index *ix, uint32_t *out8);
 
 /* Ask the search launches in flight to end: every wave looks at its workspace's abort word at the top of a query
- * and every 256 hops of a walk, and leaves.  No wait in the kernels is unbounded, so this is for the unknown: a
- * launch that never ends costs its caller's patience, not the device.  The outputs of an aborted launch are undefined
- * (counts / completion flags of unfinished queries are not written); the workspace is re-zeroed by the next launch.
- * Callable from ANY thread, also while another thread is blocked inside a search call on the same mirror.
- * hnsw_gpu_abort_all: every workspace of every mirror and context of this process; returns how many it reached.
- * HNSW_GPU_WATCHDOG_S=<seconds> in the environment makes the library do this by itself for a search launch that has
- * been running longer than that (a helper thread, off by default); the polled host-pointer calls do it after
- * HNSW_GPU_POLL_LIMIT_S (default 120). */
+ * and (all kernels but the lean narrow-row one, whose walks are a fraction of a millisecond) every 256 hops of a walk; from
+ * then on it takes the remaining queries of the launch without walking.  No wait in the kernels is unbounded, so this is for
+ * the unknown: a launch that never ends costs its caller's patience, not the device.  What an aborted launch leaves behind is
+ * DEFINED per query: a query it finished has its results and its count, every other query has count HNSW_GPU_COUNT_ABORTED
+ * (and no completion flag); the host-pointer calls return an error for such a launch, a caller of the asynchronous
+ * device-pointer forms looks at the counts (or at hnsw_gpu_index_health [5] before and after).  The workspace is re-zeroed
+ * by the next launch.  Callable from ANY thread, also while another thread is blocked inside a search call on the same mirror.
+ * hnsw_gpu_index_abort: the mirror's default workspace only.  hnsw_gpu_abort_all: every workspace of every mirror, context
+ * and shard of this process (a process-wide emergency stop; the library itself never uses it); returns how many it reached.
+ * HNSW_GPU_WATCHDOG_S=<seconds> in the environment makes the library abort, by itself, the ONE workspace whose launch has
+ * been ON the device longer than that (a helper thread, off by default; time spent queued behind other launches does not
+ * count); the polled host-pointer calls do the same for the workspace they wait on after HNSW_GPU_POLL_LIMIT_S (default 120). */
+#define HNSW_GPU_COUNT_ABORTED 0xFFFFFFFFu
 int hnsw_gpu_index_abort(hnsw_gpu_index *ix);
 int hnsw_gpu_abort_all(void);
+
+/* Configuration.  Every knob of the library is an optional integer in one table that is filled ONCE, at the library's first
+ * use, from the environment (the operational knobs of INTEGRATION.md's table) — no entry point reads the environment on a call
+ * path.  A host that wants another value later says so: hnsw_gpu_config_set(name, "value") / (name, NULL) = back to the default;
+ * hnsw_gpu_config_get returns 0 and the value, or 1 when the knob is at its default; hnsw_gpu_config_reload re-reads the
+ * environment (and resets the knobs that are not environment knobs).  Names are the HNSW_GPU_* names of INTEGRATION.md; test knobs
+ * (kernel forms and shapes the host code never picks by itself) can only be set through this call; unknown names are an error. */
+int  hnsw_gpu_config_set(const char *name, const char *value);
+int  hnsw_gpu_config_get(const char *name, long long *value);
+void hnsw_gpu_config_reload(void);
 
 /* Resident query slots (waves) the last search launch used — occupancy figure. */
 int hnsw_gpu_last_search_slots(hnsw_gpu_index *ix, uint32_t *slots);

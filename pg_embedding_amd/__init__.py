@@ -11,6 +11,6 @@ from .index import (  # noqa: F401
     GpuIndex, SearchContext, make_meta, dist_batch, l2_distance, cosine_distance, manhattan_distance,
     merge_topk_torch, merge_packed_torch, LocalShardedIndex,
 )
-from ._lib import HnswMetadata, LibraryMissing  # noqa: F401
+from ._lib import HnswMetadata, LibraryMissing, config_set, config_get, sync_env  # noqa: F401
 
 __version__ = "0.1.0"

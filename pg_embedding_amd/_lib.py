@@ -27,6 +27,27 @@ _gpu = None
 _shim = None
 
 
+def _env_sync_on() -> bool:
+    return os.environ.get("PGEMB_ENV_SYNC") == "1"
+
+
+class _EnvSyncLib:
+    """PGEMB_ENV_SYNC=1 (test tiers, experiment scripts): the library handle forwards HNSW_GPU_* changes of os.environ to the
+    library (hnsw_gpu_config_set) before every call that launches a search, an insert or a build — see sync_env below."""
+    _LAUNCH = ("hnsw_gpu_search", "hnsw_gpu_index_insert", "hnsw_gpu_index_link", "hnsw_gpu_sharded_", "hnsw_gpu_index_create")
+
+    def __init__(self, lib):
+        object.__setattr__(self, "_lib", lib)
+
+    def __getattr__(self, name):
+        if name.startswith(self._LAUNCH):
+            sync_env()
+        return getattr(self._lib, name)
+
+    def __setattr__(self, name, value):
+        setattr(self._lib, name, value)
+
+
 def _preload_torch_runtime() -> None:
     # PyTorch-ROCm ships its own libamdhip64.so.7; whichever copy is loaded first wins
     # for the whole process.  When torch is going to be used (device tensors, streams,
@@ -115,6 +136,7 @@ def gpu_lib():
     L.hnsw_gpu_index_capacity.argtypes = [vp]
     L.hnsw_gpu_search_traced_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp, vp, sz, vp, vp]
     L.hnsw_gpu_replay_roof.argtypes = [vp, vp, sz, vp, sz, C.c_uint, i32, i32, _f32p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+    L.hnsw_gpu_replay_roof_parts.argtypes = [vp, vp, sz, vp, sz, C.c_uint, i32, i32, C.c_uint, _f32p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
     L.hnsw_gpu_index_abort.argtypes = [vp]
     L.hnsw_gpu_abort_all.restype = i32
     L.hnsw_gpu_ctx_create.argtypes = [vp, C.POINTER(vp)]
@@ -146,8 +168,11 @@ def gpu_lib():
     L.hnsw_gpu_sharded_nshards.argtypes = [vp]
     L.hnsw_gpu_sharded_search_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp, vp]
     L.hnsw_gpu_sharded_search.argtypes = [vp, vp, sz, sz, vp, vp, vp]
-    _gpu = L
-    return L
+    L.hnsw_gpu_config_set.argtypes = [C.c_char_p, C.c_char_p]
+    L.hnsw_gpu_config_get.argtypes = [C.c_char_p, C.POINTER(C.c_longlong)]
+    L.hnsw_gpu_config_reload.restype = None
+    _gpu = _EnvSyncLib(L) if _env_sync_on() else L
+    return _gpu
 
 
 def shim_lib():
@@ -179,3 +204,48 @@ def check(rc: int, what: str) -> None:
     if rc != 0:
         msg = gpu_lib().hnsw_gpu_last_error()
         raise RuntimeError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Knobs.  The library resolves its configuration ONCE (operational knobs from the environment at first use) and never calls
+# getenv on a call path; a host that wants another value later says so through hnsw_gpu_config_set.  The test tiers and the
+# experiment scripts flip kernel forms inside one process by changing os.environ: with PGEMB_ENV_SYNC=1 (tests/conftest.py and
+# those scripts set it) the entry points of pg_embedding_amd forward every HNSW_GPU_* change to the library before they launch.
+# ---------------------------------------------------------------------------------------------------------------------
+def config_set(name: str, value) -> None:
+    """Set (value = None: back to its default) one knob of the library — INTEGRATION.md lists them."""
+    rc = gpu_lib().hnsw_gpu_config_set(name.encode(), None if value is None else str(value).encode())
+    check(rc, f"hnsw_gpu_config_set({name})")
+
+
+def config_get(name: str):
+    """The knob's value, or None while it is at its default."""
+    v = C.c_longlong(0)
+    rc = gpu_lib().hnsw_gpu_config_get(name.encode(), C.byref(v))
+    if rc == 1:
+        return None
+    check(rc, f"hnsw_gpu_config_get({name})")
+    return v.value
+
+
+_env_seen: dict = {}
+_NOT_KNOBS = ("HNSW_GPU_WATCHDOG_S",)          # read once by the library itself, at its first workspace
+
+
+def sync_env(force: bool = False) -> None:
+    """Forward the HNSW_GPU_* variables that changed since the last call (set, changed or removed) to the library."""
+    if not (_env_sync_on() or force):
+        return
+    global _env_seen
+    now = {k: v for k, v in os.environ.items() if k.startswith("HNSW_GPU_") and k not in _NOT_KNOBS}
+    if now == _env_seen:
+        return
+    L = gpu_lib()
+    for k in set(now) | set(_env_seen):
+        if now.get(k) != _env_seen.get(k):
+            v = now.get(k)
+            rc = L.hnsw_gpu_config_set(k.encode(), None if v is None else v.encode())
+            if rc != 0 and v is not None:
+                msg = L.hnsw_gpu_last_error()
+                raise RuntimeError(f"{k}={v}: {msg.decode() if msg else rc} (knobs of rejected experiments exist only in -DHNSW_EXPERIMENT builds)")
+    _env_seen = now

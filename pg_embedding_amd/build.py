@@ -76,6 +76,44 @@ def _run(cmd) -> None:
         raise RuntimeError("build failed: " + " ".join(cmd) + "\n" + r.stdout + r.stderr)
 
 
+
+# libhnsw_gpu.so = these translation units, compiled in parallel and linked: the host code + its small kernels, the pair sort,
+# and the search kernels of one load shape each (csrc/search_inst.hip, -DSEARCH_INST_SHAPE=n) — as one unit the 220 search
+# kernel instantiations took hipcc five and a half minutes, like this the library builds in about two.
+def _gpu_units(defines):
+    units = [("hnsw_gpu", "hnsw_gpu.hip", []), ("sort_pairs", "sort_pairs.hip", [])]
+    shapes = range(1, 7) if "HNSW_EXPERIMENT" in defines else range(1, 6)
+    return units + [(f"search_inst_{k}", "search_inst.hip", [f"-DSEARCH_INST_SHAPE={k}"]) for k in shapes]
+
+
+def _build_gpu_lib(target, sources, defines, force=False, verbose=False):
+    flags = [f for f in HIPCC_FLAGS if f != "-shared"] + [f"-D{d}" for d in defines]
+    d = _digest(sources, flags + [os.path.basename(target)])
+    if not force and _current(target, d):
+        return
+    objdir = os.path.join(LIBDIR, "obj", os.path.basename(target))
+    os.makedirs(objdir, exist_ok=True)
+    procs = []
+    for name, src, extra in _gpu_units(defines):
+        obj = os.path.join(objdir, name + ".o")
+        cmd = [_hipcc()] + flags + extra + ["-I", INC, "-I", CSRC, "-c", os.path.join(CSRC, src), "-o", obj]
+        ud = _digest(sources, flags + extra + [src])         # per-object stamp: an unchanged unit is not recompiled
+        if not force and _current(obj, ud):
+            procs.append((obj, None, None, ud))
+            continue
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((obj, cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True), ud))
+    for obj, cmd, pr, ud in procs:
+        if pr is None:
+            continue
+        out, err = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError("build failed: " + " ".join(cmd) + "\n" + out + err)
+        _built(obj, ud)
+    _run([_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC"] + [o for o, _, _, _ in procs] + ["-o", target])
+    _built(target, d)
+
 def build(force: bool = False, verbose: bool = False) -> None:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(BINDIR, exist_ok=True)
@@ -92,8 +130,7 @@ def build(force: bool = False, verbose: bool = False) -> None:
         _run(cmd)
         _built(target, d)
 
-    step(GPU_LIB, gpu_src, [_hipcc()] + HIPCC_FLAGS + ["-I", INC, "-I", CSRC, os.path.join(CSRC, "hnsw_gpu.hip"),
-                                                     os.path.join(CSRC, "sort_pairs.hip"), "-o", GPU_LIB])
+    _build_gpu_lib(GPU_LIB, gpu_src, [], force, verbose)
     host_dist = os.path.join(CSRC, "host_dist.h")
     gpu_stamp = [_stamp(GPU_LIB)]                            # the host libraries link against the device library
     shim_src = [os.path.join(CSRC, "embedding_shim.cpp"), os.path.join(CSRC, "host_walk.h"), os.path.join(CSRC, "shim_cache.h"), host_dist] + hdrs
@@ -117,8 +154,13 @@ def build_variant(tag: str, defines) -> str:
     vdir = os.path.join(LIBDIR, "variants")
     os.makedirs(vdir, exist_ok=True)
     out = os.path.join(vdir, f"libhnsw_gpu_{tag}.so")
-    _run([_hipcc()] + HIPCC_FLAGS + [f"-D{d}" for d in defines] + ["-I", INC, "-I", CSRC,
-         os.path.join(CSRC, "hnsw_gpu.hip"), os.path.join(CSRC, "sort_pairs.hip"), "-o", out])
+    defines = list(defines)
+    if any(d.split("=")[0] in ("HNSW_TEAM_COUNTERS", "HNSW_HOP_STAMPS") for d in defines) and "HNSW_EXPERIMENT" not in defines:
+        defines.append("HNSW_EXPERIMENT")                   # diagnostic builds read every knob from the environment
+    hdrs = [os.path.join(INC, h) for h in ("hnsw_abi.h", "hnsw_gpu.h", "hnsw_gpu_shim.h", "hnsw_gpu_server.h")]
+    host_only = ("hgs_io.h", "host_walk.h", "host_dist.h", "shim_cache.h")
+    gpu_src = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) and f not in host_only] + hdrs
+    _build_gpu_lib(out, gpu_src, defines)
     return out
 
 

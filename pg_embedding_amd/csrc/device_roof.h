@@ -63,7 +63,7 @@ __global__ __launch_bounds__(256) void gather_roof_kernel(const float4 *__restri
 constexpr uint32_t REPLAY_STAGE = 512;
 template <int KB, int RPG, bool CHECK>
 __global__ __launch_bounds__(256) void replay_roof_kernel(const float4 *__restrict__ base, uint32_t row_f4, const uint32_t *__restrict__ evals,
-														   uint32_t evals_cap, const uint32_t *__restrict__ nevals, uint32_t nq,
+														   uint32_t evals_cap, const uint32_t *__restrict__ nevals, uint32_t nq, uint32_t parts,
 														   uint32_t *ticket, float *out, unsigned long long *check)
 {
 	// row ids staged in LDS, REPLAY_STAGE at a time (the search kernel has its ids in LDS too: a pass must not wait for an id
@@ -78,13 +78,18 @@ __global__ __launch_bounds__(256) void replay_roof_kernel(const float4 *__restri
 	float acc = 0.f;
 	for (;;)
 	{
-		uint32_t qi = 0;
-		if (lane == 0) qi = atomicAdd(ticket, 1u);
-		qi = __builtin_amdgcn_readfirstlane(qi);
-		if (qi >= nq) break;
-		const uint32_t *gids = evals + (size_t) qi * evals_cap;
+		// (parts > 1: a query's trace is cut into `parts` equal pieces that different waves gather — the roof of a launch in which
+		// `parts` waves share one walk's rows, i.e. of fewer queries than resident waves)
+		uint32_t tk = 0;
+		if (lane == 0) tk = atomicAdd(ticket, 1u);
+		tk = __builtin_amdgcn_readfirstlane(tk);
+		if (tk >= nq * parts) break;
+		const uint32_t qi = tk / parts, part = tk - qi * parts;
 		uint32_t ne = nevals[2 * (size_t) qi];               // (the search kernel's stats array: {evals, hops} per query)
 		ne = ne < evals_cap ? ne : evals_cap;
+		const uint32_t lo = (uint32_t) ((uint64_t) ne * part / parts), hi = (uint32_t) ((uint64_t) ne * (part + 1) / parts);
+		const uint32_t *gids = evals + (size_t) qi * evals_cap + lo;
+		ne = hi - lo;
 		for (uint32_t s0 = 0; s0 < ne; s0 += STAGE)
 		{
 			const uint32_t ns = ne - s0 < STAGE ? ne - s0 : STAGE;

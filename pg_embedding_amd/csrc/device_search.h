@@ -119,6 +119,7 @@ struct SearchArgs
 //   [HEALTH_ABORTED_WAVES]    waves that left a launch because of the abort word
 //   [HEALTH_SLICES_DELIVERED] team form: slices helpers scored for walking waves (says the mechanism is in use; one
 //                             non-returning atomic per job)
+constexpr uint32_t ABORTED_COUNT = 0xFFFFFFFFu;     // out_counts[i] of a query an aborted launch did not answer (include/hnsw_gpu.h)
 enum : uint32_t { HEALTH_SLICE_TIMEOUTS = 1, HEALTH_PACKAGE_TIMEOUTS = 2, HEALTH_ABORTED_WAVES = 3, HEALTH_SLICES_DELIVERED = 4, HEALTH_WORDS = 16 };
 
 __device__ __forceinline__ bool abort_requested(const SearchArgs &a)
@@ -461,7 +462,10 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 		if (lane == 0) qi = atomicAdd(a.ticket, 1u);
 		qi = __builtin_amdgcn_readfirstlane(qi);
 		if (qi >= a.nq) break;
-		if (abort_requested(a)) { aborted = true; break; }
+		// (an abort request is sticky for this wave: it takes the remaining tickets without walking and marks every query it does not
+		// answer with count 0xFFFFFFFF, so that the caller of an interrupted launch can tell which rows of its outputs are results)
+		if (!aborted && abort_requested(a)) aborted = true;
+		if (__builtin_amdgcn_readfirstlane((int) aborted)) { if (lane == 0) a.out_counts[qi] = ABORTED_COUNT; continue; }   // (wave-uniform by construction; said explicitly)
 		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi] = __builtin_amdgcn_s_memrealtime();
 
 		const float *qsrc = a.queries + (size_t) qi * a.q_stride;
@@ -611,7 +615,7 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 			}
 		}
 
-		if (aborted) break;
+		if (__builtin_amdgcn_readfirstlane((int) aborted)) { if (lane == 0) a.out_counts[qi] = ABORTED_COUNT; continue; }      // interrupted inside its walk
 		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi + 1] = __builtin_amdgcn_s_memrealtime();
 		// ---- emit -------------------------------------------------------------------------
 		const size_t obase = (size_t) qi * a.out_stride;
@@ -848,7 +852,10 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 		if (lane == 0) qi = atomicAdd(a.ticket, 1u);
 		qi = __builtin_amdgcn_readfirstlane(qi);
 		if (qi >= a.nq) break;
-		if (abort_requested(a)) { aborted = true; break; }
+		// (an abort request is sticky for this wave: it takes the remaining tickets without walking and marks every query it does not
+		// answer with count 0xFFFFFFFF, so that the caller of an interrupted launch can tell which rows of its outputs are results)
+		if (!aborted && abort_requested(a)) aborted = true;
+		if (__builtin_amdgcn_readfirstlane((int) aborted)) { if (lane == 0) a.out_counts[qi] = ABORTED_COUNT; continue; }   // (wave-uniform by construction; said explicitly)
 		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi] = __builtin_amdgcn_s_memrealtime();
 
 		const float *qsrc = a.queries + (size_t) qi * a.q_stride;
@@ -976,7 +983,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 			}
 		}
 
-		if (aborted) break;
+		if (__builtin_amdgcn_readfirstlane((int) aborted)) { if (lane == 0) a.out_counts[qi] = ABORTED_COUNT; continue; }      // interrupted inside its walk
 		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi + 1] = __builtin_amdgcn_s_memrealtime();
 		// ---- emit: rank-sort the unsorted result array ----------------------------------------
 		// (G: the arrays are final now; drop this CU's L1 copies of them once — an earlier query of this slot
@@ -1576,7 +1583,7 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 	}
 }
 
-template <int FUNC, typename SH, int UREG, bool TEAM = false>
+template <int FUNC, typename SH, int UREG, bool TEAM = false, bool LEAN = false>
 __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MIN_WAVES) void hnsw_search_kernel_beam(const SearchArgs a)
 {
 	constexpr uint32_t UCAP = 64u * UREG;
@@ -1614,8 +1621,11 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		if (lane == 0) qi = atomicAdd(a.ticket, 1u);
 		qi = __builtin_amdgcn_readfirstlane(qi);
 		if (qi >= a.nq) break;
-		if (abort_requested(a)) { aborted = true; break; }
-		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi] = __builtin_amdgcn_s_memrealtime();
+		// (an abort request is sticky for this wave: it takes the remaining tickets without walking and marks every query it does not
+		// answer with count 0xFFFFFFFF, so that the caller of an interrupted launch can tell which rows of its outputs are results)
+		if (!aborted && abort_requested(a)) aborted = true;
+		if (__builtin_amdgcn_readfirstlane((int) aborted)) { if (lane == 0) a.out_counts[qi] = ABORTED_COUNT; continue; }   // (wave-uniform by construction; said explicitly)
+		if (!LEAN && a.out_times && lane == 0) a.out_times[2 * (size_t) qi] = __builtin_amdgcn_s_memrealtime();
 
 		const float *qsrc = a.queries + (size_t) qi * a.q_stride;
 		for (uint32_t e = lane; e < a.qpad_floats; e += 64)
@@ -1656,7 +1666,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 			wave_sync();
 			const float d0 = finish_dist<FUNC>(newdist[0], newdist[OUT2], qnorm);
 			evals = 1;
-			if (a.out_evals && a.evals_cap && lane == 0) a.out_evals[(size_t) qi * a.evals_cap] = ep;
+			if (!LEAN && a.out_evals && a.evals_cap && lane == 0) a.out_evals[(size_t) qi * a.evals_cap] = ep;
 			beam_set<UREG>(uk, 0, ((uint64_t) ord_f32(d0) << 32) | ep, lane);
 			usize = 1;
 			if (lane == 0)
@@ -1690,10 +1700,10 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				if (beam_count_lt<UREG>(uk, cd) >= ef) break;              // :70-71  best candidate > lowerBound
 				const uint32_t cur = ~(uint32_t) ckey;
 				ex |= ((uint32_t) lane == (cslot & 63)) ? (1u << (cslot >> 6)) : 0u;   // :73 pop
-				if (a.out_pops && hops < a.pops_cap && lane == 0)       // (system scope: a host that polls the sequence sees it as the walk goes)
+				if (!LEAN && a.out_pops && hops < a.pops_cap && lane == 0)       // (system scope: a host that polls the sequence sees it as the walk goes)
 					__hip_atomic_store(a.out_pops + (size_t) qi * a.pops_cap + hops, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 				hops++;
-				if ((hops & 255u) == 0u && abort_requested(a)) { aborted = true; break; }
+				if (!LEAN && (hops & 255u) == 0u && abort_requested(a)) { aborted = true; break; }
 				if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_pop += hs1 - hs0; hs0 = hs1; }
 				TeamView h0v = {};
 				if (TEAM && (TEAM_COUNT && a.team_dbg) && lane == 0) { atomicAdd(a.team_dbg + 5, 1u); if (hm) atomicAdd(a.team_dbg + 0, 1u); }
@@ -1790,7 +1800,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 					if (isnew)
 					{
 						newid[rank] = t;
-						if (a.out_evals && evals + rank < a.evals_cap) a.out_evals[(size_t) qi * a.evals_cap + evals + rank] = t;   // (measurement: the rows this walk scores, in order)
+						if (!LEAN && a.out_evals && evals + rank < a.evals_cap) a.out_evals[(size_t) qi * a.evals_cap + evals + rank] = t;   // (measurement: the rows this walk scores, in order)
 						if (TEAM && hm) reinterpret_cast<uint32_t *>(newdist)[rank] = od_pk;      // packaged distance, link order kept
 					}
 					wave_sync();
@@ -1955,8 +1965,8 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		}
 
 		if (TEAM && lane == 0) ctl[wib].state = 0u;                       // walk over: helpers let go
-		if (aborted) break;
-		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi + 1] = __builtin_amdgcn_s_memrealtime();
+		if (__builtin_amdgcn_readfirstlane((int) aborted)) { if (lane == 0) a.out_counts[qi] = ABORTED_COUNT; continue; }      // interrupted inside its walk
+		if (!LEAN && a.out_times && lane == 0) a.out_times[2 * (size_t) qi + 1] = __builtin_amdgcn_s_memrealtime();
 		uint32_t hs_walk = 0;
 		if (HOP_STAMPS && a.team_dbg) hs_walk = hop_stamp();
 		// ---- emit: the ef smallest (dist, idx) keys of the set, then the reference's output order ----

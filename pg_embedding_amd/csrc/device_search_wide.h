@@ -92,7 +92,10 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_wide(const SearchArgs 
 		if (lane == 0) qi = atomicAdd(a.ticket, 1u);
 		qi = __builtin_amdgcn_readfirstlane(qi);
 		if (qi >= a.nq) break;
-		if (abort_requested(a)) { aborted = true; break; }
+		// (an abort request is sticky for this wave: it takes the remaining tickets without walking and marks every query it does not
+		// answer with count 0xFFFFFFFF, so that the caller of an interrupted launch can tell which rows of its outputs are results)
+		if (!aborted && abort_requested(a)) aborted = true;
+		if (__builtin_amdgcn_readfirstlane((int) aborted)) { if (lane == 0) a.out_counts[qi] = ABORTED_COUNT; continue; }   // (wave-uniform by construction; said explicitly)
 		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi] = __builtin_amdgcn_s_memrealtime();
 
 		const float *qsrc = a.queries + (size_t) qi * a.q_stride;
@@ -259,7 +262,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_wide(const SearchArgs 
 			}
 		}
 
-		if (aborted) break;
+		if (__builtin_amdgcn_readfirstlane((int) aborted)) { if (lane == 0) a.out_counts[qi] = ABORTED_COUNT; continue; }      // interrupted inside its walk
 		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi + 1] = __builtin_amdgcn_s_memrealtime();
 		// ---- emit: (key, label) pairs sorted by a bitonic network in the slot's scratch ----------------------------------
 		const size_t obase = (size_t) qi * a.out_stride;

@@ -16,9 +16,7 @@
 #include <vector>
 
 #include "hnsw_gpu.h"
-#include "device_dist.h"
-#include "device_search.h"
-#include "device_search_wide.h"
+#include "search_kernels.h"
 #include "device_build.h"
 #include "device_insert.h"
 #include "device_bf_mfma.h"
@@ -60,6 +58,101 @@ extern "C" int hnsw_gpu_device_count(void)
 static inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
 // ------------------------------------------------------------------------------------
+// configuration: resolved ONCE per process, never on a call path
+// ------------------------------------------------------------------------------------
+// Every knob of the library lives in one table of optional integers.  The table is filled from the environment at the first
+// use (std::call_once) — the OPERATIONAL knobs only, the ones a deployment may want to set (include/hnsw_gpu.h,
+// INTEGRATION.md "environment") — and after that a launch reads plain words: no getenv, no parsing, no locale on the path of
+// a 0.4 ms call.  A host that wants another value later says so explicitly (hnsw_gpu_config_set; hnsw_gpu_config_reload re-reads
+// the environment): that is how the test tiers flip kernel forms inside one process.  TEST knobs (forms and shapes the host code
+// never picks by itself, forced so that every compiled kernel is exercised) can only be set through that call; experiment knobs
+// of rejected variants exist only in -DHNSW_EXPERIMENT builds, where the whole table is read from the environment.
+enum Knob : int
+{
+	// operational (environment, read once)
+	K_BEAM, K_FORCE_LDS_HEAPS, K_TEAM, K_TEAM_MAX_NQ, K_WIDE_EF_MIN, K_REF_ORDER, K_NO_POLL, K_POLL_LIMIT_S, K_INSERT_FUSED,
+	K_BLOCKS_PER_CU, K_SPLIT,
+	// test knobs (hnsw_gpu_config_set only)
+	K_BEAM16, K_NARROW5, K_LEAN, K_HASH_ENTRIES, K_LDS_SET_MIN_WAVES, K_TEAM_SPEC, K_TEAM_WPB, K_MAX_BLOCKS, K_SHARDED_NO_PEER, K_PAIR,
+#ifdef HNSW_EXPERIMENT
+	K_WIDE_WAVES, K_SHAPE_12X1, K_TEAM_MAINS, K_TEAM_COUNTERS,
+#endif
+	K_COUNT
+};
+struct KnobDef { const char *name; bool env; };
+static const KnobDef g_knob_def[K_COUNT] = {
+	{ "HNSW_GPU_BEAM", true }, { "HNSW_GPU_FORCE_LDS_HEAPS", true }, { "HNSW_GPU_TEAM", true }, { "HNSW_GPU_TEAM_MAX_NQ", true },
+	{ "HNSW_GPU_WIDE_EF_MIN", true }, { "HNSW_GPU_REF_ORDER", true }, { "HNSW_GPU_NO_POLL", true }, { "HNSW_GPU_POLL_LIMIT_S", true },
+	{ "HNSW_GPU_INSERT_FUSED", true }, { "HNSW_GPU_BLOCKS_PER_CU", true }, { "HNSW_GPU_SPLIT", true },
+	{ "HNSW_GPU_BEAM16", false }, { "HNSW_GPU_NARROW5", false }, { "HNSW_GPU_LEAN", false }, { "HNSW_GPU_HASH_ENTRIES", false }, { "HNSW_GPU_LDS_SET_MIN_WAVES", false },
+	{ "HNSW_GPU_TEAM_SPEC", false }, { "HNSW_GPU_TEAM_WPB", false }, { "HNSW_GPU_MAX_BLOCKS", false }, { "HNSW_GPU_SHARDED_NO_PEER", false },
+	{ "HNSW_GPU_PAIR", false },
+#ifdef HNSW_EXPERIMENT
+	{ "HNSW_GPU_WIDE_WAVES", false }, { "HNSW_GPU_SHAPE_12X1", false }, { "HNSW_GPU_TEAM_MAINS", false }, { "HNSW_GPU_TEAM_COUNTERS", false },
+#endif
+};
+struct KnobVal { std::atomic<long long> v{0}; std::atomic<bool> set{false}; };
+static KnobVal g_knob[K_COUNT];
+static std::once_flag g_knob_once;
+
+static void knob_store(int k, const char *text)
+{
+	if (text && *text) { g_knob[k].v.store(atoll(text), std::memory_order_relaxed); g_knob[k].set.store(true, std::memory_order_release); }
+	else g_knob[k].set.store(false, std::memory_order_release);
+}
+
+static void knobs_from_env(bool all)
+{
+	for (int k = 0; k < K_COUNT; k++)
+	{
+#ifdef HNSW_EXPERIMENT
+		(void) all;
+		knob_store(k, getenv(g_knob_def[k].name));
+#else
+		if (g_knob_def[k].env || all) knob_store(k, g_knob_def[k].env ? getenv(g_knob_def[k].name) : nullptr);
+#endif
+	}
+}
+
+static inline void knobs_init() { std::call_once(g_knob_once, [] { knobs_from_env(false); }); }
+
+// value of knob k, or `dflt` when nobody set it
+static inline long long knob(int k, long long dflt)
+{
+	return g_knob[k].set.load(std::memory_order_acquire) ? g_knob[k].v.load(std::memory_order_relaxed) : dflt;
+}
+static inline bool knob_is_set(int k) { return g_knob[k].set.load(std::memory_order_acquire); }
+
+extern "C" int hnsw_gpu_config_set(const char *name, const char *value)
+{
+	if (!name) return fail(HNSW_GPU_ERR_ARG, "knob name is NULL");
+	knobs_init();
+	for (int k = 0; k < K_COUNT; k++)
+		if (strcmp(name, g_knob_def[k].name) == 0) { knob_store(k, value); return HNSW_GPU_OK; }
+	return fail(HNSW_GPU_ERR_ARG, "unknown knob %s", name);
+}
+
+extern "C" int hnsw_gpu_config_get(const char *name, long long *value)
+{
+	if (!name || !value) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	knobs_init();
+	for (int k = 0; k < K_COUNT; k++)
+		if (strcmp(name, g_knob_def[k].name) == 0)
+		{
+			if (!knob_is_set(k)) return 1;                  // known, at its default
+			*value = knob(k, 0);
+			return HNSW_GPU_OK;
+		}
+	return fail(HNSW_GPU_ERR_ARG, "unknown knob %s", name);
+}
+
+extern "C" void hnsw_gpu_config_reload(void)
+{
+	knobs_init();
+	knobs_from_env(true);
+}
+
+// ------------------------------------------------------------------------------------
 // the device mirror
 // ------------------------------------------------------------------------------------
 // Per-stream search state: the slots' visited bitmaps + logs, the ticket word and the HIP-event ring.
@@ -86,6 +179,7 @@ struct SearchWs
 	uint32_t *health = nullptr;
 	int device = 0;
 	int abort_sent = 0;                                  // (atomic) an abort was requested: the next launch re-zeroes the workspace
+	uint32_t abort_requests = 0;                         // (atomic) abort requests this workspace has received in its life (hnsw_gpu_index_health [5])
 	int64_t busy_since_ms = 0;                           // (atomic) steady-clock ms of the last launch, 0 = known idle (watchdog)
 };
 
@@ -113,6 +207,7 @@ static int abort_ws_locked(SearchWs *w)
 {
 	if (!w->abort_host) return 0;
 	__atomic_store_n(&w->abort_sent, 1, __ATOMIC_SEQ_CST);
+	__atomic_add_fetch(&w->abort_requests, 1u, __ATOMIC_SEQ_CST);
 	__atomic_store_n(w->abort_host, 1u, __ATOMIC_SEQ_CST);
 	return 1;
 }
@@ -144,6 +239,15 @@ static void watchdog_main(int limit_s)
 				// finished (or unknown): idle unless a newer launch has stamped it meanwhile
 				int64_t expect = since;
 				(void) __atomic_compare_exchange_n(&w->busy_since_ms, &expect, (int64_t) 0, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
+				continue;
+			}
+			// The stamp was taken when the launch was ENQUEUED.  A deep queue of healthy asynchronous launches may keep it waiting
+			// longer than the limit: while its start event has not completed it is not running, so the clock restarts now.
+			hipEvent_t ev_start = w->ev0[(l - 1) % SearchWs::EV_RING];
+			if (ev_start && hipEventQuery(ev_start) == hipErrorNotReady)
+			{
+				int64_t expect = since;
+				(void) __atomic_compare_exchange_n(&w->busy_since_ms, &expect, now, false, __ATOMIC_SEQ_CST, __ATOMIC_SEQ_CST);
 				continue;
 			}
 			fprintf(stderr, "hnsw_gpu watchdog: search kernel %s on device %d has been running for %lld s (limit %d s): aborting it\n",
@@ -218,6 +322,8 @@ struct hnsw_gpu_index
 	HnswMetadata meta;
 	int      device = 0;
 	int      num_cu = 0;
+	size_t   max_lds = 64 * 1024;   // dynamic LDS one block may ask for on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
+	bool     ins_dirty = false;     // an insert failed after its kernels were enqueued: block counters may be non-zero (insert_impl)
 	size_t   n = 0, cap = 0;
 	uint32_t stride = 0;      // floats per row (dim rounded up to 4)
 	uint32_t lstride = 0;     // link slots per element (maxM rounded up to 16)
@@ -282,6 +388,10 @@ static int alloc_index(const HnswMetadata *meta, size_t capacity, int device, hn
 	hipDeviceProp_t prop;
 	if (hipGetDeviceProperties(&prop, device) == hipSuccess) ix->num_cu = prop.multiProcessorCount;
 	if (ix->num_cu <= 0) ix->num_cu = 256;
+	{
+		int maxlds = 0;
+		if (hipDeviceGetAttribute(&maxlds, hipDeviceAttributeMaxSharedMemoryPerBlock, device) == hipSuccess && maxlds > 0) ix->max_lds = (size_t) maxlds;
+	}
 	ix->cap = capacity ? capacity : 1;
 	ix->stride = (uint32_t) round_up(meta->dim, 4);
 	ix->lstride = (uint32_t) round_up(meta->maxM, 16);
@@ -627,97 +737,21 @@ extern "C" int hnsw_gpu_index_set_deleted(hnsw_gpu_index *ix, idx_t idx, int del
 // ------------------------------------------------------------------------------------
 // search
 // ------------------------------------------------------------------------------------
-typedef void (*search_kernel_t)(const SearchArgs);
-
-// rreg: 0 = generic form, sets in LDS; 1 = generic form, sets in HBM (any ef); 2 / 4 = register form for ef <= 128 / 256,
-//       -2 / -4 / -8 / -16 = beam form (counting acceptance) with that many set registers, ef <= 64 / 128 / 256 / 512
-template <typename SH, int RREG>
-static search_kernel_t pick_search_kernel_f(int func, bool team)
-{
-	if (RREG < 0)
-	{
-		constexpr int U = RREG < 0 ? -RREG : 2;
-		if (team)
-			switch (func)
-			{
-				case F_L2:     return hnsw_search_kernel_beam<F_L2, SH, U, true>;
-				case F_COSINE: return hnsw_search_kernel_beam<F_COSINE, SH, U, true>;
-				default:       return hnsw_search_kernel_beam<F_MANHATTAN, SH, U, true>;
-			}
-		switch (func)
-		{
-			case F_L2:     return hnsw_search_kernel_beam<F_L2, SH, U, false>;
-			case F_COSINE: return hnsw_search_kernel_beam<F_COSINE, SH, U, false>;
-			case F_L2_REF:        if (U == 4) return hnsw_search_kernel_beam<F_L2_REF, SH, 4, false>; return nullptr;          // (debug arithmetic:
-			case F_MANHATTAN_REF: if (U == 4) return hnsw_search_kernel_beam<F_MANHATTAN_REF, SH, 4, false>; return nullptr;   //  one set size only)
-			case F_COSINE_REF:    if (U == 4) return hnsw_search_kernel_beam<F_COSINE_REF, SH, 4, false>; return nullptr;
-			default:       return hnsw_search_kernel_beam<F_MANHATTAN, SH, U, false>;
-		}
-	}
-	if (RREG == 3)          // wide-beam form (any ef), device_search_wide.h
-		switch (func)
-		{
-			case F_L2:     return hnsw_search_kernel_wide<F_L2, SH>;
-			case F_COSINE: return hnsw_search_kernel_wide<F_COSINE, SH>;
-			default:       return hnsw_search_kernel_wide<F_MANHATTAN, SH>;
-		}
-	if (RREG == 1)          // generic form, sets in HBM
-		switch (func)
-		{
-			case F_L2:     return hnsw_search_kernel_lds<F_L2, SH, true>;
-			case F_COSINE: return hnsw_search_kernel_lds<F_COSINE, SH, true>;
-			default:       return hnsw_search_kernel_lds<F_MANHATTAN, SH, true>;
-		}
-	if (RREG == 0)
-		switch (func)
-		{
-			case F_L2:     return hnsw_search_kernel_lds<F_L2, SH, false>;
-			case F_COSINE: return hnsw_search_kernel_lds<F_COSINE, SH, false>;
-			default:       return hnsw_search_kernel_lds<F_MANHATTAN, SH, false>;
-		}
-	constexpr int R = (RREG <= 1 || RREG == 3) ? 2 : RREG;
-	switch (func)
-	{
-		case F_L2:     return hnsw_search_kernel_reg<F_L2, SH, R>;
-		case F_COSINE: return hnsw_search_kernel_reg<F_COSINE, SH, R>;
-		default:       return hnsw_search_kernel_reg<F_MANHATTAN, SH, R>;
-	}
-}
-
-template <typename SH>
-static search_kernel_t pick_search_kernel_s(int func, int rreg, bool team)
-{
-	switch (rreg)
-	{
-		case 2:  return pick_search_kernel_f<SH, 2>(func, false);
-		case 4:  return pick_search_kernel_f<SH, 4>(func, false);
-		case -2: return pick_search_kernel_f<SH, -2>(func, team);
-		case -4: return pick_search_kernel_f<SH, -4>(func, team);
-		case -8: return pick_search_kernel_f<SH, -8>(func, team);
-		case -16: return pick_search_kernel_f<SH, -16>(func, team);
-		case 1:  return pick_search_kernel_f<SH, 1>(func, false);
-		case 3:  return pick_search_kernel_f<SH, 3>(func, false);
-		default: return pick_search_kernel_f<SH, 0>(func, false);
-	}
-}
-
-static search_kernel_t pick_search_kernel(int func, uint32_t kiters, int rreg, bool team, bool narrow5)
+// which kernel a launch runs: search_kernels.h (one translation unit per load shape)
+static search_kernel_t pick_search_kernel(int func, uint32_t kiters, int rreg, bool team, bool narrow5, bool lean)
 {
 	switch (shape_index(kiters))
 	{
 		case 0:
-			if (narrow5 && !team)               // the hot narrow-row form: 8 rows per pass, 96 VGPRs, 5 waves/SIMD
-				switch (func)
-				{
-					case F_L2: return rreg == -2 ? hnsw_search_kernel_beam<F_L2, Shape2x2, 2, false> : hnsw_search_kernel_beam<F_L2, Shape2x2, 4, false>;
-					default:   return rreg == -2 ? hnsw_search_kernel_beam<F_MANHATTAN, Shape2x2, 2, false> : hnsw_search_kernel_beam<F_MANHATTAN, Shape2x2, 4, false>;
-				}
-			return pick_search_kernel_s<Shape2x4>(func, rreg, team);
-		case 1:  return pick_search_kernel_s<Shape4x2>(func, rreg, team);
-		case 2:  return pick_search_kernel_s<Shape8x2>(func, rreg, team);
+			if (narrow5 && !team) return pick_kernel_shape2x2(func, rreg, lean);      // the hot narrow-row form: 8 rows per pass, 96 VGPRs, 5 waves/SIMD
+			return pick_kernel_shape2x4(func, rreg, team);
+		case 1:  return pick_kernel_shape4x2(func, rreg, team);
+		case 2:  return pick_kernel_shape8x2(func, rreg, team);
 		default:
-			if (getenv("HNSW_GPU_SHAPE_12X1")) return pick_search_kernel_s<Shape12x1>(func, rreg, team);
-			return pick_search_kernel_s<Shape12x2>(func, rreg, team);
+#ifdef HNSW_EXPERIMENT
+			if (knob(K_SHAPE_12X1, 0)) return pick_kernel_shape12x1(func, rreg, team);
+#endif
+			return pick_kernel_shape12x2(func, rreg, team);
 	}
 }
 
@@ -769,19 +803,15 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	//   two-set register form: HNSW_GPU_BEAM=0, or mirrors of >= 2^31 elements; ef <= 256.
 	//   LDS form: everything else (HNSW_GPU_FORCE_LDS_HEAPS=1 forces it).
 	// The register forms use their LDS "res"/"cand" areas only as scratch of the emit step.
-	const char *beam = getenv("HNSW_GPU_BEAM");
-	const char *b16 = getenv("HNSW_GPU_BEAM16");
-	const char *force = getenv("HNSW_GPU_FORCE_LDS_HEAPS");
-	const bool use_beam = !(beam && atoi(beam) == 0) && ix->cap < 0x80000000ull;
-	const bool beam16 = use_beam && ef > 256 && ef <= 512 && (b16 ? atoi(b16) > 0 : shape_index(a.kiters) >= 2);
-	const char *wmin = getenv("HNSW_GPU_WIDE_EF_MIN");
-	const size_t wide_min = wmin ? (size_t) atoll(wmin) : WIDE_EF_MIN;
+	knobs_init();
+	const bool use_beam = knob(K_BEAM, 1) != 0 && ix->cap < 0x80000000ull;
+	const bool beam16 = use_beam && ef > 256 && ef <= 512 && (knob_is_set(K_BEAM16) ? knob(K_BEAM16, 0) > 0 : shape_index(a.kiters) >= 2);
+	const size_t wide_min = (size_t) knob(K_WIDE_EF_MIN, (long long) WIDE_EF_MIN);
 	// Debug arithmetic (device_dist.h, F_L2_REF / F_MANHATTAN_REF / F_COSINE_REF): the summation order of oracle/_ref's own build, for a query-by-query
 	// comparison of id lists with the compiled reference.  One kernel set only: beam form, 4 set registers, one wave per query.
 	int func_code = (int) ix->meta.dist_func;
 	bool reforder = false;
-	if (const char *ro = getenv("HNSW_GPU_REF_ORDER"))
-		if (atoi(ro) > 0)
+	if (knob(K_REF_ORDER, 0) > 0)
 		{
 			const bool ok = ef <= 128 && ix->cap < 0x80000000ull &&
 							((func_code == F_L2 && ix->meta.dim % 16 == 0) || ((func_code == F_MANHATTAN || func_code == F_COSINE) && ix->meta.dim % 4 == 0));
@@ -793,20 +823,17 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	int rreg;
 	if (reforder) rreg = -4;
 	else if (ef > wide_min) rreg = 3;
-	else if (force && atoi(force) > 0) rreg = 0;
+	else if (knob(K_FORCE_LDS_HEAPS, 0) > 0) rreg = 0;
 	else if (use_beam && (ef <= 256 || beam16)) rreg = ef <= 64 ? -2 : (ef <= 128 ? -4 : (ef <= 256 ? -8 : -16));
 	else rreg = ef <= 128 ? 2 : (ef <= 256 ? 4 : 0);
 	const size_t ucap = rreg < 0 ? (size_t) 64 * (size_t) -rreg : 0;      // beam form: slots of the accepted set
 	// Team form wanted for this launch?  (decided for good further down, once the LDS carve is known)
-	const char *tenv = getenv("HNSW_GPU_TEAM");
-	const int treq = tenv ? atoi(tenv) : -1;
-	const char *tmax = getenv("HNSW_GPU_TEAM_MAX_NQ");
-	const size_t auto_nq = tmax ? (size_t) atoll(tmax) : (size_t) ix->num_cu;
+	const int treq = (int) knob(K_TEAM, -1);
+	const size_t auto_nq = (size_t) knob(K_TEAM_MAX_NQ, (long long) ix->num_cu);
 	const bool team_wanted = rreg < 0 && !reforder && treq != 0 && (treq > 0 || ix->stride > 320 || nq <= auto_nq);
 	// narrow rows, hot form: beam kernel with <= 4 set registers, one sum per row (L2 / Manhattan), not a team
-	const char *n5 = getenv("HNSW_GPU_NARROW5");
 	const bool narrow5 = shape_index(a.kiters) == 0 && (rreg == -2 || rreg == -4) && (int) ix->meta.dist_func != F_COSINE &&
-						 !team_wanted && !reforder && !(n5 && atoi(n5) == 0);
+						 !team_wanted && !reforder && knob(K_NARROW5, 1) != 0;
 	size_t off = (size_t) a.qpad_floats * 4;
 	if (rreg == 3)
 	{
@@ -837,10 +864,11 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		// teams: 5 waves/SIMD with the 8-rows-per-pass shape — measured +6-10 % over 4 waves, profiles/r2m_*)
 		const bool wide = ix->stride > 320;
 		size_t want_waves = wide ? 8 : (narrow5 ? 20 : 16);
-		if (const char *ww = getenv("HNSW_GPU_WIDE_WAVES")) if (wide && atoi(ww) >= 4) want_waves = (size_t) atoi(ww);   // (experiment builds at 3 waves/SIMD)
+#ifdef HNSW_EXPERIMENT
+		if (wide && knob(K_WIDE_WAVES, 0) >= 4) want_waves = (size_t) knob(K_WIDE_WAVES, 0);   // (experiment builds at 3 waves/SIMD)
+#endif
 		uint32_t hcap = wide ? 4096 : (rreg < 0 ? 2048 : 0);
-		const char *henv = getenv("HNSW_GPU_HASH_ENTRIES");
-		if (henv) hcap = (uint32_t) atoi(henv);
+		if (knob_is_set(K_HASH_ENTRIES)) hcap = (uint32_t) knob(K_HASH_ENTRIES, 0);
 		// emit scratch: [keys | labels]; the beam form sorts up to `ucap` survivors (ties at the bound)
 		const size_t nkeys = ucap ? ucap : ef;
 		const size_t emit = round_up(nkeys * 8, 16) + round_up(ef * 8, 16);
@@ -872,8 +900,7 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		// generic form: [res ef+1 | cand 2ef+1] keys per wave — in LDS while at least HNSW_GPU_LDS_SET_MIN_WAVES
 		// (default 4) waves per CU fit, otherwise in a per-slot HBM area (any ef)
 		const size_t set_bytes = round_up((ef + 1) * 8, 16) + round_up((2 * ef + 1) * 8, 16);
-		const char *mw = getenv("HNSW_GPU_LDS_SET_MIN_WAVES");
-		const size_t min_waves = mw && atoi(mw) > 0 ? (size_t) atoi(mw) : 4;
+		const size_t min_waves = knob(K_LDS_SET_MIN_WAVES, 0) > 0 ? (size_t) knob(K_LDS_SET_MIN_WAVES, 0) : 4;
 		if (min_waves * (off + set_bytes + 64 * 4 + 128 * 4) > LDS_PER_CU)
 		{
 			rreg = 1;
@@ -936,13 +963,11 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 				// 7 helpers speculating: one query 0.470 -> 0.438 ms, 16 queries -3.4 %, 256 -4.1 %, 1024 -3.4 %, 10 000 -0.5 %,
 				// 40 000 -0.2 %; 3: 0.452; 0 (nobody speculates): 0.618.  128 dims: a hop rarely has more rows than one pass of 16,
 				// slices lose 1-2 %, so narrow rows let every helper speculate.  HNSW_GPU_TEAM_SPEC overrides (8 = all speculate).
-				const char *senv = getenv("HNSW_GPU_TEAM_SPEC");
-				a.tm_spec = senv ? (uint32_t) std::max(0, atoi(senv)) : (ix->stride > 320 ? 5u : 8u);
+				a.tm_spec = knob_is_set(K_TEAM_SPEC) ? (uint32_t) std::max<long long>(0, knob(K_TEAM_SPEC, 0)) : (ix->stride > 320 ? 5u : 8u);
 			}
 			int maxlds = 64 * 1024;
 			(void) hipDeviceGetAttribute(&maxlds, hipDeviceAttributeMaxSharedMemoryPerBlock, ix->device);
-			const char *wenv = getenv("HNSW_GPU_TEAM_WPB");
-			uint32_t want = wenv && atoi(wenv) > 0 ? (uint32_t) atoi(wenv) : 8u;
+			uint32_t want = knob(K_TEAM_WPB, 0) > 0 ? (uint32_t) knob(K_TEAM_WPB, 0) : 8u;
 			want = std::min(want, 8u);
 			wpb = std::max<uint32_t>(1, (uint32_t) std::min<size_t>(want, ((size_t) maxlds - 8 * sizeof(TeamCtl)) / a.wave_bytes));
 			if (wpb < 2) team = false;
@@ -951,13 +976,17 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	if (!team) { wpb = 4; while (wpb > 1 && (size_t) wpb * a.wave_bytes > 64 * 1024) wpb >>= 1; }
 	a.off_ctl = (uint32_t) ((size_t) wpb * a.wave_bytes);
 	const size_t lds = (size_t) wpb * a.wave_bytes + (team ? wpb * sizeof(TeamCtl) : 0);
-	search_kernel_t kern = pick_search_kernel(func_code, a.kiters, rreg, team, narrow5);
+	const bool lean = narrow5 && !team && !w->pops_next && !w->evals_next && !w->times_next && knob(K_LEAN, 1) != 0;
+	search_kernel_t kern = pick_search_kernel(func_code, a.kiters, rreg, team, narrow5, lean);
 	if (!kern) return fail(HNSW_GPU_ERR_INTERNAL, "no kernel for this configuration");
 	{
 		static const char *const shapes[4] = { "Shape2x4", "Shape4x2", "Shape8x2", "Shape12x2" };
-		const char *shp = (shape_index(a.kiters) == 3 && getenv("HNSW_GPU_SHAPE_12X1")) ? "Shape12x1" : shapes[shape_index(a.kiters)];
+		const char *shp = shapes[shape_index(a.kiters)];
+#ifdef HNSW_EXPERIMENT
+		if (shape_index(a.kiters) == 3 && knob(K_SHAPE_12X1, 0)) shp = "Shape12x1";
+#endif
 		if (narrow5 && !team) shp = "Shape2x2";
-		if (rreg < 0) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_beam<%d, pgemb::%s, %d, %s>", func_code, shp, -rreg, team ? "true" : "false");
+		if (rreg < 0) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_beam<%d, pgemb::%s, %d, %s, %s>", func_code, shp, -rreg, team ? "true" : "false", lean ? "true" : "false");
 		else if (rreg == 3) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_wide<%d, pgemb::%s>", (int) ix->meta.dist_func, shp);
 		else if (rreg >= 2) snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_reg<%d, pgemb::%s, %d>", (int) ix->meta.dist_func, shp, rreg);
 		else snprintf(w->kname, sizeof(w->kname), "pgemb::hnsw_search_kernel_lds<%d, pgemb::%s, %s>", (int) ix->meta.dist_func, shp, rreg == 1 ? "true" : "false");
@@ -967,8 +996,7 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	int per_cu = 0;
 	HIPCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, (int) (wpb * 64), lds));
 	if (per_cu < 1) per_cu = 1;
-	const char *env = getenv("HNSW_GPU_BLOCKS_PER_CU");
-	if (env && atoi(env) > 0) per_cu = std::min(per_cu, atoi(env));
+	if (knob(K_BLOCKS_PER_CU, 0) > 0) per_cu = std::min(per_cu, (int) knob(K_BLOCKS_PER_CU, 0));
 	size_t blocks = std::min<size_t>((nq + wpb - 1) / wpb, (size_t) per_cu * ix->num_cu);
 	a.team_mains = wpb;
 	if (team && nq < (size_t) per_cu * ix->num_cu * wpb)
@@ -978,14 +1006,13 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		a.team_mains = (uint32_t) std::min<size_t>(wpb, (nq + blocks - 1) / blocks);
 	}
 	// (experiment knob: walking waves per block of a team launch — the others help from the start; scripts/exp_spec_ab.py)
-	if (team)
-		if (const char *tm = getenv("HNSW_GPU_TEAM_MAINS"))
-			if (atoi(tm) > 0) a.team_mains = std::min<uint32_t>(a.team_mains, (uint32_t) atoi(tm));
+#ifdef HNSW_EXPERIMENT
+	if (team && knob(K_TEAM_MAINS, 0) > 0) a.team_mains = std::min<uint32_t>(a.team_mains, (uint32_t) knob(K_TEAM_MAINS, 0));
+#endif
 	// (test knob: fewer blocks than the launch would get, so that the waves with queries take SEVERAL each through the
 	// ticket counter while their siblings help — the schedule of a small launch whose other blocks start late,
 	// tests/experiments/team_second_walk_stress.py)
-	if (const char *mb = getenv("HNSW_GPU_MAX_BLOCKS"))
-		if (atoi(mb) > 0) blocks = std::min<size_t>(blocks, (size_t) atoi(mb));
+	if (knob(K_MAX_BLOCKS, 0) > 0) blocks = std::min<size_t>(blocks, (size_t) knob(K_MAX_BLOCKS, 0));
 
 	// workspace: one bitmap + log per resident wave
 	const size_t words = std::max<size_t>(1, (ix->cap + 31) / 32);   // by capacity: stable while the index grows
@@ -1007,8 +1034,8 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	if (__atomic_load_n(&w->abort_sent, __ATOMIC_SEQ_CST))
 	{
 		// the previous launch of this workspace was asked to end early: its waves left their bitmaps as they were
-		fprintf(stderr, "pg_embedding_amd: the previous search launch of this workspace (%s) was asked to end early (abort word): its outputs "
-				"are undefined; the workspace is re-zeroed\n", w->kname);
+		fprintf(stderr, "pg_embedding_amd: the previous search launch of this workspace (%s) was asked to end early (abort word): the queries it did "
+				"not answer have count HNSW_GPU_COUNT_ABORTED; the workspace is re-zeroed\n", w->kname);
 		HIPCHK(hipStreamSynchronize(stream));
 		if (stream) HIPCHK(hipStreamSynchronize(nullptr));
 		if (w->vis) HIPCHK(hipMemset(w->vis, 0, w->vis_slots * w->vis_words * 4));
@@ -1038,12 +1065,14 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		a.set_scratch = w->sets;
 	}
 	a.ticket = w->ticket;
-	if (getenv("HNSW_GPU_TEAM_COUNTERS"))
+#ifdef HNSW_EXPERIMENT
+	if (knob(K_TEAM_COUNTERS, 0))                           // (diagnostic builds only: build.py variant ... HNSW_HOP_STAMPS / HNSW_TEAM_COUNTERS)
 	{
 		if (!w->team_dbg) HIPCHK(hipMalloc(&w->team_dbg, 64));
 		HIPCHK(hipMemsetAsync(w->team_dbg, 0, 64, stream));
 		a.team_dbg = w->team_dbg;
 	}
+#endif
 	a.done = w->done_next;
 	w->done_next = nullptr;
 	a.out_pops = w->pops_next; a.pops_cap = w->pops_cap_next;
@@ -1098,11 +1127,14 @@ extern "C" int hnsw_gpu_search_base_dev(hnsw_gpu_index *ix, const coord_t *d_que
 // millisecond: the device is hung, and polling for ever would hang the caller with it).
 static int poll_limit_s()
 {
-	const char *e = getenv("HNSW_GPU_POLL_LIMIT_S");
-	return e && atoi(e) > 0 ? atoi(e) : 120;
+	knobs_init();
+	return knob(K_POLL_LIMIT_S, 0) > 0 ? (int) knob(K_POLL_LIMIT_S, 0) : 120;
 }
 
-static int poll_done_flag(const volatile uint32_t *flag, const char *what)
+// `w` = the search workspace whose launch is waited for, or nullptr when the wait is for kernels that do not read an abort word
+// (the insert kernels): on a time-out only THAT workspace is asked to end — other mirrors, contexts and shards of the process keep
+// their launches (an abort makes a launch's outputs undefined).
+static int poll_done_flag(const volatile uint32_t *flag, const char *what, SearchWs *w)
 {
 	uint64_t spins = 0;
 	struct timespec t0;
@@ -1122,10 +1154,10 @@ static int poll_done_flag(const volatile uint32_t *flag, const char *what)
 			clock_gettime(CLOCK_MONOTONIC, &t1);
 			if (t1.tv_sec - t0.tv_sec > poll_limit_s())
 			{
-				// ask the launch to end (every wave looks at the abort word between queries and every 256 hops), so that the
+				// ask THIS launch to end (every wave looks at the abort word between queries and every 256 hops), so that the
 				// device is usable again even though this call fails
-				(void) hnsw_gpu_abort_all();
-				return fail(HNSW_GPU_ERR_INTERNAL, "search kernel did not complete %s within %d s (abort requested)", what, poll_limit_s());
+				if (w) { std::lock_guard<std::mutex> g(g_ws_mu); (void) abort_ws_locked(w); }
+				return fail(HNSW_GPU_ERR_INTERNAL, "kernel did not complete %s within %d s%s", what, poll_limit_s(), w ? " (its search launch was asked to end)" : "");
 			}
 		}
 	}
@@ -1154,7 +1186,7 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 	// engine, no interrupt wake-up.  The launch stays on the default stream, so whatever touches this mirror next is
 	// ordered behind the kernel's last instruction, not behind the flags.
 	const size_t fb = round_up(nq * 4, 256);
-	if (nq <= 16 && qb + lb + db + cb + fb <= ((size_t) 4 << 20) && !getenv("HNSW_GPU_NO_POLL"))
+	if (nq <= 16 && qb + lb + db + cb + fb <= ((size_t) 4 << 20) && (knobs_init(), knob(K_NO_POLL, 0) == 0))
 	{
 		if (ix->trace_active) { HIPCHK(hipStreamSynchronize(nullptr)); ix->trace_active = false; }   // an abandoned trace still writes these buffers
 		if (ix->pin_bytes < qb + lb + db + cb + fb)
@@ -1176,7 +1208,7 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 		if (rc) return rc;
 		for (size_t i = 0; i < nq; i++)
 		{
-			rc = poll_done_flag(hf + i, "a query");
+			rc = poll_done_flag(hf + i, "a query", &ix->ws);
 			if (rc) return rc;
 		}
 		memcpy(labels, hl, nq * ef * 8);
@@ -1195,6 +1227,9 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 	HIPCHK(hipMemcpy(labels, dl, nq * ef * 8, hipMemcpyDeviceToHost));
 	if (dists) HIPCHK(hipMemcpy(dists, dd, nq * ef * 4, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(counts, dc, nq * 4, hipMemcpyDeviceToHost));
+	for (size_t i = 0; i < nq; i++)
+		if (counts[i] == ABORTED_COUNT)
+			return fail(HNSW_GPU_ERR_INTERNAL, "the search launch was asked to end early (abort word): query %zu has no result", i);
 	return HNSW_GPU_OK;
 }
 
@@ -1294,7 +1329,7 @@ extern "C" int hnsw_gpu_search_trace_end(hnsw_gpu_index *ix, label_t *labels, di
 	const uint32_t *hc = (const uint32_t *) (h + t.qb + t.lb + t.db), *hs = (const uint32_t *) (h + t.qb + t.lb + t.db + t.cb);
 	const volatile uint32_t *hf = (const volatile uint32_t *) (h + t.qb + t.lb + t.db + t.cb + t.sb + t.pb);
 	{
-		const int prc = poll_done_flag(hf, "the traced query");
+		const int prc = poll_done_flag(hf, "the traced query", &ix->ws);
 		ix->trace_active = false;
 		if (prc) return prc;
 	}
@@ -1373,6 +1408,7 @@ extern "C" int hnsw_gpu_index_health(hnsw_gpu_index *ix, uint32_t *out8)
 	HIPCHK(hipSetDevice(ix->device));
 	HIPCHK(hipMemcpy(out8, ix->ws.health, 32, hipMemcpyDeviceToHost));
 	out8[0] = __atomic_load_n(ix->ws.abort_host, __ATOMIC_SEQ_CST);
+	out8[5] = __atomic_load_n(&ix->ws.abort_requests, __ATOMIC_SEQ_CST);
 	return HNSW_GPU_OK;
 }
 
@@ -2142,8 +2178,8 @@ extern "C" void hnsw_gpu_insert_path_counts(uint64_t out[2])
 
 static bool insert_fused_wanted()
 {
-	const char *e = getenv("HNSW_GPU_INSERT_FUSED");         // 0: the four-launch path of round 3's first half (A/B runs, tests of both)
-	return !(e && e[0] == '0');
+	knobs_init();
+	return knob(K_INSERT_FUSED, 1) != 0;                     // 0: the four-launch path of round 3's first half (A/B runs, tests of both)
 }
 
 // The two-launch insert's shape for this mirror: *lds = 0 when max(efConstruction, maxM + 1) candidates are more than the chain
@@ -2165,11 +2201,13 @@ static int plan_insert(hnsw_gpu_index *ix, InsertArgs *a, size_t *lds)
 	const size_t cap = side;
 	const size_t shared = cap * 8 * 3 + side * (side / 64) * 8 + round_up(maxM + 2, 4) * 4 + 16;
 	const size_t per_wave = ((size_t) b.qpad_floats + 128) * 4;
+	const size_t lds_limit = std::min(LDS_PER_CU, ix->max_lds);                     // what ONE block may ask for on this device
+	if (lds_limit < 2048) return HNSW_GPU_OK;
 	size_t nw = 8;
-	while (nw > 1 && shared + nw * per_wave > LDS_PER_CU - 1024) nw >>= 1;
-	if (shared + nw * per_wave > LDS_PER_CU - 1024) return HNSW_GPU_OK;
+	while (nw > 1 && shared + nw * per_wave > lds_limit - 1024) nw >>= 1;
+	if (shared + nw * per_wave > lds_limit - 1024) return HNSW_GPU_OK;
 	size_t nw2 = 12;                                                                // step 2: up to 12 wavefronts around one target (device_insert.h)
-	while (nw2 > nw && shared + nw2 * per_wave > LDS_PER_CU - 1024) nw2 -= 4;
+	while (nw2 > nw && shared + nw2 * per_wave > lds_limit - 1024) nw2 -= 4;
 	if (nw2 < nw) nw2 = nw;
 	a->nw = (uint32_t) nw; a->nw2 = (uint32_t) nw2; a->side = (uint32_t) side; a->cap = (uint32_t) cap;
 	const size_t o_ci = 0, o_cd = o_ci + round_up(efc * 4, 256), o_cc = o_cd + round_up(efc * 4, 256);
@@ -2206,10 +2244,30 @@ static int insert_impl(hnsw_gpu_index *ix, const coord_t *point, label_t label, 
 	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix || !point || !mine || !others) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
 	if (cand_idx && (!cand_dist || ncand > ix->meta.efConstruction)) return fail(HNSW_GPU_ERR_ARG, "bad candidate list");
+	if (cand_idx)
+	{
+		// the kernels use these numbers as row and link addresses and rely on searchBaseLayer's order: stored elements only,
+		// strictly ascending by (dist, idx) — which also makes them distinct (at most 512 entries: nothing next to the insert)
+		for (uint32_t i = 0; i < ncand; i++)
+		{
+			if (cand_idx[i] >= idx) return fail(HNSW_GPU_ERR_ARG, "candidate %u is element %u, not below the new element %u", i, (unsigned) cand_idx[i], (unsigned) idx);
+			if (cand_dist[i] != cand_dist[i]) return fail(HNSW_GPU_ERR_ARG, "candidate %u has a NaN distance", i);
+			if (i > 0 && !(cand_dist[i - 1] < cand_dist[i] || (cand_dist[i - 1] == cand_dist[i] && cand_idx[i - 1] < cand_idx[i])))
+				return fail(HNSW_GPU_ERR_ARG, "candidates %u and %u are not in ascending (dist, idx) order", i - 1, i);
+		}
+	}
 	if ((size_t) idx != ix->n) return fail(HNSW_GPU_ERR_ARG, "insert_one(%u): the mirror holds %zu elements", (unsigned) idx, ix->n);
 	if (ix->n + 1 > ix->cap) return fail(HNSW_GPU_ERR_ARG, "insert exceeds capacity (%zu)", ix->cap);
 	HIPCHK(hipSetDevice(ix->device));
 	if (ix->trace_active) { HIPCHK(hipStreamSynchronize(nullptr)); ix->trace_active = false; }   // an abandoned trace still writes the staging
+	if (ix->ins_dirty)
+	{
+		// a previous insert failed after its kernels were enqueued: the last-block counters (misc words 3..5) may be non-zero, and
+		// with them every later insert would mis-detect its last block and never store the completion flag
+		HIPCHK(hipDeviceSynchronize());
+		HIPCHK(hipMemset(ix->misc + 3, 0, 12));
+		ix->ins_dirty = false;
+	}
 	const size_t dim = ix->meta.dim, maxM = ix->meta.maxM, ls = ix->lstride;
 	const size_t efc_ = ix->meta.efConstruction;
 	const size_t o_lab = round_up(dim * 4, 8), o_lists = round_up(o_lab + 8, 256), o_flag = o_lists + round_up((maxM + 1) * ls * 4, 256);
@@ -2231,10 +2289,10 @@ static int insert_impl(hnsw_gpu_index *ix, const coord_t *point, label_t label, 
 	int rc;
 	InsertArgs ia;
 	size_t ilds = 0;
-	if (insert_fused_wanted() && plan_insert(ix, &ia, &ilds) == HNSW_GPU_OK && ilds)
+	insert_kernel_t ksel = nullptr, krev = nullptr;
+	bool two_launch = insert_fused_wanted() && plan_insert(ix, &ia, &ilds) == HNSW_GPU_OK && ilds;
+	if (two_launch)
 	{
-		// two launches (device_insert.h): [append +] pair triangle + chain | one block per target + the flag
-		insert_kernel_t ksel, krev;
 		switch ((int) ix->meta.dist_func)
 		{
 			case F_L2:     ksel = insert_select_kernel<F_L2>;        krev = insert_reverse_kernel<F_L2>; break;
@@ -2245,10 +2303,19 @@ static int insert_impl(hnsw_gpu_index *ix, const coord_t *point, label_t label, 
 		std::atomic<size_t> &allowed = lds_allowed[std::min(std::max((int) ix->meta.dist_func, 0), 2)][ix->device & 7];
 		if (ilds > 48 * 1024 && (ilds > allowed.load() || ix->device > 7))
 		{
-			HIPCHK(hipFuncSetAttribute((const void *) ksel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ilds));
-			HIPCHK(hipFuncSetAttribute((const void *) krev, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ilds));
-			allowed.store(ilds);
+			// a device that refuses the carve takes the general builder path (plan_insert's contract), it does not fail the insert
+			if (hipFuncSetAttribute((const void *) ksel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ilds) != hipSuccess ||
+				hipFuncSetAttribute((const void *) krev, hipFuncAttributeMaxDynamicSharedMemorySize, (int) ilds) != hipSuccess)
+			{
+				(void) hipGetLastError();
+				two_launch = false;
+			}
+			else allowed.store(ilds);
 		}
+	}
+	if (two_launch)
+	{
+		// two launches (device_insert.h): [append +] pair triangle + chain | one block per target + the flag
 		ia.b.first = (uint32_t) idx; ia.b.count = 1;
 		ia.bind = idx > 0 ? 1u : 0u;
 		ia.lists_out = lists; ia.flag = (uint32_t *) (h + o_flag);
@@ -2282,9 +2349,23 @@ static int insert_impl(hnsw_gpu_index *ix, const coord_t *point, label_t label, 
 			return fail(HNSW_GPU_ERR_HIP, "insert step 1 did not launch: %s", hipGetErrorString(le));
 		}
 		hipLaunchKernelGGL(krev, dim3((uint32_t) ix->meta.M), dim3(ia.nw2 * 64), ilds, 0, ia);
-		HIPCHK(hipGetLastError());
-		rc = poll_done_flag(flag, "an insert");
-		if (rc) return rc;
+		if (hipError_t le = hipGetLastError(); le != hipSuccess)
+		{
+			// step 1 runs (row, label, own list), step 2 never will: no element points at the new one, so the mirror without it is
+			// the mirror before the call; step 1's last block has reset its own counter, the next insert re-checks all three
+			(void) hipStreamSynchronize(nullptr);
+			ix->n = idx;
+			ix->ins_dirty = true;
+			return fail(HNSW_GPU_ERR_HIP, "insert step 2 did not launch: %s", hipGetErrorString(le));
+		}
+		rc = poll_done_flag(flag, "an insert", nullptr);
+		if (rc)
+		{
+			// the element is stored and (partly) linked: the graph is searchable but not the reference's; the caller sees the error
+			// and re-mirrors (embedding_shim.cpp drops its mirror on any insert error)
+			ix->ins_dirty = true;
+			return rc;
+		}
 		compact_lists(lists, maxM, ls, mine, others);
 		g_inserts_two_launch++;
 		return HNSW_GPU_OK;
@@ -2309,8 +2390,8 @@ static int insert_impl(hnsw_gpu_index *ix, const coord_t *point, label_t label, 
 	hipLaunchKernelGGL(gather_link_lists_kernel, dim3((uint32_t) maxM + 1), dim3(64), 0, 0, ix->links, (uint32_t) ls, (uint32_t) idx,
 					   (uint32_t) ix->n, lists, ix->misc + 3, (uint32_t *) (h + o_flag));
 	HIPCHK(hipGetLastError());
-	rc = poll_done_flag(flag, "an insert");
-	if (rc) return rc;
+	rc = poll_done_flag(flag, "an insert", nullptr);
+	if (rc) { ix->ins_dirty = true; return rc; }
 	compact_lists(lists, maxM, ls, mine, others);
 	return HNSW_GPU_OK;
 }
@@ -2537,13 +2618,24 @@ extern "C" int hnsw_gpu_gather_roof(hnsw_gpu_index *ix, int loads_per_lane, int 
 // Replay roof (device_roof.h): the rows a traced launch scored, gathered again by `slots` resident waves in the same query
 // order with nothing in between.  d_stats = that launch's stats array ({evals, hops} per query).  *ms = best of 3 timed
 // repetitions (after one warm-up), *bytes = row bytes one repetition reads.
+extern "C" int hnsw_gpu_replay_roof_parts(hnsw_gpu_index *ix, const idx_t *d_evals, size_t evals_cap, const uint32_t *d_stats, size_t nq,
+										  unsigned slots, int kb, int rpg, unsigned parts, float *ms, double *bytes, uint64_t *word_sum);
 extern "C" int hnsw_gpu_replay_roof(hnsw_gpu_index *ix, const idx_t *d_evals, size_t evals_cap, const uint32_t *d_stats, size_t nq,
 									unsigned slots, int kb, int rpg, float *ms, double *bytes, uint64_t *word_sum)
+{
+	return hnsw_gpu_replay_roof_parts(ix, d_evals, evals_cap, d_stats, nq, slots, kb, rpg, 1, ms, bytes, word_sum);
+}
+
+// The same with every query's trace cut into `parts` equal pieces gathered by different waves: the roof of a launch that gives one
+// walk's rows to `parts` waves (fewer queries than resident waves).
+extern "C" int hnsw_gpu_replay_roof_parts(hnsw_gpu_index *ix, const idx_t *d_evals, size_t evals_cap, const uint32_t *d_stats, size_t nq,
+										  unsigned slots, int kb, int rpg, unsigned parts, float *ms, double *bytes, uint64_t *word_sum)
 {
 	std::unique_lock<std::recursive_mutex> lock_;
 	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
 	if (!ix || !d_evals || !d_stats || !ms) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
 	if (ix->n == 0 || nq == 0 || slots < 4 || evals_cap == 0) return fail(HNSW_GPU_ERR_ARG, "need rows, queries and at least 4 slots");
+	if (parts == 0 || parts > 64 || nq * (size_t) parts >= 0xFFFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "parts must be 1..64");
 	HIPCHK(hipSetDevice(ix->device));
 	const uint32_t row_f4 = ix->stride / 4;
 	const uint32_t blocks = slots / 4;
@@ -2564,8 +2656,8 @@ extern "C" int hnsw_gpu_replay_roof(hnsw_gpu_index *ix, const idx_t *d_evals, si
 		switch (shape)
 		{
 #define ROOF(K, R) case K * 100 + R: \
-				if (word_sum) hipLaunchKernelGGL((replay_roof_kernel<K, R, true>), dim3(blocks), dim3(256), 4 * REPLAY_STAGE * 4, nullptr, base, row_f4, d_evals, (uint32_t) evals_cap, d_stats, (uint32_t) nq, ticket, out, d_check); \
-				else hipLaunchKernelGGL((replay_roof_kernel<K, R, false>), dim3(blocks), dim3(256), 4 * REPLAY_STAGE * 4, nullptr, base, row_f4, d_evals, (uint32_t) evals_cap, d_stats, (uint32_t) nq, ticket, out, d_check); \
+				if (word_sum) hipLaunchKernelGGL((replay_roof_kernel<K, R, true>), dim3(blocks), dim3(256), 4 * REPLAY_STAGE * 4, nullptr, base, row_f4, d_evals, (uint32_t) evals_cap, d_stats, (uint32_t) nq, (uint32_t) parts, ticket, out, d_check); \
+				else hipLaunchKernelGGL((replay_roof_kernel<K, R, false>), dim3(blocks), dim3(256), 4 * REPLAY_STAGE * 4, nullptr, base, row_f4, d_evals, (uint32_t) evals_cap, d_stats, (uint32_t) nq, (uint32_t) parts, ticket, out, d_check); \
 				break
 			ROOF(2, 2); ROOF(2, 4); ROOF(2, 8); ROOF(4, 2); ROOF(4, 4); ROOF(8, 2); ROOF(12, 1); ROOF(12, 2); ROOF(6, 4);
 #undef ROOF
@@ -2669,7 +2761,7 @@ extern "C" int hnsw_gpu_sharded_create(hnsw_gpu_index *const *shards, size_t nsh
 		else
 		{
 			int can = 0;
-			if (hipDeviceCanAccessPeer(&can, dev, s->home) == hipSuccess && can && !getenv("HNSW_GPU_SHARDED_NO_PEER"))
+			if (hipDeviceCanAccessPeer(&can, dev, s->home) == hipSuccess && can && (knobs_init(), knob(K_SHARDED_NO_PEER, 0) == 0))
 			{
 				const hipError_t pe = hipDeviceEnablePeerAccess(s->home, 0);
 				if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) s->direct[i] = true;

@@ -311,13 +311,14 @@ class GpuIndex:
                                                 out["times"].data_ptr(), s), "hnsw_gpu_search_traced_dev")
         return out
 
-    def replay_roof(self, traced: dict, slots: int, kb: int = 12, rpg: int = 2, word_sum: bool = False):
+    def replay_roof(self, traced: dict, slots: int, kb: int = 12, rpg: int = 2, word_sum: bool = False, parts: int = 1):
         """(ms, bytes) of hnsw_gpu_replay_roof over the trace of a search_traced_torch launch with load shape <kb, rpg>; with
-        word_sum=True also the sum mod 2^64 of the bit patterns of every word the replay read for the trace (tests)."""
+        word_sum=True also the sum mod 2^64 of the bit patterns of every word the replay read for the trace (tests); parts > 1:
+        every query's trace is cut into that many pieces gathered by different waves (hnsw_gpu_replay_roof_parts)."""
         ms, by, ws = C.c_float(0), C.c_double(0), C.c_uint64(0)
         ev = traced["evals"]
-        check(self.L.hnsw_gpu_replay_roof(self._h, ev.data_ptr(), ev.shape[1], traced["stats"].data_ptr(), ev.shape[0], slots, kb, rpg,
-                                          C.byref(ms), C.byref(by), C.byref(ws) if word_sum else None), "hnsw_gpu_replay_roof")
+        check(self.L.hnsw_gpu_replay_roof_parts(self._h, ev.data_ptr(), ev.shape[1], traced["stats"].data_ptr(), ev.shape[0], slots, kb, rpg,
+                                                parts, C.byref(ms), C.byref(by), C.byref(ws) if word_sum else None), "hnsw_gpu_replay_roof")
         return (float(ms.value), float(by.value), int(ws.value)) if word_sum else (float(ms.value), float(by.value))
 
     def health(self) -> dict:
@@ -325,7 +326,7 @@ class GpuIndex:
         v = (C.c_uint32 * 8)()
         check(self.L.hnsw_gpu_index_health(self._h, v), "hnsw_gpu_index_health")
         return {"abort_pending": int(v[0]), "slice_timeouts": int(v[1]), "package_timeouts": int(v[2]), "aborted_waves": int(v[3]),
-                "slices_delivered": int(v[4])}
+                "slices_delivered": int(v[4]), "abort_requests": int(v[5])}
 
     def abort(self) -> None:
         """Ask the search launches of this mirror that are in flight to end (callable from any thread)."""

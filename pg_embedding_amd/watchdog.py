@@ -39,9 +39,13 @@ def _expire(seconds: float) -> None:
     os._exit(124)
 
 
-def arm(default_seconds: float = 900.0, kernel_seconds: float = 120.0) -> float:
-    """Start the limit (once per process).  Returns the limit in seconds."""
+def arm(default_seconds: float = 900.0, kernel_seconds: float = 120.0, env_sync: bool = True) -> float:
+    """Start the limit (once per process).  Returns the limit in seconds.
+    env_sync: experiment scripts flip HNSW_GPU_* knobs through os.environ while they run; the library reads its environment once,
+    so pg_embedding_amd forwards such changes before every launch (PGEMB_ENV_SYNC, _lib.sync_env).  bench.py switches it off."""
     global _armed
+    if env_sync:
+        os.environ.setdefault("PGEMB_ENV_SYNC", "1")
     seconds = default_seconds
     if "--timeout" in sys.argv:
         i = sys.argv.index("--timeout")

@@ -48,6 +48,7 @@ for bpc in bpcs:
             ix.search_torch(Q, ef, out=out)
             ms.append(ix.last_search_ms())
         best = min(ms)
+        spread = f" [min/median/max {min(ms):.3f}/{sorted(ms)[len(ms) // 2]:.3f}/{max(ms):.3f} ms over {len(ms)}]"
         import zlib
         sig = zlib.crc32(out["labels"].cpu().numpy().tobytes()) ^ zlib.crc32(out["dists"].cpu().numpy().tobytes()) ^ zlib.crc32(st.tobytes())
         stamps = ""
@@ -59,4 +60,4 @@ for bpc in bpcs:
                          f" | per query: walk {c[6] * 64 / nq:.0f} emit+cleanup {c[7] * 64 / nq:.0f} hops {c[0] / nq:.1f}"
         print(f"dim {dim} m {m} {metric} sift={sift} nq={nq:6d} blocks/CU={bpc or 'max'} slots={ix.last_search_slots():5d} "
               f"E_q {st[:, 0].mean():.0f} H_q {st[:, 1].mean():.0f} kernel {best:8.3f} ms {nq / best * 1e3:10.0f} q/s "
-              f"{byt / best / 1e6:7.0f} GB/s alg = {byt / best / 1e6 / 8000:.3f} of 8 TB/s  [{ix.last_search_kernel()}] crc {sig:08x}{stamps}", flush=True)
+              f"{byt / best / 1e6:7.0f} GB/s alg = {byt / best / 1e6 / 8000:.3f} of 8 TB/s  [{ix.last_search_kernel()}] crc {sig:08x}{stamps}{spread}", flush=True)

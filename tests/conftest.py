@@ -20,6 +20,11 @@ def pytest_configure(config):
 # instead of keeping the device until somebody's limit kills the process.  Read once, at the library's first workspace.
 os.environ.setdefault("HNSW_GPU_WATCHDOG_S", "120")
 
+# The library resolves its knobs once and never reads the environment on a call path (hnsw_gpu_config_set is how a host changes
+# one later).  The tests flip kernel forms by changing HNSW_GPU_* variables inside one process: with this set, pg_embedding_amd
+# forwards such changes to the library before every launch (pg_embedding_amd/_lib.py, sync_env); child processes inherit it.
+os.environ.setdefault("PGEMB_ENV_SYNC", "1")
+
 
 def pytest_collection_modifyitems(config, items):
     """A device test that never returns must end the run with a failure, not hang it: pytest-timeout's watchdog thread

@@ -32,24 +32,36 @@ def build_tree(csrc=CSRC, tag="", edit=None, force=False, verbose=False):
     os.makedirs(src)
     pins = 0
     for f in sorted(os.listdir(csrc)):                      # copies, so that quoted includes resolve among them
-        if f.endswith(".h") or f == "hnsw_gpu.hip":
+        if f.endswith(".h") or f in ("hnsw_gpu.hip", "search_inst.hip"):
             txt = open(os.path.join(csrc, f)).read()
             pins += txt.count('"+s"')
             txt = txt.replace('"+s"', '"+r"')
             if edit:
                 txt = edit(f, txt)
-            open(os.path.join(src, "hnsw_gpu_emu.cpp" if f == "hnsw_gpu.hip" else f), "w").write(txt)
+            open(os.path.join(src, {"hnsw_gpu.hip": "hnsw_gpu_emu.cpp", "search_inst.hip": "search_inst_emu.cpp"}.get(f, f)), "w").write(txt)
     assert pins == 1, "the emulator build expects exactly one scalar-register asm pin"
     cxx = CLANG if os.path.exists(CLANG) else "clang++"
-    cmd = [cxx, "-x", "c++", "-O0", "-std=c++17", "-mavx2", "-mfma", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
-           "-Wno-unused-value", "-Wno-pass-failed", "-Wno-unknown-attributes",
-           "-I", src, "-I", EMU, "-I", os.path.join(ROOT, "include"),
-           os.path.join(src, "hnsw_gpu_emu.cpp"), os.path.join(EMU, "sort_pairs_emu.cpp"), "-o", lib]
-    if verbose:
-        print(" ".join(cmd))
+    flags = ["-x", "c++", "-O0", "-std=c++17", "-mavx2", "-mfma", "-ffp-contract=off", "-fPIC", "-pthread",
+             "-Wno-unused-value", "-Wno-pass-failed", "-Wno-unknown-attributes",
+             "-I", src, "-I", EMU, "-I", os.path.join(ROOT, "include")]
+    # the product's translation units (build.py): the host code and one unit per load shape of the search kernels, in parallel
+    units = [("hnsw_gpu_emu", os.path.join(src, "hnsw_gpu_emu.cpp"), []), ("sort_pairs_emu", os.path.join(EMU, "sort_pairs_emu.cpp"), [])]
+    if os.path.exists(os.path.join(src, "search_inst_emu.cpp")):
+        units += [(f"search_inst_{k}", os.path.join(src, "search_inst_emu.cpp"), [f"-DSEARCH_INST_SHAPE={k}"]) for k in range(1, 6)]
+    procs = []
+    for name, path, extra in units:
+        cmd = [cxx] + flags + extra + ["-c", path, "-o", os.path.join(src, name + ".o")]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    for cmd, pr in procs:
+        _, err = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError("SIMT emulator build failed:\n" + " ".join(cmd) + "\n" + err[-6000:])
+    cmd = [cxx, "-shared", "-pthread"] + [os.path.join(src, name + ".o") for name, _, _ in units] + ["-o", lib]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
-        raise RuntimeError("SIMT emulator build failed:\n" + r.stderr[-6000:])
+        raise RuntimeError("SIMT emulator link failed:\n" + r.stderr[-6000:])
     return lib
 
 

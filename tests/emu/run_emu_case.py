@@ -225,14 +225,18 @@ def abort():
         t = threading.Timer(1.0, lambda: ix.abort())
         t0 = time.time()
         t.start()
-        ix.search(Q, ef)
+        said = ""
+        try:
+            ix.search(Q, ef)
+        except RuntimeError as e:                              # the host-pointer form reports an interrupted launch (include/hnsw_gpu.h)
+            said = str(e)
         took = time.time() - t0
         h = ix.health()
         Q2 = gmm(12, dim, k=10, seed=10)
         want = port.search_many(Q2, ef, nthreads=4)
         bad = wrong(ix.search(Q2, ef), want, 12)
         out.append({"env": env, "kernel": ix.last_search_kernel(), "seconds_until_the_launch_ended": round(took, 2), "health_after_abort": h,
-                    "health_after_next": ix.health(), "wrong_after": bad})
+                    "health_after_next": ix.health(), "wrong_after": bad, "error_of_the_interrupted_call": said})
         ix.close()
     return out
 

@@ -329,7 +329,6 @@ def test_many_queries_reuse_slots():
     {"HNSW_GPU_HASH_ENTRIES": "512"},        # tiny LDS visited set: most ids spill to the HBM bitmap
     {"HNSW_GPU_HASH_ENTRIES": "0"},          # bitmap only
     {"HNSW_GPU_FORCE_LDS_HEAPS": "1"},       # generic kernel (sorted arrays in LDS) at small ef
-    {"HNSW_GPU_SHAPE_12X1": "1"},
     {"HNSW_GPU_BEAM": "0"},                  # two-set register form instead of the beam form
     {"HNSW_GPU_BEAM": "0", "HNSW_GPU_HASH_ENTRIES": "512"},
     {"HNSW_GPU_BEAM16": "0"},                # ef in (256, 512]: LDS form instead of 16 set registers

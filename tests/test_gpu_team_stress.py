@@ -185,14 +185,24 @@ def test_a_launch_that_is_asked_to_end_does_end(env, monkeypatch):
     torch.cuda.synchronize()
     t0 = time.time()
     with torch.cuda.stream(side):
-        ix.search_torch(Q, ef)
+        big = ix.search_torch(Q, ef)
     time.sleep(0.05)
     ix.abort()
     side.synchronize()
     took = time.time() - t0
     h = ix.health()
     print(f"\n[abort {env}] kernel {ix.last_search_kernel()}: launch ended {took * 1e3:.0f} ms after it began; health {h}")
-    assert h["aborted_waves"] > 0 and h["abort_pending"] == 1, h
+    assert h["aborted_waves"] > 0 and h["abort_pending"] == 1 and h["abort_requests"] == 1, h
+    # what an interrupted launch leaves is defined per query (include/hnsw_gpu.h): a result with its count, or HNSW_GPU_COUNT_ABORTED
+    cnt = big["counts"].cpu().numpy()
+    unanswered = cnt == 0xFFFFFFFF
+    assert unanswered.any() and (cnt[~unanswered] <= ef).all(), (int(unanswered.sum()), cnt[~unanswered].max() if (~unanswered).any() else None)
+    answered = np.nonzero(~unanswered)[0]
+    if len(answered):                                           # ... and the results it did deliver are results
+        pick = answered[:: max(1, len(answered) // 64)][:64]
+        wantb = port.search_many(Q[pick].cpu().numpy(), ef, nthreads=8)
+        gotl = big["labels"].cpu().numpy().view(np.uint64)[pick]
+        assert (gotl == wantb["labels"]).all(), "a query the interrupted launch answered differs from the oracle"
     Q2 = gmm(300, dim, k=40, seed=78, stream=2)
     want = port.search_many(Q2, ef, nthreads=8)
     out = ix.search_torch(torch.from_numpy(Q2).cuda(), ef, stats=True)

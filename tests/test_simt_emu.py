@@ -38,8 +38,8 @@ def test_every_kernel_form_walks_and_emits_like_the_oracle(emu_lib):
     bad = [r for r in res if r["wrong"]]
     assert not bad, bad
     kernels = {r["kernel"] for r in res}
-    for needle in ("hnsw_search_kernel_beam<0, pgemb::Shape2x2, 2, false>", "hnsw_search_kernel_reg<", "hnsw_search_kernel_lds<",
-                   "Shape12x2, 2, true>", "Shape4x2", "kernel_beam<1,", "kernel_beam<2,"):
+    for needle in ("hnsw_search_kernel_beam<0, pgemb::Shape2x2, 2, false, true>", "hnsw_search_kernel_reg<", "hnsw_search_kernel_lds<",
+                   "Shape12x2, 2, true, false>", "Shape4x2", "kernel_beam<1,", "kernel_beam<2,"):
         assert any(needle in k for k in kernels), (needle, sorted(kernels))
 
 
@@ -125,6 +125,7 @@ def test_a_launch_that_is_asked_to_end_does_end(emu_lib):
         assert r["seconds_until_the_launch_ended"] < 30, r
         assert r["health_after_abort"]["aborted_waves"] > 0 and r["health_after_abort"]["abort_pending"] == 1, r
         assert r["health_after_next"]["abort_pending"] == 0 and r["wrong_after"] == 0, r
+        assert "asked to end early" in r["error_of_the_interrupted_call"], r
 
 
 def test_the_evaluation_trace_is_the_walk_and_the_replay_runs_over_it(emu_lib):
