@@ -159,6 +159,11 @@ int hnsw_gpu_last_search_ms(hnsw_gpu_index *ix, float *ms);
 /* Same for the launch `back` launches ago (0 = most recent; the last 64 are kept). */
 int hnsw_gpu_search_ms(hnsw_gpu_index *ix, unsigned back, float *ms);
 
+/* Where the device time of the last hnsw_gpu_search_batch call (host pointers, more than 16 queries: the copy path) went:
+ * out[0] = upload of the queries, out[1] = the search kernel, out[2] = download of labels / distances / counts, in milliseconds
+ * (HIP events on the default stream around the three steps; SURVEY.md 8(d): the PCIe share is reported, never hidden). */
+int hnsw_gpu_last_batch_ms(hnsw_gpu_index *ix, float out[3]);
+
 /* Symbol of the kernel the mirror's last search launch ran, spelled as rocprofv3 prints it
  * (e.g. "pgemb::hnsw_search_kernel_beam<0, pgemb::Shape12x2, 4>"), so a bench line and a kernel trace
  * can be matched by name. */
@@ -228,6 +233,16 @@ int hnsw_gpu_abort_all(void);
 int  hnsw_gpu_config_set(const char *name, const char *value);
 int  hnsw_gpu_config_get(const char *name, long long *value);
 void hnsw_gpu_config_reload(void);
+
+/* Tail split.  A launch ends with its slowest walks: once its queries run out the resident waves leave one by one and the device
+ * drains for about one long walk (a fifth of a 40 000-query launch on 128-float rows).  hnsw_gpu_search_batch[_dev] and
+ * hnsw_gpu_search_base_dev therefore send the LAST queries of a mid-size batch (2x to 16x the resident slots) out as a second
+ * launch on an internal stream at the same moment: its blocks are placed as the main launch's blocks retire — in its drain — and
+ * being a small launch it runs as a team, so its own drain is short.  Per-query results do not depend on which part ran a query;
+ * both parts are ordered on the caller's stream like one launch, and hnsw_gpu_last_search_ms covers both.  HNSW_GPU_SPLIT=0
+ * switches it off, =T forces a tail of T queries.  *tail_queries = the tail part of the mirror's last call (0 = one launch),
+ * kernel (may be NULL) = the symbol the tail part ran. */
+int hnsw_gpu_last_search_tail(hnsw_gpu_index *ix, uint32_t *tail_queries, char *kernel, size_t len);
 
 /* Resident query slots (waves) the last search launch used — occupancy figure. */
 int hnsw_gpu_last_search_slots(hnsw_gpu_index *ix, uint32_t *slots);
@@ -349,6 +364,11 @@ int    hnsw_gpu_sharded_search_dev(hnsw_gpu_sharded *s, const coord_t *d_queries
 								   label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, void *stream);
 int    hnsw_gpu_sharded_search(hnsw_gpu_sharded *s, const coord_t *queries, size_t nq, size_t ef,
 							   label_t *labels, dist_t *dists, uint32_t *counts);
+/* Where the time of the last sharded call went, from HIP events on each shard's own device (waits for the call): search_ms[i] =
+ * shard i's search kernel (with peer access its result stores over xGMI are part of it), peer_ms[i] = what followed on that
+ * shard's stream until its lists were in the merge device's buffer (the staged peer copy; ~0 with direct stores), *merge_ms = the
+ * merge kernel, direct[i] (may be NULL) = 1 when shard i writes the merge device's memory itself.  Arrays of nshards values. */
+int    hnsw_gpu_sharded_last_ms(hnsw_gpu_sharded *s, float *search_ms, float *peer_ms, float *merge_ms, int *direct);
 
 /* ------------------------------------------------------------------ measurement */
 

@@ -169,6 +169,7 @@ struct SearchWs
 	hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};
 	uint64_t launches = 0;
 	uint32_t last_slots = 0;
+	size_t last_nq = 0, last_ef = 0;                     // ... and its size: the tail split (search_split) sizes itself by the launch before
 	uint32_t *done_next = nullptr;                       // completion flags for the next launch only
 	uint32_t *pops_next = nullptr; uint32_t pops_cap_next = 0;   // pop-sequence output for the next launch only
 	uint32_t *evals_next = nullptr; uint32_t evals_cap_next = 0; uint64_t *times_next = nullptr;   // evaluation trace, next launch only
@@ -331,6 +332,12 @@ struct hnsw_gpu_index
 	uint32_t *links = nullptr;
 	uint64_t *labels = nullptr;
 	SearchWs ws;              // default search state (grow-only)
+	// tail split (search_split): a second workspace + an internal stream for the LAST queries of a mid-size batch, launched beside
+	// the main launch so that its walks fill the main launch's drain; made on first use
+	SearchWs ws2; bool ws2_ready = false;
+	hipStream_t split_stream = nullptr;
+	hipEvent_t sp_ready = nullptr, sp_done = nullptr;
+	uint64_t splits = 0; uint32_t last_tail = 0;
 	uint64_t generation = 0;  // bumped when capacity changes (bitmap width changes)
 	uint32_t *misc = nullptr; // small device scratch words (import error counter, ...)
 	// scratch for the host-pointer entry points
@@ -347,6 +354,8 @@ struct hnsw_gpu_index
 	float *xnorm = nullptr; size_t xnorm_n = 0, xnorm_cap = 0;
 	void *bf = nullptr; size_t bf_bytes = 0;
 	hipEvent_t bf_e0 = nullptr, bf_e1 = nullptr;
+	// hnsw_gpu_search_batch, copy path: before the upload / after the last download (hnsw_gpu_last_batch_ms)
+	hipEvent_t hb0 = nullptr, hb1 = nullptr; bool hb_valid = false;
 };
 
 static int ensure_scratch(hnsw_gpu_index *ix, size_t bytes)
@@ -422,6 +431,10 @@ extern "C" void hnsw_gpu_index_destroy(hnsw_gpu_index *ix)
 	if (ix->links) (void) hipFree(ix->links);
 	if (ix->labels) (void) hipFree(ix->labels);
 	ws_free(&ix->ws);
+	if (ix->ws2_ready) ws_free(&ix->ws2);
+	if (ix->split_stream) (void) hipStreamDestroy(ix->split_stream);
+	if (ix->sp_ready) (void) hipEventDestroy(ix->sp_ready);
+	if (ix->sp_done) (void) hipEventDestroy(ix->sp_done);
 	if (ix->misc) (void) hipFree(ix->misc);
 	if (ix->scratch) (void) hipFree(ix->scratch);
 	if (ix->pin) (void) hipHostFree(ix->pin);
@@ -431,6 +444,8 @@ extern "C" void hnsw_gpu_index_destroy(hnsw_gpu_index *ix)
 	if (ix->bf) (void) hipFree(ix->bf);
 	if (ix->bf_e0) (void) hipEventDestroy(ix->bf_e0);
 	if (ix->bf_e1) (void) hipEventDestroy(ix->bf_e1);
+	if (ix->hb0) (void) hipEventDestroy(ix->hb0);
+	if (ix->hb1) (void) hipEventDestroy(ix->hb1);
 	delete ix;
 }
 
@@ -762,9 +777,11 @@ static const size_t SET_BUDGET_BYTES = (size_t) 8 << 30;      // cap on the HBM 
 // device_search_wide.h; what bounds a beam is the per-slot scratch, 24 bytes per result slot, under SET_BUDGET_BYTES)
 static const size_t WIDE_EF_MIN = 2048;
 
+// tail = the launch is the tail part of a split batch (search_split): it runs as a team whatever the row width, because it exists
+// to END early — its walks start on slots another launch is leaving and every one of them should have helpers.
 static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries, size_t q_stride, size_t nq, size_t ef, int mode,
 						 uint64_t *d_labels, uint32_t *d_idx, float *d_dists, uint32_t *d_counts,
-						 uint32_t *d_stats, hipStream_t stream)
+						 uint32_t *d_stats, hipStream_t stream, bool tail = false)
 {
 	std::unique_lock<std::recursive_mutex> lock_;
 	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
@@ -830,7 +847,7 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	// Team form wanted for this launch?  (decided for good further down, once the LDS carve is known)
 	const int treq = (int) knob(K_TEAM, -1);
 	const size_t auto_nq = (size_t) knob(K_TEAM_MAX_NQ, (long long) ix->num_cu);
-	const bool team_wanted = rreg < 0 && !reforder && treq != 0 && (treq > 0 || ix->stride > 320 || nq <= auto_nq);
+	const bool team_wanted = rreg < 0 && !reforder && treq != 0 && (treq > 0 || ix->stride > 320 || nq <= auto_nq || tail);
 	// narrow rows, hot form: beam kernel with <= 4 set registers, one sum per row (L2 / Manhattan), not a team
 	const bool narrow5 = shape_index(a.kiters) == 0 && (rreg == -2 || rreg == -4) && (int) ix->meta.dist_func != F_COSINE &&
 						 !team_wanted && !reforder && knob(K_NARROW5, 1) != 0;
@@ -1089,6 +1106,89 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	HIPCHK(hipEventRecord(w->ev1[evi], stream));
 	__atomic_store_n(&w->launches, w->launches + 1, __ATOMIC_SEQ_CST);
 	w->last_slots = (uint32_t) slots;
+	w->last_nq = nq; w->last_ef = ef;
+	return HNSW_GPU_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// Tail split.  A launch ends with its slowest walks: once the ticket counter runs out, the resident waves leave one by one and
+// the chip drains for about one long walk — 1.1 ms of a 5.9 ms launch of 40 000 queries on 128-float rows (5 120 waves, a walk is
+// 0.44-0.77 ms, the longest 1.6 ms: profiles/r4a_c2_regression_and_timelines.txt: 78 % of the slot time is walks), 1.4 ms of a 6.8 ms
+// launch of 10 000 queries at 768 floats.  The walks cannot be shortened or reordered, but the drain can be FILLED: the last T
+// queries of the batch go out as a second launch on an internal stream at the same moment.  The main launch's grid takes every
+// resident slot first (it is a fixed set of waves pulling tickets), so the second launch's blocks are placed as the main launch's
+// blocks retire — exactly in its drain — and because it is a small launch it runs as a team (every walk with helpers from its
+// first hop), i.e. its own drain is the short one of a handful of fast walks.  Same kernels, same per-query results (a query's walk
+// does not depend on which launch runs it); both parts are ordered on the caller's stream (the internal stream waits for the
+// caller's work enqueued so far, the caller's stream waits for the tail part before anything after the call).
+// Used for batches of 2x to 16x the resident slots of the previous launch of the same shape (smaller batches are teams already,
+// larger ones amortise their drain; the headline 40 000 x 768 launch is not split); HNSW_GPU_SPLIT=0 switches it off, = T forces
+// a tail of T queries.
+// ------------------------------------------------------------------------------------
+static size_t split_tail_size(hnsw_gpu_index *ix, size_t nq, size_t ef)
+{
+	knobs_init();
+	const long long k = knob(K_SPLIT, -1);
+	if (k == 0) return 0;
+	if (k > 0) return (size_t) k < nq ? (size_t) k : 0;
+	const SearchWs &w = ix->ws;
+	if (w.last_slots == 0 || w.last_ef != ef || w.last_nq < w.last_slots) return 0;      // no full launch of this shape to go by
+	const size_t slots = w.last_slots;
+	if (nq < 2 * slots || nq > 16 * slots) return 0;
+	size_t t = nq / 8;
+	t = std::min(t, slots / 2);
+	t = std::max<size_t>(t, 256);
+	return t & ~(size_t) 63;
+}
+
+static int search_split(hnsw_gpu_index *ix, const float *d_queries, size_t nq, size_t ef, int mode,
+						uint64_t *d_labels, uint32_t *d_idx, float *d_dists, uint32_t *d_counts, uint32_t *d_stats, hipStream_t stream)
+{
+	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
+	std::unique_lock<std::recursive_mutex> lock_(ix->mu);
+	const size_t dim = ix->meta.dim;
+	const bool plain = !ix->ws.done_next && !ix->ws.pops_next && !ix->ws.evals_next && !ix->ws.times_next && d_queries && d_counts;
+	const size_t T = plain ? split_tail_size(ix, nq, ef) : 0;
+	ix->last_tail = 0;
+	if (T == 0 || T >= nq)
+		return launch_search(ix, &ix->ws, d_queries, dim, nq, ef, mode, d_labels, d_idx, d_dists, d_counts, d_stats, stream);
+	HIPCHK(hipSetDevice(ix->device));
+	if (!ix->ws2_ready)
+	{
+		int rc = ws_init(&ix->ws2);
+		if (rc) return rc;
+		ix->ws2_ready = true;
+	}
+	if (!ix->split_stream) HIPCHK(hipStreamCreateWithFlags(&ix->split_stream, hipStreamNonBlocking));
+	if (!ix->sp_ready)
+	{
+		HIPCHK(hipEventCreateWithFlags(&ix->sp_ready, hipEventDisableTiming));
+		HIPCHK(hipEventCreateWithFlags(&ix->sp_done, hipEventDisableTiming));
+	}
+	const size_t n1 = nq - T, stride = ef;                                     // (output rows are the caller's ef apart)
+	HIPCHK(hipEventRecord(ix->sp_ready, stream));                              // the queries (and whatever else the caller enqueued) are ready
+	HIPCHK(hipStreamWaitEvent(ix->split_stream, ix->sp_ready, 0));
+	int rc = launch_search(ix, &ix->ws, d_queries, dim, n1, ef, mode, d_labels, d_idx, d_dists, d_counts, d_stats, stream);
+	if (rc) return rc;
+	rc = launch_search(ix, &ix->ws2, d_queries + n1 * dim, dim, T, ef, mode, d_labels ? d_labels + n1 * stride : nullptr,
+					   d_idx ? d_idx + n1 * stride : nullptr, d_dists ? d_dists + n1 * stride : nullptr, d_counts + n1,
+					   d_stats ? d_stats + 2 * n1 : nullptr, ix->split_stream, true);
+	if (rc) { (void) hipStreamSynchronize(stream); return rc; }
+	HIPCHK(hipEventRecord(ix->sp_done, ix->split_stream));
+	HIPCHK(hipStreamWaitEvent(stream, ix->sp_done, 0));
+	// the call's device time (hnsw_gpu_last_search_ms) = from the main launch's start to the end of BOTH parts
+	HIPCHK(hipEventRecord(ix->ws.ev1[(ix->ws.launches - 1) % SearchWs::EV_RING], stream));
+	ix->ws.last_nq = nq;                                                       // the shape the NEXT call sizes its split by is this call's
+	ix->splits++;
+	ix->last_tail = (uint32_t) T;
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_last_search_tail(hnsw_gpu_index *ix, uint32_t *tail_queries, char *kernel, size_t len)
+{
+	if (!ix || !tail_queries) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	*tail_queries = ix->last_tail;
+	if (kernel && len) snprintf(kernel, len, "%s", ix->last_tail && ix->ws2_ready ? ix->ws2.kname : "");
 	return HNSW_GPU_OK;
 }
 
@@ -1096,7 +1196,7 @@ extern "C" int hnsw_gpu_search_batch_dev(hnsw_gpu_index *ix, const coord_t *d_qu
 										 label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
 										 void *stream)
 {
-	return launch_search(ix, ix ? &ix->ws : nullptr, d_queries, ix ? ix->meta.dim : 0, nq, ef, 0, d_labels, nullptr, d_dists, d_counts, d_stats, (hipStream_t) stream);
+	return search_split(ix, d_queries, nq, ef, 0, d_labels, nullptr, d_dists, d_counts, d_stats, (hipStream_t) stream);
 }
 
 // The same launch as hnsw_gpu_search_batch_dev that also writes its evaluation trace: d_evals[i * evals_cap + j] = the j-th row
@@ -1119,7 +1219,7 @@ extern "C" int hnsw_gpu_search_base_dev(hnsw_gpu_index *ix, const coord_t *d_que
 										idx_t *d_idx, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
 										void *stream)
 {
-	return launch_search(ix, ix ? &ix->ws : nullptr, d_queries, ix ? ix->meta.dim : 0, nq, ef, 1, nullptr, d_idx, d_dists, d_counts, d_stats, (hipStream_t) stream);
+	return search_split(ix, d_queries, nq, ef, 1, nullptr, d_idx, d_dists, d_counts, d_stats, (hipStream_t) stream);
 }
 
 // Poll a completion flag the kernel stores into pinned host memory.  0 = set; otherwise an error: the kernel ended
@@ -1221,12 +1321,17 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 	char *p = (char *) ix->scratch;
 	float *dq = (float *) p; uint64_t *dl = (uint64_t *) (p + qb); float *dd = (float *) (p + qb + lb);
 	uint32_t *dc = (uint32_t *) (p + qb + lb + db);
+	if (!ix->hb0) { HIPCHK(hipEventCreate(&ix->hb0)); HIPCHK(hipEventCreate(&ix->hb1)); }
+	ix->hb_valid = false;
+	HIPCHK(hipEventRecord(ix->hb0, nullptr));
 	HIPCHK(hipMemcpy(dq, queries, nq * dim * 4, hipMemcpyHostToDevice));
-	rc = launch_search(ix, &ix->ws, dq, dim, nq, ef, 0, dl, nullptr, dd, dc, nullptr, nullptr);
+	rc = search_split(ix, dq, nq, ef, 0, dl, nullptr, dd, dc, nullptr, nullptr);
 	if (rc) return rc;
 	HIPCHK(hipMemcpy(labels, dl, nq * ef * 8, hipMemcpyDeviceToHost));
 	if (dists) HIPCHK(hipMemcpy(dists, dd, nq * ef * 4, hipMemcpyDeviceToHost));
 	HIPCHK(hipMemcpy(counts, dc, nq * 4, hipMemcpyDeviceToHost));
+	HIPCHK(hipEventRecord(ix->hb1, nullptr));
+	ix->hb_valid = true;
 	for (size_t i = 0; i < nq; i++)
 		if (counts[i] == ABORTED_COUNT)
 			return fail(HNSW_GPU_ERR_INTERNAL, "the search launch was asked to end early (abort word): query %zu has no result", i);
@@ -1375,6 +1480,23 @@ extern "C" int hnsw_gpu_search_ms(hnsw_gpu_index *ix, unsigned back, float *ms)
 
 extern "C" int hnsw_gpu_last_search_ms(hnsw_gpu_index *ix, float *ms) { return hnsw_gpu_search_ms(ix, 0, ms); }
 
+// Where the time of the last hnsw_gpu_search_batch call (host pointers, copy path: more than 16 queries) went on the device:
+// out[0] = upload of the queries, out[1] = the search kernel, out[2] = download of labels / distances / counts (milliseconds,
+// HIP events on the default stream around the three steps).  SURVEY.md §8(d): "report H2D separately".
+extern "C" int hnsw_gpu_last_batch_ms(hnsw_gpu_index *ix, float out[3])
+{
+	if (!ix || !out) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	std::lock_guard<std::recursive_mutex> g(ix->mu);
+	if (!ix->hb_valid || ix->ws.launches == 0) return fail(HNSW_GPU_ERR_ARG, "no host-pointer batch call (copy path) has completed on this mirror");
+	HIPCHK(hipSetDevice(ix->device));
+	const int evi = (int) ((ix->ws.launches - 1) % SearchWs::EV_RING);
+	HIPCHK(hipEventSynchronize(ix->hb1));
+	HIPCHK(hipEventElapsedTime(&out[0], ix->hb0, ix->ws.ev0[evi]));
+	HIPCHK(hipEventElapsedTime(&out[1], ix->ws.ev0[evi], ix->ws.ev1[evi]));
+	HIPCHK(hipEventElapsedTime(&out[2], ix->ws.ev1[evi], ix->hb1));
+	return HNSW_GPU_OK;
+}
+
 extern "C" int hnsw_gpu_last_search_kernel(hnsw_gpu_index *ix, char *buf, size_t len)
 {
 	if (!ix || !buf || len == 0) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
@@ -1398,6 +1520,7 @@ extern "C" int hnsw_gpu_index_abort(hnsw_gpu_index *ix)
 	// no ix->mu here: the thread that holds it may be the one waiting for the launch this call is meant to end
 	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
 	std::lock_guard<std::mutex> g(g_ws_mu);
+	if (ix->ws2_ready) (void) abort_ws_locked(&ix->ws2);                       // (the tail part of a split batch)
 	return abort_ws_locked(&ix->ws) ? HNSW_GPU_OK : fail(HNSW_GPU_ERR_INTERNAL, "the workspace has no abort word");
 }
 
@@ -2057,6 +2180,12 @@ extern "C" int hnsw_gpu_index_reserve(hnsw_gpu_index *ix, size_t capacity)
 	if (ix->ws.vis) (void) hipFree(ix->ws.vis);
 	if (ix->ws.vlog) (void) hipFree(ix->ws.vlog);
 	ix->ws.vis = nullptr; ix->ws.vlog = nullptr; ix->ws.vis_slots = 0; ix->ws.vis_words = 0;
+	if (ix->ws2_ready)
+	{
+		if (ix->ws2.vis) (void) hipFree(ix->ws2.vis);
+		if (ix->ws2.vlog) (void) hipFree(ix->ws2.vlog);
+		ix->ws2.vis = nullptr; ix->ws2.vlog = nullptr; ix->ws2.vis_slots = 0; ix->ws2.vis_words = 0;
+	}
 	ix->generation++;         // contexts notice and rebuild their bitmaps
 	return HNSW_GPU_OK;
 }
@@ -2699,7 +2828,9 @@ struct hnsw_gpu_sharded
 	std::vector<hipStream_t> streams;               // one per shard, on the shard's device
 	std::vector<SearchWs *> ws;                     // ... and a search workspace of its own per shard: a direct search on a shard
 	                                                // (its default workspace) and a sharded call never share tickets or bitmaps
-	std::vector<hipEvent_t> done;
+	std::vector<hipEvent_t> done;                   // shard i's results are in the home device's gather buffer (timing enabled)
+	hipEvent_t merge_start = nullptr;               // home: every shard's `done` has been waited for, the merge kernel is next
+	bool timed = false;                             // a call has completed its enqueue: hnsw_gpu_sharded_last_ms has something to read
 	std::vector<bool> direct;                       // the shard's device writes home memory directly
 	std::vector<float *> q_local; std::vector<size_t> q_cap;          // query copy on a remote shard's device
 	std::vector<char *> out_local; std::vector<size_t> out_cap;       // result block when not `direct`
@@ -2725,6 +2856,7 @@ extern "C" void hnsw_gpu_sharded_destroy(hnsw_gpu_sharded *s)
 	(void) hipSetDevice(s->home);
 	if (s->ready) (void) hipEventDestroy(s->ready);
 	if (s->merged) (void) hipEventDestroy(s->merged);
+	if (s->merge_start) (void) hipEventDestroy(s->merge_start);
 	if (s->gather) (void) hipFree(s->gather);
 	if (s->io) (void) hipFree(s->io);
 	if (s->home_stream) (void) hipStreamDestroy(s->home_stream);
@@ -2754,7 +2886,7 @@ extern "C" int hnsw_gpu_sharded_create(hnsw_gpu_index *const *shards, size_t nsh
 		const int dev = shards[i]->device;
 		if ((e = hipSetDevice(dev)) != hipSuccess) break;
 		if ((e = hipStreamCreateWithFlags(&s->streams[i], hipStreamNonBlocking)) != hipSuccess) break;
-		if ((e = hipEventCreateWithFlags(&s->done[i], hipEventDisableTiming)) != hipSuccess) break;
+		if ((e = hipEventCreate(&s->done[i])) != hipSuccess) break;
 		s->ws[i] = new (std::nothrow) SearchWs();
 		if (!s->ws[i] || ws_init(s->ws[i]) != HNSW_GPU_OK) { e = hipErrorOutOfMemory; break; }
 		if (dev == s->home) s->direct[i] = true;
@@ -2771,7 +2903,8 @@ extern "C" int hnsw_gpu_sharded_create(hnsw_gpu_index *const *shards, size_t nsh
 	}
 	if (e == hipSuccess) e = hipSetDevice(s->home);
 	if (e == hipSuccess) e = hipEventCreateWithFlags(&s->ready, hipEventDisableTiming);
-	if (e == hipSuccess) e = hipEventCreateWithFlags(&s->merged, hipEventDisableTiming);
+	if (e == hipSuccess) e = hipEventCreate(&s->merged);
+	if (e == hipSuccess) e = hipEventCreate(&s->merge_start);
 	if (e == hipSuccess) e = hipStreamCreateWithFlags(&s->home_stream, hipStreamNonBlocking);
 	if (e != hipSuccess)
 	{
@@ -2844,12 +2977,42 @@ extern "C" int hnsw_gpu_sharded_search_dev(hnsw_gpu_sharded *s, const coord_t *d
 	}
 	HIPCHK(hipSetDevice(s->home));
 	for (size_t i = 0; i < ns; i++) HIPCHK(hipStreamWaitEvent(stream, s->done[i], 0));
+	HIPCHK(hipEventRecord(s->merge_start, stream));
 	rc = hnsw_gpu_merge_topk_strided_dev(s->home, (const label_t *) s->gather, block / 8, (const dist_t *) (s->gather + o_d), block / 4,
 										 ns, nq, ef, d_labels, d_dists, d_counts, stream);
 	if (rc) return rc;
 	HIPCHK(hipSetDevice(s->home));
 	HIPCHK(hipEventRecord(s->merged, stream));
 	s->merged_set = true;
+	s->timed = true;
+	return HNSW_GPU_OK;
+}
+
+// Where the time of the last hnsw_gpu_sharded_search[_dev] call went, per shard, from HIP events on each shard's own device:
+// search_ms[i] = shard i's search kernel, peer_ms[i] = what followed it on that shard's stream until its results were in the home
+// device's buffer (0 when the kernel stores them there itself through peer access: then the xGMI stores are part of search_ms;
+// otherwise the staged peer copy), *merge_ms = the merge kernel on the home device.  Arrays of hnsw_gpu_sharded_nshards values;
+// waits for the call to finish.
+extern "C" int hnsw_gpu_sharded_last_ms(hnsw_gpu_sharded *s, float *search_ms, float *peer_ms, float *merge_ms, int *direct)
+{
+	if (!s || !search_ms || !peer_ms || !merge_ms) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	std::lock_guard<std::mutex> lk(s->mu);
+	if (!s->timed) return fail(HNSW_GPU_ERR_ARG, "no sharded search has run yet");
+	HIPCHK(hipSetDevice(s->home));
+	HIPCHK(hipEventSynchronize(s->merged));
+	HIPCHK(hipEventElapsedTime(merge_ms, s->merge_start, s->merged));
+	for (size_t i = 0; i < s->shards.size(); i++)
+	{
+		SearchWs *w = s->ws[i];
+		if (w->launches == 0) return fail(HNSW_GPU_ERR_INTERNAL, "shard %zu has no launch on record", i);
+		const int evi = (int) ((w->launches - 1) % SearchWs::EV_RING);
+		HIPCHK(hipSetDevice(s->shards[i]->device));
+		HIPCHK(hipEventSynchronize(s->done[i]));
+		HIPCHK(hipEventElapsedTime(&search_ms[i], w->ev0[evi], w->ev1[evi]));
+		HIPCHK(hipEventElapsedTime(&peer_ms[i], w->ev1[evi], s->done[i]));
+		if (direct) direct[i] = s->direct[i] ? 1 : 0;
+	}
+	HIPCHK(hipSetDevice(s->home));
 	return HNSW_GPU_OK;
 }
 

@@ -266,6 +266,12 @@ class GpuIndex:
         check(self.L.hnsw_gpu_search_ms(self._h, back, C.byref(ms)), "hnsw_gpu_search_ms")
         return float(ms.value)
 
+    def last_batch_ms(self):
+        """(upload ms, kernel ms, download ms) of the last host-pointer search of more than 16 queries (hnsw_gpu_last_batch_ms)."""
+        v = (C.c_float * 3)()
+        check(self.L.hnsw_gpu_last_batch_ms(self._h, v), "hnsw_gpu_last_batch_ms")
+        return float(v[0]), float(v[1]), float(v[2])
+
     def last_search_kernel(self) -> str:
         """Symbol of the kernel the last search launch ran, as rocprofv3 prints it."""
         buf = C.create_string_buffer(128)
@@ -331,6 +337,13 @@ class GpuIndex:
     def abort(self) -> None:
         """Ask the search launches of this mirror that are in flight to end (callable from any thread)."""
         check(self.L.hnsw_gpu_index_abort(self._h), "hnsw_gpu_index_abort")
+
+    def last_search_tail(self):
+        """(queries, kernel) of the tail part of the last call when the library split it (include/hnsw_gpu.h, tail split); (0, "") otherwise."""
+        t = C.c_uint32(0)
+        buf = C.create_string_buffer(160)
+        check(self.L.hnsw_gpu_last_search_tail(self._h, C.byref(t), buf, 160), "hnsw_gpu_last_search_tail")
+        return int(t.value), buf.value.decode()
 
     def last_search_slots(self) -> int:
         v = C.c_uint32(0)
@@ -536,6 +549,15 @@ class LocalShardedIndex:
         check(self.L.hnsw_gpu_sharded_search_dev(self._h, queries.data_ptr(), nq, ef, ol.data_ptr(), od.data_ptr(),
                                                  oc.data_ptr(), s), "hnsw_gpu_sharded_search_dev")
         return ol, od, oc
+
+    def last_ms(self) -> dict:
+        """Where the last search's time went (hnsw_gpu_sharded_last_ms): per shard the search kernel and what followed it until its
+        lists were in the merge device's buffer, the merge kernel, and whether a shard stores into the merge device directly."""
+        n = len(self.shards)
+        sm, pm, mm, dr = (C.c_float * n)(), (C.c_float * n)(), C.c_float(0), (C.c_int * n)()
+        check(self.L.hnsw_gpu_sharded_last_ms(self._h, sm, pm, C.byref(mm), dr), "hnsw_gpu_sharded_last_ms")
+        return {"search_ms": [float(x) for x in sm], "peer_ms": [float(x) for x in pm], "merge_ms": float(mm.value),
+                "direct_peer_stores": [bool(x) for x in dr], "devices": [int(sh.device) for sh in self.shards]}
 
 
 def merge_packed_torch(blocks, nq: int, ef: int):

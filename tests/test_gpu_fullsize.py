@@ -19,7 +19,7 @@ import pytest
 import oracle
 import pg_embedding_amd as pg
 from pg_embedding_amd.datasets import gmm_torch, recall_at_k
-from util import bits, classify_against_reference
+from util import foreign_toolchain, bits, classify_against_reference
 
 pytestmark = pytest.mark.gpu
 
@@ -164,7 +164,7 @@ def test_reference_order_mode_equals_the_compiled_reference_for_every_query(cfg,
     dst = out["dists"].cpu().numpy()
     X0 = cfg["X"][torch.from_numpy(lab[0].astype(np.int64)).cuda()].cpu().numpy()
     if not (bits(dst[0]) == bits(oracle.ref_dist_many(func, Qh[0], X0))).all():
-        pytest.skip("this host's oracle/_ref build sums in another order than the one score_rows_ref restates")
+        foreign_toolchain("the distance bits of the first query differ between HNSW_GPU_REF_ORDER=1 and oracle/_ref")
     same = (lab == r["labels"]).all(axis=1)
     print(f"\n[{cfg['name']}] reference-order mode: {int(same.sum())} of {nq} id lists equal the compiled reference's")
     assert same.all()

@@ -96,3 +96,18 @@ def evals_from_pops(raw, meta, n, entry, pops):
                 seen.add(t)
                 out.append(t)
     return np.asarray(out, np.uint32)
+
+
+def foreign_toolchain(what: str):
+    """The reference-order debug arithmetic (HNSW_GPU_REF_ORDER=1, csrc/device_dist.h score_rows_ref) restates the summation order of
+    ONE build of distfunc.c: gcc 11.4 -Ofast, the toolchain of this image, read off its disassembly.  Where oracle/_ref was built by
+    a compiler that vectorises differently the direct device-vs-reference comparison cannot hold — and must not disappear silently:
+    the test FAILS unless PGEMB_FOREIGN_REF_TOOLCHAIN=1 says that this is known (then it is skipped, loudly, and what remains is
+    the classification chain of test_gpu_fullsize.py: every differing id list explained by a decision within 1e-5)."""
+    import os
+    import pytest
+    msg = (f"{what}: this host's oracle/_ref build sums in another order than the one score_rows_ref restates (a different compiler?).  "
+           "Set PGEMB_FOREIGN_REF_TOOLCHAIN=1 to acknowledge it and skip the direct comparison")
+    if os.environ.get("PGEMB_FOREIGN_REF_TOOLCHAIN") == "1":
+        pytest.skip(msg)
+    pytest.fail(msg)
