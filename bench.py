@@ -1219,8 +1219,10 @@ def cpu_baseline(args, ix, Q, gpu_labels, gpu_dists, func):
                     # compiler built _ref, the comparison means nothing and says so instead of disappearing
                     od0 = oo["dists"][0].cpu().numpy()
                     c0 = int(oo["counts"][0].item())
-                    rows0 = ix.export_flat() if False else None
-                    avail = bool((od0[:c0].view(np.uint32) == np.asarray(rt["dists"][0][:c0], dtype=np.float32).view(np.uint32)).all()) if "dists" in rt else None
+                    meta = ix.meta
+                    img = np.frombuffer(memoryview(raw), dtype=np.uint8).reshape(args.n, int(meta.size_data_per_element))
+                    rows0 = np.ascontiguousarray(img[olab[0][:c0].astype(np.int64), int(meta.offset_data):int(meta.offset_label)]).view(np.float32)
+                    avail = bool((od0[:c0].view(np.uint32) == oracle.ref_dist_many(func, Qh[0], rows0).view(np.uint32)).all())
                     ordered = {"available": avail, "queries": nt, "queries_with_the_references_id_list": int(osame.sum()),
                                "kernel": ix.last_search_kernel(),
                                "note": "debug arithmetic in the reference build's own summation order (one compiler's output: `available` says whether "

@@ -234,16 +234,6 @@ int  hnsw_gpu_config_set(const char *name, const char *value);
 int  hnsw_gpu_config_get(const char *name, long long *value);
 void hnsw_gpu_config_reload(void);
 
-/* Tail split.  A launch ends with its slowest walks: once its queries run out the resident waves leave one by one and the device
- * drains for about one long walk (a fifth of a 40 000-query launch on 128-float rows).  hnsw_gpu_search_batch[_dev] and
- * hnsw_gpu_search_base_dev therefore send the LAST queries of a mid-size batch (2x to 16x the resident slots) out as a second
- * launch on an internal stream at the same moment: its blocks are placed as the main launch's blocks retire — in its drain — and
- * being a small launch it runs as a team, so its own drain is short.  Per-query results do not depend on which part ran a query;
- * both parts are ordered on the caller's stream like one launch, and hnsw_gpu_last_search_ms covers both.  HNSW_GPU_SPLIT=0
- * switches it off, =T forces a tail of T queries.  *tail_queries = the tail part of the mirror's last call (0 = one launch),
- * kernel (may be NULL) = the symbol the tail part ran. */
-int hnsw_gpu_last_search_tail(hnsw_gpu_index *ix, uint32_t *tail_queries, char *kernel, size_t len);
-
 /* Resident query slots (waves) the last search launch used — occupancy figure. */
 int hnsw_gpu_last_search_slots(hnsw_gpu_index *ix, uint32_t *slots);
 

@@ -170,7 +170,6 @@ def gpu_lib():
     L.hnsw_gpu_sharded_search.argtypes = [vp, vp, sz, sz, vp, vp, vp]
     L.hnsw_gpu_sharded_last_ms.argtypes = [vp, _f32p, _f32p, _f32p, C.POINTER(C.c_int)]
     L.hnsw_gpu_last_batch_ms.argtypes = [vp, _f32p]
-    L.hnsw_gpu_last_search_tail.argtypes = [vp, _u32p, C.c_char_p, sz]
     L.hnsw_gpu_config_set.argtypes = [C.c_char_p, C.c_char_p]
     L.hnsw_gpu_config_get.argtypes = [C.c_char_p, C.POINTER(C.c_longlong)]
     L.hnsw_gpu_config_reload.restype = None

@@ -71,9 +71,9 @@ enum Knob : int
 {
 	// operational (environment, read once)
 	K_BEAM, K_FORCE_LDS_HEAPS, K_TEAM, K_TEAM_MAX_NQ, K_WIDE_EF_MIN, K_REF_ORDER, K_NO_POLL, K_POLL_LIMIT_S, K_INSERT_FUSED,
-	K_BLOCKS_PER_CU, K_SPLIT,
+	K_BLOCKS_PER_CU,
 	// test knobs (hnsw_gpu_config_set only)
-	K_BEAM16, K_NARROW5, K_LEAN, K_HASH_ENTRIES, K_LDS_SET_MIN_WAVES, K_TEAM_SPEC, K_TEAM_WPB, K_MAX_BLOCKS, K_SHARDED_NO_PEER, K_PAIR,
+	K_BEAM16, K_NARROW5, K_LEAN, K_HASH_ENTRIES, K_LDS_SET_MIN_WAVES, K_TEAM_SPEC, K_TEAM_WPB, K_MAX_BLOCKS, K_SHARDED_NO_PEER,
 #ifdef HNSW_EXPERIMENT
 	K_WIDE_WAVES, K_SHAPE_12X1, K_TEAM_MAINS, K_TEAM_COUNTERS,
 #endif
@@ -83,10 +83,9 @@ struct KnobDef { const char *name; bool env; };
 static const KnobDef g_knob_def[K_COUNT] = {
 	{ "HNSW_GPU_BEAM", true }, { "HNSW_GPU_FORCE_LDS_HEAPS", true }, { "HNSW_GPU_TEAM", true }, { "HNSW_GPU_TEAM_MAX_NQ", true },
 	{ "HNSW_GPU_WIDE_EF_MIN", true }, { "HNSW_GPU_REF_ORDER", true }, { "HNSW_GPU_NO_POLL", true }, { "HNSW_GPU_POLL_LIMIT_S", true },
-	{ "HNSW_GPU_INSERT_FUSED", true }, { "HNSW_GPU_BLOCKS_PER_CU", true }, { "HNSW_GPU_SPLIT", true },
+	{ "HNSW_GPU_INSERT_FUSED", true }, { "HNSW_GPU_BLOCKS_PER_CU", true },
 	{ "HNSW_GPU_BEAM16", false }, { "HNSW_GPU_NARROW5", false }, { "HNSW_GPU_LEAN", false }, { "HNSW_GPU_HASH_ENTRIES", false }, { "HNSW_GPU_LDS_SET_MIN_WAVES", false },
 	{ "HNSW_GPU_TEAM_SPEC", false }, { "HNSW_GPU_TEAM_WPB", false }, { "HNSW_GPU_MAX_BLOCKS", false }, { "HNSW_GPU_SHARDED_NO_PEER", false },
-	{ "HNSW_GPU_PAIR", false },
 #ifdef HNSW_EXPERIMENT
 	{ "HNSW_GPU_WIDE_WAVES", false }, { "HNSW_GPU_SHAPE_12X1", false }, { "HNSW_GPU_TEAM_MAINS", false }, { "HNSW_GPU_TEAM_COUNTERS", false },
 #endif
@@ -169,7 +168,6 @@ struct SearchWs
 	hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};
 	uint64_t launches = 0;
 	uint32_t last_slots = 0;
-	size_t last_nq = 0, last_ef = 0;                     // ... and its size: the tail split (search_split) sizes itself by the launch before
 	uint32_t *done_next = nullptr;                       // completion flags for the next launch only
 	uint32_t *pops_next = nullptr; uint32_t pops_cap_next = 0;   // pop-sequence output for the next launch only
 	uint32_t *evals_next = nullptr; uint32_t evals_cap_next = 0; uint64_t *times_next = nullptr;   // evaluation trace, next launch only
@@ -332,12 +330,6 @@ struct hnsw_gpu_index
 	uint32_t *links = nullptr;
 	uint64_t *labels = nullptr;
 	SearchWs ws;              // default search state (grow-only)
-	// tail split (search_split): a second workspace + an internal stream for the LAST queries of a mid-size batch, launched beside
-	// the main launch so that its walks fill the main launch's drain; made on first use
-	SearchWs ws2; bool ws2_ready = false;
-	hipStream_t split_stream = nullptr;
-	hipEvent_t sp_ready = nullptr, sp_done = nullptr;
-	uint64_t splits = 0; uint32_t last_tail = 0;
 	uint64_t generation = 0;  // bumped when capacity changes (bitmap width changes)
 	uint32_t *misc = nullptr; // small device scratch words (import error counter, ...)
 	// scratch for the host-pointer entry points
@@ -431,10 +423,6 @@ extern "C" void hnsw_gpu_index_destroy(hnsw_gpu_index *ix)
 	if (ix->links) (void) hipFree(ix->links);
 	if (ix->labels) (void) hipFree(ix->labels);
 	ws_free(&ix->ws);
-	if (ix->ws2_ready) ws_free(&ix->ws2);
-	if (ix->split_stream) (void) hipStreamDestroy(ix->split_stream);
-	if (ix->sp_ready) (void) hipEventDestroy(ix->sp_ready);
-	if (ix->sp_done) (void) hipEventDestroy(ix->sp_done);
 	if (ix->misc) (void) hipFree(ix->misc);
 	if (ix->scratch) (void) hipFree(ix->scratch);
 	if (ix->pin) (void) hipHostFree(ix->pin);
@@ -777,11 +765,9 @@ static const size_t SET_BUDGET_BYTES = (size_t) 8 << 30;      // cap on the HBM 
 // device_search_wide.h; what bounds a beam is the per-slot scratch, 24 bytes per result slot, under SET_BUDGET_BYTES)
 static const size_t WIDE_EF_MIN = 2048;
 
-// tail = the launch is the tail part of a split batch (search_split): it runs as a team whatever the row width, because it exists
-// to END early — its walks start on slots another launch is leaving and every one of them should have helpers.
 static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries, size_t q_stride, size_t nq, size_t ef, int mode,
 						 uint64_t *d_labels, uint32_t *d_idx, float *d_dists, uint32_t *d_counts,
-						 uint32_t *d_stats, hipStream_t stream, bool tail = false)
+						 uint32_t *d_stats, hipStream_t stream)
 {
 	std::unique_lock<std::recursive_mutex> lock_;
 	if (ix) lock_ = std::unique_lock<std::recursive_mutex>(ix->mu);
@@ -847,7 +833,7 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	// Team form wanted for this launch?  (decided for good further down, once the LDS carve is known)
 	const int treq = (int) knob(K_TEAM, -1);
 	const size_t auto_nq = (size_t) knob(K_TEAM_MAX_NQ, (long long) ix->num_cu);
-	const bool team_wanted = rreg < 0 && !reforder && treq != 0 && (treq > 0 || ix->stride > 320 || nq <= auto_nq || tail);
+	const bool team_wanted = rreg < 0 && !reforder && treq != 0 && (treq > 0 || ix->stride > 320 || nq <= auto_nq);
 	// narrow rows, hot form: beam kernel with <= 4 set registers, one sum per row (L2 / Manhattan), not a team
 	const bool narrow5 = shape_index(a.kiters) == 0 && (rreg == -2 || rreg == -4) && (int) ix->meta.dist_func != F_COSINE &&
 						 !team_wanted && !reforder && knob(K_NARROW5, 1) != 0;
@@ -1106,89 +1092,6 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	HIPCHK(hipEventRecord(w->ev1[evi], stream));
 	__atomic_store_n(&w->launches, w->launches + 1, __ATOMIC_SEQ_CST);
 	w->last_slots = (uint32_t) slots;
-	w->last_nq = nq; w->last_ef = ef;
-	return HNSW_GPU_OK;
-}
-
-// ------------------------------------------------------------------------------------
-// Tail split.  A launch ends with its slowest walks: once the ticket counter runs out, the resident waves leave one by one and
-// the chip drains for about one long walk — 1.1 ms of a 5.9 ms launch of 40 000 queries on 128-float rows (5 120 waves, a walk is
-// 0.44-0.77 ms, the longest 1.6 ms: profiles/r4a_c2_regression_and_timelines.txt: 78 % of the slot time is walks), 1.4 ms of a 6.8 ms
-// launch of 10 000 queries at 768 floats.  The walks cannot be shortened or reordered, but the drain can be FILLED: the last T
-// queries of the batch go out as a second launch on an internal stream at the same moment.  The main launch's grid takes every
-// resident slot first (it is a fixed set of waves pulling tickets), so the second launch's blocks are placed as the main launch's
-// blocks retire — exactly in its drain — and because it is a small launch it runs as a team (every walk with helpers from its
-// first hop), i.e. its own drain is the short one of a handful of fast walks.  Same kernels, same per-query results (a query's walk
-// does not depend on which launch runs it); both parts are ordered on the caller's stream (the internal stream waits for the
-// caller's work enqueued so far, the caller's stream waits for the tail part before anything after the call).
-// Used for batches of 2x to 16x the resident slots of the previous launch of the same shape (smaller batches are teams already,
-// larger ones amortise their drain; the headline 40 000 x 768 launch is not split); HNSW_GPU_SPLIT=0 switches it off, = T forces
-// a tail of T queries.
-// ------------------------------------------------------------------------------------
-static size_t split_tail_size(hnsw_gpu_index *ix, size_t nq, size_t ef)
-{
-	knobs_init();
-	const long long k = knob(K_SPLIT, -1);
-	if (k == 0) return 0;
-	if (k > 0) return (size_t) k < nq ? (size_t) k : 0;
-	const SearchWs &w = ix->ws;
-	if (w.last_slots == 0 || w.last_ef != ef || w.last_nq < w.last_slots) return 0;      // no full launch of this shape to go by
-	const size_t slots = w.last_slots;
-	if (nq < 2 * slots || nq > 16 * slots) return 0;
-	size_t t = nq / 8;
-	t = std::min(t, slots / 2);
-	t = std::max<size_t>(t, 256);
-	return t & ~(size_t) 63;
-}
-
-static int search_split(hnsw_gpu_index *ix, const float *d_queries, size_t nq, size_t ef, int mode,
-						uint64_t *d_labels, uint32_t *d_idx, float *d_dists, uint32_t *d_counts, uint32_t *d_stats, hipStream_t stream)
-{
-	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
-	std::unique_lock<std::recursive_mutex> lock_(ix->mu);
-	const size_t dim = ix->meta.dim;
-	const bool plain = !ix->ws.done_next && !ix->ws.pops_next && !ix->ws.evals_next && !ix->ws.times_next && d_queries && d_counts;
-	const size_t T = plain ? split_tail_size(ix, nq, ef) : 0;
-	ix->last_tail = 0;
-	if (T == 0 || T >= nq)
-		return launch_search(ix, &ix->ws, d_queries, dim, nq, ef, mode, d_labels, d_idx, d_dists, d_counts, d_stats, stream);
-	HIPCHK(hipSetDevice(ix->device));
-	if (!ix->ws2_ready)
-	{
-		int rc = ws_init(&ix->ws2);
-		if (rc) return rc;
-		ix->ws2_ready = true;
-	}
-	if (!ix->split_stream) HIPCHK(hipStreamCreateWithFlags(&ix->split_stream, hipStreamNonBlocking));
-	if (!ix->sp_ready)
-	{
-		HIPCHK(hipEventCreateWithFlags(&ix->sp_ready, hipEventDisableTiming));
-		HIPCHK(hipEventCreateWithFlags(&ix->sp_done, hipEventDisableTiming));
-	}
-	const size_t n1 = nq - T, stride = ef;                                     // (output rows are the caller's ef apart)
-	HIPCHK(hipEventRecord(ix->sp_ready, stream));                              // the queries (and whatever else the caller enqueued) are ready
-	HIPCHK(hipStreamWaitEvent(ix->split_stream, ix->sp_ready, 0));
-	int rc = launch_search(ix, &ix->ws, d_queries, dim, n1, ef, mode, d_labels, d_idx, d_dists, d_counts, d_stats, stream);
-	if (rc) return rc;
-	rc = launch_search(ix, &ix->ws2, d_queries + n1 * dim, dim, T, ef, mode, d_labels ? d_labels + n1 * stride : nullptr,
-					   d_idx ? d_idx + n1 * stride : nullptr, d_dists ? d_dists + n1 * stride : nullptr, d_counts + n1,
-					   d_stats ? d_stats + 2 * n1 : nullptr, ix->split_stream, true);
-	if (rc) { (void) hipStreamSynchronize(stream); return rc; }
-	HIPCHK(hipEventRecord(ix->sp_done, ix->split_stream));
-	HIPCHK(hipStreamWaitEvent(stream, ix->sp_done, 0));
-	// the call's device time (hnsw_gpu_last_search_ms) = from the main launch's start to the end of BOTH parts
-	HIPCHK(hipEventRecord(ix->ws.ev1[(ix->ws.launches - 1) % SearchWs::EV_RING], stream));
-	ix->ws.last_nq = nq;                                                       // the shape the NEXT call sizes its split by is this call's
-	ix->splits++;
-	ix->last_tail = (uint32_t) T;
-	return HNSW_GPU_OK;
-}
-
-extern "C" int hnsw_gpu_last_search_tail(hnsw_gpu_index *ix, uint32_t *tail_queries, char *kernel, size_t len)
-{
-	if (!ix || !tail_queries) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
-	*tail_queries = ix->last_tail;
-	if (kernel && len) snprintf(kernel, len, "%s", ix->last_tail && ix->ws2_ready ? ix->ws2.kname : "");
 	return HNSW_GPU_OK;
 }
 
@@ -1196,7 +1099,7 @@ extern "C" int hnsw_gpu_search_batch_dev(hnsw_gpu_index *ix, const coord_t *d_qu
 										 label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
 										 void *stream)
 {
-	return search_split(ix, d_queries, nq, ef, 0, d_labels, nullptr, d_dists, d_counts, d_stats, (hipStream_t) stream);
+	return launch_search(ix, ix ? &ix->ws : nullptr, d_queries, ix ? ix->meta.dim : 0, nq, ef, 0, d_labels, nullptr, d_dists, d_counts, d_stats, (hipStream_t) stream);
 }
 
 // The same launch as hnsw_gpu_search_batch_dev that also writes its evaluation trace: d_evals[i * evals_cap + j] = the j-th row
@@ -1219,7 +1122,7 @@ extern "C" int hnsw_gpu_search_base_dev(hnsw_gpu_index *ix, const coord_t *d_que
 										idx_t *d_idx, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
 										void *stream)
 {
-	return search_split(ix, d_queries, nq, ef, 1, nullptr, d_idx, d_dists, d_counts, d_stats, (hipStream_t) stream);
+	return launch_search(ix, ix ? &ix->ws : nullptr, d_queries, ix ? ix->meta.dim : 0, nq, ef, 1, nullptr, d_idx, d_dists, d_counts, d_stats, (hipStream_t) stream);
 }
 
 // Poll a completion flag the kernel stores into pinned host memory.  0 = set; otherwise an error: the kernel ended
@@ -1325,7 +1228,7 @@ extern "C" int hnsw_gpu_search_batch(hnsw_gpu_index *ix, const coord_t *queries,
 	ix->hb_valid = false;
 	HIPCHK(hipEventRecord(ix->hb0, nullptr));
 	HIPCHK(hipMemcpy(dq, queries, nq * dim * 4, hipMemcpyHostToDevice));
-	rc = search_split(ix, dq, nq, ef, 0, dl, nullptr, dd, dc, nullptr, nullptr);
+	rc = launch_search(ix, &ix->ws, dq, dim, nq, ef, 0, dl, nullptr, dd, dc, nullptr, nullptr);
 	if (rc) return rc;
 	HIPCHK(hipMemcpy(labels, dl, nq * ef * 8, hipMemcpyDeviceToHost));
 	if (dists) HIPCHK(hipMemcpy(dists, dd, nq * ef * 4, hipMemcpyDeviceToHost));
@@ -1520,7 +1423,6 @@ extern "C" int hnsw_gpu_index_abort(hnsw_gpu_index *ix)
 	// no ix->mu here: the thread that holds it may be the one waiting for the launch this call is meant to end
 	if (!ix) return fail(HNSW_GPU_ERR_ARG, "index is NULL");
 	std::lock_guard<std::mutex> g(g_ws_mu);
-	if (ix->ws2_ready) (void) abort_ws_locked(&ix->ws2);                       // (the tail part of a split batch)
 	return abort_ws_locked(&ix->ws) ? HNSW_GPU_OK : fail(HNSW_GPU_ERR_INTERNAL, "the workspace has no abort word");
 }
 
@@ -2180,12 +2082,6 @@ extern "C" int hnsw_gpu_index_reserve(hnsw_gpu_index *ix, size_t capacity)
 	if (ix->ws.vis) (void) hipFree(ix->ws.vis);
 	if (ix->ws.vlog) (void) hipFree(ix->ws.vlog);
 	ix->ws.vis = nullptr; ix->ws.vlog = nullptr; ix->ws.vis_slots = 0; ix->ws.vis_words = 0;
-	if (ix->ws2_ready)
-	{
-		if (ix->ws2.vis) (void) hipFree(ix->ws2.vis);
-		if (ix->ws2.vlog) (void) hipFree(ix->ws2.vlog);
-		ix->ws2.vis = nullptr; ix->ws2.vlog = nullptr; ix->ws2.vis_slots = 0; ix->ws2.vis_words = 0;
-	}
 	ix->generation++;         // contexts notice and rebuild their bitmaps
 	return HNSW_GPU_OK;
 }

@@ -338,13 +338,6 @@ class GpuIndex:
         """Ask the search launches of this mirror that are in flight to end (callable from any thread)."""
         check(self.L.hnsw_gpu_index_abort(self._h), "hnsw_gpu_index_abort")
 
-    def last_search_tail(self):
-        """(queries, kernel) of the tail part of the last call when the library split it (include/hnsw_gpu.h, tail split); (0, "") otherwise."""
-        t = C.c_uint32(0)
-        buf = C.create_string_buffer(160)
-        check(self.L.hnsw_gpu_last_search_tail(self._h, C.byref(t), buf, 160), "hnsw_gpu_last_search_tail")
-        return int(t.value), buf.value.decode()
-
     def last_search_slots(self) -> int:
         v = C.c_uint32(0)
         check(self.L.hnsw_gpu_last_search_slots(self._h, C.byref(v)), "hnsw_gpu_last_search_slots")

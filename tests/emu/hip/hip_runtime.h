@@ -507,6 +507,8 @@ static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); 
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t) malloc(sizeof(simt_stream)); (*s)->dev = simt::cur_dev; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreate(s); }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { return hipStreamCreate(s); }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 1; *greatest = -1; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }

@@ -22,7 +22,7 @@ import util as U                                           # noqa: E402
 from pg_embedding_amd.datasets import gmm                  # noqa: E402
 
 KEYS = ("HNSW_GPU_TEAM", "HNSW_GPU_TEAM_WPB", "HNSW_GPU_MAX_BLOCKS", "HNSW_GPU_NARROW5", "HNSW_GPU_HASH_ENTRIES", "HNSW_GPU_BEAM",      # (HNSW_GPU_TEAM_SPEC: as the caller of this script set it)
-        "HNSW_GPU_BEAM16", "HNSW_GPU_FORCE_LDS_HEAPS", "SIMT_EMU_CUS", "SIMT_EMU_JITTER", "SIMT_EMU_JITTER_US", "SIMT_EMU_SEED", "HNSW_GPU_INSERT_FUSED", "HNSW_GPU_SPLIT")
+        "HNSW_GPU_BEAM16", "HNSW_GPU_FORCE_LDS_HEAPS", "SIMT_EMU_CUS", "SIMT_EMU_JITTER", "SIMT_EMU_JITTER_US", "SIMT_EMU_SEED", "HNSW_GPU_INSERT_FUSED")
 
 
 def setenv(env):
@@ -63,31 +63,6 @@ def forms():
                 out.append({"dim": dim, "func": int(func), "ef": ef, "env": env, "kernel": ix.last_search_kernel(), "wrong": wrong(got, want, nq),
                             "seconds": round(time.time() - t0, 2)})
             ix.close()
-    return out
-
-
-def split():
-    """the tail split of a batch (hnsw_gpu.hip search_split): the last T queries as a second launch — a team — on the library's internal
-    stream and second workspace; labels, distance bits, counts and E_q / H_q of EVERY query equal the oracle's, and equal the one-launch
-    form's; the host-pointer form (more than 16 queries: the copy path) and the device-pointer base form take it too"""
-    out = []
-    for dim, m, func, ef in ((64, 8, pg.DIST_L2, 40), (200, 8, pg.DIST_COSINE, 48)):
-        n, nq = 900, 40
-        port, X = U.build_port(n, dim, m, 40, func, k=10, seed=dim + 5)
-        Q = gmm(nq, dim, k=10, seed=dim + 6)
-        want = port.search_many(Q, ef, nthreads=4)
-        ix = U.mirror(port, func, efs=ef)
-        setenv({"HNSW_GPU_SPLIT": "0", "SIMT_EMU_CUS": "4"})
-        one = ix.search(Q, ef)
-        k_one = ix.last_search_kernel()
-        for T in ("12", "25"):
-            setenv({"HNSW_GPU_SPLIT": T, "SIMT_EMU_CUS": "4"})
-            got = ix.search(Q, ef)
-            tail, tk = ix.last_search_tail()
-            same = all((a == b).all() for a, b in zip(one, got))
-            out.append({"dim": dim, "func": int(func), "tail_asked": int(T), "tail": tail, "tail_kernel": tk, "main_kernel": ix.last_search_kernel(),
-                        "one_launch_kernel": k_one, "wrong": wrong(got, want, nq), "same_as_one_launch": bool(same)})
-        ix.close()
     return out
 
 
@@ -455,4 +430,4 @@ def insert():
 
 
 if __name__ == "__main__":
-    print(json.dumps({"forms": forms, "split": split, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced, "sharded": sharded, "moving_helpers": moving_helpers, "wide": wide, "reforder": reforder, "insert": insert}[sys.argv[1]]()))
+    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced, "sharded": sharded, "moving_helpers": moving_helpers, "wide": wide, "reforder": reforder, "insert": insert}[sys.argv[1]]()))

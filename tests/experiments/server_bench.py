@@ -43,7 +43,16 @@ def main():
     ap.add_argument("--hwq", type=int, default=0, help="GPU_MAX_HW_QUEUES for the server process (0 = leave it alone)")
     ap.add_argument("--binary", default=None, help="server binary (default: the shipped one)")
     ap.add_argument("--check", type=int, default=200, help="queries compared with the CPU reference")
+    ap.add_argument("--configs", default="", help="sweep: comma-separated dispatchers:lanes[:readers] — one server per entry over the same "
+                                                  "rows (data generated once); the parity check runs for the first entry only")
     a = ap.parse_args()
+    if a.configs:
+        cfgs = []
+        for c in a.configs.split(","):
+            f = [int(x) for x in c.split(":")]
+            cfgs.append((f[0], f[1], f[2] if len(f) > 2 else a.readers))
+    else:
+        cfgs = [(a.dispatchers, a.lanes, a.readers)]
 
     import oracle
     import pg_embedding_amd as pg
@@ -67,65 +76,75 @@ def main():
     qf, of = os.path.join(tmp, "q.f32"), os.path.join(tmp, "out.u64")
     Q.tofile(qf)
     key, gen = 1, 1
-    srv = ServerProcess(dispatchers=a.dispatchers, readers=a.readers, lanes=a.lanes, binary=a.binary,
-                        env={"GPU_MAX_HW_QUEUES": str(a.hwq)} if a.hwq else None)
-    with srv:
-        c = RemoteClient(srv.socket_path)
-        t = time.time()
-        c.upload(meta, key, gen, img.reshape(-1), a.rows)
-        t_up = time.time() - t
-        t = time.time()
-        c.link(key, 0, a.rows, 0)
-        t_link = time.time() - t
-        print(f"# upload {img.nbytes / 1e9:.2f} GB through a memfd: {t_up:.2f} s; device build (LINK): {t_link:.2f} s", flush=True)
-        env = dict(os.environ, PG_EMBEDDING_GPU_SERVER=srv.socket_path)
-        rows = []
-        labels = None
-        for P in [int(x) for x in a.procs.split(",")]:
-            nq = max(P, min(a.queries, max(P * 8, 512)))
-            # short calibration run, then as many rounds as fill the target time
-            args = [exe, str(key), str(gen), str(a.dims), str(a.m), str(a.efc), str(a.efs), "0", qf, str(nq), str(P), of]
-            r = subprocess.run(args + ["1"], capture_output=True, text=True, env=env, timeout=600)
-            assert r.returncode == 0, r.stderr
-            cal = json.loads(r.stdout)
-            rounds = int(max(1, min(200, a.target_seconds * cal["qps"] / nq)))
-            before = c.stats()
-            r = subprocess.run(args + [str(rounds)], capture_output=True, text=True, env=env, timeout=600)
-            assert r.returncode == 0, r.stderr
-            info = json.loads(r.stdout)
-            st = c.stats()
-            d = {k: st[k] - before[k] for k in ("searches", "batches", "batch_ns", "kernel_ns")}
-            info.update(mean_batch=d["searches"] / max(1, d["batches"]), batches=d["batches"],
-                        ms_per_batch=d["batch_ns"] / 1e6 / max(1, d["batches"]),
-                        kernel_ms_per_batch=d["kernel_ns"] / 1e6 / max(1, d["batches"]),
-                        latency_ms=1e3 * P / info["qps"])
-            rows.append(info)
-            print(json.dumps(info), flush=True)
-            out = np.fromfile(of, np.uint64)
-            labels = (nq, out[:nq * a.efs].reshape(nq, a.efs).copy(), out[nq * a.efs:].copy())
-        # parity of what the backends received, against the reference's code on the same graph bytes
-        graph = c.export(key, a.rows * esz)
-        nq, lab, cnt = labels
-        ncheck = min(a.check, nq)
-        checks = [("C restatement in the device's summation order (oracle/hnsw_port.c)", oracle.PortIndex)]
-        if oracle.have_ref():
-            checks.append(("reference binary, -Ofast summation order (oracle/_ref)", oracle.RefIndex))
-        for kind, cls in checks:
-            cpu = cls(a.dims, a.m, a.efc, a.efs, pg.DIST_L2)
-            cpu.load_raw(graph, a.rows)
-            same = 0
-            for q in range(ncheck):
-                w = cpu.search(Q[q], a.efs)
-                w = w[0] if isinstance(w, tuple) else w
-                same += int(cnt[q] == len(w) and (lab[q, :len(w)] == w).all())
-            print(f"# parity: {same}/{ncheck} sampled hnsw_search() answers identical to the {kind} on the exported graph", flush=True)
-            del cpu
-        st = c.stats()
-        print("# server totals:", json.dumps({k: st[k] for k in ("connections", "searches", "batches", "max_batch", "search_errors")}))
-        c.close()
-    print("\n| backends | queries/s | mean batch | ms per batch (host) | kernel ms per batch | round trip ms |\n|---|---|---|---|---|---|")
-    for r in rows:
-        print(f"| {r['nproc']} | {r['qps']:.0f} | {r['mean_batch']:.1f} | {r['ms_per_batch']:.2f} | {r['kernel_ms_per_batch']:.2f} | {r['latency_ms']:.2f} |")
+    table = []
+    for ci, (nd, nl, nr) in enumerate(cfgs):
+      print(f"## server with {nd} dispatchers x {nl} lanes, {nr} readers", flush=True)
+      srv = ServerProcess(dispatchers=nd, readers=nr, lanes=nl, binary=a.binary,
+                          env={"GPU_MAX_HW_QUEUES": str(a.hwq)} if a.hwq else None)
+      with srv:
+          c = RemoteClient(srv.socket_path)
+          t = time.time()
+          c.upload(meta, key, gen, img.reshape(-1), a.rows)
+          t_up = time.time() - t
+          t = time.time()
+          c.link(key, 0, a.rows, 0)
+          t_link = time.time() - t
+          print(f"# upload {img.nbytes / 1e9:.2f} GB through a memfd: {t_up:.2f} s; device build (LINK): {t_link:.2f} s", flush=True)
+          env = dict(os.environ, PG_EMBEDDING_GPU_SERVER=srv.socket_path)
+          rows = []
+          labels = None
+          for P in [int(x) for x in a.procs.split(",")]:
+              nq = max(P, min(a.queries, max(P * 8, 512)))
+              # short calibration run, then as many rounds as fill the target time
+              args = [exe, str(key), str(gen), str(a.dims), str(a.m), str(a.efc), str(a.efs), "0", qf, str(nq), str(P), of]
+              r = subprocess.run(args + ["1"], capture_output=True, text=True, env=env, timeout=600)
+              assert r.returncode == 0, r.stderr
+              cal = json.loads(r.stdout)
+              rounds = int(max(1, min(200, a.target_seconds * cal["qps"] / nq)))
+              before = c.stats()
+              r = subprocess.run(args + [str(rounds)], capture_output=True, text=True, env=env, timeout=600)
+              assert r.returncode == 0, r.stderr
+              info = json.loads(r.stdout)
+              st = c.stats()
+              d = {k: st[k] - before[k] for k in ("searches", "batches", "batch_ns", "kernel_ns")}
+              info.update(mean_batch=d["searches"] / max(1, d["batches"]), batches=d["batches"],
+                          ms_per_batch=d["batch_ns"] / 1e6 / max(1, d["batches"]),
+                          kernel_ms_per_batch=d["kernel_ns"] / 1e6 / max(1, d["batches"]),
+                          latency_ms=1e3 * P / info["qps"])
+              rows.append(info)
+              print(json.dumps(info), flush=True)
+              out = np.fromfile(of, np.uint64)
+              labels = (nq, out[:nq * a.efs].reshape(nq, a.efs).copy(), out[nq * a.efs:].copy())
+          if ci > 0:                                      # (the sweep's later servers: throughput only)
+              st = c.stats()
+              print("# server totals:", json.dumps({k: st[k] for k in ("connections", "searches", "batches", "max_batch", "search_errors")}))
+              c.close()
+              table += [(nd, nl, nr, r) for r in rows]
+              continue
+          # parity of what the backends received, against the reference's code on the same graph bytes
+          graph = c.export(key, a.rows * esz)
+          nq, lab, cnt = labels
+          ncheck = min(a.check, nq)
+          checks = [("C restatement in the device's summation order (oracle/hnsw_port.c)", oracle.PortIndex)]
+          if oracle.have_ref():
+              checks.append(("reference binary, -Ofast summation order (oracle/_ref)", oracle.RefIndex))
+          for kind, cls in checks:
+              cpu = cls(a.dims, a.m, a.efc, a.efs, pg.DIST_L2)
+              cpu.load_raw(graph, a.rows)
+              same = 0
+              for q in range(ncheck):
+                  w = cpu.search(Q[q], a.efs)
+                  w = w[0] if isinstance(w, tuple) else w
+                  same += int(cnt[q] == len(w) and (lab[q, :len(w)] == w).all())
+              print(f"# parity: {same}/{ncheck} sampled hnsw_search() answers identical to the {kind} on the exported graph", flush=True)
+              del cpu
+          st = c.stats()
+          print("# server totals:", json.dumps({k: st[k] for k in ("connections", "searches", "batches", "max_batch", "search_errors")}))
+          c.close()
+          table += [(nd, nl, nr, r) for r in rows]
+    print("\n| dispatchers x lanes (readers) | backends | queries/s | mean batch | ms per batch (host) | kernel ms per batch | round trip ms |\n|---|---|---|---|---|---|---|")
+    for nd, nl, nr, r in table:
+        print(f"| {nd} x {nl} ({nr}) | {r['nproc']} | {r['qps']:.0f} | {r['mean_batch']:.1f} | {r['ms_per_batch']:.2f} | {r['kernel_ms_per_batch']:.2f} | {r['latency_ms']:.2f} |")
 
 
 if __name__ == "__main__":

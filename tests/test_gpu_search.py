@@ -420,44 +420,6 @@ def test_team_form_is_exact_at_every_launch_size(func, dim, m, monkeypatch):
     ix.close()
 
 
-@pytest.mark.parametrize("dim,m,func", [(128, 16, pg.DIST_L2), (768, 16, pg.DIST_L2), (100, 8, pg.DIST_COSINE)])
-def test_a_split_batch_answers_every_query_like_one_launch(dim, m, func, monkeypatch):
-    """The tail split (include/hnsw_gpu.h): the last T queries of a batch go out as a second launch — a team — on the library's
-    internal stream, beside the main launch.  Whatever T is (forced here; by itself the library picks one for batches of 2x-16x the
-    resident slots), every query's labels, distance bits, counts, E_q and H_q equal the one-launch form's and the oracle's, the
-    device-pointer and the host-pointer form alike, also when calls follow each other without a wait in between."""
-    import torch
-    n, nq, ef = 20000, 6000, 96
-    port, X = build_port(n, dim, m, 48, func, k=40, seed=5 * dim + func)
-    Q = gmm(nq, dim, k=40, seed=5 * dim + func, stream=1)
-    ix = mirror(port, func)
-    dQ = torch.from_numpy(Q).cuda()
-    monkeypatch.setenv("HNSW_GPU_SPLIT", "0")
-    one = ix.search_torch(dQ, ef, stats=True)
-    torch.cuda.synchronize()
-    assert ix.last_search_tail() == (0, "")
-    ref = {k: one[k].clone() for k in ("labels", "dists", "counts", "stats")}
-    pick = np.r_[0:150, nq - 150:nq]                           # the oracle on both ends of the batch (the tail part is at the end)
-    want = port.search_many(Q[pick], ef, nthreads=8)
-    assert (ref["labels"].cpu().numpy().view(np.uint64)[pick] == want["labels"]).all()
-    for T in ("64", "700", "2500"):
-        monkeypatch.setenv("HNSW_GPU_SPLIT", T)
-        outs = [ix.search_torch(dQ, ef, stats=True) for _ in range(3)]     # back to back: the second call's parts queue behind the first's
-        torch.cuda.synchronize()
-        tail, tk = ix.last_search_tail()
-        assert tail == int(T) and ", true, " in tk, (tail, tk)
-        for out in outs:
-            for k in ("labels", "counts", "stats"):
-                assert (out[k] == ref[k]).all(), (T, k)
-            assert (out["dists"].view(torch.int32) == ref["dists"].view(torch.int32)).all(), T
-    monkeypatch.setenv("HNSW_GPU_SPLIT", "333")
-    lab, dst, cnt = ix.search(Q, ef)                              # host pointers: the copy path splits too
-    assert ix.last_search_tail()[0] == 333
-    assert (lab.view(np.int64) == ref["labels"].cpu().numpy()).all() and (bits(dst) == bits(ref["dists"].cpu().numpy())).all()
-    assert (cnt == ref["counts"].cpu().numpy().view(np.uint32)).all()
-    ix.close()
-
-
 @pytest.mark.parametrize("ef", [1, 5, 64, 128, 256])
 def test_beam_prune_with_ties_at_the_bound(ef):
     """0/1 vectors in 6 dimensions: only 7 distinct L2 distances, so the ef-th smallest distance is

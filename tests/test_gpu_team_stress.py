@@ -194,7 +194,7 @@ def test_a_launch_that_is_asked_to_end_does_end(env, monkeypatch):
     print(f"\n[abort {env}] kernel {ix.last_search_kernel()}: launch ended {took * 1e3:.0f} ms after it began; health {h}")
     assert h["aborted_waves"] > 0 and h["abort_pending"] == 1 and h["abort_requests"] == 1, h
     # what an interrupted launch leaves is defined per query (include/hnsw_gpu.h): a result with its count, or HNSW_GPU_COUNT_ABORTED
-    cnt = big["counts"].cpu().numpy()
+    cnt = big["counts"].cpu().numpy().view(np.uint32)
     unanswered = cnt == 0xFFFFFFFF
     assert unanswered.any() and (cnt[~unanswered] <= ef).all(), (int(unanswered.sum()), cnt[~unanswered].max() if (~unanswered).any() else None)
     answered = np.nonzero(~unanswered)[0]

@@ -43,16 +43,6 @@ def test_every_kernel_form_walks_and_emits_like_the_oracle(emu_lib):
         assert any(needle in k for k in kernels), (needle, sorted(kernels))
 
 
-def test_a_split_batch_answers_every_query_like_one_launch(emu_lib):
-    """The tail split (include/hnsw_gpu.h): the last T queries of a batch as a second launch — a team — on the library's internal stream
-    and second workspace.  Every query's labels, distance bits and counts equal the oracle's and the one-launch form's."""
-    res = run_case("split", emu_lib)
-    assert len(res) == 4
-    for r in res:
-        assert r["wrong"] == 0 and r["same_as_one_launch"] and r["tail"] == r["tail_asked"], r
-        assert ", true, " in r["tail_kernel"], r              # the tail part runs as a team
-
-
 def test_the_other_kernels_behind_the_c_abi(emu_lib):
     """serial device insert == the oracle's graph bytes, the walk's pop sequence, vacuum flags, a batched build that the
     search finds its way in; and the distance entry points: the device tier's own test file, unchanged, on the emulated library"""
