@@ -244,6 +244,16 @@ int hnsw_gpu_last_search_slots(hnsw_gpu_index *ix, uint32_t *slots);
 typedef struct hnsw_gpu_ctx hnsw_gpu_ctx;
 int  hnsw_gpu_ctx_create(hnsw_gpu_index *ix, hnsw_gpu_ctx **out);
 void hnsw_gpu_ctx_destroy(hnsw_gpu_ctx *ctx);
+/* Walking waves per block for the context's SMALL launches (fewer queries than resident waves run as teams: by default the queries
+ * are spread over as many blocks as the device holds and the other waves of a block help — one walk per 8-wave block for a launch of
+ * up to one query per CU: the shape of a lone launch).  A host that keeps several small launches in flight at once (the batching
+ * server) knows what a single launch cannot: together they ask for more waves than the device has, and every helper then displaces
+ * somebody's walk.  per_block = 1..8 makes at least that many waves of a block walk (8 = every wave walks; helpers appear only when
+ * the launch's queries run out); 0 = back to the default.  Results do not depend on it. */
+int  hnsw_gpu_ctx_set_walkers(hnsw_gpu_ctx *ctx, unsigned per_block);
+/* 8-wave team blocks `device` holds at once (one per compute unit for rows wider than 320 floats): with W walks in flight over all
+ * launches, ceil(W / blocks) walking waves per block keep every walk on the device.  <= 0: no such device. */
+int  hnsw_gpu_device_blocks(int device);
 int  hnsw_gpu_search_batch_ctx(hnsw_gpu_ctx *ctx, const coord_t *d_queries, size_t nq, size_t ef,
 							   label_t *d_labels, dist_t *d_dists, uint32_t *d_counts, uint32_t *d_stats,
 							   void *stream);

@@ -221,6 +221,54 @@ static void cmd_create_index(Table *t, const char *name, const char *opclass, co
 	t->nidx++;
 }
 
+/* save_index / attach_index: the page image of an index written to / read from a file, so that ONE build (e.g. the batched device
+ * build through the patched glue) can be searched by several binaries (the reference's objects, the drop-in libraries) over the very
+ * same pages.  The table must hold the same rows (same `generate` line) — heap TIDs are positions.  Test infrastructure only. */
+static void cmd_save_index(Table *t, const char *name, const char *path)
+{
+	for (int i = 0; i < t->nidx; i++)
+		if (strcmp(t->idx[i].rel->name, name) == 0)
+		{
+			Relation rel = t->idx[i].rel;
+			FILE *f = fopen(path, "wb");
+			if (!f) pgmock_error("could not create file \"%s\"", path);
+			const uint32 hdr[2] = { 0x58444947u, rel->npages[MAIN_FORKNUM] };
+			bool ok = fwrite(hdr, sizeof(hdr), 1, f) == 1;
+			for (BlockNumber b = 0; ok && b < rel->npages[MAIN_FORKNUM]; b++) ok = fwrite(rel->pages[MAIN_FORKNUM][b], BLCKSZ, 1, f) == 1;
+			ok = fclose(f) == 0 && ok;
+			if (!ok) pgmock_error("could not write file \"%s\"", path);
+			printf("SAVE %u pages\n", hdr[1]);
+			return;
+		}
+	pgmock_error("index \"%s\" does not exist", name);
+}
+
+static void cmd_attach_index(Table *t, const char *name, const char *opclass, const char *opts, const char *path)
+{
+	const int op = strcmp(opclass, "l2") == 0 ? 0 : strcmp(opclass, "cos") == 0 ? 1 : strcmp(opclass, "manhattan") == 0 ? 2 : -1;
+	if (op < 0 || t->nidx == MAX_INDEXES) pgmock_error("operator class \"%s\" does not exist for access method \"hnsw\"", opclass);
+	FILE *f = fopen(path, "rb");
+	if (!f) pgmock_error("could not open file \"%s\"", path);
+	uint32 hdr[2] = { 0, 0 };
+	if (fread(hdr, sizeof(hdr), 1, f) != 1 || hdr[0] != 0x58444947u) { fclose(f); pgmock_error("\"%s\" is not a saved index", path); }
+	bytea *parsed = g_am->amoptions(PointerGetDatum(opts), true);
+	Relation rel = pgmock_create_index_relation(name, &t->heap, g_distfn[op], g_needs_wal);
+	rel->rd_options = parsed;
+	rel->pages[MAIN_FORKNUM] = (char **) repalloc(rel->pages[MAIN_FORKNUM], (Size) (hdr[1] ? hdr[1] : 1) * sizeof(char *));
+	rel->cappages[MAIN_FORKNUM] = hdr[1] ? hdr[1] : 1;
+	for (BlockNumber b = 0; b < hdr[1]; b++)
+	{
+		rel->pages[MAIN_FORKNUM][b] = (char *) palloc(BLCKSZ);
+		if (fread(rel->pages[MAIN_FORKNUM][b], BLCKSZ, 1, f) != 1) { fclose(f); pgmock_error("\"%s\" is truncated", path); }
+		rel->npages[MAIN_FORKNUM] = b + 1;
+	}
+	fclose(f);
+	t->idx[t->nidx].rel = rel;
+	t->idx[t->nidx].op = op;
+	t->nidx++;
+	printf("ATTACH %u pages\n", hdr[1]);
+}
+
 typedef struct { float4 d; bool null; size_t row; } SortRow;
 static int cmp_sortrow(const void *a, const void *b)
 {
@@ -457,6 +505,8 @@ static void run(char *line)
 		after_am_call("generate");
 	}
 	else if (strcmp(tok[0], "create_index") == 0 && n == 5) cmd_create_index(table(tok[1]), tok[2], tok[3], tok[4]);
+	else if (strcmp(tok[0], "save_index") == 0 && n == 4) cmd_save_index(table(tok[1]), tok[2], tok[3]);
+	else if (strcmp(tok[0], "attach_index") == 0 && n == 6) cmd_attach_index(table(tok[1]), tok[2], tok[3], tok[4], tok[5]);
 	else if (strcmp(tok[0], "select") == 0 && n == 6) cmd_select(table(tok[1]), tok[2], tok[3], tok[4], atol(tok[5]));
 	else if (strcmp(tok[0], "count") == 0 && n == 2)
 	{
@@ -517,7 +567,8 @@ int main(void)
 		{
 			struct timespec t0, t1;
 			const bool timed = strncmp(line, "create_index", 12) == 0 || strncmp(line, "generate", 8) == 0 ||
-							   (strncmp(line, "select", 6) == 0 && getenv("PGEMB_TIME_SELECTS"));
+							   (strncmp(line, "select", 6) == 0 && getenv("PGEMB_TIME_SELECTS")) ||
+							   (strncmp(line, "insert", 6) == 0 && getenv("PGEMB_TIME_INSERTS"));
 			char what[64];
 			snprintf(what, sizeof(what), "%.60s", line);
 			clock_gettime(CLOCK_MONOTONIC, &t0);

@@ -170,6 +170,8 @@ def gpu_lib():
     L.hnsw_gpu_sharded_search.argtypes = [vp, vp, sz, sz, vp, vp, vp]
     L.hnsw_gpu_sharded_last_ms.argtypes = [vp, _f32p, _f32p, _f32p, C.POINTER(C.c_int)]
     L.hnsw_gpu_last_batch_ms.argtypes = [vp, _f32p]
+    L.hnsw_gpu_ctx_set_walkers.argtypes = [vp, C.c_uint]
+    L.hnsw_gpu_device_blocks.argtypes = [i32]
     L.hnsw_gpu_config_set.argtypes = [C.c_char_p, C.c_char_p]
     L.hnsw_gpu_config_get.argtypes = [C.c_char_p, C.POINTER(C.c_longlong)]
     L.hnsw_gpu_config_reload.restype = None

@@ -1703,9 +1703,6 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				if (!LEAN && a.out_pops && hops < a.pops_cap && lane == 0)       // (system scope: a host that polls the sequence sees it as the walk goes)
 					__hip_atomic_store(a.out_pops + (size_t) qi * a.pops_cap + hops, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 				hops++;
-#ifdef HNSW_X_LONGWALK_PRIO
-				if (hops == HNSW_X_LONGWALK_PRIO) __builtin_amdgcn_s_setprio(3);      // (experiment: a walk that is already long gets issue priority)
-#endif
 				if (!LEAN && (hops & 255u) == 0u && abort_requested(a)) { aborted = true; break; }
 				if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_pop += hs1 - hs0; hs0 = hs1; }
 				TeamView h0v = {};
@@ -1967,9 +1964,6 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 			}
 		}
 
-#ifdef HNSW_X_LONGWALK_PRIO
-		__builtin_amdgcn_s_setprio(0);
-#endif
 		if (TEAM && lane == 0) ctl[wib].state = 0u;                       // walk over: helpers let go
 		if (__builtin_amdgcn_readfirstlane((int) aborted)) { if (lane == 0) a.out_counts[qi] = ABORTED_COUNT; continue; }      // interrupted inside its walk
 		if (!LEAN && a.out_times && lane == 0) a.out_times[2 * (size_t) qi + 1] = __builtin_amdgcn_s_memrealtime();

@@ -168,6 +168,7 @@ struct SearchWs
 	hipEvent_t ev0[EV_RING] = {}, ev1[EV_RING] = {};
 	uint64_t launches = 0;
 	uint32_t last_slots = 0;
+	uint32_t walkers_hint = 0;                           // hnsw_gpu_ctx_set_walkers: walking waves per block of a small team launch (0 = by launch size)
 	uint32_t *done_next = nullptr;                       // completion flags for the next launch only
 	uint32_t *pops_next = nullptr; uint32_t pops_cap_next = 0;   // pop-sequence output for the next launch only
 	uint32_t *evals_next = nullptr; uint32_t evals_cap_next = 0; uint64_t *times_next = nullptr;   // evaluation trace, next launch only
@@ -1007,6 +1008,15 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		// fewer queries than resident waves: spread them over the blocks, the other waves of a block start as helpers
 		blocks = std::min<size_t>(nq, (size_t) per_cu * ix->num_cu);
 		a.team_mains = (uint32_t) std::min<size_t>(wpb, (nq + blocks - 1) / blocks);
+		// ... unless the caller knows better: a host that keeps SEVERAL small launches in flight (the batching server's lanes) says
+		// how many waves of a block should walk — one walk per 8-wave block is the latency shape of a lone launch; six such launches
+		// of 190 queries want 9 000 waves of a device that holds 2 048, i.e. at most 256 walks run at a time however many wait
+		// (profiles/r4d_server_sweep.txt: the server's 0.54 M q/s ceiling is exactly 256 walks of 0.47 ms)
+		if (w->walkers_hint > a.team_mains)
+		{
+			a.team_mains = std::min<uint32_t>(wpb, w->walkers_hint);
+			blocks = std::min<size_t>((nq + a.team_mains - 1) / a.team_mains, (size_t) per_cu * ix->num_cu);
+		}
 	}
 	// (experiment knob: walking waves per block of a team launch — the others help from the start; scripts/exp_spec_ab.py)
 #ifdef HNSW_EXPERIMENT
@@ -2502,6 +2512,22 @@ extern "C" int hnsw_gpu_search_batch_ctx(hnsw_gpu_ctx *c, const coord_t *d_queri
 	if (!c) return fail(HNSW_GPU_ERR_ARG, "context is NULL");
 	return launch_search(c->ix, &c->ws, d_queries, c->ix->meta.dim, nq, ef, 0, d_labels, nullptr, d_dists, d_counts, d_stats,
 						 (hipStream_t) stream);
+}
+
+// 8-wave team blocks the device holds at once for rows wider than 320 floats (one per CU: 2 waves/SIMD): the figure a host sizes
+// hnsw_gpu_ctx_set_walkers by.  <= 0: no such device.
+extern "C" int hnsw_gpu_device_blocks(int device)
+{
+	hipDeviceProp_t prop;
+	if (hipGetDeviceProperties(&prop, device) != hipSuccess) { (void) hipGetLastError(); return 0; }
+	return prop.multiProcessorCount;
+}
+
+extern "C" int hnsw_gpu_ctx_set_walkers(hnsw_gpu_ctx *c, unsigned per_block)
+{
+	if (!c) return fail(HNSW_GPU_ERR_ARG, "context is NULL");
+	c->ws.walkers_hint = per_block;
+	return HNSW_GPU_OK;
 }
 
 extern "C" int hnsw_gpu_ctx_search_ms(hnsw_gpu_ctx *c, unsigned back, float *ms)

@@ -65,11 +65,19 @@ struct Options
 	int backlog = 1024;
 	bool verbose = false;
 	int ready_fd = -1;
+	int walkers = -1;              // walking waves per block of a search launch: -1 = by load (below), 0 = the library's default, 1..8 fixed
 } g_opt;
 
 std::atomic<bool> g_stop{false};
 int g_wake_fd = -1;                // eventfd: wakes every epoll loop at shutdown
 std::chrono::steady_clock::time_point g_t0;
+
+// Walks in flight over ALL lanes (queries launched and not yet answered) and the 8-wave team blocks the device holds: a lone small
+// launch gives every walk a block of its own (seven helpers: the latency shape), but the lanes' launches share ONE device — with W
+// walks in flight, ceil(W / blocks) waves per block must walk or the helpers of some walks keep other walks off the device
+// (include/hnsw_gpu.h, hnsw_gpu_ctx_set_walkers; profiles/r4d_server_sweep.txt).
+std::atomic<long> g_walks_in_flight{0};
+int g_device_blocks = 256;
 
 struct Counters
 {
@@ -414,6 +422,16 @@ bool lane_launch(int ctx_slot, Lane &ln)
 		for (size_t i = 0; i < nq; i++) memcpy(Q + i * dim, ln.batch[i].q.data(), dim * 4);
 		memset((void *) ln.F, 0, fb);
 		ln.ctx = e->context(ctx_slot);
+		if (ln.ctx)
+		{
+			unsigned walkers = g_opt.walkers < 0 ? 0u : (unsigned) g_opt.walkers;
+			if (g_opt.walkers < 0)
+			{
+				const long w = g_walks_in_flight.load(std::memory_order_relaxed) + (long) nq;
+				walkers = (unsigned) std::min<long>(8, std::max<long>(1, (w + g_device_blocks - 1) / g_device_blocks));
+			}
+			(void) hnsw_gpu_ctx_set_walkers(ln.ctx, walkers);
+		}
 		rc = ln.ctx ? hnsw_gpu_search_batch_ctx_flags(ln.ctx, Q, nq, ef, ln.L, ln.D, ln.C, nullptr, (uint32_t *) ln.F)
 					: HNSW_GPU_ERR_HIP;
 	}
@@ -434,6 +452,7 @@ bool lane_launch(int ctx_slot, Lane &ln)
 	for (size_t i = 0; i < nq; i++) ln.pending[i] = (uint32_t) i;
 	ln.t0 = ln.t_check = now_ns();
 	ln.active = true;
+	g_walks_in_flight.fetch_add((long) nq, std::memory_order_relaxed);
 	g_cnt.batches++;
 	g_cnt.searches += nq;
 	uint64_t mb = g_cnt.max_batch.load();
@@ -457,6 +476,7 @@ bool lane_poll(Lane &ln)
 						 gen);
 			ln.pending[k] = ln.pending.back();
 			ln.pending.pop_back();
+			g_walks_in_flight.fetch_sub(1, std::memory_order_relaxed);
 			progress = true;
 		}
 		else k++;
@@ -480,6 +500,7 @@ bool lane_poll(Lane &ln)
 		logf("search launch lost %zu of %zu queries: %s", ln.pending.size(), ln.batch.size(), hnsw_gpu_last_error());
 		g_cnt.search_errors += ln.pending.size();
 		for (uint32_t i : ln.pending) ln.batch[i].c->respond(ln.batch[i].h, HNSW_GPU_ERR_INTERNAL);
+		g_walks_in_flight.fetch_sub((long) ln.pending.size(), std::memory_order_relaxed);
 		ln.pending.clear();
 		progress = true;
 	}
@@ -543,6 +564,7 @@ void dispatcher_lanes(int d)
 		if (ln.active)
 		{
 			for (uint32_t i : ln.pending) ln.batch[i].c->respond(ln.batch[i].h, HGS_ERR_SHUTDOWN);
+			g_walks_in_flight.fetch_sub((long) ln.pending.size(), std::memory_order_relaxed);
 			ln.e->end_read();
 			ln.active = false;
 		}
@@ -1081,7 +1103,9 @@ void usage()
 {
 	fprintf(stderr,
 			"usage: hnsw_gpu_server --socket PATH [--device N] [--dispatchers N] [--readers N]\n"
-			"                       [--max-batch N] [--lanes N] [--linger-us N --min-batch N] [--verbose] [--ready-fd N]\n");
+			"                       [--max-batch N] [--lanes N] [--linger-us N --min-batch N] [--walkers auto|0..8] [--verbose] [--ready-fd N]\n"
+			"  --walkers  walking waves per 8-wave block of a search launch: auto (default) = by the walks in flight over all lanes,\n"
+			"             0 = the library's choice per launch (every walk gets a block while the launch is small), 1..8 = fixed\n");
 }
 
 }  // namespace
@@ -1102,6 +1126,7 @@ int main(int argc, char **argv)
 		else if (a == "--max-batch") g_opt.max_batch = (size_t) atol(val("--max-batch"));
 		else if (a == "--lanes") g_opt.lanes = atoi(val("--lanes"));
 		else if (a == "--linger-us") g_opt.linger_us = atol(val("--linger-us"));
+		else if (a == "--walkers") { const std::string v = val("--walkers"); g_opt.walkers = v == "auto" ? -1 : atoi(v.c_str()); }
 		else if (a == "--min-batch") g_opt.min_batch = (size_t) atol(val("--min-batch"));
 		else if (a == "--ready-fd") g_opt.ready_fd = atoi(val("--ready-fd"));
 		else if (a == "--verbose") g_opt.verbose = true;
@@ -1126,6 +1151,10 @@ int main(int argc, char **argv)
 		return 3;
 	}
 	g_t0 = std::chrono::steady_clock::now();
+	{
+		const int blk = hnsw_gpu_device_blocks(g_opt.device);
+		if (blk > 0) g_device_blocks = blk;
+	}
 
 	{
 		// one descriptor per backend: take what the hard limit allows

@@ -383,6 +383,10 @@ class SearchContext:
         except Exception:
             pass
 
+    def set_walkers(self, per_block: int) -> None:
+        """Walking waves per block of this context's small (team) launches: hnsw_gpu_ctx_set_walkers; 0 = by launch size."""
+        check(self.L.hnsw_gpu_ctx_set_walkers(self._h, int(per_block)), "hnsw_gpu_ctx_set_walkers")
+
     def search_torch(self, queries, ef: int, out: dict, stream=None):
         """Enqueue one batch on `stream` (a torch.cuda.Stream; default: the current one)."""
         torch = _torch()

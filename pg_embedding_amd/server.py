@@ -141,7 +141,7 @@ class ServerProcess:
 
     def __init__(self, socket_path: Optional[str] = None, device: int = 0, dispatchers: int = 2,
                  max_batch: int = 16384, linger_us: int = 0, min_batch: int = 1, readers: int = 4, lanes: int = 3, binary: Optional[str] = None,
-                 env: Optional[dict] = None, verbose: bool = False, start_timeout: float = 120.0):
+                 env: Optional[dict] = None, verbose: bool = False, start_timeout: float = 120.0, walkers: Optional[str] = None):
         self.binary = binary or _build.SERVER_BIN
         if not os.path.exists(self.binary):
             _build.build()
@@ -154,6 +154,8 @@ class ServerProcess:
         self.socket_path = socket_path
         self.args = [self.binary, "--socket", socket_path, "--device", str(device), "--dispatchers", str(dispatchers),
                      "--max-batch", str(max_batch), "--readers", str(readers), "--lanes", str(lanes)]
+        if walkers is not None:
+            self.args += ["--walkers", str(walkers)]
         if linger_us:
             self.args += ["--linger-us", str(linger_us), "--min-batch", str(min_batch)]
         if verbose:

@@ -308,6 +308,16 @@ int hnsw_gpu_search_batch_ctx_host(hnsw_gpu_ctx *c, const coord_t *queries, size
 }
 
 int hnsw_gpu_ctx_search_ms(hnsw_gpu_ctx *c, unsigned back, float *ms) { (void) c; (void) back; *ms = 0.f; return HNSW_GPU_OK; }
+static unsigned g_walkers_last = 0, g_walkers_max = 0;     /* what the server asked for (tests read them through the stats of the double) */
+int hnsw_gpu_ctx_set_walkers(hnsw_gpu_ctx *c, unsigned per_block)
+{
+	(void) c;
+	g_walkers_last = per_block;
+	if (per_block > g_walkers_max) g_walkers_max = per_block;
+	return HNSW_GPU_OK;
+}
+unsigned engine_double_walkers_max(void) { return g_walkers_max; }
+int hnsw_gpu_device_blocks(int device) { (void) device; return 4; }   /* a tiny "device": the server's load policy is exercised with a handful of backends */
 
 static void *flags_worker(void *arg)
 {

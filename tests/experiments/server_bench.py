@@ -43,16 +43,17 @@ def main():
     ap.add_argument("--hwq", type=int, default=0, help="GPU_MAX_HW_QUEUES for the server process (0 = leave it alone)")
     ap.add_argument("--binary", default=None, help="server binary (default: the shipped one)")
     ap.add_argument("--check", type=int, default=200, help="queries compared with the CPU reference")
-    ap.add_argument("--configs", default="", help="sweep: comma-separated dispatchers:lanes[:readers] — one server per entry over the same "
-                                                  "rows (data generated once); the parity check runs for the first entry only")
+    ap.add_argument("--walkers", default=None, help="server --walkers (auto | 0..8): walking waves per block of a search launch")
+    ap.add_argument("--configs", default="", help="sweep: comma-separated dispatchers:lanes[:readers[:walkers]] — one server per entry over the "
+                                                  "same rows (data generated once); the parity check runs for the first entry only")
     a = ap.parse_args()
     if a.configs:
         cfgs = []
         for c in a.configs.split(","):
-            f = [int(x) for x in c.split(":")]
-            cfgs.append((f[0], f[1], f[2] if len(f) > 2 else a.readers))
+            f = c.split(":")
+            cfgs.append((int(f[0]), int(f[1]), int(f[2]) if len(f) > 2 else a.readers, f[3] if len(f) > 3 else a.walkers))
     else:
-        cfgs = [(a.dispatchers, a.lanes, a.readers)]
+        cfgs = [(a.dispatchers, a.lanes, a.readers, a.walkers)]
 
     import oracle
     import pg_embedding_amd as pg
@@ -77,9 +78,9 @@ def main():
     Q.tofile(qf)
     key, gen = 1, 1
     table = []
-    for ci, (nd, nl, nr) in enumerate(cfgs):
-      print(f"## server with {nd} dispatchers x {nl} lanes, {nr} readers", flush=True)
-      srv = ServerProcess(dispatchers=nd, readers=nr, lanes=nl, binary=a.binary,
+    for ci, (nd, nl, nr, nw) in enumerate(cfgs):
+      print(f"## server with {nd} dispatchers x {nl} lanes, {nr} readers, walkers {nw or 'default (auto)'}", flush=True)
+      srv = ServerProcess(dispatchers=nd, readers=nr, lanes=nl, binary=a.binary, walkers=nw,
                           env={"GPU_MAX_HW_QUEUES": str(a.hwq)} if a.hwq else None)
       with srv:
           c = RemoteClient(srv.socket_path)
@@ -119,7 +120,7 @@ def main():
               st = c.stats()
               print("# server totals:", json.dumps({k: st[k] for k in ("connections", "searches", "batches", "max_batch", "search_errors")}))
               c.close()
-              table += [(nd, nl, nr, r) for r in rows]
+              table += [(nd, nl, nr, nw, r) for r in rows]
               continue
           # parity of what the backends received, against the reference's code on the same graph bytes
           graph = c.export(key, a.rows * esz)
@@ -141,10 +142,10 @@ def main():
           st = c.stats()
           print("# server totals:", json.dumps({k: st[k] for k in ("connections", "searches", "batches", "max_batch", "search_errors")}))
           c.close()
-          table += [(nd, nl, nr, r) for r in rows]
-    print("\n| dispatchers x lanes (readers) | backends | queries/s | mean batch | ms per batch (host) | kernel ms per batch | round trip ms |\n|---|---|---|---|---|---|---|")
-    for nd, nl, nr, r in table:
-        print(f"| {nd} x {nl} ({nr}) | {r['nproc']} | {r['qps']:.0f} | {r['mean_batch']:.1f} | {r['ms_per_batch']:.2f} | {r['kernel_ms_per_batch']:.2f} | {r['latency_ms']:.2f} |")
+          table += [(nd, nl, nr, nw, r) for r in rows]
+    print("\n| dispatchers x lanes (readers, walkers) | backends | queries/s | mean batch | ms per batch (host) | kernel ms per batch | round trip ms |\n|---|---|---|---|---|---|---|")
+    for nd, nl, nr, nw, r in table:
+        print(f"| {nd} x {nl} ({nr}, {nw or 'auto'}) | {r['nproc']} | {r['qps']:.0f} | {r['mean_batch']:.1f} | {r['ms_per_batch']:.2f} | {r['kernel_ms_per_batch']:.2f} | {r['latency_ms']:.2f} |")
 
 
 if __name__ == "__main__":

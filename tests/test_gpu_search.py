@@ -420,6 +420,38 @@ def test_team_form_is_exact_at_every_launch_size(func, dim, m, monkeypatch):
     ix.close()
 
 
+@pytest.mark.parametrize("dim,m", [(768, 16), (128, 16)])
+def test_walkers_per_block_of_a_small_launch_change_nothing_but_its_shape(dim, m):
+    """hnsw_gpu_ctx_set_walkers (the batching server's load policy): a small team launch with 1 .. 8 walking waves per block —
+    from every walk with seven helpers to every wave walking — answers every query alike: labels, distance bits, E_q, H_q equal the
+    oracle's, with several such launches in flight on different streams too."""
+    import torch
+    func, n, ef = pg.DIST_L2, 8000, 96
+    port, X = build_port(n, dim, m, 48, func, k=40, seed=11 * dim)
+    Q = gmm(300, dim, k=40, seed=11 * dim, stream=1)
+    want = port.search_many(Q, ef, nthreads=8)
+    ix = mirror(port, func)
+    dQ = torch.from_numpy(Q).cuda()
+    ctxs = [pg.SearchContext(ix) for _ in range(3)]
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    outs = [ix.search_torch(dQ, ef, stats=True) for _ in range(3)]
+    torch.cuda.synchronize()
+    for walkers in (0, 1, 2, 3, 8):
+        for nq in (5, 190, 300):
+            for k in range(3):
+                ctxs[k].set_walkers(walkers)
+                ctxs[k].search_torch(dQ[:nq].contiguous(), ef, outs[k], streams[k])
+            torch.cuda.synchronize()
+            for k in range(3):
+                assert (outs[k]["labels"][:nq].cpu().numpy().view(np.uint64) == want["labels"][:nq]).all(), (walkers, nq, k)
+                assert (bits(outs[k]["dists"][:nq].cpu().numpy()) == bits(want["dists"][:nq])).all(), (walkers, nq, k)
+                st = outs[k]["stats"][:nq].cpu().numpy().astype(np.uint32)
+                assert (st[:, 0] == want["evals"][:nq]).all() and (st[:, 1] == want["hops"][:nq]).all(), (walkers, nq, k)
+    for c in ctxs:
+        c.close()
+    ix.close()
+
+
 @pytest.mark.parametrize("ef", [1, 5, 64, 128, 256])
 def test_beam_prune_with_ties_at_the_bound(ef):
     """0/1 vectors in 6 dimensions: only 7 distinct L2 distances, so the ef-th smallest distance is
