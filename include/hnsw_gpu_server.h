@@ -107,6 +107,11 @@ typedef struct hgs_stats
 	uint64_t batch_ns;                           /* host time inside search launches, summed over dispatchers */
 	uint64_t kernel_ns;                          /* device time of the search kernels (HIP events), summed     */
 	uint64_t uptime_ns;
+	/* where a SEARCH spends its time inside the server, summed over answered searches (streamed-completion lanes): from the
+	 * request's arrival (parsed by a reader) to its launch, from the launch to the moment the dispatcher saw its completion flag
+	 * (the walk + the poll), and the write of the answer; a backend's round trip minus their sum is the socket hops and its own
+	 * wake-up */
+	uint64_t queue_ns, walk_ns, answer_ns;
 } hgs_stats;
 
 /* ------------------------------------------------- client side (libembedding_gpuc.so) */

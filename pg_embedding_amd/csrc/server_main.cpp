@@ -82,7 +82,8 @@ int g_device_blocks = 256;
 struct Counters
 {
 	std::atomic<uint64_t> connections{0}, connections_now{0}, searches{0}, batches{0}, max_batch{0},
-		search_errors{0}, uploads{0}, upload_bytes{0}, updates{0}, binds{0}, evictions{0}, batch_ns{0}, kernel_ns{0};
+		search_errors{0}, uploads{0}, upload_bytes{0}, updates{0}, binds{0}, evictions{0}, batch_ns{0}, kernel_ns{0},
+		queue_ns{0}, walk_ns{0}, answer_ns{0};
 } g_cnt;
 
 uint64_t now_ns()
@@ -256,6 +257,7 @@ struct SReq            // one backend's hnsw_search
 	EntryP e;
 	hgs_hdr h;
 	std::vector<float> q;
+	uint64_t t_in = 0;             // arrival (parsed by a reader), for hgs_stats.queue_ns
 };
 std::mutex g_q_mu;
 std::condition_variable g_q_cv;
@@ -452,6 +454,11 @@ bool lane_launch(int ctx_slot, Lane &ln)
 	for (size_t i = 0; i < nq; i++) ln.pending[i] = (uint32_t) i;
 	ln.t0 = ln.t_check = now_ns();
 	ln.active = true;
+	{
+		uint64_t waited = 0;
+		for (const SReq &r : ln.batch) waited += ln.t0 - std::min(ln.t0, r.t_in);
+		g_cnt.queue_ns += waited;
+	}
 	g_walks_in_flight.fetch_add((long) nq, std::memory_order_relaxed);
 	g_cnt.batches++;
 	g_cnt.searches += nq;
@@ -472,8 +479,11 @@ bool lane_poll(Lane &ln)
 		{
 			SReq &r = ln.batch[i];
 			const size_t cnt = ln.C[i] <= ln.ef ? ln.C[i] : 0;
+			const uint64_t t_seen = now_ns();
 			r.c->respond(r.h, HGS_OK, cnt, 0, ln.L + (size_t) i * ln.ef, cnt * 8, r.h.a0 ? ln.D + (size_t) i * ln.ef : nullptr, cnt * 4,
 						 gen);
+			g_cnt.walk_ns += t_seen - ln.t0;
+			g_cnt.answer_ns += now_ns() - t_seen;
 			ln.pending[k] = ln.pending.back();
 			ln.pending.pop_back();
 			g_walks_in_flight.fetch_sub(1, std::memory_order_relaxed);
@@ -931,6 +941,7 @@ void fill_stats(hgs_stats *s)
 	s->search_errors = g_cnt.search_errors;
 	s->uploads = g_cnt.uploads; s->upload_bytes = g_cnt.upload_bytes; s->updates = g_cnt.updates;
 	s->binds = g_cnt.binds; s->evictions = g_cnt.evictions; s->batch_ns = g_cnt.batch_ns; s->kernel_ns = g_cnt.kernel_ns;
+	s->queue_ns = g_cnt.queue_ns; s->walk_ns = g_cnt.walk_ns; s->answer_ns = g_cnt.answer_ns;
 	{
 		std::lock_guard<std::mutex> lk(g_map_mu);
 		s->mirrors = g_map.size();
@@ -980,6 +991,7 @@ bool handle_message(const ConnP &c, const hgs_hdr &h, const char *payload)
 		r.c = c; r.e = std::move(e); r.h = h;
 		r.q.resize(h.len / 4);
 		memcpy(r.q.data(), payload, h.len);
+		r.t_in = now_ns();
 		{
 			std::lock_guard<std::mutex> lk(g_q_mu);
 			g_q.push_back(std::move(r));

@@ -30,7 +30,7 @@ class hgs_stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "connections", "connections_now", "searches", "batches", "max_batch", "search_errors",
         "uploads", "upload_bytes", "updates", "binds", "evictions", "mirrors", "mirror_elements",
-        "batch_ns", "kernel_ns", "uptime_ns")]
+        "batch_ns", "kernel_ns", "uptime_ns", "queue_ns", "walk_ns", "answer_ns")]
 
 
 HGS_ERR_NOKEY, HGS_ERR_STALE, HGS_ERR_IO = -21, -22, -23

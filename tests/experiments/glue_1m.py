@@ -66,12 +66,23 @@ def session(exe, label, env=None):
     return r.stdout
 
 
+def compare(name, out):
+    same = out_ref == out
+    print(f"   {name}: same result tables as the reference (every scan, before and after the inserts): {same}", flush=True)
+    if not same:
+        a, b = out_ref.splitlines(), out.splitlines()
+        diff = [i for i in range(min(len(a), len(b))) if a[i] != b[i]]
+        print(f"   {len(diff)} of {len(a)} lines differ, first at line {diff[0] if diff else -1}: {a[diff[0]] if diff else ''!r} vs {b[diff[0]] if diff else ''!r}")
+
+
 out_ref = session(SU.PG_REGRESS_REF, "reference glue + hnswalg.o + distfunc.o, one host core")
-out_gpu = session(SU.build_pg_regress("shimdouble" if DRY else "gpu"), "reference glue + libembedding_gpu.so in process (validated mirror cache)")
-same = out_ref == out_gpu
-print(f"same result tables (every scan, before and after the inserts): {same}")
-if not same:
-    a, b = out_ref.splitlines(), out_gpu.splitlines()
-    diff = [i for i in range(min(len(a), len(b))) if a[i] != b[i]]
-    print(f"   {len(diff)} of {len(a)} lines differ, first at line {diff[0] if diff else -1}: {a[diff[0]] if diff else ''!r} vs {b[diff[0]] if diff else ''!r}")
+out_gpu = session(SU.build_pg_regress("shimdouble" if DRY else "gpu"),
+                  "UNMODIFIED glue + libembedding_gpu.so in process (validated mirror cache: every walk is checked against the host's pages)")
+compare("in process", out_gpu)
+# the trusted mirror: the 49-line maintainer patch gives the mirror an identity + generation, the server keeps ONE mirror for all
+# backends and no walk is re-read on the host; the first scan of this fresh process uploads the attached pages
+with ServerProcess(binary=SU.build_double_server() if DRY else None) as srv:
+    out_srv = session(SU.build_pg_regress("patched"), "PATCHED glue (49 lines) + libembedding_gpuc.so + hnsw_gpu_server (trusted mirror)",
+                      env={"PG_EMBEDDING_GPU_SERVER": srv.socket_path})
+compare("server", out_srv)
 os.remove(idxf)

@@ -107,11 +107,14 @@ def main():
               assert r.returncode == 0, r.stderr
               info = json.loads(r.stdout)
               st = c.stats()
-              d = {k: st[k] - before[k] for k in ("searches", "batches", "batch_ns", "kernel_ns")}
+              d = {k: st[k] - before[k] for k in ("searches", "batches", "batch_ns", "kernel_ns", "queue_ns", "walk_ns", "answer_ns")}
               info.update(mean_batch=d["searches"] / max(1, d["batches"]), batches=d["batches"],
                           ms_per_batch=d["batch_ns"] / 1e6 / max(1, d["batches"]),
                           kernel_ms_per_batch=d["kernel_ns"] / 1e6 / max(1, d["batches"]),
-                          latency_ms=1e3 * P / info["qps"])
+                          latency_ms=1e3 * P / info["qps"],
+                          # inside the server, per search: waiting for a lane / launch to completion flag seen / writing the answer
+                          queue_ms=d["queue_ns"] / 1e6 / max(1, d["searches"]), walk_ms=d["walk_ns"] / 1e6 / max(1, d["searches"]),
+                          answer_ms=d["answer_ns"] / 1e6 / max(1, d["searches"]))
               rows.append(info)
               print(json.dumps(info), flush=True)
               out = np.fromfile(of, np.uint64)
@@ -143,9 +146,9 @@ def main():
           print("# server totals:", json.dumps({k: st[k] for k in ("connections", "searches", "batches", "max_batch", "search_errors")}))
           c.close()
           table += [(nd, nl, nr, nw, r) for r in rows]
-    print("\n| dispatchers x lanes (readers, walkers) | backends | queries/s | mean batch | ms per batch (host) | kernel ms per batch | round trip ms |\n|---|---|---|---|---|---|---|")
+    print("\n| dispatchers x lanes (readers, walkers) | backends | queries/s | mean batch | ms per batch (host) | kernel ms per batch | round trip ms | in server: queue + walk + answer ms |\n|---|---|---|---|---|---|---|---|")
     for nd, nl, nr, nw, r in table:
-        print(f"| {nd} x {nl} ({nr}, {nw or 'auto'}) | {r['nproc']} | {r['qps']:.0f} | {r['mean_batch']:.1f} | {r['ms_per_batch']:.2f} | {r['kernel_ms_per_batch']:.2f} | {r['latency_ms']:.2f} |")
+        print(f"| {nd} x {nl} ({nr}, {nw or 'auto'}) | {r['nproc']} | {r['qps']:.0f} | {r['mean_batch']:.1f} | {r['ms_per_batch']:.2f} | {r['kernel_ms_per_batch']:.2f} | {r['latency_ms']:.2f} | {r['queue_ms']:.2f} + {r['walk_ms']:.2f} + {r['answer_ms']:.3f} |")
 
 
 if __name__ == "__main__":

@@ -203,3 +203,28 @@ def test_fails_loudly_without_a_device(gpu_count):
     with pytest.raises(RuntimeError):
         pg.dist_batch(pg.DIST_L2, np.zeros(8, np.float32), np.zeros((2, 8), np.float32))
     assert gpu_lib().hnsw_gpu_last_error()
+
+
+def test_the_shipped_library_knows_only_the_documented_knobs():
+    """The library resolves its configuration once (no getenv on a call path: INTEGRATION.md §6) and carries no experiment knobs: the
+    HNSW_GPU_* names in the shipped binary are exactly the operational + test knobs of INTEGRATION.md's two tables (plus
+    HNSW_GPU_WATCHDOG_S, read once at the first workspace, and the HNSW_GPU_COUNT_ABORTED of a message)."""
+    import re
+    import subprocess
+    lib = os.path.join(ROOT, "pg_embedding_amd", "lib", "libhnsw_gpu.so")
+    if not os.path.exists(lib):
+        pytest.skip("library not built")
+    out = subprocess.run(["strings", "-n", "8", lib], capture_output=True, text=True, check=True).stdout
+    in_lib = set(re.findall(r"HNSW_GPU_[A-Z0-9_]+", out)) - {"HNSW_GPU_COUNT_ABORTED"}
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    sec = doc[doc.index("## 6. Configuration"):]
+    sec = sec[:sec.index("Every setting returns the same bytes")]
+    documented = set(re.findall(r"`(HNSW_GPU_[A-Z0-9_]+)`", "\n".join(ln for ln in sec.splitlines() if ln.startswith("| `"))))
+    assert in_lib == documented, (sorted(in_lib - documented), sorted(documented - in_lib))
+    for gone in ("HNSW_GPU_WIDE_WAVES", "HNSW_GPU_SHAPE_12X1", "HNSW_GPU_TEAM_MAINS", "HNSW_GPU_TEAM_COUNTERS"):
+        assert gone not in in_lib
+    # ... and no entry point of the search / insert paths imports getenv-by-name machinery beyond the once-only table: the symbol is
+    # referenced (the table, the watchdog), but the call path reads plain words — checked by the source: launch_search has no getenv
+    src = open(os.path.join(ROOT, "pg_embedding_amd", "csrc", "hnsw_gpu.hip")).read()
+    body = src[src.index("static int launch_search("):src.index('extern "C" int hnsw_gpu_search_batch_dev(')]
+    assert "getenv" not in body
