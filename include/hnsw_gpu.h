@@ -277,6 +277,33 @@ int  hnsw_gpu_search_batch_ctx_flags(hnsw_gpu_ctx *ctx, const coord_t *d_queries
 									 uint32_t *d_done);
 int  hnsw_gpu_ctx_idle(hnsw_gpu_ctx *ctx);
 
+/* Streams: ONE resident search launch that the host feeds while it runs (csrc/device_search.h, "Stream mode") — the shape for
+ * queries that arrive one at a time from many callers (the reference hands the path one query per hnsw_search call, embedding.c:317,
+ * from one process per connection): a query starts the moment a walking wave is free instead of waiting for a launch in flight to end.
+ *   hnsw_gpu_stream_open    launches the kernel on the context's own stream: every block the device holds, `walkers` (1..8, 0 = 4)
+ *                           walking waves per 8-wave block, the others help them; ring = slots of the query / result ring (a power of
+ *                           two in [64, 2^20]) in pinned host memory the library allocates; the context serves the stream until
+ *                           _close (no other call on it).  Needs the team form of the beam kernel (ef <= 256; <= 512 on wide rows).
+ *   hnsw_gpu_stream_buffers the ring: queries ring x dim, labels / dists ring x ef, counts, completion flags ring (host pointers).
+ *                           Query number t (t = 0, 1, 2, ... in publication order) lives in slot t & (ring - 1): the host writes its
+ *                           dim floats, zeroes the slot's flag, and only then publishes; it reuses a slot when the query that held
+ *                           it a ring ago has been answered.
+ *   hnsw_gpu_stream_publish published_total = how many queries have been written so far (a counter mod 2^32): a release store — the
+ *                           kernel's doorbell wave forwards it to the waiting waves within about two microseconds.
+ *   results                 flags[slot] becomes 1 once labels / dists / counts of that slot are complete (system-scope release: the
+ *                           streamed completion of hnsw_gpu_search_batch_ctx_flags); rows are what hnsw_gpu_search_batch returns.
+ *   hnsw_gpu_stream_alive   1 while the launch is on the device.
+ *   hnsw_gpu_stream_close   stop: every wave leaves at its next look (a walking wave after its query); waits for the launch to end
+ *                           (a launch that does not end within 2 s is asked through its abort word), frees the ring.  Queries
+ *                           published but not yet started are dropped: close a stream when nothing is outstanding.
+ * Results do not depend on the mode: a query's walk is the same walk in a plain launch, a team launch or a stream. */
+typedef struct hnsw_gpu_stream hnsw_gpu_stream;
+int  hnsw_gpu_stream_open(hnsw_gpu_ctx *ctx, size_t ef, size_t ring, unsigned walkers, hnsw_gpu_stream **out);
+int  hnsw_gpu_stream_buffers(hnsw_gpu_stream *s, coord_t **queries, label_t **labels, dist_t **dists, uint32_t **counts, uint32_t **flags);
+int  hnsw_gpu_stream_publish(hnsw_gpu_stream *s, uint32_t published_total);
+int  hnsw_gpu_stream_alive(hnsw_gpu_stream *s);
+int  hnsw_gpu_stream_close(hnsw_gpu_stream *s);
+
 /* One query together with its walk: the results of hnsw_gpu_search_batch plus the sequence of elements the walk expanded
  * (candidateSet pops, hnswalg.cpp:73; *npops of them, the first min(*npops, pops_cap) stored) and the number of distance
  * evaluations.  A walk is a deterministic function of the elements it touched — the expanded ones and their link

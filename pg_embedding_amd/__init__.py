@@ -8,7 +8,7 @@ implementation: every entry point fails loudly without the built HIP library and
 from .index import (  # noqa: F401
     DIST_L2, DIST_COSINE, DIST_MANHATTAN, OPCLASS, LABEL_DELETED, NO_LABEL,
     DEFAULT_M, DEFAULT_EF_CONSTRUCTION, DEFAULT_EF_SEARCH,
-    GpuIndex, SearchContext, make_meta, dist_batch, l2_distance, cosine_distance, manhattan_distance,
+    GpuIndex, SearchContext, SearchStream, make_meta, dist_batch, l2_distance, cosine_distance, manhattan_distance,
     merge_topk_torch, merge_packed_torch, LocalShardedIndex,
 )
 from ._lib import HnswMetadata, LibraryMissing, config_set, config_get, sync_env  # noqa: F401

@@ -172,6 +172,11 @@ def gpu_lib():
     L.hnsw_gpu_last_batch_ms.argtypes = [vp, _f32p]
     L.hnsw_gpu_ctx_set_walkers.argtypes = [vp, C.c_uint]
     L.hnsw_gpu_device_blocks.argtypes = [i32]
+    L.hnsw_gpu_stream_open.argtypes = [vp, sz, sz, C.c_uint, C.POINTER(vp)]
+    L.hnsw_gpu_stream_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)]
+    L.hnsw_gpu_stream_publish.argtypes = [vp, C.c_uint32]
+    L.hnsw_gpu_stream_alive.argtypes = [vp]
+    L.hnsw_gpu_stream_close.argtypes = [vp]
     L.hnsw_gpu_config_set.argtypes = [C.c_char_p, C.c_char_p]
     L.hnsw_gpu_config_get.argtypes = [C.c_char_p, C.POINTER(C.c_longlong)]
     L.hnsw_gpu_config_reload.restype = None

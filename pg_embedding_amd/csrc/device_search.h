@@ -104,6 +104,10 @@ struct SearchArgs
 	uint32_t *health;           // HEALTH_WORDS device words: time-out and abort counters of the workspace
 	uint32_t *team_dbg;         // null, or 16 counters for the whole launch (hnsw_gpu_team_counters): hops with helpers,
 	                            // link-list hits, ids looked up, distance hits, hops that still scored rows, all hops
+	// stream mode (team form of the beam kernel; banner "Stream mode" at the kernel): a RESIDENT launch that the host feeds
+	const uint32_t *stream_host;  // null = a plain launch.  Pinned host words: [0] = queries published so far, [1] = non-zero: leave
+	uint32_t *stream_dev;         // device words [0] / [1]: the doorbell wave's copies of the two, what every other wave polls
+	uint32_t stream_ring;         // slots of the query / result ring (a power of two): ticket t lives in slot t & (ring - 1)
 };
 
 // Abort word + health words of a search workspace.
@@ -1608,6 +1612,39 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 	bool aborted = false;              // the host asked this launch to end (abort word)
 	TeamCtl *ctl = reinterpret_cast<TeamCtl *>(smem + a.off_ctl);
 	const uint32_t wpb = blockDim.x >> 6;
+	// Stream mode (TEAM kernels; host side: hnsw_gpu_stream_*, hnsw_gpu.hip).  One query per call from hundreds of backends makes
+	// small launches, and a query that arrives while every launch in flight is busy waits for a launch to END before it can even
+	// start (0.4-0.5 ms of a 1.8 ms round trip at 1 024 backends, profiles/r4f_server_walkers_and_breakdown.txt).  A stream is ONE
+	// resident launch: its walking waves take tickets as always, but a ticket is a slot of a ring in pinned host memory that the
+	// host fills while the kernel runs — the wave that holds ticket t waits until the host has PUBLISHED more than t queries, walks
+	// query t & (ring - 1), writes its results and completion flag into the same slot of the result ring (streamed completion, as
+	// the server's launches do), and takes the next ticket.  A query starts the moment a walking wave is free, never later.
+	//   * block 0 of the grid is the doorbell (the first block the dispatcher places: it must be resident for anybody to make
+	//     progress, so the grid is never larger than what the device holds at once): its first wave copies the host's two control words (published count, stop)
+	//     into device memory about once a microsecond; every other wave polls the device copy (L2), so an idle stream costs one
+	//     read across the host link per microsecond, not one per resident wave;
+	//   * the team geometry is fixed for the life of the stream (team_mains walking waves per block, the others help them: the
+	//     helpers of a block have walking siblings for as long as the stream lives, so the helper protocol runs unchanged);
+	//   * stop: every wave leaves at its next look — a walking wave after its current query (the host stops a stream when nothing
+	//     is outstanding, or gives the stragglers up).  The abort word works as in every launch and also ends the wave.
+	const bool stream = TEAM && a.stream_host != nullptr;
+	if (stream && blockIdx.x == 0)
+	{
+		if (wib != 0) return;
+		for (;;)
+		{
+			const uint32_t pub = __hip_atomic_load(a.stream_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			const uint32_t stop = __hip_atomic_load(a.stream_host + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");              // what the host wrote before it published is visible to loads issued from here on
+			if (lane == 0)
+			{
+				__hip_atomic_store(a.stream_dev, pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+				if (stop) __hip_atomic_store(a.stream_dev + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+			}
+			if (__builtin_amdgcn_readfirstlane((int) stop)) return;
+			__builtin_amdgcn_s_sleep(24);
+		}
+	}
 	if (TEAM)
 	{
 		if (lane == 0) { ctl[wib].state = wib < a.team_mains ? 0u : 2u; ctl[wib].helpers = 0u; ctl[wib].job = 0u; ctl[wib].jobseq = 0u; ctl[wib].done = 0u; }
@@ -1620,19 +1657,56 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		uint32_t qi = 0;
 		if (lane == 0) qi = atomicAdd(a.ticket, 1u);
 		qi = __builtin_amdgcn_readfirstlane(qi);
-		if (qi >= a.nq) break;
+		if (stream)
+		{
+			bool leave = false;
+			for (uint32_t nap = 8;;)                                      // wait until the host has published query qi (or says stop)
+			{
+				uint32_t pub = 0, stop = 0;
+				if (lane == 0)
+				{
+					pub = __hip_atomic_load(a.stream_dev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+					stop = __hip_atomic_load(a.stream_dev + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+				}
+				pub = __builtin_amdgcn_readfirstlane(pub); stop = __builtin_amdgcn_readfirstlane(stop);
+				if ((int32_t) (pub - qi) > 0) break;                     // (wrap-safe: tickets and the published count are counters mod 2^32)
+				if (stop) { leave = true; break; }
+				if (nap == 8) __builtin_amdgcn_s_sleep(8); else if (nap == 32) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(127);
+				nap = nap < 127 ? nap * 4 : 127;
+			}
+			if (__builtin_amdgcn_readfirstlane((int) leave)) break;
+			qi &= a.stream_ring - 1u;                                     // from here on qi is the slot: query, outputs and flag of this ticket
+		}
+		else if (qi >= a.nq) break;
 		// (an abort request is sticky for this wave: it takes the remaining tickets without walking and marks every query it does not
 		// answer with count 0xFFFFFFFF, so that the caller of an interrupted launch can tell which rows of its outputs are results)
 		if (!aborted && abort_requested(a)) aborted = true;
-		if (__builtin_amdgcn_readfirstlane((int) aborted)) { if (lane == 0) a.out_counts[qi] = ABORTED_COUNT; continue; }   // (wave-uniform by construction; said explicitly)
+		if (__builtin_amdgcn_readfirstlane((int) aborted))
+		{
+			if (lane == 0) a.out_counts[qi] = ABORTED_COUNT;
+			if (stream) break;                                            // (a stream has no last ticket to run to)
+			continue;
+		}
 		if (!LEAN && a.out_times && lane == 0) a.out_times[2 * (size_t) qi] = __builtin_amdgcn_s_memrealtime();
 
 		const float *qsrc = a.queries + (size_t) qi * a.q_stride;
-		for (uint32_t e = lane; e < a.qpad_floats; e += 64)
+		if (stream)
 		{
-			const float t = qsrc[e < a.dim ? e : a.dim - 1];
-			qf[e] = (e < a.dim) ? t : 0.f;
+			// the ring lives in pinned host memory and this slot held another query a ring ago: system-scope loads, so that no cache of
+			// the device can answer with the old one
+			const uint32_t *qw = reinterpret_cast<const uint32_t *>(qsrc);
+			for (uint32_t e = lane; e < a.qpad_floats; e += 64)
+			{
+				const uint32_t t = __hip_atomic_load(qw + (e < a.dim ? e : a.dim - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				qf[e] = (e < a.dim) ? __uint_as_float(t) : 0.f;
+			}
 		}
+		else
+			for (uint32_t e = lane; e < a.qpad_floats; e += 64)
+			{
+				const float t = qsrc[e < a.dim ? e : a.dim - 1];
+				qf[e] = (e < a.dim) ? t : 0.f;
+			}
 		wave_sync();
 		float qnorm = 0.f;
 		if (FUNC == F_COSINE) qnorm = query_norm(q4, a.nchunks, a.kiters, lane);
@@ -1965,7 +2039,12 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		}
 
 		if (TEAM && lane == 0) ctl[wib].state = 0u;                       // walk over: helpers let go
-		if (__builtin_amdgcn_readfirstlane((int) aborted)) { if (lane == 0) a.out_counts[qi] = ABORTED_COUNT; continue; }      // interrupted inside its walk
+		if (__builtin_amdgcn_readfirstlane((int) aborted))                 // interrupted inside its walk
+		{
+			if (lane == 0) a.out_counts[qi] = ABORTED_COUNT;
+			if (stream) break;
+			continue;
+		}
 		if (!LEAN && a.out_times && lane == 0) a.out_times[2 * (size_t) qi + 1] = __builtin_amdgcn_s_memrealtime();
 		uint32_t hs_walk = 0;
 		if (HOP_STAMPS && a.team_dbg) hs_walk = hop_stamp();

@@ -169,6 +169,8 @@ struct SearchWs
 	uint64_t launches = 0;
 	uint32_t last_slots = 0;
 	uint32_t walkers_hint = 0;                           // hnsw_gpu_ctx_set_walkers: walking waves per block of a small team launch (0 = by launch size)
+	// stream mode, the next launch only (hnsw_gpu_stream_open): the host's control words, their device copies, ring size, walking waves per block
+	const uint32_t *stream_host_next = nullptr; uint32_t *stream_dev_next = nullptr; uint32_t stream_ring_next = 0, stream_walkers_next = 0;
 	uint32_t *done_next = nullptr;                       // completion flags for the next launch only
 	uint32_t *pops_next = nullptr; uint32_t pops_cap_next = 0;   // pop-sequence output for the next launch only
 	uint32_t *evals_next = nullptr; uint32_t evals_cap_next = 0; uint64_t *times_next = nullptr;   // evaluation trace, next launch only
@@ -834,7 +836,8 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	// Team form wanted for this launch?  (decided for good further down, once the LDS carve is known)
 	const int treq = (int) knob(K_TEAM, -1);
 	const size_t auto_nq = (size_t) knob(K_TEAM_MAX_NQ, (long long) ix->num_cu);
-	const bool team_wanted = rreg < 0 && !reforder && treq != 0 && (treq > 0 || ix->stride > 320 || nq <= auto_nq);
+	const bool stream_launch = w->stream_host_next != nullptr;
+	const bool team_wanted = rreg < 0 && !reforder && (stream_launch || (treq != 0 && (treq > 0 || ix->stride > 320 || nq <= auto_nq)));
 	// narrow rows, hot form: beam kernel with <= 4 set registers, one sum per row (L2 / Manhattan), not a team
 	const bool narrow5 = shape_index(a.kiters) == 0 && (rreg == -2 || rreg == -4) && (int) ix->meta.dist_func != F_COSINE &&
 						 !team_wanted && !reforder && knob(K_NARROW5, 1) != 0;
@@ -1022,6 +1025,16 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 #ifdef HNSW_EXPERIMENT
 	if (team && knob(K_TEAM_MAINS, 0) > 0) a.team_mains = std::min<uint32_t>(a.team_mains, (uint32_t) knob(K_TEAM_MAINS, 0));
 #endif
+	if (stream_launch)
+	{
+		// a resident launch fed by the host (device_search.h, "Stream mode"): exactly the blocks the device holds at once — block 0 is the
+		// doorbell and must be resident for any other block to make progress
+		if (!team) { w->stream_host_next = nullptr; return fail(HNSW_GPU_ERR_ARG, "a stream needs the team form of the beam kernel (ef <= 256, or <= 512 on wide rows)"); }
+		blocks = std::max<size_t>(2, (size_t) per_cu * ix->num_cu);
+		a.team_mains = std::min<uint32_t>(wpb, std::max<uint32_t>(1u, w->stream_walkers_next));
+		a.stream_host = w->stream_host_next; a.stream_dev = w->stream_dev_next; a.stream_ring = w->stream_ring_next;
+		w->stream_host_next = nullptr; w->stream_dev_next = nullptr;
+	}
 	// (test knob: fewer blocks than the launch would get, so that the waves with queries take SEVERAL each through the
 	// ticket counter while their siblings help — the schedule of a small launch whose other blocks start late,
 	// tests/experiments/team_second_walk_stress.py)
@@ -2589,6 +2602,130 @@ extern "C" int hnsw_gpu_search_batch_ctx_flags(hnsw_gpu_ctx *c, const coord_t *d
 	int rc = launch_search(c->ix, &c->ws, d_queries, c->ix->meta.dim, nq, ef, 0, d_labels, nullptr, d_dists, d_counts, d_stats,
 						   c->stream);
 	c->ws.done_next = nullptr;
+	return rc;
+}
+
+// ------------------------------------------------------------------------------------
+// streams: ONE resident search launch that the host feeds while it runs (device_search.h, "Stream mode")
+// ------------------------------------------------------------------------------------
+struct hnsw_gpu_stream
+{
+	hnsw_gpu_ctx *ctx = nullptr;
+	size_t ef = 0, ring = 0, dim = 0;
+	char *pin = nullptr;                      // pinned, coherent: [queries | labels | dists | counts | flags | control words]
+	float *Q = nullptr; label_t *L = nullptr; dist_t *D = nullptr; uint32_t *C = nullptr; uint32_t *F = nullptr;
+	uint32_t *host_ctl = nullptr;             // [0] = queries published so far, [1] = stop
+	uint32_t *dev_ctl = nullptr;              // the doorbell wave's device copies
+	unsigned walkers = 0;
+};
+
+extern "C" int hnsw_gpu_stream_close(hnsw_gpu_stream *s);
+
+extern "C" int hnsw_gpu_stream_open(hnsw_gpu_ctx *c, size_t ef, size_t ring, unsigned walkers, hnsw_gpu_stream **out)
+{
+	if (!c || !out) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	if (ring < 64 || ring > ((size_t) 1 << 20) || (ring & (ring - 1))) return fail(HNSW_GPU_ERR_ARG, "ring must be a power of two in [64, 2^20]");
+	if (ef == 0 || ef > 512) return fail(HNSW_GPU_ERR_ARG, "a stream needs ef <= 512 (the team form of the beam kernel)");
+#ifdef PGEMB_SIMT_EMULATOR
+	return fail(HNSW_GPU_ERR_ARG, "streams need a device whose launches are asynchronous (not the emulator)");
+#endif
+	hnsw_gpu_index *ix = c->ix;
+	HIPCHK(hipSetDevice(ix->device));
+	if (!c->stream) HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+	hnsw_gpu_stream *s = new (std::nothrow) hnsw_gpu_stream();
+	if (!s) return fail(HNSW_GPU_ERR_NOMEM, "out of host memory");
+	s->ctx = c; s->ef = ef; s->ring = ring; s->dim = ix->meta.dim; s->walkers = walkers ? walkers : 4u;
+	const size_t qb = round_up(ring * s->dim * 4, 256), lb = round_up(ring * ef * 8, 256), db = round_up(ring * ef * 4, 256),
+				 cb = round_up(ring * 4, 256), fb = round_up(ring * 4, 256);
+	hipError_t e = hipHostMalloc((void **) &s->pin, qb + lb + db + cb + fb + 256, hipHostMallocCoherent);
+	if (e == hipSuccess) e = hipMalloc((void **) &s->dev_ctl, 256);
+	if (e == hipSuccess) e = hipMemset(s->dev_ctl, 0, 256);
+	if (e != hipSuccess)
+	{
+		(void) hipGetLastError();
+		if (s->pin) (void) hipHostFree(s->pin);
+		if (s->dev_ctl) (void) hipFree(s->dev_ctl);
+		delete s;
+		return fail(e == hipErrorOutOfMemory ? HNSW_GPU_ERR_NOMEM : HNSW_GPU_ERR_HIP, "stream buffers: %s", hipGetErrorString(e));
+	}
+	memset(s->pin, 0, qb + lb + db + cb + fb + 256);
+	s->Q = (float *) s->pin; s->L = (label_t *) (s->pin + qb); s->D = (dist_t *) (s->pin + qb + lb);
+	s->C = (uint32_t *) (s->pin + qb + lb + db); s->F = (uint32_t *) (s->pin + qb + lb + db + cb);
+	s->host_ctl = (uint32_t *) (s->pin + qb + lb + db + cb + fb);
+	int rc;
+	{
+		std::unique_lock<std::recursive_mutex> lock_(ix->mu);       // the "next launch only" fields and the launch are one step
+		c->ws.done_next = s->F;
+		c->ws.stream_host_next = s->host_ctl; c->ws.stream_dev_next = s->dev_ctl;
+		c->ws.stream_ring_next = (uint32_t) ring; c->ws.stream_walkers_next = s->walkers;
+		rc = launch_search(ix, &c->ws, s->Q, s->dim, ring, ef, 0, s->L, nullptr, s->D, s->C, nullptr, c->stream);
+		c->ws.done_next = nullptr; c->ws.stream_host_next = nullptr; c->ws.stream_dev_next = nullptr;
+	}
+	if (rc)
+	{
+		(void) hipHostFree(s->pin); (void) hipFree(s->dev_ctl);
+		delete s;
+		return rc;
+	}
+	*out = s;
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_stream_buffers(hnsw_gpu_stream *s, coord_t **queries, label_t **labels, dist_t **dists, uint32_t **counts, uint32_t **flags)
+{
+	if (!s) return fail(HNSW_GPU_ERR_ARG, "stream is NULL");
+	if (queries) *queries = s->Q;
+	if (labels) *labels = s->L;
+	if (dists) *dists = s->D;
+	if (counts) *counts = s->C;
+	if (flags) *flags = s->F;
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_stream_publish(hnsw_gpu_stream *s, uint32_t published_total)
+{
+	if (!s) return fail(HNSW_GPU_ERR_ARG, "stream is NULL");
+	__atomic_store_n(&s->host_ctl[0], published_total, __ATOMIC_RELEASE);      // (everything written into the slots before this store is visible before it)
+	return HNSW_GPU_OK;
+}
+
+// 1 = the stream's launch is still on the device, 0 = it has left (stopped, aborted or failed), < 0 = error
+extern "C" int hnsw_gpu_stream_alive(hnsw_gpu_stream *s)
+{
+	if (!s) return fail(HNSW_GPU_ERR_ARG, "stream is NULL");
+	const int idle = hnsw_gpu_ctx_idle(s->ctx);
+	return idle < 0 ? idle : (idle ? 0 : 1);
+}
+
+extern "C" int hnsw_gpu_stream_close(hnsw_gpu_stream *s)
+{
+	if (!s) return HNSW_GPU_OK;
+	hnsw_gpu_ctx *c = s->ctx;
+	(void) hipSetDevice(c->ix->device);
+	__atomic_store_n(&s->host_ctl[1], 1u, __ATOMIC_SEQ_CST);
+	// every wave leaves at its next look (a walking wave after its query: under a millisecond); a launch that does not is a
+	// hung launch: its workspace's abort word, then the wait again
+	int rc = HNSW_GPU_OK;
+	const int64_t t0 = now_ms();
+	bool asked = false;
+	while (hipStreamQuery(c->stream) == hipErrorNotReady)
+	{
+		if (!asked && now_ms() - t0 > 2000)
+		{
+			std::lock_guard<std::mutex> g(g_ws_mu);
+			(void) abort_ws_locked(&c->ws);
+			asked = true;
+		}
+		if (now_ms() - t0 > 1000ll * poll_limit_s()) { rc = fail(HNSW_GPU_ERR_INTERNAL, "the stream's launch did not end"); break; }
+		std::this_thread::sleep_for(std::chrono::microseconds(20));
+	}
+	(void) hipGetLastError();
+	if (rc == HNSW_GPU_OK)
+	{
+		(void) hipHostFree(s->pin);
+		(void) hipFree(s->dev_ctl);
+	}                                                            // (a launch that never ended may still write them: leaked on purpose)
+	delete s;
 	return rc;
 }
 

@@ -447,6 +447,64 @@ class SearchContext:
 
 
 # ---------------------------------------------------------------------- distances
+class SearchStream:
+    """A resident search launch fed from the host (include/hnsw_gpu.h, "Streams"): numpy views of the pinned ring + publish / poll.
+    `submit(Q)` writes queries into the next slots and publishes them, returning their slot numbers; `wait(slots)` spins on their
+    completion flags and returns (labels, dists, counts) rows.  One producer thread."""
+
+    def __init__(self, ctx: "SearchContext", ef: int, ring: int = 4096, walkers: int = 0):
+        self.ctx, self.L, self.ef, self.ring = ctx, ctx.L, ef, ring
+        h = C.c_void_p()
+        check(self.L.hnsw_gpu_stream_open(ctx._h, ef, ring, walkers, C.byref(h)), "hnsw_gpu_stream_open")
+        self._h = h
+        ptr = [C.c_void_p() for _ in range(5)]
+        check(self.L.hnsw_gpu_stream_buffers(h, *[C.byref(p) for p in ptr]), "hnsw_gpu_stream_buffers")
+        dim = int(ctx.index.meta.dim)
+
+        def view(p, ctype, shape):
+            n = int(np.prod(shape))
+            return np.ctypeslib.as_array(C.cast(p, C.POINTER(ctype)), shape=(n,)).reshape(shape)
+        self.q = view(ptr[0], C.c_float, (ring, dim))
+        self.labels = view(ptr[1], C.c_uint64, (ring, ef))
+        self.dists = view(ptr[2], C.c_float, (ring, ef))
+        self.counts = view(ptr[3], C.c_uint32, (ring,))
+        self.flags = view(ptr[4], C.c_uint32, (ring,))
+        self.published = 0
+
+    def submit(self, Q: np.ndarray) -> np.ndarray:
+        Q = np.ascontiguousarray(Q, dtype=np.float32).reshape(-1, self.q.shape[1])
+        slots = (self.published + np.arange(Q.shape[0], dtype=np.int64)) & (self.ring - 1)
+        self.q[slots] = Q
+        self.flags[slots] = 0
+        self.published = (self.published + Q.shape[0]) & 0xFFFFFFFF
+        check(self.L.hnsw_gpu_stream_publish(self._h, self.published), "hnsw_gpu_stream_publish")
+        return slots
+
+    def wait(self, slots: np.ndarray, timeout: float = 30.0):
+        import time as _t
+        t0 = _t.time()
+        while not self.flags[slots].all():
+            if _t.time() - t0 > timeout:
+                raise TimeoutError(f"{int((self.flags[slots] == 0).sum())} of {len(slots)} stream queries unanswered after {timeout} s "
+                                   f"(launch alive: {self.alive()})")
+        return self.labels[slots].copy(), self.dists[slots].copy(), self.counts[slots].copy()
+
+    def alive(self) -> bool:
+        return self.L.hnsw_gpu_stream_alive(self._h) == 1
+
+    def close(self) -> None:
+        if self._h:
+            h, self._h = self._h, C.c_void_p()
+            self.q = self.labels = self.dists = self.counts = self.flags = None
+            check(self.L.hnsw_gpu_stream_close(h), "hnsw_gpu_stream_close")
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def dist_batch(func: int, q: np.ndarray, rows: np.ndarray) -> np.ndarray:
     """out[i] = hnsw_dist_func(func, q, rows[i]) on the device (distfunc.c:171-174)."""
     L = gpu_lib()

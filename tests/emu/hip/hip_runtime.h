@@ -17,6 +17,7 @@
 //   * LDS is one array per block; atomics are real atomics; fences are full fences; s_sleep yields the processor.
 // Not modelled: timing, the memory model's weakness (x86 is stronger), MFMA (the exhaustive scorer aborts here).
 #pragma once
+#define PGEMB_SIMT_EMULATOR 1      /* (launches are synchronous here: what needs a kernel that runs WHILE the host works says so) */
 #include <pthread.h>
 #include <sched.h>
 #include <signal.h>
@@ -362,7 +363,7 @@ typedef struct simt_stream *hipStream_t;
 struct simt_event { std::chrono::steady_clock::time_point t; int dev = 0; };
 typedef simt_event *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
-enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0 };
+enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocCoherent = 0x40000000 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 enum hipDeviceAttribute_t { hipDeviceAttributeMaxSharedMemoryPerBlock = 1, hipDeviceAttributeMultiprocessorCount = 2 };
 struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcessorCount; size_t totalGlobalMem; };

@@ -452,6 +452,47 @@ def test_walkers_per_block_of_a_small_launch_change_nothing_but_its_shape(dim, m
     ix.close()
 
 
+@pytest.mark.timeout(180, method="thread")
+@pytest.mark.parametrize("dim,m,func,walkers", [(768, 16, pg.DIST_L2, 4), (128, 16, pg.DIST_L2, 8), (100, 8, pg.DIST_COSINE, 1), (1536, 32, pg.DIST_COSINE, 2)])
+def test_a_stream_answers_like_a_launch(dim, m, func, walkers):
+    """Streams (include/hnsw_gpu.h): ONE resident launch fed from the host while it runs.  Queries published a few at a time while
+    others are still walking, a ring far smaller than the number of queries (every slot reused many times), the stream closed and
+    another opened: every answer — labels, distance bits, counts — equals the oracle's, i.e. a plain launch's; the mirror's ordinary
+    launches work before, between and after."""
+    import torch
+    n, ef, nq, ring = 8000, 96, 1500, 64
+    port, X = build_port(n, dim, m, 48, func, k=40, seed=17 * dim + walkers)
+    Q = gmm(nq, dim, k=40, seed=17 * dim + walkers, stream=1)
+    want = port.search_many(Q, ef, nthreads=8)
+    ix = mirror(port, func)
+    assert_same_as_oracle(ix, port, Q[:40], ef)
+    ctx = pg.SearchContext(ix)
+    for round_ in range(2):
+        st = pg.SearchStream(ctx, ef, ring=ring, walkers=walkers)
+        assert st.alive()
+        done = 0
+        rng = np.random.default_rng(round_)
+        pending = []                                             # (first query number, slots)
+        while done < nq or pending:
+            # keep up to ring/2 queries in flight, published in irregular chunks
+            inflight = sum(len(sl) for _, sl in pending)
+            if done < nq and inflight <= ring // 2:
+                k = int(min(nq - done, rng.integers(1, ring // 2 - 1), ring - inflight - 1))
+                pending.append((done, st.submit(Q[done:done + k])))
+                done += k
+                continue
+            first, slots = pending.pop(0)
+            lab, dst, cnt = st.wait(slots)
+            k = len(slots)
+            assert (cnt == want["counts"][first:first + k]).all(), (round_, first)
+            assert (lab == want["labels"][first:first + k]).all(), (round_, first)
+            assert (bits(dst) == bits(want["dists"][first:first + k])).all(), (round_, first)
+        st.close()
+        assert_same_as_oracle(ix, port, Q[40:80], ef)            # an ordinary launch on the mirror after the stream has left
+    ctx.close()
+    ix.close()
+
+
 @pytest.mark.parametrize("ef", [1, 5, 64, 128, 256])
 def test_beam_prune_with_ties_at_the_bound(ef):
     """0/1 vectors in 6 dimensions: only 7 distinct L2 distances, so the ef-th smallest distance is
