@@ -1109,7 +1109,8 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 
 	const int evi = (int) (w->launches % SearchWs::EV_RING);
 	HIPCHK(hipEventRecord(w->ev0[evi], stream));
-	__atomic_store_n(&w->busy_since_ms, now_ms(), __ATOMIC_SEQ_CST);
+	// (a stream is resident by design: the library's watchdog does not time it — its host stops it, hnsw_gpu_stream_close)
+	__atomic_store_n(&w->busy_since_ms, stream_launch ? (int64_t) 0 : now_ms(), __ATOMIC_SEQ_CST);
 	hipLaunchKernelGGL(kern, dim3((uint32_t) blocks), dim3(wpb * 64), lds, stream, a);
 	HIPCHK(hipGetLastError());
 	HIPCHK(hipEventRecord(w->ev1[evi], stream));

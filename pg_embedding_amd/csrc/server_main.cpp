@@ -66,6 +66,8 @@ struct Options
 	bool verbose = false;
 	int ready_fd = -1;
 	int walkers = -1;              // walking waves per block of a search launch: -1 = by load (below), 0 = the library's default, 1..8 fixed
+	int stream = 0;                // 1 = searches go through ONE resident launch per (mirror, ef) fed through a pinned ring (stream_manager)
+	size_t ring = 4096;            // slots of that ring
 } g_opt;
 
 std::atomic<bool> g_stop{false};
@@ -160,6 +162,11 @@ struct Entry
 	{
 		std::lock_guard<std::mutex> lk(gmu);
 		if (--readers == 0) gcv.notify_all();
+	}
+	bool writer_wants()            // somebody is changing, or waiting to change, this mirror (a stream session gives way)
+	{
+		std::lock_guard<std::mutex> lk(gmu);
+		return writing || writers_waiting > 0;
 	}
 	void begin_write()
 	{
@@ -587,6 +594,242 @@ void dispatcher_main(int d)
 	else dispatcher_blocking(d);
 }
 
+
+// ----------------------------------------------------------------------------- stream mode (--stream 1)
+// One resident search launch per (mirror, ef) at a time, fed through a ring in pinned host memory (include/hnsw_gpu.h, "Streams"):
+// a SEARCH is written into the next ring slot by the READER thread that parsed it and published with one store; the kernel's
+// walking waves pick queries up as they become free, the answer threads poll the ring's completion flags and answer each backend
+// the moment its walk has ended.  No batch is formed, nothing waits for a launch to end: the 0.4-0.5 ms a query spent waiting for a
+// lane at 1 024 backends (profiles/r4f_server_walkers_and_breakdown.txt) is gone.  The session gives way — stops accepting, lets its
+// walks finish, closes — when a writer wants the mirror, when searches for another (mirror, ef) are waiting, when nothing has been
+// outstanding for a while (a resident launch holds the whole device), when the load calls for another team geometry, at shutdown.
+struct Session
+{
+	std::mutex mu;                          // producers: ticket + slot write + publish are one step
+	EntryP e;
+	size_t ef = 0, dim = 0;
+	hnsw_gpu_ctx *ctx = nullptr;
+	hnsw_gpu_stream *st = nullptr;
+	float *Q = nullptr; label_t *L = nullptr; dist_t *D = nullptr; uint32_t *C = nullptr; volatile uint32_t *F = nullptr;
+	uint32_t ring = 0, pub = 0;
+	unsigned walkers = 0;
+	long capacity = 0;                      // walks the launch runs at once
+	std::vector<SReq> req;                  // per slot
+	std::vector<uint64_t> t_pub;            // per slot: when it was published
+	std::unique_ptr<std::atomic<uint8_t>[]> busy;   // per slot: 1 = published, not answered yet
+	std::atomic<long> outstanding{0};
+	std::atomic<bool> accepting{false};
+	std::atomic<uint64_t> t_active{0};      // last publish or answer
+	std::atomic<uint64_t> t_crowded{0}, t_roomy{0};   // since when the launch has been too small / far too large for the load (0 = it is not)
+
+	// reader threads.  false = not taken (the caller queues the request; the manager sees to it)
+	bool submit(SReq &r)
+	{
+		std::lock_guard<std::mutex> lk(mu);
+		if (!accepting.load(std::memory_order_relaxed)) return false;
+		const uint32_t slot = pub & (ring - 1);
+		if (busy[slot].load(std::memory_order_acquire)) return false;          // the ring is full
+		memcpy(Q + (size_t) slot * dim, r.q.data(), dim * 4);
+		F[slot] = 0;
+		const uint64_t now = now_ns();
+		g_cnt.queue_ns += now - std::min(now, r.t_in);
+		t_pub[slot] = now;
+		req[slot] = std::move(r);
+		busy[slot].store(1, std::memory_order_release);
+		pub++;
+		outstanding.fetch_add(1, std::memory_order_relaxed);
+		(void) hnsw_gpu_stream_publish(st, pub);
+		t_active.store(now, std::memory_order_relaxed);
+		return true;
+	}
+};
+using SessionP = std::shared_ptr<Session>;
+std::mutex g_sess_mu;
+SessionP g_sess;                            // the open session, if any (g_sess_mu)
+
+SessionP current_session()
+{
+	std::lock_guard<std::mutex> lk(g_sess_mu);
+	return g_sess;
+}
+
+// answer thread k of n: its stripe of the ring
+void stream_answer_main(int k, int n)
+{
+	unsigned idle = 0;
+	while (!g_stop.load())
+	{
+		SessionP ss = current_session();
+		if (!ss) { std::this_thread::sleep_for(std::chrono::microseconds(50)); continue; }
+		bool progress = false;
+		const uint64_t gen = ss->e->gen.load();
+		for (uint32_t slot = (uint32_t) k; slot < ss->ring; slot += (uint32_t) n)
+		{
+			if (!ss->busy[slot].load(std::memory_order_acquire)) continue;
+			if (!__atomic_load_n((const uint32_t *) &ss->F[slot], __ATOMIC_ACQUIRE)) continue;
+			const uint64_t t_seen = now_ns();
+			SReq r = std::move(ss->req[slot]);
+			const size_t ef = ss->ef;
+			const uint32_t c = ss->C[slot];
+			const size_t cnt = c <= ef ? c : 0;
+			if (c > ef) { g_cnt.search_errors++; r.c->respond(r.h, HNSW_GPU_ERR_INTERNAL); }
+			else r.c->respond(r.h, HGS_OK, cnt, 0, ss->L + (size_t) slot * ef, cnt * 8, r.h.a0 ? ss->D + (size_t) slot * ef : nullptr, cnt * 4, gen);
+			g_cnt.walk_ns += t_seen - ss->t_pub[slot];
+			g_cnt.answer_ns += now_ns() - t_seen;
+			g_cnt.searches++;
+			ss->busy[slot].store(0, std::memory_order_release);
+			ss->outstanding.fetch_sub(1, std::memory_order_relaxed);
+			ss->t_active.store(t_seen, std::memory_order_relaxed);
+			progress = true;
+		}
+		if (progress) idle = 0;
+		else if (++idle > 256) std::this_thread::yield();
+		else __builtin_ia32_pause();
+	}
+}
+
+// Close the session: no new queries, let the walks in flight finish (bounded), stop the launch, release the mirror.
+void close_session(SessionP &ss, const char *why)
+{
+	{
+		std::lock_guard<std::mutex> lk(ss->mu);
+		ss->accepting.store(false);
+	}
+	const uint64_t t0 = now_ns();
+	while (ss->outstanding.load() > 0 && now_ns() - t0 < 200000000ull) std::this_thread::sleep_for(std::chrono::microseconds(20));
+	{
+		std::lock_guard<std::mutex> lk(g_sess_mu);
+		g_sess.reset();                     // the answer threads let go of it at their next look
+	}
+	// the answer threads and readers that still hold the session let go at their next look: only then may the ring be freed
+	for (int spin = 0; ss.use_count() > 1 && spin < 50000; spin++) std::this_thread::sleep_for(std::chrono::microseconds(20));
+	const int rc = hnsw_gpu_stream_close(ss->st);
+	if (rc != HNSW_GPU_OK) logf("closing the stream: %s", hnsw_gpu_last_error());
+	long lost = 0;
+	for (uint32_t slot = 0; slot < ss->ring; slot++)
+		if (ss->busy[slot].load())
+		{
+			ss->req[slot].c->respond(ss->req[slot].h, HNSW_GPU_ERR_INTERNAL);
+			lost++;
+		}
+	if (lost) { g_cnt.search_errors += (uint64_t) lost; logf("stream closed (%s) with %ld queries unanswered", why, lost); }
+	VLOG("stream on %llu closed: %s (%u queries)", (unsigned long long) ss->e->key, why, ss->pub);
+	ss->e->last_used.store(now_ns());
+	ss->e->end_read();
+	g_cnt.batches++;
+}
+
+SessionP open_session(const EntryP &e, size_t ef, size_t backlog)
+{
+	SessionP ss = std::make_shared<Session>();
+	ss->e = e; ss->ef = ef; ss->dim = e->meta.dim;
+	ss->ring = (uint32_t) g_opt.ring;
+	ss->ctx = e->context(0);
+	if (!ss->ctx) return nullptr;
+	// team geometry by the load that is waiting (g_device_blocks - 1 walking blocks: block 0 is the doorbell)
+	const long blocks = std::max(1, g_device_blocks - 1);
+	unsigned walkers = g_opt.walkers > 0 ? (unsigned) g_opt.walkers
+										  : (unsigned) std::min<long>(8, std::max<long>(1, ((long) backlog + blocks - 1) / blocks));
+	if (hnsw_gpu_stream_open(ss->ctx, ef, ss->ring, walkers, &ss->st) != HNSW_GPU_OK) return nullptr;
+	uint32_t *f = nullptr;
+	(void) hnsw_gpu_stream_buffers(ss->st, &ss->Q, &ss->L, &ss->D, &ss->C, &f);
+	ss->F = f;
+	ss->walkers = walkers;
+	ss->capacity = blocks * (long) walkers;
+	ss->req.resize(ss->ring);
+	ss->t_pub.assign(ss->ring, 0);
+	ss->busy.reset(new std::atomic<uint8_t>[ss->ring]);
+	for (uint32_t i = 0; i < ss->ring; i++) ss->busy[i].store(0);
+	ss->t_active.store(now_ns());
+	ss->accepting.store(true);
+	VLOG("stream on %llu opened: ef %zu, %u walking waves per block (backlog %zu)", (unsigned long long) e->key, ef, walkers, backlog);
+	return ss;
+}
+
+void stream_manager_main()
+{
+	Pinned pin;
+	std::vector<SReq> batch;
+	const uint64_t IDLE_NS = 2000000ull, CROWDED_NS = 2000000ull, ROOMY_NS = 100000000ull;
+	while (!g_stop.load())
+	{
+		SessionP ss = current_session();
+		if (ss)
+		{
+			const uint64_t now = now_ns();
+			const long out = ss->outstanding.load();
+			// too small / far too large a launch for the load?  (hysteresis: a change costs one drain)
+			if (g_opt.walkers <= 0)
+			{
+				if (out > ss->capacity - ss->capacity / 8 && ss->walkers < 8) { uint64_t z = 0; ss->t_crowded.compare_exchange_strong(z, now); }
+				else ss->t_crowded.store(0);
+				if (ss->walkers > 1 && out < ss->capacity / 4 / 2) { uint64_t z = 0; ss->t_roomy.compare_exchange_strong(z, now); }
+				else ss->t_roomy.store(0);
+			}
+			const char *why = nullptr;
+			size_t hint = 0;
+			if (ss->e->writer_wants()) why = "a writer wants the mirror";
+			else if (out == 0 && now - ss->t_active.load() > IDLE_NS) why = "idle";
+			else if (ss->t_crowded.load() && now - ss->t_crowded.load() > CROWDED_NS) { why = "more walking waves per block needed"; hint = (size_t) out * 2; }
+			else if (ss->t_roomy.load() && now - ss->t_roomy.load() > ROOMY_NS) { why = "fewer walking waves per block suffice"; hint = (size_t) std::max<long>(out * 2, 1); }
+			else
+			{
+				// requests that did not get in by themselves (arrived between sessions, ring full): in order; another (mirror, ef) ends the session
+				std::unique_lock<std::mutex> lk(g_q_mu);
+				while (!g_q.empty())
+				{
+					SReq &r = g_q.front();
+					if (r.e.get() != ss->e.get() || r.h.aux != ss->ef) { why = "searches for another mirror or beam are waiting"; break; }
+					if (!ss->submit(r)) break;
+					g_q.pop_front();
+				}
+			}
+			if (why)
+			{
+				close_session(ss, why);
+				if (hint && !g_stop.load() && !ss->e->writer_wants() && ss->e->try_read())
+				{
+					SessionP nn = open_session(ss->e, ss->ef, hint);
+					if (nn) { std::lock_guard<std::mutex> lk(g_sess_mu); g_sess = nn; }
+					else ss->e->end_read();
+				}
+				continue;
+			}
+			std::this_thread::sleep_for(std::chrono::microseconds(100));
+			continue;
+		}
+		// no session: wait for work, open one for the oldest request's (mirror, ef)
+		batch.clear();
+		EntryP e;
+		size_t ef = 0, backlog = 0;
+		{
+			std::unique_lock<std::mutex> lk(g_q_mu);
+			g_q_cv.wait_for(lk, std::chrono::milliseconds(50), [] { return g_stop.load() || !g_q.empty(); });
+			if (g_stop.load()) break;
+			if (g_q.empty()) continue;
+			e = g_q.front().e; ef = g_q.front().h.aux; backlog = g_q.size();
+		}
+		if (!e->try_read()) { std::this_thread::sleep_for(std::chrono::microseconds(50)); continue; }      // a writer is at work
+		SessionP nn = open_session(e, ef, backlog);
+		if (nn)
+		{
+			std::lock_guard<std::mutex> lk(g_sess_mu);
+			g_sess = nn;
+			continue;                        // (the loop above moves the queue into it)
+		}
+		// no stream for this shape (a beam too wide for the team form, ...): one blocking batch, as --lanes 0 does
+		e->end_read();
+		{
+			std::unique_lock<std::mutex> lk(g_q_mu);
+			if (!g_q.empty()) take_batch(batch);
+		}
+		if (!batch.empty()) run_batch(0, batch, pin);
+	}
+	SessionP ss = current_session();
+	if (ss) close_session(ss, "shutdown");
+	answer_leftovers();
+}
+
 // ----------------------------------------------------------------------------- control thread
 struct Mapping            // a received memfd, mapped
 {
@@ -992,6 +1235,18 @@ bool handle_message(const ConnP &c, const hgs_hdr &h, const char *payload)
 		r.q.resize(h.len / 4);
 		memcpy(r.q.data(), payload, h.len);
 		r.t_in = now_ns();
+		if (g_opt.stream)
+		{
+			// straight into the ring of the open session when it serves this (mirror, beam) — unless older requests are still queued
+			// (between sessions): those go first
+			SessionP ss = current_session();
+			if (ss && ss->e.get() == r.e.get() && ss->ef == h.aux)
+			{
+				bool queued;
+				{ std::lock_guard<std::mutex> lk(g_q_mu); queued = !g_q.empty(); }
+				if (!queued && ss->submit(r)) return true;
+			}
+		}
 		{
 			std::lock_guard<std::mutex> lk(g_q_mu);
 			g_q.push_back(std::move(r));
@@ -1115,7 +1370,10 @@ void usage()
 {
 	fprintf(stderr,
 			"usage: hnsw_gpu_server --socket PATH [--device N] [--dispatchers N] [--readers N]\n"
-			"                       [--max-batch N] [--lanes N] [--linger-us N --min-batch N] [--walkers auto|0..8] [--verbose] [--ready-fd N]\n"
+			"                       [--max-batch N] [--lanes N] [--linger-us N --min-batch N] [--walkers auto|0..8] [--stream 0|1 --ring N]\n"
+			"                       [--verbose] [--ready-fd N]\n"
+			"  --stream   1 = searches go through ONE resident launch per (mirror, efsearch), fed through a ring of N slots in pinned\n"
+			"             memory (no batches, no launch per query); the --dispatchers threads answer; 0 (default) = launches on lanes\n"
 			"  --walkers  walking waves per 8-wave block of a search launch: auto (default) = by the walks in flight over all lanes,\n"
 			"             0 = the library's choice per launch (every walk gets a block while the launch is small), 1..8 = fixed\n");
 }
@@ -1139,12 +1397,15 @@ int main(int argc, char **argv)
 		else if (a == "--lanes") g_opt.lanes = atoi(val("--lanes"));
 		else if (a == "--linger-us") g_opt.linger_us = atol(val("--linger-us"));
 		else if (a == "--walkers") { const std::string v = val("--walkers"); g_opt.walkers = v == "auto" ? -1 : atoi(v.c_str()); }
+		else if (a == "--stream") g_opt.stream = atoi(val("--stream"));
+		else if (a == "--ring") g_opt.ring = (size_t) atol(val("--ring"));
 		else if (a == "--min-batch") g_opt.min_batch = (size_t) atol(val("--min-batch"));
 		else if (a == "--ready-fd") g_opt.ready_fd = atoi(val("--ready-fd"));
 		else if (a == "--verbose") g_opt.verbose = true;
 		else { usage(); return 2; }
 	}
 	if (g_opt.path.empty() || g_opt.dispatchers < 1 || g_opt.readers < 1 || g_opt.max_batch < 1 || g_opt.lanes < 0 || g_opt.lanes > 16) { usage(); return 2; }
+	if (g_opt.stream && (g_opt.ring < 64 || g_opt.ring > ((size_t) 1 << 20) || (g_opt.ring & (g_opt.ring - 1)))) { usage(); return 2; }
 	if (g_opt.path.size() >= sizeof(((struct sockaddr_un *) nullptr)->sun_path)) { logf("socket path too long"); return 2; }
 
 	// Every lane launches on its own HIP stream.  The runtime spreads streams over GPU_MAX_HW_QUEUES
@@ -1209,7 +1470,13 @@ int main(int argc, char **argv)
 		epfds.push_back(ep);
 		threads.emplace_back(reader_main, ep);
 	}
-	for (int d = 0; d < g_opt.dispatchers; d++) threads.emplace_back(dispatcher_main, d);
+	if (g_opt.stream)
+	{
+		for (int d = 0; d < g_opt.dispatchers; d++) threads.emplace_back(stream_answer_main, d, g_opt.dispatchers);
+		threads.emplace_back(stream_manager_main);
+	}
+	else
+		for (int d = 0; d < g_opt.dispatchers; d++) threads.emplace_back(dispatcher_main, d);
 	threads.emplace_back(control_main);
 
 	logf("listening on %s (device %d of %d, %d dispatchers x %d lanes, max batch %zu)", g_opt.path.c_str(), g_opt.device, ndev,

@@ -141,7 +141,8 @@ class ServerProcess:
 
     def __init__(self, socket_path: Optional[str] = None, device: int = 0, dispatchers: int = 2,
                  max_batch: int = 16384, linger_us: int = 0, min_batch: int = 1, readers: int = 4, lanes: int = 3, binary: Optional[str] = None,
-                 env: Optional[dict] = None, verbose: bool = False, start_timeout: float = 120.0, walkers: Optional[str] = None):
+                 env: Optional[dict] = None, verbose: bool = False, start_timeout: float = 120.0, walkers: Optional[str] = None,
+                 stream: bool = False, ring: int = 4096):
         self.binary = binary or _build.SERVER_BIN
         if not os.path.exists(self.binary):
             _build.build()
@@ -156,6 +157,8 @@ class ServerProcess:
                      "--max-batch", str(max_batch), "--readers", str(readers), "--lanes", str(lanes)]
         if walkers is not None:
             self.args += ["--walkers", str(walkers)]
+        if stream:
+            self.args += ["--stream", "1", "--ring", str(ring)]
         if linger_us:
             self.args += ["--linger-us", str(linger_us), "--min-batch", str(min_batch)]
         if verbose:

@@ -317,6 +317,18 @@ int hnsw_gpu_ctx_set_walkers(hnsw_gpu_ctx *c, unsigned per_block)
 	return HNSW_GPU_OK;
 }
 unsigned engine_double_walkers_max(void) { return g_walkers_max; }
+/* streams need a device: the server falls back to one blocking batch per request group when opening one fails */
+typedef struct hnsw_gpu_stream hnsw_gpu_stream;
+int hnsw_gpu_stream_open(hnsw_gpu_ctx *c, size_t ef, size_t ring, unsigned walkers, hnsw_gpu_stream **out)
+{
+	(void) c; (void) ef; (void) ring; (void) walkers; (void) out;
+	snprintf(t_err, sizeof(t_err), "the engine double has no streams");
+	return HNSW_GPU_ERR_ARG;
+}
+int hnsw_gpu_stream_buffers(hnsw_gpu_stream *s, coord_t **q, label_t **l, dist_t **d, uint32_t **c, uint32_t **f) { (void) s; (void) q; (void) l; (void) d; (void) c; (void) f; return HNSW_GPU_ERR_ARG; }
+int hnsw_gpu_stream_publish(hnsw_gpu_stream *s, uint32_t n) { (void) s; (void) n; return HNSW_GPU_ERR_ARG; }
+int hnsw_gpu_stream_alive(hnsw_gpu_stream *s) { (void) s; return 0; }
+int hnsw_gpu_stream_close(hnsw_gpu_stream *s) { (void) s; return HNSW_GPU_OK; }
 int hnsw_gpu_device_blocks(int device) { (void) device; return 4; }   /* a tiny "device": the server's load policy is exercised with a handful of backends */
 
 static void *flags_worker(void *arg)

@@ -44,16 +44,18 @@ def main():
     ap.add_argument("--binary", default=None, help="server binary (default: the shipped one)")
     ap.add_argument("--check", type=int, default=200, help="queries compared with the CPU reference")
     ap.add_argument("--walkers", default=None, help="server --walkers (auto | 0..8): walking waves per block of a search launch")
-    ap.add_argument("--configs", default="", help="sweep: comma-separated dispatchers:lanes[:readers[:walkers]] — one server per entry over the "
+    ap.add_argument("--stream", action="store_true", help="server --stream 1: one resident launch fed through a ring instead of launches on lanes")
+    ap.add_argument("--configs", default="", help="sweep: comma-separated dispatchers:lanes[:readers[:walkers[:stream]]] — one server per entry over the "
                                                   "same rows (data generated once); the parity check runs for the first entry only")
     a = ap.parse_args()
     if a.configs:
         cfgs = []
         for c in a.configs.split(","):
             f = c.split(":")
-            cfgs.append((int(f[0]), int(f[1]), int(f[2]) if len(f) > 2 else a.readers, f[3] if len(f) > 3 else a.walkers))
+            cfgs.append((int(f[0]), int(f[1]), int(f[2]) if len(f) > 2 else a.readers, (f[3] or None) if len(f) > 3 else a.walkers,
+                         len(f) > 4 and f[4] == "stream"))
     else:
-        cfgs = [(a.dispatchers, a.lanes, a.readers, a.walkers)]
+        cfgs = [(a.dispatchers, a.lanes, a.readers, a.walkers, a.stream)]
 
     import oracle
     import pg_embedding_amd as pg
@@ -78,9 +80,9 @@ def main():
     Q.tofile(qf)
     key, gen = 1, 1
     table = []
-    for ci, (nd, nl, nr, nw) in enumerate(cfgs):
-      print(f"## server with {nd} dispatchers x {nl} lanes, {nr} readers, walkers {nw or 'default (auto)'}", flush=True)
-      srv = ServerProcess(dispatchers=nd, readers=nr, lanes=nl, binary=a.binary, walkers=nw,
+    for ci, (nd, nl, nr, nw, strm) in enumerate(cfgs):
+      print(f"## server with {nd} dispatchers x {nl} lanes, {nr} readers, walkers {nw or 'default (auto)'}" + (", STREAM mode" if strm else ""), flush=True)
+      srv = ServerProcess(dispatchers=nd, readers=nr, lanes=nl, binary=a.binary, walkers=nw, stream=strm,
                           env={"GPU_MAX_HW_QUEUES": str(a.hwq)} if a.hwq else None)
       with srv:
           c = RemoteClient(srv.socket_path)
@@ -123,7 +125,7 @@ def main():
               st = c.stats()
               print("# server totals:", json.dumps({k: st[k] for k in ("connections", "searches", "batches", "max_batch", "search_errors")}))
               c.close()
-              table += [(nd, nl, nr, nw, r) for r in rows]
+              table += [(nd, nl, nr, nw, strm, r) for r in rows]
               continue
           # parity of what the backends received, against the reference's code on the same graph bytes
           graph = c.export(key, a.rows * esz)
@@ -145,10 +147,10 @@ def main():
           st = c.stats()
           print("# server totals:", json.dumps({k: st[k] for k in ("connections", "searches", "batches", "max_batch", "search_errors")}))
           c.close()
-          table += [(nd, nl, nr, nw, r) for r in rows]
+          table += [(nd, nl, nr, nw, strm, r) for r in rows]
     print("\n| dispatchers x lanes (readers, walkers) | backends | queries/s | mean batch | ms per batch (host) | kernel ms per batch | round trip ms | in server: queue + walk + answer ms |\n|---|---|---|---|---|---|---|---|")
-    for nd, nl, nr, nw, r in table:
-        print(f"| {nd} x {nl} ({nr}, {nw or 'auto'}) | {r['nproc']} | {r['qps']:.0f} | {r['mean_batch']:.1f} | {r['ms_per_batch']:.2f} | {r['kernel_ms_per_batch']:.2f} | {r['latency_ms']:.2f} | {r['queue_ms']:.2f} + {r['walk_ms']:.2f} + {r['answer_ms']:.3f} |")
+    for nd, nl, nr, nw, strm, r in table:
+        print(f"| {'stream, ' + str(nd) + ' answer threads' if strm else str(nd) + ' x ' + str(nl)} ({nr}, {nw or 'auto'}) | {r['nproc']} | {r['qps']:.0f} | {r['mean_batch']:.1f} | {r['ms_per_batch']:.2f} | {r['kernel_ms_per_batch']:.2f} | {r['latency_ms']:.2f} | {r['queue_ms']:.2f} + {r['walk_ms']:.2f} + {r['answer_ms']:.3f} |")
 
 
 if __name__ == "__main__":
