@@ -106,7 +106,8 @@ struct SearchArgs
 	                            // link-list hits, ids looked up, distance hits, hops that still scored rows, all hops
 	// stream mode (team form of the beam kernel; banner "Stream mode" at the kernel): a RESIDENT launch that the host feeds
 	const uint32_t *stream_host;  // null = a plain launch.  Pinned host words: [0] = queries published so far, [1] = non-zero: leave
-	uint32_t *stream_dev;         // device words [0] / [1]: the doorbell wave's copies of the two, what every other wave polls
+	uint32_t *stream_dev;         // device: STREAM_COPIES copies of the two words, 128 bytes apart (the doorbell wave's 64 lanes store one each):
+	                              // wave w polls copy w % STREAM_COPIES, so that the idle waves of a stream do not all read ONE line of ONE L2 channel
 	uint32_t stream_ring;         // slots of the query / result ring (a power of two): ticket t lives in slot t & (ring - 1)
 };
 
@@ -123,6 +124,7 @@ struct SearchArgs
 //   [HEALTH_ABORTED_WAVES]    waves that left a launch because of the abort word
 //   [HEALTH_SLICES_DELIVERED] team form: slices helpers scored for walking waves (says the mechanism is in use; one
 //                             non-returning atomic per job)
+constexpr uint32_t STREAM_COPIES = 64, STREAM_COPY_WORDS = 32;      // stream mode: copies of the control words, words between two copies
 constexpr uint32_t ABORTED_COUNT = 0xFFFFFFFFu;     // out_counts[i] of a query an aborted launch did not answer (include/hnsw_gpu.h)
 enum : uint32_t { HEALTH_SLICE_TIMEOUTS = 1, HEALTH_PACKAGE_TIMEOUTS = 2, HEALTH_ABORTED_WAVES = 3, HEALTH_SLICES_DELIVERED = 4, HEALTH_WORDS = 16 };
 
@@ -134,9 +136,20 @@ __device__ __forceinline__ bool abort_requested(const SearchArgs &a)
 
 // Streamed completion: everything this wave wrote for the query becomes visible system-wide, then
 // the flag.  Once per query, outside the hop loop.
-__device__ __forceinline__ void signal_done(uint32_t *flag, int lane)
+// host_coherent = the launch's outputs AND flags live in fine-grained (coherent) pinned host memory that the library allocated
+// itself (the ring of a stream): stores to such memory are not held in the device's L2, so "every store of this wave has been
+// acknowledged" (vmcnt 0) orders the results before the flag without the L2 write-back a system-scope release costs on gfx950 —
+// per ANSWERED QUERY.  That write-back was the batching server's ceiling: 0.59 -> 0.77 M q/s at 1 024 backends with nothing else
+// changed (profiles/r4o_light_completion.txt).  Caller-provided buffers of unknown kind keep the full release.
+__device__ __forceinline__ void signal_done(uint32_t *flag, int lane, bool host_coherent = false)
 {
-	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");            // system scope
+	if (host_coherent)
+	{
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_s_waitcnt(0);
+	}
+	else
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "");        // system scope
 	if (lane == 0) __hip_atomic_store(flag, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
@@ -1636,10 +1649,10 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 			const uint32_t pub = __hip_atomic_load(a.stream_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			const uint32_t stop = __hip_atomic_load(a.stream_host + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");              // what the host wrote before it published is visible to loads issued from here on
-			if (lane == 0)
 			{
-				__hip_atomic_store(a.stream_dev, pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-				if (stop) __hip_atomic_store(a.stream_dev + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+				uint32_t *copy = a.stream_dev + (uint32_t) lane * STREAM_COPY_WORDS;       // (64 lanes = STREAM_COPIES copies)
+				__hip_atomic_store(copy, pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+				if (stop) __hip_atomic_store(copy + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 			}
 			if (__builtin_amdgcn_readfirstlane((int) stop)) return;
 			__builtin_amdgcn_s_sleep(24);
@@ -1660,19 +1673,23 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		if (stream)
 		{
 			bool leave = false;
+			const uint32_t *ctlw = a.stream_dev + ((blockIdx.x * wpb + wib) % STREAM_COPIES) * STREAM_COPY_WORDS;
 			for (uint32_t nap = 8;;)                                      // wait until the host has published query qi (or says stop)
 			{
 				uint32_t pub = 0, stop = 0;
 				if (lane == 0)
 				{
-					pub = __hip_atomic_load(a.stream_dev, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-					stop = __hip_atomic_load(a.stream_dev + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					// (relaxed: an acquire here would invalidate this CU's vector cache at every look of every idle wave, under the
+					// walking waves' feet — one acquire fence when the wait is over)
+					pub = __hip_atomic_load(ctlw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					stop = __hip_atomic_load(ctlw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 				}
 				pub = __builtin_amdgcn_readfirstlane(pub); stop = __builtin_amdgcn_readfirstlane(stop);
-				if ((int32_t) (pub - qi) > 0) break;                     // (wrap-safe: tickets and the published count are counters mod 2^32)
+				if ((int32_t) (pub - qi) > 0) { __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); break; }   // (wrap-safe: counters mod 2^32)
 				if (stop) { leave = true; break; }
 				if (nap == 8) __builtin_amdgcn_s_sleep(8); else if (nap == 32) __builtin_amdgcn_s_sleep(32); else __builtin_amdgcn_s_sleep(127);
-				nap = nap < 127 ? nap * 4 : 127;
+				if (nap > 128) __builtin_amdgcn_s_sleep(127);                // (a wave that has waited long looks every ~7 us)
+				nap = nap < 512 ? nap * 4 : 512;
 			}
 			if (__builtin_amdgcn_readfirstlane((int) leave)) break;
 			qi &= a.stream_ring - 1u;                                     // from here on qi is the slot: query, outputs and flag of this ticket
@@ -2160,7 +2177,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 			a.out_counts[qi] = nout;
 			if (a.out_stats) { a.out_stats[2 * (size_t) qi] = evals; a.out_stats[2 * (size_t) qi + 1] = hops; }
 		}
-		if (a.done) signal_done(a.done + qi, lane);
+		if (a.done) signal_done(a.done + qi, lane, stream);       // (a stream's ring is the library's own coherent pinned memory)
 
 		wave_sync();
 		if (logn <= a.logcap)

@@ -2639,8 +2639,8 @@ extern "C" int hnsw_gpu_stream_open(hnsw_gpu_ctx *c, size_t ef, size_t ring, uns
 	const size_t qb = round_up(ring * s->dim * 4, 256), lb = round_up(ring * ef * 8, 256), db = round_up(ring * ef * 4, 256),
 				 cb = round_up(ring * 4, 256), fb = round_up(ring * 4, 256);
 	hipError_t e = hipHostMalloc((void **) &s->pin, qb + lb + db + cb + fb + 256, hipHostMallocCoherent);
-	if (e == hipSuccess) e = hipMalloc((void **) &s->dev_ctl, 256);
-	if (e == hipSuccess) e = hipMemset(s->dev_ctl, 0, 256);
+	if (e == hipSuccess) e = hipMalloc((void **) &s->dev_ctl, STREAM_COPIES * STREAM_COPY_WORDS * 4);
+	if (e == hipSuccess) e = hipMemset(s->dev_ctl, 0, STREAM_COPIES * STREAM_COPY_WORDS * 4);
 	if (e != hipSuccess)
 	{
 		(void) hipGetLastError();
@@ -2686,7 +2686,11 @@ extern "C" int hnsw_gpu_stream_buffers(hnsw_gpu_stream *s, coord_t **queries, la
 extern "C" int hnsw_gpu_stream_publish(hnsw_gpu_stream *s, uint32_t published_total)
 {
 	if (!s) return fail(HNSW_GPU_ERR_ARG, "stream is NULL");
-	__atomic_store_n(&s->host_ctl[0], published_total, __ATOMIC_RELEASE);      // (everything written into the slots before this store is visible before it)
+	// Monotonic (a counter mod 2^32, compared by signed difference): several producer threads may publish, and a call that arrives
+	// late with a smaller count must not take the word back.  Release: everything written into the slots before is visible before it.
+	uint32_t cur = __atomic_load_n(&s->host_ctl[0], __ATOMIC_RELAXED);
+	while ((int32_t) (published_total - cur) > 0 &&
+		   !__atomic_compare_exchange_n(&s->host_ctl[0], &cur, published_total, true, __ATOMIC_RELEASE, __ATOMIC_RELAXED)) {}
 	return HNSW_GPU_OK;
 }
 

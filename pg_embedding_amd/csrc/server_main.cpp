@@ -269,6 +269,7 @@ struct SReq            // one backend's hnsw_search
 std::mutex g_q_mu;
 std::condition_variable g_q_cv;
 std::deque<SReq> g_q;
+std::atomic<long> g_q_waiting{0};          // stream mode: requests in g_q (the readers' "is anything queued" without the lock)
 
 struct CReq            // a control request
 {
@@ -590,6 +591,7 @@ void dispatcher_lanes(int d)
 
 void dispatcher_main(int d)
 {
+	pthread_setname_np(pthread_self(), "hgs-dispatch");
 	if (g_opt.lanes > 0) dispatcher_lanes(d);
 	else dispatcher_blocking(d);
 }
@@ -605,13 +607,17 @@ void dispatcher_main(int d)
 // outstanding for a while (a resident launch holds the whole device), when the load calls for another team geometry, at shutdown.
 struct Session
 {
-	std::mutex mu;                          // producers: ticket + slot write + publish are one step
 	EntryP e;
 	size_t ef = 0, dim = 0;
 	hnsw_gpu_ctx *ctx = nullptr;
 	hnsw_gpu_stream *st = nullptr;
 	float *Q = nullptr; label_t *L = nullptr; dist_t *D = nullptr; uint32_t *C = nullptr; volatile uint32_t *F = nullptr;
-	uint32_t ring = 0, pub = 0;
+	uint32_t ring = 0;
+	// producers (the reader threads) share no lock: a ticket is claimed with one atomic add, its slot is written by its owner alone,
+	// and the published count is advanced over the tickets that are ready IN ORDER by whoever gets there (a mutex around "ticket +
+	// 3 KB copy + publish" capped the whole server at one critical section per 2.3 us = 0.44 M q/s, profiles/r4i_*)
+	std::atomic<uint32_t> claim{0}, pub{0};
+	std::unique_ptr<std::atomic<uint32_t>[]> ready;   // per slot: ticket + 1 once its query is written
 	unsigned walkers = 0;
 	long capacity = 0;                      // walks the launch runs at once
 	std::vector<SReq> req;                  // per slot
@@ -625,10 +631,15 @@ struct Session
 	// reader threads.  false = not taken (the caller queues the request; the manager sees to it)
 	bool submit(SReq &r)
 	{
-		std::lock_guard<std::mutex> lk(mu);
-		if (!accepting.load(std::memory_order_relaxed)) return false;
-		const uint32_t slot = pub & (ring - 1);
-		if (busy[slot].load(std::memory_order_acquire)) return false;          // the ring is full
+		if (!accepting.load(std::memory_order_acquire)) return false;
+		// (room: a backend has one search outstanding, the ring has several slots per backend; a full ring means stragglers a whole
+		// ring old — the request waits in the queue instead)
+		if (outstanding.load(std::memory_order_relaxed) >= (long) ring - 64) return false;
+		outstanding.fetch_add(1, std::memory_order_acq_rel);
+		const uint32_t t = claim.fetch_add(1, std::memory_order_acq_rel);
+		const uint32_t slot = t & (ring - 1);
+		for (unsigned spin = 0; busy[slot].load(std::memory_order_acquire); spin++)     // its occupant of a ring ago is being answered right now
+			if (spin > 1000) std::this_thread::yield(); else __builtin_ia32_pause();
 		memcpy(Q + (size_t) slot * dim, r.q.data(), dim * 4);
 		F[slot] = 0;
 		const uint64_t now = now_ns();
@@ -636,9 +647,14 @@ struct Session
 		t_pub[slot] = now;
 		req[slot] = std::move(r);
 		busy[slot].store(1, std::memory_order_release);
-		pub++;
-		outstanding.fetch_add(1, std::memory_order_relaxed);
-		(void) hnsw_gpu_stream_publish(st, pub);
+		ready[slot].store(t + 1, std::memory_order_release);
+		// advance the published count over every ticket that is ready, in order; whoever is behind an unready ticket leaves the rest
+		// to that ticket's owner (it runs this loop after its own store)
+		uint32_t p = pub.load(std::memory_order_acquire);
+		bool moved = false;
+		while (ready[p & (ring - 1)].load(std::memory_order_acquire) == p + 1)
+			if (pub.compare_exchange_weak(p, p + 1, std::memory_order_acq_rel)) { p = p + 1; moved = true; }
+		if (moved) (void) hnsw_gpu_stream_publish(st, p);                  // (the library keeps the maximum: two advancers may arrive out of order)
 		t_active.store(now, std::memory_order_relaxed);
 		return true;
 	}
@@ -646,20 +662,40 @@ struct Session
 using SessionP = std::shared_ptr<Session>;
 std::mutex g_sess_mu;
 SessionP g_sess;                            // the open session, if any (g_sess_mu)
+std::atomic<uint64_t> g_sess_gen{0};        // bumped at every change of g_sess: the hot paths keep a thread-local copy and look at this word only
+
+std::atomic<uint64_t> g_answer_gen[64];     // per answer thread: the session generation it has refreshed to
+
+void set_session(const SessionP &ss)
+{
+	std::lock_guard<std::mutex> lk(g_sess_mu);
+	g_sess = ss;
+	g_sess_gen.fetch_add(1, std::memory_order_release);
+}
 
 SessionP current_session()
 {
-	std::lock_guard<std::mutex> lk(g_sess_mu);
-	return g_sess;
+	static thread_local SessionP mine;
+	static thread_local uint64_t seen = ~0ull;
+	const uint64_t gen = g_sess_gen.load(std::memory_order_acquire);
+	if (gen != seen)
+	{
+		std::lock_guard<std::mutex> lk(g_sess_mu);
+		mine = g_sess;
+		seen = g_sess_gen.load(std::memory_order_relaxed);
+	}
+	return mine;
 }
 
 // answer thread k of n: its stripe of the ring
 void stream_answer_main(int k, int n)
 {
+	pthread_setname_np(pthread_self(), "hgs-answer");
 	unsigned idle = 0;
 	while (!g_stop.load())
 	{
 		SessionP ss = current_session();
+		g_answer_gen[k].store(g_sess_gen.load(std::memory_order_acquire), std::memory_order_release);   // "I hold nothing older than this"
 		if (!ss) { std::this_thread::sleep_for(std::chrono::microseconds(50)); continue; }
 		bool progress = false;
 		const uint64_t gen = ss->e->gen.load();
@@ -691,18 +727,21 @@ void stream_answer_main(int k, int n)
 // Close the session: no new queries, let the walks in flight finish (bounded), stop the launch, release the mirror.
 void close_session(SessionP &ss, const char *why)
 {
-	{
-		std::lock_guard<std::mutex> lk(ss->mu);
-		ss->accepting.store(false);
-	}
+	ss->accepting.store(false, std::memory_order_release);
 	const uint64_t t0 = now_ns();
-	while (ss->outstanding.load() > 0 && now_ns() - t0 < 200000000ull) std::this_thread::sleep_for(std::chrono::microseconds(20));
+	// producers that were past the check finish their slot; then every claimed ticket is published and, walked, answered
+	while ((ss->outstanding.load() > 0 || ss->pub.load() != ss->claim.load()) && now_ns() - t0 < 200000000ull)
+		std::this_thread::sleep_for(std::chrono::microseconds(20));
+	set_session(nullptr);                   // the answer threads and readers let go of it at their next look ...
+	// ... (their thread-local copies: a reader that is idle keeps one until its next request, so the count cannot be waited on; what
+	// matters is that nobody is INSIDE the ring: producers are out since `accepting` fell under the session's lock, and the answer
+	// threads have refreshed once every one of them has passed the generation check)
 	{
-		std::lock_guard<std::mutex> lk(g_sess_mu);
-		g_sess.reset();                     // the answer threads let go of it at their next look
+		const uint64_t t1 = now_ns(), gen = g_sess_gen.load();
+		for (int k = 0; k < g_opt.dispatchers && k < 64; k++)
+			while (g_answer_gen[k].load(std::memory_order_acquire) < gen && !g_stop.load() && now_ns() - t1 < 1000000000ull)
+				std::this_thread::sleep_for(std::chrono::microseconds(20));
 	}
-	// the answer threads and readers that still hold the session let go at their next look: only then may the ring be freed
-	for (int spin = 0; ss.use_count() > 1 && spin < 50000; spin++) std::this_thread::sleep_for(std::chrono::microseconds(20));
 	const int rc = hnsw_gpu_stream_close(ss->st);
 	if (rc != HNSW_GPU_OK) logf("closing the stream: %s", hnsw_gpu_last_error());
 	long lost = 0;
@@ -713,7 +752,7 @@ void close_session(SessionP &ss, const char *why)
 			lost++;
 		}
 	if (lost) { g_cnt.search_errors += (uint64_t) lost; logf("stream closed (%s) with %ld queries unanswered", why, lost); }
-	VLOG("stream on %llu closed: %s (%u queries)", (unsigned long long) ss->e->key, why, ss->pub);
+	VLOG("stream on %llu closed: %s (%u queries)", (unsigned long long) ss->e->key, why, ss->pub.load());
 	ss->e->last_used.store(now_ns());
 	ss->e->end_read();
 	g_cnt.batches++;
@@ -739,7 +778,8 @@ SessionP open_session(const EntryP &e, size_t ef, size_t backlog)
 	ss->req.resize(ss->ring);
 	ss->t_pub.assign(ss->ring, 0);
 	ss->busy.reset(new std::atomic<uint8_t>[ss->ring]);
-	for (uint32_t i = 0; i < ss->ring; i++) ss->busy[i].store(0);
+	ss->ready.reset(new std::atomic<uint32_t>[ss->ring]);
+	for (uint32_t i = 0; i < ss->ring; i++) { ss->busy[i].store(0); ss->ready[i].store(0); }
 	ss->t_active.store(now_ns());
 	ss->accepting.store(true);
 	VLOG("stream on %llu opened: ef %zu, %u walking waves per block (backlog %zu)", (unsigned long long) e->key, ef, walkers, backlog);
@@ -748,6 +788,7 @@ SessionP open_session(const EntryP &e, size_t ef, size_t backlog)
 
 void stream_manager_main()
 {
+	pthread_setname_np(pthread_self(), "hgs-manager");
 	Pinned pin;
 	std::vector<SReq> batch;
 	const uint64_t IDLE_NS = 2000000ull, CROWDED_NS = 2000000ull, ROOMY_NS = 100000000ull;
@@ -761,17 +802,19 @@ void stream_manager_main()
 			// too small / far too large a launch for the load?  (hysteresis: a change costs one drain)
 			if (g_opt.walkers <= 0)
 			{
-				if (out > ss->capacity - ss->capacity / 8 && ss->walkers < 8) { uint64_t z = 0; ss->t_crowded.compare_exchange_strong(z, now); }
+				// (walking waves per block = just enough for the walks in flight: every further one is a helper less for somebody)
+				if (out > ss->capacity - ss->capacity / 16 && ss->walkers < 8) { uint64_t z = 0; ss->t_crowded.compare_exchange_strong(z, now); }
 				else ss->t_crowded.store(0);
-				if (ss->walkers > 1 && out < ss->capacity / 4 / 2) { uint64_t z = 0; ss->t_roomy.compare_exchange_strong(z, now); }
+				const long blocks = std::max(1, g_device_blocks - 1);
+				if (ss->walkers > 1 && out * 5 / 4 <= blocks * (long) (ss->walkers - 1)) { uint64_t z = 0; ss->t_roomy.compare_exchange_strong(z, now); }
 				else ss->t_roomy.store(0);
 			}
 			const char *why = nullptr;
 			size_t hint = 0;
 			if (ss->e->writer_wants()) why = "a writer wants the mirror";
 			else if (out == 0 && now - ss->t_active.load() > IDLE_NS) why = "idle";
-			else if (ss->t_crowded.load() && now - ss->t_crowded.load() > CROWDED_NS) { why = "more walking waves per block needed"; hint = (size_t) out * 2; }
-			else if (ss->t_roomy.load() && now - ss->t_roomy.load() > ROOMY_NS) { why = "fewer walking waves per block suffice"; hint = (size_t) std::max<long>(out * 2, 1); }
+			else if (ss->t_crowded.load() && now - ss->t_crowded.load() > CROWDED_NS) { why = "more walking waves per block needed"; hint = (size_t) (out + out / 8 + 1); }
+			else if (ss->t_roomy.load() && now - ss->t_roomy.load() > ROOMY_NS) { why = "fewer walking waves per block suffice"; hint = (size_t) std::max<long>(out + out / 4, 1); }
 			else
 			{
 				// requests that did not get in by themselves (arrived between sessions, ring full): in order; another (mirror, ef) ends the session
@@ -783,6 +826,7 @@ void stream_manager_main()
 					if (!ss->submit(r)) break;
 					g_q.pop_front();
 				}
+				g_q_waiting.store((long) g_q.size(), std::memory_order_release);
 			}
 			if (why)
 			{
@@ -790,12 +834,12 @@ void stream_manager_main()
 				if (hint && !g_stop.load() && !ss->e->writer_wants() && ss->e->try_read())
 				{
 					SessionP nn = open_session(ss->e, ss->ef, hint);
-					if (nn) { std::lock_guard<std::mutex> lk(g_sess_mu); g_sess = nn; }
+					if (nn) set_session(nn);
 					else ss->e->end_read();
 				}
 				continue;
 			}
-			std::this_thread::sleep_for(std::chrono::microseconds(100));
+			if (g_q_waiting.load(std::memory_order_acquire) == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
 			continue;
 		}
 		// no session: wait for work, open one for the oldest request's (mirror, ef)
@@ -813,8 +857,7 @@ void stream_manager_main()
 		SessionP nn = open_session(e, ef, backlog);
 		if (nn)
 		{
-			std::lock_guard<std::mutex> lk(g_sess_mu);
-			g_sess = nn;
+			set_session(nn);
 			continue;                        // (the loop above moves the queue into it)
 		}
 		// no stream for this shape (a beam too wide for the team form, ...): one blocking batch, as --lanes 0 does
@@ -822,6 +865,7 @@ void stream_manager_main()
 		{
 			std::unique_lock<std::mutex> lk(g_q_mu);
 			if (!g_q.empty()) take_batch(batch);
+			g_q_waiting.store((long) g_q.size(), std::memory_order_release);
 		}
 		if (!batch.empty()) run_batch(0, batch, pin);
 	}
@@ -1148,6 +1192,7 @@ void do_control(CReq &r)
 
 void control_main()
 {
+	pthread_setname_np(pthread_self(), "hgs-control");
 	while (true)
 	{
 		CReq r;
@@ -1237,19 +1282,16 @@ bool handle_message(const ConnP &c, const hgs_hdr &h, const char *payload)
 		r.t_in = now_ns();
 		if (g_opt.stream)
 		{
-			// straight into the ring of the open session when it serves this (mirror, beam) — unless older requests are still queued
-			// (between sessions): those go first
+			// straight into the ring of the open session when it serves this (mirror, beam).  (Not "unless older requests are still
+			// queued": a backend has one search outstanding, so there is no order between requests to keep — and that rule turned one
+			// queued request into a convoy: everything behind it went through the manager thread, 0.35-0.4 M q/s, profiles/r4l_*.)
 			SessionP ss = current_session();
-			if (ss && ss->e.get() == r.e.get() && ss->ef == h.aux)
-			{
-				bool queued;
-				{ std::lock_guard<std::mutex> lk(g_q_mu); queued = !g_q.empty(); }
-				if (!queued && ss->submit(r)) return true;
-			}
+			if (ss && ss->e.get() == r.e.get() && ss->ef == h.aux && ss->submit(r)) return true;
 		}
 		{
 			std::lock_guard<std::mutex> lk(g_q_mu);
 			g_q.push_back(std::move(r));
+			g_q_waiting.store((long) g_q.size(), std::memory_order_release);
 		}
 		g_q_cv.notify_one();
 		return true;
@@ -1336,6 +1378,7 @@ bool on_readable(const ConnP &c)
 
 void reader_main(int epfd)
 {
+	pthread_setname_np(pthread_self(), "hgs-reader");
 	std::vector<struct epoll_event> evs(256);
 	while (!g_stop.load())
 	{

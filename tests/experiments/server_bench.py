@@ -27,6 +27,22 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 from pg_embedding_amd import watchdog; watchdog.arm()      # --timeout SECONDS (default 900): a hung device run costs one case, not the round
 
 
+def thread_cpu(pid):
+    """{tid: (thread name, user + system CPU seconds)} of a process, from /proc"""
+    out = {}
+    tick = os.sysconf("SC_CLK_TCK")
+    try:
+        for tid in os.listdir(f"/proc/{pid}/task"):
+            with open(f"/proc/{pid}/task/{tid}/stat") as f:
+                st = f.read()
+            name = st[st.index("(") + 1:st.rindex(")")]
+            f2 = st[st.rindex(")") + 2:].split()
+            out[tid] = (name, (int(f2[11]) + int(f2[12])) / tick)
+    except OSError:
+        pass
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rows", type=int, default=1000000)
@@ -43,6 +59,7 @@ def main():
     ap.add_argument("--hwq", type=int, default=0, help="GPU_MAX_HW_QUEUES for the server process (0 = leave it alone)")
     ap.add_argument("--binary", default=None, help="server binary (default: the shipped one)")
     ap.add_argument("--check", type=int, default=200, help="queries compared with the CPU reference")
+    ap.add_argument("--server-env", default="", help="K=V[,K=V] added to the server's environment (e.g. LD_PRELOAD of a variant library)")
     ap.add_argument("--walkers", default=None, help="server --walkers (auto | 0..8): walking waves per block of a search launch")
     ap.add_argument("--stream", action="store_true", help="server --stream 1: one resident launch fed through a ring instead of launches on lanes")
     ap.add_argument("--configs", default="", help="sweep: comma-separated dispatchers:lanes[:readers[:walkers[:stream]]] — one server per entry over the "
@@ -83,7 +100,8 @@ def main():
     for ci, (nd, nl, nr, nw, strm) in enumerate(cfgs):
       print(f"## server with {nd} dispatchers x {nl} lanes, {nr} readers, walkers {nw or 'default (auto)'}" + (", STREAM mode" if strm else ""), flush=True)
       srv = ServerProcess(dispatchers=nd, readers=nr, lanes=nl, binary=a.binary, walkers=nw, stream=strm,
-                          env={"GPU_MAX_HW_QUEUES": str(a.hwq)} if a.hwq else None)
+                          env=dict(([("GPU_MAX_HW_QUEUES", str(a.hwq))] if a.hwq else []) +
+                                   [tuple(kv.split("=", 1)) for kv in a.server_env.split(",") if "=" in kv]) or None)
       with srv:
           c = RemoteClient(srv.socket_path)
           t = time.time()
@@ -105,9 +123,18 @@ def main():
               cal = json.loads(r.stdout)
               rounds = int(max(1, min(200, a.target_seconds * cal["qps"] / nq)))
               before = c.stats()
+              cpu0 = thread_cpu(srv.proc.pid)
+              wall0 = time.time()
               r = subprocess.run(args + [str(rounds)], capture_output=True, text=True, env=env, timeout=600)
               assert r.returncode == 0, r.stderr
               info = json.loads(r.stdout)
+              cpu1, wall = thread_cpu(srv.proc.pid), time.time() - wall0
+              # how busy the server's threads were over the run (user + system CPU seconds / wall seconds), by thread name
+              busy = {}
+              for tid, (name, sec) in cpu1.items():
+                  d0 = cpu0.get(tid, (name, 0.0))[1]
+                  busy.setdefault(name, []).append(round((sec - d0) / max(wall, 1e-9), 2))
+              info["server_thread_busy_fraction"] = {k: sorted(v, reverse=True) for k, v in busy.items()}
               st = c.stats()
               d = {k: st[k] - before[k] for k in ("searches", "batches", "batch_ns", "kernel_ns", "queue_ns", "walk_ns", "answer_ns")}
               info.update(mean_batch=d["searches"] / max(1, d["batches"]), batches=d["batches"],
