@@ -353,26 +353,7 @@ def main():
     # fills the CUs the previous one frees while it drains).  Extra figure, not `value`.
     pipelined = None
     if small is not None:
-        ctxs = [pg.SearchContext(ix), pg.SearchContext(ix)]
-        streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
-        Qs = Q[:args.nq_small].contiguous()
-        outs = [ix.search_torch(Qs, args.ef), ix.search_torch(Qs, args.ef)]
-        torch.cuda.synchronize()
-        reps = 12
-        for i in range(2):
-            ctxs[i].search_torch(Qs, args.ef, outs[i], streams[i])
-        torch.cuda.synchronize()
-        tp = time.perf_counter()
-        for i in range(reps):
-            ctxs[i & 1].search_torch(Qs, args.ef, outs[i & 1], streams[i & 1])
-        torch.cuda.synchronize()
-        tp = time.perf_counter() - tp
-        ok = bool((outs[0]["labels"] == labels0[:args.nq_small]).all().item() and
-                  (outs[1]["labels"] == labels0[:args.nq_small]).all().item())
-        pipelined = {"queries_per_launch": args.nq_small, "launches": reps, "streams": 2,
-                     "queries_per_s": args.nq_small * reps / tp, "results_identical": ok}
-        for c in ctxs:
-            c.close()
+        pipelined = two_streams(ix, Q[:args.nq_small].contiguous(), args.ef, labels0[:args.nq_small], dev)
 
     # ---- single query per launch: the reference's own call shape (embedding.c:317), device time only.  Measured twice: right here,
     # behind seconds of sustained full-chip load (the device's clocks are down: the state `value` is measured in), and after one
@@ -500,21 +481,31 @@ def main():
     }
 
     # ---- the host-pointer form of the same batch (hnsw_gpu_search_batch): what a caller without device buffers pays on top
+    # (Everything from here on is an extra leg next to a headline that is already complete: a leg that fails says so under its own key
+    # — with the exception's text — and the line is printed all the same.)
+    def leg(fn, *fargs):
+        try:
+            return fn(*fargs)
+        except Exception as e:                                   # noqa: BLE001 (reported, not swallowed)
+            import traceback
+            sys.stderr.write(traceback.format_exc())
+            return {"failed": f"{type(e).__name__}: {e}"[:400]}
+
     if rank == 0 and world == 1:
-        result["host_pointer_batch"] = host_pointer_batch(args, ix, Q, labels0)
+        result["host_pointer_batch"] = leg(host_pointer_batch, args, ix, Q, labels0)
     # ---- CPU baseline: the reference's own code on the same graph bytes, rank 0, N=1 only --
     if rank == 0 and world == 1 and not args.no_cpu:
-        result["cpu_baseline"] = cpu_baseline(args, ix, Q, labels0, out["dists"], func)
+        result["cpu_baseline"] = leg(cpu_baseline, args, ix, Q, labels0, out["dists"], func)
     ix.close()
     del ix, out, bufs, labels0
 
     # ---- a dataset whose rows do not repeat inside a launch (N=1 only): the Infinity-Cache share made visible
     if rank == 0 and world == 1 and args.hostile_rows > 0:
-        result["roofline"]["hbm_only"] = hostile(args, dev, local, func)
+        result["roofline"]["hbm_only"] = leg(hostile, args, dev, local, func)
     # ---- the other BASELINE configs and the stress datasets of SURVEY.md §8(d), same kernels, N=1 only (extras, not `value`)
     if rank == 0 and world == 1 and not args.no_side_configs:
-        result["other_configs"] = side_configs(args, dev, local)
-        result["serial_insert"] = serial_insert(args, dev)
+        result["other_configs"] = leg(side_configs, args, dev, local)
+        result["serial_insert"] = leg(serial_insert, args, dev)
     if use_dist and world > 1 and not args.no_multi_gpu_extras:
         multi_gpu_extras(args, result, world, rank, local, dev)       # prints the line itself (also when the extras time out)
     elif rank == 0:
@@ -644,6 +635,31 @@ def host_pointer_batch(args, ix, Q, labels0):
     return out
 
 
+def two_streams(ix, Qs, ef, labels_want, dev, reps=12):
+    """Launches of the same batch alternating on two search contexts / two streams: the next launch's walks fill the slots the previous
+    one frees while its last walks drain (what a caller that has the next batch ready gets; ONE call cannot do it for itself — splitting
+    a batch in the library was measured slower, profiles/r4c_tail_split_rejected.txt).  Wall-clock over `reps` launches."""
+    import torch
+    import pg_embedding_amd as pg
+    ctxs = [pg.SearchContext(ix), pg.SearchContext(ix)]
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    outs = [ix.search_torch(Qs, ef), ix.search_torch(Qs, ef)]
+    torch.cuda.synchronize()
+    for i in range(2):
+        ctxs[i].search_torch(Qs, ef, outs[i], streams[i])
+    torch.cuda.synchronize()
+    tp = time.perf_counter()
+    for i in range(reps):
+        ctxs[i & 1].search_torch(Qs, ef, outs[i & 1], streams[i & 1])
+    torch.cuda.synchronize()
+    tp = time.perf_counter() - tp
+    ok = bool((outs[0]["labels"] == labels_want).all().item() and (outs[1]["labels"] == labels_want).all().item())
+    for c in ctxs:
+        c.close()
+    return {"queries_per_launch": int(Qs.shape[0]), "launches": reps, "streams": 2,
+            "queries_per_s": int(Qs.shape[0]) * reps / tp, "results_identical": ok}
+
+
 def side_configs(args, dev, local):
     """BASELINE.json configs 2, 3 and 5 at 1M rows, and two stress datasets for the headline shape: i.i.d. Gaussian rows
     (no cluster structure: E_q several times larger, recall far below the gate — SURVEY.md §8d says report it, never gate
@@ -742,6 +758,12 @@ def side_configs(args, dev, local):
                      "datagen_plus_build_seconds": t_build}
         if mfma:
             res[name]["exhaustive_mfma_gemm"] = mfma
+        if nq >= 10000:
+            # the same launches back to back on two streams: what the drain of a launch's last walks costs a caller that has no next batch
+            # ready (frac_of_8TBps above) and what one that has gets (here)
+            ts = two_streams(ix, Q, args.ef, out["labels"], dev)
+            ts["frac_of_8TBps"] = float(bq.sum()) * ts["queries_per_s"] / nq / 1e9 / HBM_PEAK_GBS
+            res[name]["two_streams"] = ts
         ix.close()
         del ix, out, Q
         torch.cuda.empty_cache()

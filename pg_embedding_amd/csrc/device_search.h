@@ -109,6 +109,8 @@ struct SearchArgs
 	uint32_t *stream_dev;         // device: STREAM_COPIES copies of the two words, 128 bytes apart (the doorbell wave's 64 lanes store one each):
 	                              // wave w polls copy w % STREAM_COPIES, so that the idle waves of a stream do not all read ONE line of ONE L2 channel
 	uint32_t stream_ring;         // slots of the query / result ring (a power of two): ticket t lives in slot t & (ring - 1)
+	uint32_t stream_light;        // 1 = a stream's results are written with system-scope stores and its completion flag follows vmcnt(0);
+	                              // 0 = plain stores + a full system-scope release per answered query (signal_done)
 };
 
 // Abort word + health words of a search workspace.
@@ -136,14 +138,15 @@ __device__ __forceinline__ bool abort_requested(const SearchArgs &a)
 
 // Streamed completion: everything this wave wrote for the query becomes visible system-wide, then
 // the flag.  Once per query, outside the hop loop.
-// host_coherent = the launch's outputs AND flags live in fine-grained (coherent) pinned host memory that the library allocated
-// itself (the ring of a stream): stores to such memory are not held in the device's L2, so "every store of this wave has been
-// acknowledged" (vmcnt 0) orders the results before the flag without the L2 write-back a system-scope release costs on gfx950 —
-// per ANSWERED QUERY.  That write-back was the batching server's ceiling: 0.59 -> 0.77 M q/s at 1 024 backends with nothing else
-// changed (profiles/r4o_light_completion.txt).  Caller-provided buffers of unknown kind keep the full release.
-__device__ __forceinline__ void signal_done(uint32_t *flag, int lane, bool host_coherent = false)
+// written_through = every result of this query was written with SYSTEM-SCOPE stores (write-through: nothing of them is held in the
+// device's L2) into the library's own coherent pinned ring (a stream): then "every store of this wave has been acknowledged" (vmcnt 0)
+// orders them before the flag, and the L2 write-back of a system-scope release — buffer_wbl2, per ANSWERED QUERY, of everybody's
+// lines — is not needed.  That write-back was the stream server's ceiling: 0.67 -> 0.75 M q/s at 1 024 backends, 0.49 -> 0.61 M at
+// 2 048.  With PLAIN result stores the shortcut is unsound and was measured to be: 15 % of the answers the host read were not the
+// query's (profiles/r4q_stream_completion_forms.txt).  Caller-provided buffers keep plain stores + the full release.
+__device__ __forceinline__ void signal_done(uint32_t *flag, int lane, bool written_through = false)
 {
-	if (host_coherent)
+	if (written_through)
 	{
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_s_waitcnt(0);
@@ -2081,6 +2084,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		}
 		wave_sync();
 		const size_t obase = (size_t) qi * a.out_stride;
+		const bool sys_out = stream && a.stream_light != 0 && a.mode == 0;      // (a stream's results: system-scope stores, banner at signal_done)
 		uint32_t nout = 0;
 		// rank by (dist, idx); only ranks < ef are results (topCandidates, hnswalg.cpp:237-240).  Four broadcast
 		// keys per step: the loop is a chain of LDS round trips, not of compares.
@@ -2161,23 +2165,40 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				}
 				if (keep)
 				{
-					a.out_labels[obase + rank] = li;
-					if (a.out_dists) a.out_dists[obase + rank] = unord_f32(di);
+					if (sys_out)
+					{
+						__hip_atomic_store(a.out_labels + obase + rank, li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+						if (a.out_dists) __hip_atomic_store(reinterpret_cast<uint32_t *>(a.out_dists) + obase + rank, __float_as_uint(unord_f32(di)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					}
+					else
+					{
+						a.out_labels[obase + rank] = li;
+						if (a.out_dists) a.out_dists[obase + rank] = unord_f32(di);
+					}
 				}
 				nout += (uint32_t) __builtin_popcountll(kmask);
 			}
 			for (uint32_t i = nout + lane; i < a.out_stride; i += 64)
 			{
-				a.out_labels[obase + i] = ~0ull;
-				if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
+				if (sys_out)
+				{
+					__hip_atomic_store(a.out_labels + obase + i, (uint64_t) ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					if (a.out_dists) __hip_atomic_store(reinterpret_cast<uint32_t *>(a.out_dists) + obase + i, 0x7F800000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				}
+				else
+				{
+					a.out_labels[obase + i] = ~0ull;
+					if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
+				}
 			}
 		}
 		if (lane == 0)
 		{
-			a.out_counts[qi] = nout;
+			if (sys_out) __hip_atomic_store(a.out_counts + qi, nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			else a.out_counts[qi] = nout;
 			if (a.out_stats) { a.out_stats[2 * (size_t) qi] = evals; a.out_stats[2 * (size_t) qi + 1] = hops; }
 		}
-		if (a.done) signal_done(a.done + qi, lane, stream);       // (a stream's ring is the library's own coherent pinned memory)
+		if (a.done) signal_done(a.done + qi, lane, sys_out);       // (a stream's ring is the library's own coherent pinned memory)
 
 		wave_sync();
 		if (logn <= a.logcap)

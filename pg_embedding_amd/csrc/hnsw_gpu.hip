@@ -71,7 +71,7 @@ enum Knob : int
 {
 	// operational (environment, read once)
 	K_BEAM, K_FORCE_LDS_HEAPS, K_TEAM, K_TEAM_MAX_NQ, K_WIDE_EF_MIN, K_REF_ORDER, K_NO_POLL, K_POLL_LIMIT_S, K_INSERT_FUSED,
-	K_BLOCKS_PER_CU,
+	K_BLOCKS_PER_CU, K_STREAM_LIGHT,
 	// test knobs (hnsw_gpu_config_set only)
 	K_BEAM16, K_NARROW5, K_LEAN, K_HASH_ENTRIES, K_LDS_SET_MIN_WAVES, K_TEAM_SPEC, K_TEAM_WPB, K_MAX_BLOCKS, K_SHARDED_NO_PEER,
 #ifdef HNSW_EXPERIMENT
@@ -83,7 +83,7 @@ struct KnobDef { const char *name; bool env; };
 static const KnobDef g_knob_def[K_COUNT] = {
 	{ "HNSW_GPU_BEAM", true }, { "HNSW_GPU_FORCE_LDS_HEAPS", true }, { "HNSW_GPU_TEAM", true }, { "HNSW_GPU_TEAM_MAX_NQ", true },
 	{ "HNSW_GPU_WIDE_EF_MIN", true }, { "HNSW_GPU_REF_ORDER", true }, { "HNSW_GPU_NO_POLL", true }, { "HNSW_GPU_POLL_LIMIT_S", true },
-	{ "HNSW_GPU_INSERT_FUSED", true }, { "HNSW_GPU_BLOCKS_PER_CU", true },
+	{ "HNSW_GPU_INSERT_FUSED", true }, { "HNSW_GPU_BLOCKS_PER_CU", true }, { "HNSW_GPU_STREAM_LIGHT", true },
 	{ "HNSW_GPU_BEAM16", false }, { "HNSW_GPU_NARROW5", false }, { "HNSW_GPU_LEAN", false }, { "HNSW_GPU_HASH_ENTRIES", false }, { "HNSW_GPU_LDS_SET_MIN_WAVES", false },
 	{ "HNSW_GPU_TEAM_SPEC", false }, { "HNSW_GPU_TEAM_WPB", false }, { "HNSW_GPU_MAX_BLOCKS", false }, { "HNSW_GPU_SHARDED_NO_PEER", false },
 #ifdef HNSW_EXPERIMENT
@@ -1033,6 +1033,7 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 		blocks = std::max<size_t>(2, (size_t) per_cu * ix->num_cu);
 		a.team_mains = std::min<uint32_t>(wpb, std::max<uint32_t>(1u, w->stream_walkers_next));
 		a.stream_host = w->stream_host_next; a.stream_dev = w->stream_dev_next; a.stream_ring = w->stream_ring_next;
+		a.stream_light = knob(K_STREAM_LIGHT, 1) != 0 ? 1u : 0u;
 		w->stream_host_next = nullptr; w->stream_dev_next = nullptr;
 	}
 	// (test knob: fewer blocks than the launch would get, so that the waves with queries take SEVERAL each through the

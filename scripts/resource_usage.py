@@ -1,15 +1,20 @@
 #!/usr/bin/env python3
 """Per-kernel register / spill / occupancy table from hipcc's -Rpass-analysis=kernel-resource-usage.
 
-usage: scripts/resource_usage.py [filter-substring]
-Compiles pg_embedding_amd/csrc/hnsw_gpu.hip for gfx950 (object only, into /tmp) and prints one line per kernel.
+usage: scripts/resource_usage.py [filter-substring] [unit]
+Compiles one translation unit of the library for gfx950 (object only, into /tmp) and prints one line per kernel.  unit: "main"
+(hnsw_gpu.hip, default), "sort" (sort_pairs.hip) or 1..5 (search_inst.hip with -DSEARCH_INST_SHAPE=unit: the beam kernels of one
+row shape — 1 Shape2x4, 2 Shape4x2, 3 Shape8x2, 4 Shape12x2, 5 Shape2x2; pg_embedding_amd/build.py).
 """
 import re, subprocess, sys, tempfile, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
+unit = sys.argv[2] if len(sys.argv) > 2 else "main"
+src = {"main": "hnsw_gpu.hip", "sort": "sort_pairs.hip"}.get(unit, "search_inst.hip")
+extra = ["-DSEARCH_INST_SHAPE=" + unit] if src == "search_inst.hip" else []
 with tempfile.TemporaryDirectory() as td:
     r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
-                        "-I" + os.path.join(ROOT, "include"), "-c", os.path.join(ROOT, "pg_embedding_amd/csrc/hnsw_gpu.hip"),
+                        "-I" + os.path.join(ROOT, "include"), *extra, "-c", os.path.join(ROOT, "pg_embedding_amd/csrc", src),
                         "-o", os.path.join(td, "x.o"), "-Rpass-analysis=kernel-resource-usage"],
                        capture_output=True, text=True)
 cur = None

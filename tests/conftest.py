@@ -40,9 +40,10 @@ def pytest_collection_modifyitems(config, items):
         if deselected_all:
             return                                            # the CPU tier collects them only to deselect them
         raise pytest.UsageError(f"the device tests need the pytest-timeout plugin (a hung kernel must fail, not hang): {e}")
+    limit = int(os.environ.get("PGEMB_TEST_TIMEOUT", "600"))        # (a device session that hunts a hang sets it lower)
     for it in gpu_items:
         if not it.get_closest_marker("timeout"):
-            it.add_marker(pytest.mark.timeout(600, method="thread"))
+            it.add_marker(pytest.mark.timeout(limit, method="thread"))
 
 
 @pytest.fixture(scope="session", autouse=True)

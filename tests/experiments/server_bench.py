@@ -148,18 +148,12 @@ def main():
               print(json.dumps(info), flush=True)
               out = np.fromfile(of, np.uint64)
               labels = (nq, out[:nq * a.efs].reshape(nq, a.efs).copy(), out[nq * a.efs:].copy())
-          if ci > 0:                                      # (the sweep's later servers: throughput only)
-              st = c.stats()
-              print("# server totals:", json.dumps({k: st[k] for k in ("connections", "searches", "batches", "max_batch", "search_errors")}))
-              c.close()
-              table += [(nd, nl, nr, nw, strm, r) for r in rows]
-              continue
           # parity of what the backends received, against the reference's code on the same graph bytes
           graph = c.export(key, a.rows * esz)
           nq, lab, cnt = labels
           ncheck = min(a.check, nq)
           checks = [("C restatement in the device's summation order (oracle/hnsw_port.c)", oracle.PortIndex)]
-          if oracle.have_ref():
+          if oracle.have_ref() and ci == 0:               # (the sweep's later servers: the bit-exact oracle only)
               checks.append(("reference binary, -Ofast summation order (oracle/_ref)", oracle.RefIndex))
           for kind, cls in checks:
               cpu = cls(a.dims, a.m, a.efc, a.efs, pg.DIST_L2)

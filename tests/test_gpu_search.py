@@ -468,29 +468,39 @@ def test_a_stream_answers_like_a_launch(dim, m, func, walkers):
     assert_same_as_oracle(ix, port, Q[:40], ef)
     ctx = pg.SearchContext(ix)
     for round_ in range(2):
+        # round 0: the default completion form (results as system-scope stores, the flag behind vmcnt(0)); round 1: plain stores and a
+        # full system-scope release per answered query (HNSW_GPU_STREAM_LIGHT)
+        pg.config_set("HNSW_GPU_STREAM_LIGHT", None if round_ == 0 else 0)
         st = pg.SearchStream(ctx, ef, ring=ring, walkers=walkers)
-        assert st.alive()
-        done = 0
-        rng = np.random.default_rng(round_)
-        pending = []                                             # (first query number, slots)
-        while done < nq or pending:
-            # keep up to ring/2 queries in flight, published in irregular chunks
-            inflight = sum(len(sl) for _, sl in pending)
-            if done < nq and inflight <= ring // 2:
-                k = int(min(nq - done, rng.integers(1, ring // 2 - 1), ring - inflight - 1))
-                pending.append((done, st.submit(Q[done:done + k])))
-                done += k
-                continue
-            first, slots = pending.pop(0)
-            lab, dst, cnt = st.wait(slots)
-            k = len(slots)
-            assert (cnt == want["counts"][first:first + k]).all(), (round_, first)
-            assert (lab == want["labels"][first:first + k]).all(), (round_, first)
-            assert (bits(dst) == bits(want["dists"][first:first + k])).all(), (round_, first)
-        st.close()
+        try:
+            _drive_stream(st, Q, want, nq, ring, round_)
+        finally:
+            pg.config_set("HNSW_GPU_STREAM_LIGHT", None)
+            st.close()                                          # (a resident launch left behind holds the whole device: everything after it would wait)
         assert_same_as_oracle(ix, port, Q[40:80], ef)            # an ordinary launch on the mirror after the stream has left
     ctx.close()
     ix.close()
+
+
+def _drive_stream(st, Q, want, nq, ring, round_):
+    assert st.alive()
+    done = 0
+    rng = np.random.default_rng(round_)
+    pending = []                                             # (first query number, slots)
+    while done < nq or pending:
+        # keep up to ring/2 queries in flight, published in irregular chunks
+        inflight = sum(len(sl) for _, sl in pending)
+        if done < nq and inflight <= ring // 2:
+            k = int(min(nq - done, rng.integers(1, ring // 2 - 1), ring - inflight - 1))
+            pending.append((done, st.submit(Q[done:done + k])))
+            done += k
+            continue
+        first, slots = pending.pop(0)
+        lab, dst, cnt = st.wait(slots)
+        k = len(slots)
+        assert (cnt == want["counts"][first:first + k]).all(), (round_, first)
+        assert (lab == want["labels"][first:first + k]).all(), (round_, first)
+        assert (bits(dst) == bits(want["dists"][first:first + k])).all(), (round_, first)
 
 
 @pytest.mark.parametrize("ef", [1, 5, 64, 128, 256])
