@@ -648,16 +648,20 @@ def two_streams(ix, Qs, ef, labels_want, dev, reps=12):
     for i in range(2):
         ctxs[i].search_torch(Qs, ef, outs[i], streams[i])
     torch.cuda.synchronize()
-    tp = time.perf_counter()
-    for i in range(reps):
-        ctxs[i & 1].search_torch(Qs, ef, outs[i & 1], streams[i & 1])
-    torch.cuda.synchronize()
-    tp = time.perf_counter() - tp
+    # three rounds, each reported: the rounds directly behind seconds of sustained load (the index build) run at whatever clocks that load
+    # left — the VALU-bound narrow-row kernel feels it, the HBM-bound one does not (profiles/r4x_launches_back_to_back.txt); the median counts
+    rounds = []
+    for _ in range(3):
+        tp = time.perf_counter()
+        for i in range(reps):
+            ctxs[i & 1].search_torch(Qs, ef, outs[i & 1], streams[i & 1])
+        torch.cuda.synchronize()
+        rounds.append(int(Qs.shape[0]) * reps / (time.perf_counter() - tp))
     ok = bool((outs[0]["labels"] == labels_want).all().item() and (outs[1]["labels"] == labels_want).all().item())
     for c in ctxs:
         c.close()
-    return {"queries_per_launch": int(Qs.shape[0]), "launches": reps, "streams": 2,
-            "queries_per_s": int(Qs.shape[0]) * reps / tp, "results_identical": ok}
+    return {"queries_per_launch": int(Qs.shape[0]), "launches": reps, "streams": 2, "queries_per_s": sorted(rounds)[1],
+            "queries_per_s_of_each_round": rounds, "results_identical": ok}
 
 
 def side_configs(args, dev, local):

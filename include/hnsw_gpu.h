@@ -290,8 +290,11 @@ int  hnsw_gpu_ctx_idle(hnsw_gpu_ctx *ctx);
  *                           it a ring ago has been answered.
  *   hnsw_gpu_stream_publish published_total = how many queries have been written so far (a counter mod 2^32): a release store — the
  *                           kernel's doorbell wave forwards it to the waiting waves within about two microseconds.
- *   results                 flags[slot] becomes 1 once labels / dists / counts of that slot are complete (system-scope release: the
- *                           streamed completion of hnsw_gpu_search_batch_ctx_flags); rows are what hnsw_gpu_search_batch returns.
+ *   results                 flags[slot] becomes 1 once labels / dists / counts of that slot are complete; rows are what
+ *                           hnsw_gpu_search_batch returns.  A stream writes its results with system-scope (write-through) stores and
+ *                           stores the flag once they are acknowledged — the L2 write-back of a full release per answered query was
+ *                           the ceiling of a many-backend server; HNSW_GPU_STREAM_LIGHT=0 restores plain stores + the full release
+ *                           (what hnsw_gpu_search_batch_ctx_flags does for caller-provided buffers).
  *   hnsw_gpu_stream_alive   1 while the launch is on the device.
  *   hnsw_gpu_stream_close   stop: every wave leaves at its next look (a walking wave after its query); waits for the launch to end
  *                           (a launch that does not end within 2 s is asked through its abort word), frees the ring.  Queries
