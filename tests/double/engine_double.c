@@ -312,23 +312,115 @@ static unsigned g_walkers_last = 0, g_walkers_max = 0;     /* what the server as
 int hnsw_gpu_ctx_set_walkers(hnsw_gpu_ctx *c, unsigned per_block)
 {
 	(void) c;
-	g_walkers_last = per_block;
-	if (per_block > g_walkers_max) g_walkers_max = per_block;
+	__atomic_store_n(&g_walkers_last, per_block, __ATOMIC_RELAXED);          /* (several dispatcher lanes call this at once) */
+	unsigned m = __atomic_load_n(&g_walkers_max, __ATOMIC_RELAXED);
+	while (per_block > m && !__atomic_compare_exchange_n(&g_walkers_max, &m, per_block, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) { }
 	return HNSW_GPU_OK;
 }
-unsigned engine_double_walkers_max(void) { return g_walkers_max; }
-/* streams need a device: the server falls back to one blocking batch per request group when opening one fails */
-typedef struct hnsw_gpu_stream hnsw_gpu_stream;
+unsigned engine_double_walkers_max(void) { return __atomic_load_n(&g_walkers_max, __ATOMIC_RELAXED); }
+/* Streams (include/hnsw_gpu.h): the resident launch is played by threads — 3 x walkers of them, the "walking waves" of the three
+ * walking blocks of this 4-block "device" — that take tickets, wait until the host has published past their ticket, answer the ring
+ * slot through the oracle and raise its flag; walks end out of order (HGS_DOUBLE_SLEEP_US stretches every third one).  What the server
+ * does with a stream — lock-free producers, ring reuse, answer threads, opening / closing / re-shaping sessions, mirror changes and
+ * shutdown while one is open — runs in the CPU tier against this.  HGS_DOUBLE_NO_STREAMS=1: opening fails (the server's fallback). */
+struct hnsw_gpu_stream
+{
+	hnsw_gpu_ctx *c;
+	size_t ef, ring, dim;
+	coord_t *Q; label_t *L; dist_t *D; uint32_t *C; uint32_t *F;
+	uint32_t published, next;
+	int stop, nthreads, alive;
+	pthread_t th[24];
+};
+static unsigned g_streams_opened = 0;
+unsigned engine_double_streams_opened(void) { return __atomic_load_n(&g_streams_opened, __ATOMIC_RELAXED); }
+
+static void *stream_walker(void *arg)
+{
+	hnsw_gpu_stream *s = (hnsw_gpu_stream *) arg;
+	const char *us = getenv("HGS_DOUBLE_SLEEP_US");
+	const long stretch = us ? atol(us) : 0;
+	for (;;)
+	{
+		const uint32_t t = __atomic_fetch_add(&s->next, 1u, __ATOMIC_ACQ_REL);
+		for (;;)
+		{
+			if ((int32_t) (__atomic_load_n(&s->published, __ATOMIC_ACQUIRE) - t) > 0) break;
+			if (__atomic_load_n(&s->stop, __ATOMIC_ACQUIRE)) { __atomic_fetch_sub(&s->alive, 1, __ATOMIC_ACQ_REL); return NULL; }
+			struct timespec ts = { 0, 20000 };
+			nanosleep(&ts, NULL);
+		}
+		const size_t slot = t & (s->ring - 1), ef = s->ef;
+		if (stretch > 0 && t % 3 == 0)
+		{
+			struct timespec ts = { 0, (stretch % 1000000) * 1000 / 4 };
+			nanosleep(&ts, NULL);
+		}
+		size_t n = 0;
+		for (size_t i = 0; i < ef; i++) { s->L[slot * ef + i] = ~(label_t) 0; s->D[slot * ef + i] = 1.0f / 0.0f; }
+		port_search(s->c->ix->p, s->Q + slot * s->dim, ef, s->L + slot * ef, s->D + slot * ef, &n, NULL, NULL);
+		s->C[slot] = (uint32_t) n;
+		__atomic_store_n(&s->F[slot], 1u, __ATOMIC_RELEASE);
+	}
+}
+
 int hnsw_gpu_stream_open(hnsw_gpu_ctx *c, size_t ef, size_t ring, unsigned walkers, hnsw_gpu_stream **out)
 {
-	(void) c; (void) ef; (void) ring; (void) walkers; (void) out;
-	snprintf(t_err, sizeof(t_err), "the engine double has no streams");
-	return HNSW_GPU_ERR_ARG;
+	if (!c || !out || ef == 0 || ring < 64 || (ring & (ring - 1))) { snprintf(t_err, sizeof(t_err), "double: bad stream arguments"); return HNSW_GPU_ERR_ARG; }
+	if (getenv("HGS_DOUBLE_NO_STREAMS")) { snprintf(t_err, sizeof(t_err), "double: streams switched off"); return HNSW_GPU_ERR_INTERNAL; }
+	if (ef > 512) { snprintf(t_err, sizeof(t_err), "a stream needs ef <= 512 (the team form of the beam kernel)"); return HNSW_GPU_ERR_ARG; }
+	if (c->busy) { snprintf(t_err, sizeof(t_err), "double: context busy"); return HNSW_GPU_ERR_INTERNAL; }
+	hnsw_gpu_stream *s = (hnsw_gpu_stream *) calloc(1, sizeof(*s));
+	if (!s) return HNSW_GPU_ERR_NOMEM;
+	s->c = c; s->ef = ef; s->ring = ring; s->dim = c->ix->meta.dim;
+	s->Q = (coord_t *) calloc(ring * s->dim, sizeof(coord_t));
+	s->L = (label_t *) calloc(ring * ef, sizeof(label_t));
+	s->D = (dist_t *) calloc(ring * ef, sizeof(dist_t));
+	s->C = (uint32_t *) calloc(ring, 4);
+	s->F = (uint32_t *) calloc(ring, 4);
+	if (!s->Q || !s->L || !s->D || !s->C || !s->F) { free(s->Q); free(s->L); free(s->D); free(s->C); free(s->F); free(s); return HNSW_GPU_ERR_NOMEM; }
+	if (walkers == 0) walkers = 4;
+	if (walkers > 8) walkers = 8;
+	s->nthreads = (int) (3 * walkers);
+	s->alive = s->nthreads;
+	c->busy = 1;                                           /* the context serves the stream until it is closed */
+	for (int i = 0; i < s->nthreads; i++) pthread_create(&s->th[i], NULL, stream_walker, s);
+	__atomic_fetch_add(&g_streams_opened, 1u, __ATOMIC_RELAXED);
+	*out = s;
+	return HNSW_GPU_OK;
 }
-int hnsw_gpu_stream_buffers(hnsw_gpu_stream *s, coord_t **q, label_t **l, dist_t **d, uint32_t **c, uint32_t **f) { (void) s; (void) q; (void) l; (void) d; (void) c; (void) f; return HNSW_GPU_ERR_ARG; }
-int hnsw_gpu_stream_publish(hnsw_gpu_stream *s, uint32_t n) { (void) s; (void) n; return HNSW_GPU_ERR_ARG; }
-int hnsw_gpu_stream_alive(hnsw_gpu_stream *s) { (void) s; return 0; }
-int hnsw_gpu_stream_close(hnsw_gpu_stream *s) { (void) s; return HNSW_GPU_OK; }
+
+int hnsw_gpu_stream_buffers(hnsw_gpu_stream *s, coord_t **q, label_t **l, dist_t **d, uint32_t **c, uint32_t **f)
+{
+	if (!s) return HNSW_GPU_ERR_ARG;
+	if (q) *q = s->Q;
+	if (l) *l = s->L;
+	if (d) *d = s->D;
+	if (c) *c = s->C;
+	if (f) *f = s->F;
+	return HNSW_GPU_OK;
+}
+
+int hnsw_gpu_stream_publish(hnsw_gpu_stream *s, uint32_t n)
+{
+	if (!s) return HNSW_GPU_ERR_ARG;
+	uint32_t cur = __atomic_load_n(&s->published, __ATOMIC_ACQUIRE);                 /* keeps the maximum, as the library does */
+	while ((int32_t) (n - cur) > 0 && !__atomic_compare_exchange_n(&s->published, &cur, n, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) { }
+	return HNSW_GPU_OK;
+}
+
+int hnsw_gpu_stream_alive(hnsw_gpu_stream *s) { return s && __atomic_load_n(&s->alive, __ATOMIC_ACQUIRE) > 0 && !s->stop; }
+
+int hnsw_gpu_stream_close(hnsw_gpu_stream *s)
+{
+	if (!s) return HNSW_GPU_OK;
+	__atomic_store_n(&s->stop, 1, __ATOMIC_RELEASE);
+	for (int i = 0; i < s->nthreads; i++) pthread_join(s->th[i], NULL);
+	__atomic_store_n(&s->c->busy, 0, __ATOMIC_RELEASE);
+	free(s->Q); free(s->L); free(s->D); free(s->C); free(s->F);
+	free(s);
+	return HNSW_GPU_OK;
+}
 int hnsw_gpu_device_blocks(int device) { (void) device; return 4; }   /* a tiny "device": the server's load policy is exercised with a handful of backends */
 
 static void *flags_worker(void *arg)

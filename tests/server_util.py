@@ -56,6 +56,27 @@ def build_double_server() -> str:
     return DOUBLE_BIN
 
 
+def build_double_server_tsan() -> str:
+    """The same link with every object compiled under ThreadSanitizer (gcc -fsanitize=thread): the server's threads — readers,
+    dispatcher lanes, stream producers / answer threads / manager, control — against the double's "device" threads."""
+    target = DOUBLE_BIN + "_tsan"
+    src = [os.path.join(CSRC, "server_main.cpp"), os.path.join(CSRC, "hgs_io.h"),
+           os.path.join(ROOT, "tests", "double", "engine_double.c"), os.path.join(ROOT, "oracle", "hnsw_port.c"),
+           os.path.join(INC, "hnsw_gpu_server.h"), os.path.join(INC, "hnsw_gpu.h")]
+    with _Lock():
+        if _stale(target, src):
+            objs = []
+            for name, c, flags in (
+                    ("engine_double_tsan.o", src[2], ["-O1", "-g", "-fsanitize=thread", "-std=gnu11"]),
+                    ("hnsw_port_tsan.o", src[3], ["-O2", "-g", "-fsanitize=thread", "-mavx2", "-mfma", "-ffp-contract=off", "-fno-fast-math", "-std=gnu11"])):
+                o = os.path.join(OUT, name)
+                _run(["gcc"] + flags + ["-I", INC, "-c", c, "-o", o])
+                objs.append(o)
+            _run(["g++", "-O1", "-g", "-fsanitize=thread", "-std=c++17", "-Wall", "-I", INC, "-I", CSRC, src[0]] + objs +
+                 ["-o", target, "-lpthread", "-lm"])
+    return target
+
+
 def build_c_client(name: str, link_client_lib: bool = True) -> str:
     """tests/dropin_c/<name>.c + the flat host, linked against libembedding_gpuc.so (the four
     reference symbols as a client of the server)."""

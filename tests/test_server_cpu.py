@@ -9,6 +9,7 @@ import socket
 import struct
 import subprocess
 import threading
+import time
 
 import numpy as np
 import pytest
@@ -25,11 +26,15 @@ def double_bin():
     return SU.build_double_server()
 
 
-@pytest.fixture(params=[2, 0], ids=["streamed", "blocking"])
+@pytest.fixture(params=[(2, False), (0, False), (2, True)], ids=["streamed", "blocking", "resident"])
 def srv(double_bin, request):
-    """Both dispatcher forms: streamed completion (2 launches in flight per dispatcher, answers leave as
-    their walks end) and one blocking launch at a time."""
-    with ServerProcess(binary=double_bin, lanes=request.param) as s:
+    """The dispatcher forms: streamed completion (2 launches in flight per dispatcher, answers leave as
+    their walks end), one blocking launch at a time, and --stream 1: searches through one resident launch
+    per (mirror, efsearch) fed through a ring (the engine double plays the launch with threads that take
+    tickets and answer ring slots out of order, tests/double/engine_double.c) — a small ring, so that
+    every slot is reused many times."""
+    lanes, stream = request.param
+    with ServerProcess(binary=double_bin, lanes=lanes, stream=stream, ring=64) as s:
         yield s
 
 
@@ -172,6 +177,101 @@ def test_many_backends_are_batched_and_each_gets_its_own_answer(double_bin, tmp_
         assert st["max_batch"] > 8 and st["batches"] < len(Q) // 4, st       # really coalesced
         assert st["connections"] >= 49
         c.close()
+
+
+@pytest.mark.parametrize("walkers", [None, 1])
+def test_many_backends_through_a_resident_launch(double_bin, tmp_path, walkers):
+    """--stream 1: 48 single-threaded processes call hnsw_search() one query at a time; reader threads write ring slots without a
+    lock, the launch's walking threads answer them out of order, answer threads hand each backend its own result: every call returns
+    exactly the oracle's array, through a ring (64 slots) far smaller than the number of queries; sessions are opened, re-shaped by
+    load (walkers auto) and closed when idle — several per run."""
+    dim, m, n, efs = 32, 5, 2000, 24
+    port, X = port_index(n, dim, m, 24, efs, pg.DIST_L2, seed=23)
+    meta = pg.make_meta(dim, m, 24, efs, pg.DIST_L2)
+    Q = gmm(960, dim, k=20, seed=23, stream=1)
+    with ServerProcess(binary=double_bin, lanes=2, stream=True, ring=64, walkers=walkers, env={"HGS_DOUBLE_SLEEP_US": "2000"}) as s:
+        c = RemoteClient(s.socket_path)
+        c.upload(meta, 78, 3, port.raw(), n)
+        info, labels, counts = run_clients(s.socket_path, 78, 3, dim, m, 24, efs, pg.DIST_L2, Q, 48, tmp_path)
+        want = port.search_many(Q, efs)
+        assert (counts == want["counts"]).all()
+        for q in range(len(Q)):
+            k = int(counts[q])
+            assert (labels[q, :k] == want["labels"][q, :k]).all()
+        time.sleep(0.05)                                            # the idle session closes (2 ms) and is counted
+        st = c.stats()
+        assert st["searches"] == len(Q) and st["search_errors"] == 0, st
+        assert st["max_batch"] == 0 and 1 <= st["batches"] < len(Q) // 8, st      # no batch was formed: sessions, a few of them
+        c.close()
+
+
+def test_a_server_whose_device_has_no_streams_falls_back_to_launches(double_bin, tmp_path):
+    """--stream 1 on a device that cannot open a stream (the double with HGS_DOUBLE_NO_STREAMS; on hardware: efsearch > 512): the
+    manager answers through ordinary launches, same arrays."""
+    dim, m, n, efs = 24, 4, 900, 16
+    port, X = port_index(n, dim, m, 16, efs, pg.DIST_L2, seed=27)
+    Q = gmm(96, dim, k=20, seed=27, stream=1)
+    with ServerProcess(binary=double_bin, lanes=2, stream=True, ring=64, env={"HGS_DOUBLE_NO_STREAMS": "1"}) as s:
+        c = RemoteClient(s.socket_path)
+        c.upload(pg.make_meta(dim, m, 16, efs, pg.DIST_L2), 79, 1, port.raw(), n)
+        for q in Q:
+            lab, dst = c.search(79, q, efs)
+            wl, wd = port.search(q, efs)[:2]
+            assert (lab == wl).all() and (bits(dst) == bits(wd)).all()
+        st = c.stats()
+        assert st["searches"] == len(Q) and st["search_errors"] == 0 and st["max_batch"] >= 1, st
+        c.close()
+
+
+@pytest.mark.parametrize("stream", [False, True], ids=["lanes", "resident"])
+def test_the_servers_threads_are_race_free(tmp_path, stream):
+    """The server's own source under ThreadSanitizer (every object of the double link built with -fsanitize=thread): twelve client
+    threads with two beams search while a writer toggles a delete flag — readers, dispatcher lanes or lock-free stream producers /
+    answer threads / session manager, the mirror's gate, the control thread and the double's device threads: no report.  (The
+    searches' answers are checked too: each equals the oracle's for one of the two states of the flag.)"""
+    import glob
+    binary = SU.build_double_server_tsan()
+    dim, m, n, efs = 24, 4, 900, 16
+    port, X = port_index(n, dim, m, 16, efs, pg.DIST_L2, seed=51)
+    Q = gmm(30, dim, k=20, seed=51, stream=1)
+    victim = 3
+    want = {}
+    for ef in (8, efs):
+        a = [port.search(q, ef)[0] for q in Q]
+        port.set_deleted(victim, True)
+        b = [port.search(q, ef)[0] for q in Q]
+        port.set_deleted(victim, False)
+        want[ef] = (a, b)
+    log = str(tmp_path / "tsan")
+    env = {"TSAN_OPTIONS": f"log_path={log} exitcode=0 halt_on_error=0", "HGS_DOUBLE_SLEEP_US": "500"}
+    bad = []
+    with ServerProcess(binary=binary, lanes=2, stream=stream, ring=64, env=env) as s:
+        c0 = RemoteClient(s.socket_path)
+        c0.upload(pg.make_meta(dim, m, 16, efs, pg.DIST_L2), 5, 1, port.raw(), n)
+
+        def worker(t):
+            try:
+                c = RemoteClient(s.socket_path)
+                ef = efs if t % 2 else 8
+                for i, q in enumerate(Q):
+                    lab = c.search(5, q, ef)[0]
+                    if not (np.array_equal(lab, want[ef][0][i]) or np.array_equal(lab, want[ef][1][i])):
+                        bad.append((t, i))
+                c.close()
+            except Exception as ex:            # noqa: BLE001
+                bad.append((t, repr(ex)))
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(12)]
+        [t.start() for t in th]
+        for i in range(40):
+            c0.set_deleted(5, victim, i % 2 == 0)
+        [t.join() for t in th]
+        st = c0.stats()
+        c0.close()
+    assert not bad, bad
+    assert st["searches"] == 12 * len(Q) and st["search_errors"] == 0, st
+    reports = "".join(open(f).read() for f in glob.glob(log + "*"))
+    assert "ThreadSanitizer" not in reports, reports[:4000]
 
 
 def test_batches_never_mix_beams_or_mirrors(srv):
