@@ -51,16 +51,14 @@
 
 namespace {
 
-// Timed waits go through the wall clock (pthread_cond_timedwait) rather than condition_variable::wait_for's steady clock
-// (pthread_cond_clockwait): the timeouts are milliseconds of patience, not measurements, and ThreadSanitizer (gcc 11) does not know
-// the latter call — it believes the mutex stays held across the wait and reports every queue access behind it
-// (tests/test_server_cpu.py::test_the_servers_threads_are_race_free).
-template <typename Rep, typename Period, typename Pred>
-bool timed_wait(std::condition_variable &cv, std::unique_lock<std::mutex> &lk, std::chrono::duration<Rep, Period> d, Pred pred)
-{
-	return cv.wait_until(lk, std::chrono::system_clock::now() + d, pred);
-}
-
+// Timed waits: condition_variable::wait_for — except in the ThreadSanitizer build of the CPU tier (-DHGS_TSAN,
+// tests/server_util.py), where they go through the wall clock (pthread_cond_timedwait): gcc 11's ThreadSanitizer does not know
+// pthread_cond_clockwait, believes the mutex stays held across the wait and reports every queue access behind it.
+#ifdef HGS_TSAN
+#define HGS_TIMED_WAIT(cv, lk, d, ...) (cv).wait_until((lk), std::chrono::system_clock::now() + (d), __VA_ARGS__)
+#else
+#define HGS_TIMED_WAIT(cv, lk, d, ...) (cv).wait_for((lk), (d), __VA_ARGS__)
+#endif
 
 // ----------------------------------------------------------------------------- options / globals
 struct Options
@@ -387,7 +385,7 @@ void dispatcher_blocking(int d)
 			g_q_cv.wait(lk, [] { return g_stop.load() || !g_q.empty(); });
 			if (g_stop.load()) break;
 			if (g_opt.linger_us > 0 && g_q.size() < g_opt.min_batch)
-				timed_wait(g_q_cv, lk, std::chrono::microseconds(g_opt.linger_us),
+				HGS_TIMED_WAIT(g_q_cv, lk, std::chrono::microseconds(g_opt.linger_us),
 								[] { return g_stop.load() || g_q.size() >= g_opt.min_batch; });
 			if (g_q.empty()) continue;
 			take_batch(batch);
@@ -568,7 +566,7 @@ void dispatcher_lanes(int d)
 					g_q_cv.wait(lk, [] { return g_stop.load() || !g_q.empty(); });
 					if (g_stop.load()) break;
 					if (g_opt.linger_us > 0 && g_q.size() < g_opt.min_batch)
-						timed_wait(g_q_cv, lk, std::chrono::microseconds(g_opt.linger_us),
+						HGS_TIMED_WAIT(g_q_cv, lk, std::chrono::microseconds(g_opt.linger_us),
 										[] { return g_stop.load() || g_q.size() >= g_opt.min_batch; });
 				}
 				if (g_q.empty()) break;
@@ -616,6 +614,22 @@ void dispatcher_main(int d)
 // lane at 1 024 backends (profiles/r4f_server_walkers_and_breakdown.txt) is gone.  The session gives way — stops accepting, lets its
 // walks finish, closes — when a writer wants the mirror, when searches for another (mirror, ef) are waiting, when nothing has been
 // outstanding for a while (a resident launch holds the whole device), when the load calls for another team geometry, at shutdown.
+// Who is inside Session::submit right now: one mark per producer thread (a cache line each: nobody shares one), set to the session on the
+// way in and cleared on the way out.  close_session stores accepting = false and then waits until no mark names the session — both sides
+// sequentially consistent, so a producer either sees the session closing and leaves, or the closer sees its mark and waits: nobody touches
+// the ring (or calls hnsw_gpu_stream_publish) after hnsw_gpu_stream_close has freed it.  Two shared counters would do the same at the
+// price of two more contended read-modify-writes per search.
+struct alignas(64) InSubmit { std::atomic<const void *> s{nullptr}; };
+constexpr int MAX_PRODUCERS = 256;
+InSubmit g_in_submit[MAX_PRODUCERS];
+std::atomic<int> g_producers{0};
+InSubmit &my_submit_mark()
+{
+	static thread_local InSubmit *mine = nullptr;
+	if (!mine) mine = &g_in_submit[std::min(g_producers.fetch_add(1), MAX_PRODUCERS - 1)];   // (readers + the manager: far fewer than 256)
+	return *mine;
+}
+
 struct Session
 {
 	EntryP e;
@@ -643,9 +657,16 @@ struct Session
 	bool submit(SReq &r)
 	{
 		if (!accepting.load(std::memory_order_acquire)) return false;
+		struct Mark
+		{
+			InSubmit &m;
+			Mark(InSubmit &mm, const void *who) : m(mm) { m.s.store(who); }                       // (sequentially consistent)
+			~Mark() { m.s.store(nullptr, std::memory_order_release); }
+		} inside(my_submit_mark(), this);
+		if (!accepting.load()) return false;                                                      // closing: the closer may not have seen my mark
 		// (room: a backend has one search outstanding, the ring has several slots per backend; a full ring means stragglers a whole
 		// ring old — the request waits in the queue instead)
-		if (outstanding.load(std::memory_order_relaxed) >= (long) ring - (long) std::min<uint32_t>(64u, ring / 4)) return false;   // (a ring of 64 slots had no room at all with a fixed margin of 64: found by the CPU tier's resident-launch tests)
+		if (outstanding.load(std::memory_order_relaxed) >= (long) ring - 64) return false;
 		outstanding.fetch_add(1, std::memory_order_acq_rel);
 		const uint32_t t = claim.fetch_add(1, std::memory_order_acq_rel);
 		const uint32_t slot = t & (ring - 1);
@@ -738,14 +759,17 @@ void stream_answer_main(int k, int n)
 // Close the session: no new queries, let the walks in flight finish (bounded), stop the launch, release the mirror.
 void close_session(SessionP &ss, const char *why)
 {
-	ss->accepting.store(false, std::memory_order_release);
+	ss->accepting.store(false);             // (sequentially consistent, as the producers' marks: Session::submit)
 	const uint64_t t0 = now_ns();
+	for (int i = 0, n = std::min(g_producers.load(), MAX_PRODUCERS); i < n; i++)        // producers inside submit finish their slot and leave
+		while (g_in_submit[i].s.load() == (const void *) ss.get() && now_ns() - t0 < 1000000000ull)
+			std::this_thread::yield();
 	// producers that were past the check finish their slot; then every claimed ticket is published and, walked, answered
 	while ((ss->outstanding.load() > 0 || ss->pub.load() != ss->claim.load()) && now_ns() - t0 < 200000000ull)
 		std::this_thread::sleep_for(std::chrono::microseconds(20));
 	set_session(nullptr);                   // the answer threads and readers let go of it at their next look ...
 	// ... (their thread-local copies: a reader that is idle keeps one until its next request, so the count cannot be waited on; what
-	// matters is that nobody is INSIDE the ring: producers are out since `accepting` fell under the session's lock, and the answer
+	// matters is that nobody is INSIDE the ring: producers have left (their marks, above) and none enters any more, and the answer
 	// threads have refreshed once every one of them has passed the generation check)
 	{
 		const uint64_t t1 = now_ns(), gen = g_sess_gen.load();
@@ -859,7 +883,7 @@ void stream_manager_main()
 		size_t ef = 0, backlog = 0;
 		{
 			std::unique_lock<std::mutex> lk(g_q_mu);
-			timed_wait(g_q_cv, lk, std::chrono::milliseconds(50), [] { return g_stop.load() || !g_q.empty(); });
+			HGS_TIMED_WAIT(g_q_cv, lk, std::chrono::milliseconds(50), [] { return g_stop.load() || !g_q.empty(); });
 			if (g_stop.load()) break;
 			if (g_q.empty()) continue;
 			e = g_q.front().e; ef = g_q.front().h.aux; backlog = g_q.size();
@@ -1459,7 +1483,9 @@ int main(int argc, char **argv)
 		else { usage(); return 2; }
 	}
 	if (g_opt.path.empty() || g_opt.dispatchers < 1 || g_opt.readers < 1 || g_opt.max_batch < 1 || g_opt.lanes < 0 || g_opt.lanes > 16) { usage(); return 2; }
-	if (g_opt.stream && (g_opt.ring < 64 || g_opt.ring > ((size_t) 1 << 20) || (g_opt.ring & (g_opt.ring - 1)))) { usage(); return 2; }
+	// (the ring keeps a margin of 64 slots, Session::submit: a 64-slot ring would take nothing at all and every request would queue for ever —
+	// what the CPU tier's first resident-launch run did; 256 is the smallest ring the server accepts)
+	if (g_opt.stream && (g_opt.ring < 256 || g_opt.ring > ((size_t) 1 << 20) || (g_opt.ring & (g_opt.ring - 1)))) { usage(); return 2; }
 	if (g_opt.path.size() >= sizeof(((struct sockaddr_un *) nullptr)->sun_path)) { logf("socket path too long"); return 2; }
 
 	// Every lane launches on its own HIP stream.  The runtime spreads streams over GPU_MAX_HW_QUEUES

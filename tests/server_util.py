@@ -72,7 +72,7 @@ def build_double_server_tsan() -> str:
                 o = os.path.join(OUT, name)
                 _run(["gcc"] + flags + ["-I", INC, "-c", c, "-o", o])
                 objs.append(o)
-            _run(["g++", "-O1", "-g", "-fsanitize=thread", "-std=c++17", "-Wall", "-I", INC, "-I", CSRC, src[0]] + objs +
+            _run(["g++", "-O1", "-g", "-fsanitize=thread", "-DHGS_TSAN", "-std=c++17", "-Wall", "-I", INC, "-I", CSRC, src[0]] + objs +
                  ["-o", target, "-lpthread", "-lm"])
     return target
 

@@ -31,10 +31,9 @@ def srv(double_bin, request):
     """The dispatcher forms: streamed completion (2 launches in flight per dispatcher, answers leave as
     their walks end), one blocking launch at a time, and --stream 1: searches through one resident launch
     per (mirror, efsearch) fed through a ring (the engine double plays the launch with threads that take
-    tickets and answer ring slots out of order, tests/double/engine_double.c) — a small ring, so that
-    every slot is reused many times."""
+    tickets and answer ring slots out of order, tests/double/engine_double.c) — the smallest ring the server accepts (256 slots)."""
     lanes, stream = request.param
-    with ServerProcess(binary=double_bin, lanes=lanes, stream=stream, ring=64) as s:
+    with ServerProcess(binary=double_bin, lanes=lanes, stream=stream, ring=256) as s:
         yield s
 
 
@@ -183,13 +182,13 @@ def test_many_backends_are_batched_and_each_gets_its_own_answer(double_bin, tmp_
 def test_many_backends_through_a_resident_launch(double_bin, tmp_path, walkers):
     """--stream 1: 48 single-threaded processes call hnsw_search() one query at a time; reader threads write ring slots without a
     lock, the launch's walking threads answer them out of order, answer threads hand each backend its own result: every call returns
-    exactly the oracle's array, through a ring (64 slots) far smaller than the number of queries; sessions are opened, re-shaped by
+    exactly the oracle's array, through a ring (256 slots) far smaller than the number of queries; sessions are opened, re-shaped by
     load (walkers auto) and closed when idle — several per run."""
     dim, m, n, efs = 32, 5, 2000, 24
     port, X = port_index(n, dim, m, 24, efs, pg.DIST_L2, seed=23)
     meta = pg.make_meta(dim, m, 24, efs, pg.DIST_L2)
     Q = gmm(960, dim, k=20, seed=23, stream=1)
-    with ServerProcess(binary=double_bin, lanes=2, stream=True, ring=64, walkers=walkers, env={"HGS_DOUBLE_SLEEP_US": "2000"}) as s:
+    with ServerProcess(binary=double_bin, lanes=2, stream=True, ring=256, walkers=walkers, env={"HGS_DOUBLE_SLEEP_US": "2000"}) as s:
         c = RemoteClient(s.socket_path)
         c.upload(meta, 78, 3, port.raw(), n)
         info, labels, counts = run_clients(s.socket_path, 78, 3, dim, m, 24, efs, pg.DIST_L2, Q, 48, tmp_path)
@@ -211,7 +210,7 @@ def test_a_server_whose_device_has_no_streams_falls_back_to_launches(double_bin,
     dim, m, n, efs = 24, 4, 900, 16
     port, X = port_index(n, dim, m, 16, efs, pg.DIST_L2, seed=27)
     Q = gmm(96, dim, k=20, seed=27, stream=1)
-    with ServerProcess(binary=double_bin, lanes=2, stream=True, ring=64, env={"HGS_DOUBLE_NO_STREAMS": "1"}) as s:
+    with ServerProcess(binary=double_bin, lanes=2, stream=True, ring=256, env={"HGS_DOUBLE_NO_STREAMS": "1"}) as s:
         c = RemoteClient(s.socket_path)
         c.upload(pg.make_meta(dim, m, 16, efs, pg.DIST_L2), 79, 1, port.raw(), n)
         for q in Q:
@@ -245,7 +244,7 @@ def test_the_servers_threads_are_race_free(tmp_path, stream):
     log = str(tmp_path / "tsan")
     env = {"TSAN_OPTIONS": f"log_path={log} exitcode=0 halt_on_error=0", "HGS_DOUBLE_SLEEP_US": "500"}
     bad = []
-    with ServerProcess(binary=binary, lanes=2, stream=stream, ring=64, env=env) as s:
+    with ServerProcess(binary=binary, lanes=2, stream=stream, ring=256, env=env) as s:
         c0 = RemoteClient(s.socket_path)
         c0.upload(pg.make_meta(dim, m, 16, efs, pg.DIST_L2), 5, 1, port.raw(), n)
 
