@@ -82,9 +82,36 @@ enum
 	                            hnsw_gpu_index_link (CREATE INDEX offload)                              */
 	HGS_OP_EXPORT      = 11, /* key, fd = writable memfd of count*size_data_per_element bytes -> element images */
 	HGS_OP_SET_DELETED = 12, /* key, aux = idx, a0 = 0/1 (embedding.c:920-926)                                */
-	HGS_OP_SETGEN      = 13  /* key, gen = NEW generation, payload = u64 expected current generation: the mirror
+	HGS_OP_SETGEN      = 13, /* key, gen = NEW generation, payload = u64 expected current generation: the mirror
 	                            already holds the new state (it was changed through BIND), only its name moves   */
+	HGS_OP_SHM         = 14  /* fd = a memfd laid out as an hgs_shm (below): from now on this connection may POST its SEARCH
+	                            requests there instead of writing them to the socket, and finds the answers there          */
 };
+
+/* Searches through shared memory.  A backend's hnsw_search is one small request and one small answer, a thousand backends make a
+ * million of each per second, and on the socket every one of them is two system calls on either side plus the wake-ups of an epoll
+ * thread — measured, the CPU time of that (not the device, not the server's logic) is what a many-backend host runs out of first
+ * (profiles/r4ag_stream_server_run_to_run.txt).  With HGS_OP_SHM a connection gets a mailbox of its own: the backend writes request
+ * header + query into it and sets `state` = POSTED with a release store; server threads that poll the mailboxes take it (TAKEN), run
+ * it exactly as a SEARCH that arrived on the socket, write response header + labels [+ distances] back and set DONE; the backend
+ * spins briefly and otherwise sleeps in futex(FUTEX_WAIT) on `state` (it says so in `sleeping`, and only then does the server spend
+ * a FUTEX_WAKE).  One request at a time per connection, as on the socket; everything but SEARCH stays on the socket, and so does a
+ * SEARCH that does not fit the mailbox.  OPT-IN on both sides (server --shm-pollers N, backend PG_EMBEDDING_GPU_SHM=1): the pollers spin, and on
+ * the CPU-capped box this was measured on the mailboxes gained nothing over the socket (profiles/r4aj_mailboxes.txt).  Layout: this header, then at offset HGS_SHM_DATA `qcap` floats of query, `rcap` labels
+ * (u64), `rcap` distances (f32); the server takes the capacities from the size of the file, never from these words. */
+#define HGS_SHM_MAGIC 0x4D534748u            /* "HGSM": magic of a request header that was posted through a mailbox */
+#define HGS_SHM_DATA  128u
+typedef struct hgs_shm
+{
+	uint32_t state;      /* HGS_SHM_*                                                                  */
+	uint32_t sleeping;   /* backend: 1 while it sleeps in futex_wait(&state)                           */
+	uint32_t qcap, rcap; /* backend's note of the capacities it laid the file out for (informational)  */
+	hgs_hdr  req;        /* op = HGS_OP_SEARCH, len = dim * 4; the query follows at HGS_SHM_DATA       */
+	hgs_hdr  resp;       /* as on the socket; labels / distances in their areas                        */
+} hgs_shm;               /* 112 bytes */
+enum { HGS_SHM_IDLE = 0, HGS_SHM_POSTED = 1, HGS_SHM_TAKEN = 2, HGS_SHM_DONE = 3 };
+/* bytes of a mailbox with these capacities (qcap even) */
+#define HGS_SHM_BYTES(qcap, rcap) ((size_t) HGS_SHM_DATA + (size_t) (qcap) * 4u + (size_t) (rcap) * 12u)
 
 enum
 {
@@ -112,6 +139,7 @@ typedef struct hgs_stats
 	 * (the walk + the poll), and the write of the answer; a backend's round trip minus their sum is the socket hops and its own
 	 * wake-up */
 	uint64_t queue_ns, walk_ns, answer_ns;
+	uint64_t shm_searches;                       /* of `searches`: posted through a mailbox (HGS_OP_SHM) instead of the socket */
 } hgs_stats;
 
 /* ------------------------------------------------- client side (libembedding_gpuc.so) */

@@ -25,6 +25,8 @@
 
 #include <fcntl.h>
 #include <sys/mman.h>
+#include <sys/syscall.h>
+#include <linux/futex.h>
 #include <sys/un.h>
 
 #include "hgs_io.h"
@@ -41,6 +43,10 @@ thread_local int   t_fd = -1;
 thread_local pid_t t_pid = 0;
 thread_local char  t_err[512] = "";
 thread_local std::vector<char> t_resp;    // payload of the last response
+// this connection's mailbox (HGS_OP_SHM, include/hnsw_gpu_server.h): SEARCH requests are posted there instead of written to the socket
+struct Mailbox { hgs_shm *m = nullptr; size_t bytes = 0; uint32_t qcap = 0, rcap = 0; int state = 0; };   // state: 0 not tried, 1 ready, -1 none
+thread_local Mailbox t_box;
+std::atomic<bool> g_shm_refused{false};   // a server that does not know HGS_OP_SHM (it dropped the connection): never asked again
 
 struct Attachment { HnswMetadata *meta; uint64_t key, gen; bool own = false; };   // own: a private mirror under an ephemeral key
 std::vector<Attachment> g_attached;
@@ -60,6 +66,8 @@ void drop_connection()
 {
 	if (t_fd >= 0) close(t_fd);
 	t_fd = -1;
+	if (t_box.m) munmap(t_box.m, t_box.bytes);
+	t_box = Mailbox();                     // (a new connection sets up a new mailbox)
 }
 
 std::vector<std::string> split_paths(const std::string &list)
@@ -250,6 +258,109 @@ struct Shm
 	}
 };
 
+// Is there a mailbox on this connection that takes a query of `dim` floats and `ef` results?  Sets one up at the first search
+// when PG_EMBEDDING_GPU_SHM=1 (default: every request on the socket).
+bool mailbox_ready(size_t dim, size_t ef)
+{
+	if (t_box.state == 0)
+	{
+		t_box.state = -1;
+		const char *want = getenv("PG_EMBEDDING_GPU_SHM");            // opt-in (and the server must run mailbox pollers: --shm-pollers N)
+		if (!(want && *want == '1') || g_shm_refused.load()) return false;
+		const uint32_t qcap = (uint32_t) std::max<size_t>(2048, (dim + 1) & ~(size_t) 1), rcap = (uint32_t) std::max<size_t>(1024, ef);
+		if (dim > (1u << 20) || ef > (1u << 20)) return false;
+		Shm box;
+		const size_t bytes = (HGS_SHM_BYTES(qcap, rcap) + 4095) & ~(size_t) 4095;
+		if (!box.create(bytes)) return false;
+		hgs_shm *m = (hgs_shm *) box.p;
+		memset(m, 0, sizeof(*m));
+		m->qcap = qcap; m->rcap = rcap;
+		hgs_hdr h, r;
+		memset(&h, 0, sizeof(h));
+		h.op = HGS_OP_SHM; h.a0 = qcap; h.a1 = rcap;
+		const int rc = rpc(&h, nullptr, 0, nullptr, 0, box.fd, &r);
+		if (rc != HGS_OK)
+		{
+			if (rc == HGS_ERR_PROTOCOL) g_shm_refused.store(true);     // an older server: it has dropped this connection, too
+			return false;                                             // (the mapping goes with `box`)
+		}
+		t_box.m = m; t_box.bytes = box.bytes; t_box.qcap = qcap; t_box.rcap = rcap; t_box.state = 1;
+		box.p = nullptr;                                              // the mapping stays, the descriptor is not needed any more
+	}
+	return t_box.state == 1 && dim <= t_box.qcap && ef <= t_box.rcap && ef > 0;
+}
+
+// One SEARCH through the mailbox.  HGS_OK / a server status (t_err set) — or 1: the connection is gone, take the socket path (which
+// makes a fresh connection and retries once, as for every repeatable request).
+int mailbox_search(uint64_t key, uint64_t generation, const coord_t *query, size_t dim, size_t ef, label_t *labels, dist_t *dists, size_t *count)
+{
+	static const int timeout_ms = [] {
+		const char *e = getenv("PG_EMBEDDING_GPU_TIMEOUT_MS");
+		const long v = e ? atol(e) : 600000;
+		return v <= 0 ? -1 : (int) v;
+	}();
+	hgs_shm *m = t_box.m;
+	hgs_hdr h;
+	memset(&h, 0, sizeof(h));
+	h.magic = HGS_MAGIC; h.op = HGS_OP_SEARCH; h.len = (uint32_t) (dim * 4); h.aux = (uint32_t) ef;
+	h.key = key; h.gen = generation; h.a0 = dists ? 1 : 0;
+	char *data = reinterpret_cast<char *>(m) + HGS_SHM_DATA;
+	memcpy(&m->req, &h, sizeof(h));
+	memcpy(data, query, dim * 4);
+	__atomic_store_n(&m->sleeping, 0u, __ATOMIC_RELAXED);
+	__atomic_store_n(&m->state, (uint32_t) HGS_SHM_POSTED, __ATOMIC_RELEASE);
+	struct timespec t0;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+	bool done = false;
+	for (int spin = 0; spin < 256 && !done; spin++)                    // a walk takes a fraction of a millisecond: look a few times, then sleep
+	{
+		done = __atomic_load_n(&m->state, __ATOMIC_ACQUIRE) == (uint32_t) HGS_SHM_DONE;
+		if (!done) __builtin_ia32_pause();
+	}
+	while (!done)
+	{
+		__atomic_store_n(&m->sleeping, 1u, __ATOMIC_SEQ_CST);           // (the server stores DONE, then looks at this word)
+		if (__atomic_load_n(&m->state, __ATOMIC_SEQ_CST) == (uint32_t) HGS_SHM_DONE) break;
+		struct timespec nap = { 0, 100 * 1000 * 1000 };
+		(void) syscall(SYS_futex, &m->state, FUTEX_WAIT, (uint32_t) HGS_SHM_POSTED, &nap, nullptr, 0);
+		if (__atomic_load_n(&m->state, __ATOMIC_ACQUIRE) == (uint32_t) HGS_SHM_DONE) break;
+		// still nothing: is the server there at all?  (an answer can only be late; a closed socket means it never comes)
+		struct pollfd pf = { t_fd, POLLIN, 0 };
+		char peek;
+		if (poll(&pf, 1, 0) > 0 && ((pf.revents & (POLLHUP | POLLERR)) || ((pf.revents & POLLIN) && recv(t_fd, &peek, 1, MSG_PEEK | MSG_DONTWAIT) == 0)))
+		{
+			drop_connection();
+			return 1;
+		}
+		struct timespec t1;
+		clock_gettime(CLOCK_MONOTONIC, &t1);
+		const long waited = (long) (t1.tv_sec - t0.tv_sec) * 1000 + (t1.tv_nsec - t0.tv_nsec) / 1000000;
+		if (timeout_ms >= 0 && waited > timeout_ms)
+		{
+			drop_connection();
+			return fail(HGS_ERR_IO, "hnsw_gpu_server did not answer request %u within %d ms", (unsigned) HGS_OP_SEARCH, timeout_ms);
+		}
+	}
+	__atomic_store_n(&m->sleeping, 0u, __ATOMIC_RELAXED);
+	hgs_hdr r;
+	memcpy(&r, &m->resp, sizeof(r));
+	int rc = HGS_OK;
+	const size_t cnt = (size_t) r.a0;
+	if (r.magic != HGS_MAGIC || r.op != HGS_OP_SEARCH) rc = fail(HGS_ERR_PROTOCOL, "bad response from hnsw_gpu_server");
+	else if (r.status != HGS_OK) rc = fail(r.status, "hnsw_gpu_server refused request %u: status %d", (unsigned) HGS_OP_SEARCH, (int) r.status);
+	else if (cnt > ef || r.len != cnt * (dists ? 12 : 8)) rc = fail(HGS_ERR_PROTOCOL, "bad SEARCH response");
+	else
+	{
+		const char *res = data + (size_t) t_box.qcap * 4u;
+		memcpy(labels, res, cnt * 8);
+		if (dists) memcpy(dists, res + (size_t) t_box.rcap * 8u, cnt * 4);
+		*count = cnt;
+	}
+	__atomic_store_n(&m->state, (uint32_t) HGS_SHM_IDLE, __ATOMIC_RELEASE);
+	if (rc == HGS_ERR_PROTOCOL) drop_connection();
+	return rc;
+}
+
 bool find_attached(HnswMetadata *meta, Attachment *out)
 {
 	std::lock_guard<std::mutex> lk(g_mu);
@@ -364,6 +475,11 @@ static int hnsw_gpu_remote_search_impl(uint64_t key, uint64_t generation, const 
 {
 	if (!query || !labels || !count) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
 	if (ef == 0 || ef > 0xFFFFFFFFull) return fail(HNSW_GPU_ERR_ARG, "ef out of range");
+	if (ensure_connected() == HGS_OK && mailbox_ready(dim, ef))
+	{
+		const int mrc = mailbox_search(key, generation, query, dim, ef, labels, dists, count);
+		if (mrc != 1) return mrc;                  // 1 = the connection went away: below, on a fresh one
+	}
 	hgs_hdr h, r;
 	memset(&h, 0, sizeof(h));
 	h.op = HGS_OP_SEARCH; h.key = key; h.gen = generation; h.aux = (uint32_t) ef; h.a0 = dists ? 1 : 0;

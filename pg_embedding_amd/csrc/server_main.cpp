@@ -44,7 +44,9 @@
 #include <sys/mman.h>
 #include <sys/resource.h>
 #include <sys/stat.h>
+#include <sys/syscall.h>
 #include <sys/un.h>
+#include <linux/futex.h>
 
 #include "hgs_io.h"
 #include "hnsw_gpu.h"
@@ -77,6 +79,9 @@ struct Options
 	int walkers = -1;              // walking waves per block of a search launch: -1 = by load (below), 0 = the library's default, 1..8 fixed
 	int stream = 0;                // 1 = searches go through ONE resident launch per (mirror, ef) fed through a pinned ring (stream_manager)
 	size_t ring = 4096;            // slots of that ring
+	int shm_pollers = 0;           // threads that poll the backends' mailboxes (HGS_OP_SHM); 0 (default) = mailboxes are refused: every
+	                               // request on the socket.  Opt-in: measured, the mailboxes gain nothing on a host whose CPU time is capped
+	                               // (the pollers spin), profiles/r4aj_mailboxes.txt
 } g_opt;
 
 std::atomic<bool> g_stop{false};
@@ -94,7 +99,7 @@ struct Counters
 {
 	std::atomic<uint64_t> connections{0}, connections_now{0}, searches{0}, batches{0}, max_batch{0},
 		search_errors{0}, uploads{0}, upload_bytes{0}, updates{0}, binds{0}, evictions{0}, batch_ns{0}, kernel_ns{0},
-		queue_ns{0}, walk_ns{0}, answer_ns{0};
+		queue_ns{0}, walk_ns{0}, answer_ns{0}, shm_searches{0};
 } g_cnt;
 
 uint64_t now_ns()
@@ -244,10 +249,32 @@ struct Conn
 	std::mutex wmu;
 	std::atomic<bool> closed{false};
 	std::atomic<int> inflight{0};  // SEARCH requests not answered yet (a backend has one; the cap stops a flood)
+	// the backend's mailbox (HGS_OP_SHM, include/hnsw_gpu_server.h): mapped here; capacities from the file's size
+	hgs_shm *shm = nullptr;
+	size_t shm_bytes = 0;
+	uint32_t shm_qcap = 0, shm_rcap = 0;
+	std::atomic<bool> shm_busy{false};   // a posted request has been taken and not answered yet (server-side word: the backend cannot touch it)
 	~Conn()
 	{
 		for (int f : fds) close(f);
 		if (fd >= 0) close(fd);
+		if (shm) munmap(shm, shm_bytes);
+	}
+	// the answer of a request that was posted through the mailbox
+	void respond_shm(const hgs_hdr &h, const void *p1, size_t l1, const void *p2, size_t l2)
+	{
+		char *base = reinterpret_cast<char *>(shm) + HGS_SHM_DATA + (size_t) shm_qcap * 4u;
+		hgs_hdr out = h;
+		if (l1 > (size_t) shm_rcap * 8u || l2 > (size_t) shm_rcap * 4u) { out.status = (int16_t) HGS_ERR_PROTOCOL; out.len = 0; l1 = l2 = 0; }
+		if (l1) memcpy(base, p1, l1);
+		if (l2) memcpy(base + (size_t) shm_rcap * 8u, p2, l2);
+		memcpy(&shm->resp, &out, sizeof(out));
+		__atomic_store_n(&shm->state, (uint32_t) HGS_SHM_DONE, __ATOMIC_SEQ_CST);
+		shm_busy.store(false, std::memory_order_release);       // (after DONE: a poller that saw "not busy" while the word still said POSTED would take the request twice)
+		// the backend says when it sleeps (it stores `sleeping` before it looks at `state` a last time inside futex_wait, we store `state`
+		// before we look at `sleeping`): either it sees DONE and does not sleep, or we see it sleeping and wake it
+		if (__atomic_load_n(&shm->sleeping, __ATOMIC_SEQ_CST))
+			(void) syscall(SYS_futex, &shm->state, FUTEX_WAKE, 1, nullptr, nullptr, 0);
 	}
 	void respond(const hgs_hdr &req, int status, uint64_t a0 = 0, uint64_t a1 = 0, const void *p1 = nullptr,
 				 size_t l1 = 0, const void *p2 = nullptr, size_t l2 = 0, uint64_t gen = 0)
@@ -259,6 +286,7 @@ struct Conn
 		h.magic = HGS_MAGIC; h.op = req.op; h.status = (int16_t) status;
 		h.len = (uint32_t) ((p1 ? l1 : 0) + (p2 ? l2 : 0));
 		h.key = req.key; h.gen = gen ? gen : req.gen; h.a0 = a0; h.a1 = a1;
+		if (req.magic == HGS_SHM_MAGIC) { respond_shm(h, p1, p1 ? l1 : 0, p2, p2 ? l2 : 0); return; }
 		std::lock_guard<std::mutex> lk(wmu);
 		// a backend that does not read its answer may hold a dispatcher for 2 s, once: then it is cut off
 		if (hgs::send_msg(fd, &h, p1, l1, p2, l2, -1, 2000) != 0) { closed.store(true); shutdown(fd, SHUT_RDWR); }
@@ -765,7 +793,9 @@ void close_session(SessionP &ss, const char *why)
 		while (g_in_submit[i].s.load() == (const void *) ss.get() && now_ns() - t0 < 1000000000ull)
 			std::this_thread::yield();
 	// producers that were past the check finish their slot; then every claimed ticket is published and, walked, answered
-	while ((ss->outstanding.load() > 0 || ss->pub.load() != ss->claim.load()) && now_ns() - t0 < 200000000ull)
+	// (2 s: on a host whose CPU time is capped the whole process is frozen for tens of milliseconds at a time — a bound of 0.2 s gave up
+	// on a straggler that was merely not running, and its backend got an error: profiles/r4aj_mailboxes.txt)
+	while ((ss->outstanding.load() > 0 || ss->pub.load() != ss->claim.load()) && now_ns() - t0 < 2000000000ull)
 		std::this_thread::sleep_for(std::chrono::microseconds(20));
 	set_session(nullptr);                   // the answer threads and readers let go of it at their next look ...
 	// ... (their thread-local copies: a reader that is idle keeps one until its next request, so the count cannot be waited on; what
@@ -1265,6 +1295,7 @@ void fill_stats(hgs_stats *s)
 	s->uploads = g_cnt.uploads; s->upload_bytes = g_cnt.upload_bytes; s->updates = g_cnt.updates;
 	s->binds = g_cnt.binds; s->evictions = g_cnt.evictions; s->batch_ns = g_cnt.batch_ns; s->kernel_ns = g_cnt.kernel_ns;
 	s->queue_ns = g_cnt.queue_ns; s->walk_ns = g_cnt.walk_ns; s->answer_ns = g_cnt.answer_ns;
+	s->shm_searches = g_cnt.shm_searches;
 	{
 		std::lock_guard<std::mutex> lk(g_map_mu);
 		s->mirrors = g_map.size();
@@ -1276,6 +1307,132 @@ void fill_stats(hgs_stats *s)
 bool needs_fd(uint16_t op, const hgs_hdr &h)
 {
 	return (op == HGS_OP_UPLOAD && h.a0 > 0) || op == HGS_OP_UPDATE || op == HGS_OP_EXPORT;
+}
+
+// One SEARCH — from the socket (handle_message) or from a backend's mailbox (shm_poller_main; the header's magic says which, and
+// Conn::respond answers accordingly).  False = protocol violation, drop the connection.
+bool handle_search(const ConnP &c, const hgs_hdr &h, const char *payload)
+{
+	if (c->inflight.fetch_add(1) >= MAX_INFLIGHT_PER_CONN) { c->respond(h, HGS_ERR_PROTOCOL); return false; }
+	EntryP e = find_entry(h.key);
+	if (!e) { c->respond(h, HGS_ERR_NOKEY); return true; }
+	const uint64_t gen = e->gen.load();
+	if (h.gen && h.gen != gen) { c->respond(h, HGS_ERR_STALE, 0, 0, nullptr, 0, nullptr, 0, gen); return true; }
+	if (h.len != e->meta.dim * 4 || h.aux == 0) { c->respond(h, HNSW_GPU_ERR_ARG); return true; }
+	SReq r;
+	r.c = c; r.e = std::move(e); r.h = h;
+	r.q.resize(h.len / 4);
+	memcpy(r.q.data(), payload, h.len);
+	r.t_in = now_ns();
+	if (g_opt.stream)
+	{
+		// straight into the ring of the open session when it serves this (mirror, beam).  (Not "unless older requests are still
+		// queued": a backend has one search outstanding, so there is no order between requests to keep — and that rule turned one
+		// queued request into a convoy: everything behind it went through the manager thread, 0.35-0.4 M q/s, profiles/r4l_*.)
+		SessionP ss = current_session();
+		if (ss && ss->e.get() == r.e.get() && ss->ef == h.aux && ss->submit(r)) return true;
+	}
+	{
+		std::lock_guard<std::mutex> lk(g_q_mu);
+		g_q.push_back(std::move(r));
+		g_q_waiting.store((long) g_q.size(), std::memory_order_release);
+	}
+	g_q_cv.notify_one();
+	return true;
+}
+
+// ----------------------------------------------------------------------------- mailboxes (HGS_OP_SHM, include/hnsw_gpu_server.h)
+// Poller k owns the connections registered with it: nobody else looks at their mailboxes, so "taken" needs no word in shared memory.
+struct ShmSet
+{
+	std::mutex mu;
+	std::vector<ConnP> conns;
+	std::atomic<uint64_t> gen{0};
+};
+constexpr int MAX_SHM_POLLERS = 16;
+ShmSet g_shm[MAX_SHM_POLLERS];
+std::atomic<unsigned> g_shm_next{0};
+
+void shm_unregister(const ConnP &c)
+{
+	for (int k = 0; k < g_opt.shm_pollers; k++)
+	{
+		std::lock_guard<std::mutex> lk(g_shm[k].mu);
+		auto &v = g_shm[k].conns;
+		const size_t before = v.size();
+		v.erase(std::remove(v.begin(), v.end(), c), v.end());
+		if (v.size() != before) g_shm[k].gen.fetch_add(1, std::memory_order_release);
+	}
+}
+
+// HGS_OP_SHM: a0 = query capacity (floats, even), a1 = result capacity, fd = the memfd.  Once per connection.
+bool handle_shm(const ConnP &c, const hgs_hdr &h)
+{
+	if (c->fds.empty()) { c->respond(h, HGS_ERR_PROTOCOL); return false; }
+	const int fd = c->fds.front();
+	c->fds.pop_front();
+	struct stat st;
+	const uint64_t qcap = h.a0, rcap = h.a1;
+	const int seals = fcntl(fd, F_GET_SEALS);
+	bool ok = g_opt.shm_pollers > 0 && !c->shm && fstat(fd, &st) == 0 && seals >= 0 && (seals & F_SEAL_SHRINK) &&
+			  qcap >= 2 && qcap <= (1u << 20) && (qcap & 1u) == 0 && rcap >= 1 && rcap <= (1u << 20) &&
+			  (uint64_t) st.st_size >= HGS_SHM_BYTES(qcap, rcap) && (uint64_t) st.st_size <= ((uint64_t) 64 << 20);
+	void *m = MAP_FAILED;
+	if (ok) m = mmap(nullptr, (size_t) st.st_size, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+	close(fd);
+	if (!ok || m == MAP_FAILED) { c->respond(h, HNSW_GPU_ERR_ARG); return true; }          // the backend stays on the socket
+	c->shm = (hgs_shm *) m; c->shm_bytes = (size_t) st.st_size;
+	c->shm_qcap = (uint32_t) qcap; c->shm_rcap = (uint32_t) rcap;
+	__atomic_store_n(&c->shm->state, (uint32_t) HGS_SHM_IDLE, __ATOMIC_RELEASE);
+	const unsigned k = g_shm_next.fetch_add(1) % (unsigned) g_opt.shm_pollers;
+	{
+		std::lock_guard<std::mutex> lk(g_shm[k].mu);
+		g_shm[k].conns.push_back(c);
+	}
+	g_shm[k].gen.fetch_add(1, std::memory_order_release);
+	c->respond(h, HGS_OK, qcap, rcap);
+	return true;
+}
+
+void shm_poller_main(int k)
+{
+	pthread_setname_np(pthread_self(), "hgs-mailbox");
+	std::vector<ConnP> mine;
+	uint64_t seen = ~0ull;
+	unsigned idle = 0;
+	while (!g_stop.load())
+	{
+		if (g_shm[k].gen.load(std::memory_order_acquire) != seen)
+		{
+			std::lock_guard<std::mutex> lk(g_shm[k].mu);
+			mine = g_shm[k].conns;
+			seen = g_shm[k].gen.load(std::memory_order_relaxed);
+		}
+		bool any = false;
+		for (const ConnP &c : mine)
+		{
+			if (c->shm_busy.load(std::memory_order_acquire) || c->closed.load(std::memory_order_relaxed)) continue;
+			hgs_shm *m = c->shm;
+			if (__atomic_load_n(&m->state, __ATOMIC_ACQUIRE) != (uint32_t) HGS_SHM_POSTED) continue;
+			any = true;
+			hgs_hdr h;
+			memcpy(&h, &m->req, sizeof(h));                      // one copy: what is checked is what is used
+			c->shm_busy.store(true, std::memory_order_release);
+			const bool fits = h.magic == HGS_MAGIC && h.op == HGS_OP_SEARCH && h.len <= (uint64_t) c->shm_qcap * 4u && h.aux <= c->shm_rcap;
+			h.magic = HGS_SHM_MAGIC;                             // (the answer goes back through the mailbox)
+			h.op = HGS_OP_SEARCH;
+			if (!fits) { c->inflight++; c->respond(h, HGS_ERR_PROTOCOL); continue; }
+			g_cnt.shm_searches++;
+			bool keep = false;
+			try { keep = handle_search(c, h, reinterpret_cast<const char *>(m) + HGS_SHM_DATA); }
+			catch (const std::exception &ex) { logf("mailbox request failed: %s", ex.what()); }
+			if (!keep) { c->closed.store(true); shutdown(c->fd, SHUT_RDWR); }      // (its reader thread takes the connection apart)
+		}
+		// nothing posted: look again at once for a while (a search is a fraction of a millisecond away), then nap
+		if (any) idle = 0;
+		else if (++idle < 4096) __builtin_ia32_pause();
+		else std::this_thread::sleep_for(std::chrono::microseconds(idle < 8192 ? 20 : 100));
+	}
 }
 
 // One complete request.  False = protocol violation, drop the connection.
@@ -1303,34 +1460,9 @@ bool handle_message(const ConnP &c, const hgs_hdr &h, const char *payload)
 		return true;
 	}
 	case HGS_OP_SEARCH:
-	{
-		if (c->inflight.fetch_add(1) >= MAX_INFLIGHT_PER_CONN) { c->respond(h, HGS_ERR_PROTOCOL); return false; }
-		EntryP e = find_entry(h.key);
-		if (!e) { c->respond(h, HGS_ERR_NOKEY); return true; }
-		const uint64_t gen = e->gen.load();
-		if (h.gen && h.gen != gen) { c->respond(h, HGS_ERR_STALE, 0, 0, nullptr, 0, nullptr, 0, gen); return true; }
-		if (h.len != e->meta.dim * 4 || h.aux == 0) { c->respond(h, HNSW_GPU_ERR_ARG); return true; }
-		SReq r;
-		r.c = c; r.e = std::move(e); r.h = h;
-		r.q.resize(h.len / 4);
-		memcpy(r.q.data(), payload, h.len);
-		r.t_in = now_ns();
-		if (g_opt.stream)
-		{
-			// straight into the ring of the open session when it serves this (mirror, beam).  (Not "unless older requests are still
-			// queued": a backend has one search outstanding, so there is no order between requests to keep — and that rule turned one
-			// queued request into a convoy: everything behind it went through the manager thread, 0.35-0.4 M q/s, profiles/r4l_*.)
-			SessionP ss = current_session();
-			if (ss && ss->e.get() == r.e.get() && ss->ef == h.aux && ss->submit(r)) return true;
-		}
-		{
-			std::lock_guard<std::mutex> lk(g_q_mu);
-			g_q.push_back(std::move(r));
-			g_q_waiting.store((long) g_q.size(), std::memory_order_release);
-		}
-		g_q_cv.notify_one();
-		return true;
-	}
+		return handle_search(c, h, payload);
+	case HGS_OP_SHM:
+		return handle_shm(c, h);
 	case HGS_OP_UPLOAD: case HGS_OP_UPDATE: case HGS_OP_BIND: case HGS_OP_DROP: case HGS_OP_LINK:
 	case HGS_OP_EXPORT: case HGS_OP_SET_DELETED: case HGS_OP_DIST: case HGS_OP_SETGEN:
 	{
@@ -1429,6 +1561,7 @@ void reader_main(int epfd)
 			{
 				epoll_ctl(epfd, EPOLL_CTL_DEL, (*holder)->fd, nullptr);
 				(*holder)->closed.store(true);
+				if ((*holder)->shm) shm_unregister(*holder);
 				shutdown((*holder)->fd, SHUT_RDWR);
 				g_cnt.connections_now--;
 				delete holder;               // the descriptor closes when the last pending request lets go
@@ -1449,7 +1582,8 @@ void usage()
 	fprintf(stderr,
 			"usage: hnsw_gpu_server --socket PATH [--device N] [--dispatchers N] [--readers N]\n"
 			"                       [--max-batch N] [--lanes N] [--linger-us N --min-batch N] [--walkers auto|0..8] [--stream 0|1 --ring N]\n"
-			"                       [--verbose] [--ready-fd N]\n"
+			"                       [--shm-pollers N] [--verbose] [--ready-fd N]\n"
+			"  --shm-pollers  threads that poll the backends' mailboxes (searches through shared memory instead of the socket); 0 = off (default)\n"
 			"  --stream   1 = searches go through ONE resident launch per (mirror, efsearch), fed through a ring of N slots in pinned\n"
 			"             memory (no batches, no launch per query); the --dispatchers threads answer; 0 (default) = launches on lanes\n"
 			"  --walkers  walking waves per 8-wave block of a search launch: auto (default) = by the walks in flight over all lanes,\n"
@@ -1477,11 +1611,13 @@ int main(int argc, char **argv)
 		else if (a == "--walkers") { const std::string v = val("--walkers"); g_opt.walkers = v == "auto" ? -1 : atoi(v.c_str()); }
 		else if (a == "--stream") g_opt.stream = atoi(val("--stream"));
 		else if (a == "--ring") g_opt.ring = (size_t) atol(val("--ring"));
+		else if (a == "--shm-pollers") g_opt.shm_pollers = atoi(val("--shm-pollers"));
 		else if (a == "--min-batch") g_opt.min_batch = (size_t) atol(val("--min-batch"));
 		else if (a == "--ready-fd") g_opt.ready_fd = atoi(val("--ready-fd"));
 		else if (a == "--verbose") g_opt.verbose = true;
 		else { usage(); return 2; }
 	}
+	if (g_opt.shm_pollers < 0 || g_opt.shm_pollers > MAX_SHM_POLLERS) { usage(); return 2; }
 	if (g_opt.path.empty() || g_opt.dispatchers < 1 || g_opt.readers < 1 || g_opt.max_batch < 1 || g_opt.lanes < 0 || g_opt.lanes > 16) { usage(); return 2; }
 	// (the ring keeps a margin of 64 slots, Session::submit: a 64-slot ring would take nothing at all and every request would queue for ever —
 	// what the CPU tier's first resident-launch run did; 256 is the smallest ring the server accepts)
@@ -1558,6 +1694,7 @@ int main(int argc, char **argv)
 	else
 		for (int d = 0; d < g_opt.dispatchers; d++) threads.emplace_back(dispatcher_main, d);
 	threads.emplace_back(control_main);
+	for (int k = 0; k < g_opt.shm_pollers; k++) threads.emplace_back(shm_poller_main, k);
 
 	logf("listening on %s (device %d of %d, %d dispatchers x %d lanes, max batch %zu)", g_opt.path.c_str(), g_opt.device, ndev,
 		 g_opt.dispatchers, g_opt.lanes, g_opt.max_batch);

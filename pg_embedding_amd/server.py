@@ -30,7 +30,7 @@ class hgs_stats(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "connections", "connections_now", "searches", "batches", "max_batch", "search_errors",
         "uploads", "upload_bytes", "updates", "binds", "evictions", "mirrors", "mirror_elements",
-        "batch_ns", "kernel_ns", "uptime_ns", "queue_ns", "walk_ns", "answer_ns")]
+        "batch_ns", "kernel_ns", "uptime_ns", "queue_ns", "walk_ns", "answer_ns", "shm_searches")]
 
 
 HGS_ERR_NOKEY, HGS_ERR_STALE, HGS_ERR_IO = -21, -22, -23
@@ -142,7 +142,7 @@ class ServerProcess:
     def __init__(self, socket_path: Optional[str] = None, device: int = 0, dispatchers: int = 2,
                  max_batch: int = 16384, linger_us: int = 0, min_batch: int = 1, readers: int = 4, lanes: int = 3, binary: Optional[str] = None,
                  env: Optional[dict] = None, verbose: bool = False, start_timeout: float = 120.0, walkers: Optional[str] = None,
-                 stream: bool = False, ring: int = 4096):
+                 stream: bool = False, ring: int = 4096, shm_pollers: Optional[int] = None):
         self.binary = binary or _build.SERVER_BIN
         if not os.path.exists(self.binary):
             _build.build()
@@ -159,6 +159,8 @@ class ServerProcess:
             self.args += ["--walkers", str(walkers)]
         if stream:
             self.args += ["--stream", "1", "--ring", str(ring)]
+        if shm_pollers is not None:
+            self.args += ["--shm-pollers", str(shm_pollers)]
         if linger_us:
             self.args += ["--linger-us", str(linger_us), "--min-batch", str(min_batch)]
         if verbose:

@@ -61,6 +61,7 @@ def main():
     ap.add_argument("--check", type=int, default=200, help="queries compared with the CPU reference")
     ap.add_argument("--server-env", default="", help="K=V[,K=V] added to the server's environment (e.g. LD_PRELOAD of a variant library)")
     ap.add_argument("--walkers", default=None, help="server --walkers (auto | 0..8): walking waves per block of a search launch")
+    ap.add_argument("--shm-pollers", type=int, default=None, help="server --shm-pollers (0 = no mailboxes: every search on the socket)")
     ap.add_argument("--verbose-server", action="store_true", help="server --verbose: sessions opened / closed with their team geometry on stderr")
     ap.add_argument("--stream", action="store_true", help="server --stream 1: one resident launch fed through a ring instead of launches on lanes")
     ap.add_argument("--configs", default="", help="sweep: comma-separated dispatchers:lanes[:readers[:walkers[:stream]]] — one server per entry over the "
@@ -100,7 +101,7 @@ def main():
     table = []
     for ci, (nd, nl, nr, nw, strm) in enumerate(cfgs):
       print(f"## server with {nd} dispatchers x {nl} lanes, {nr} readers, walkers {nw or 'default (auto)'}" + (", STREAM mode" if strm else ""), flush=True)
-      srv = ServerProcess(dispatchers=nd, readers=nr, lanes=nl, binary=a.binary, walkers=nw, stream=strm, verbose=a.verbose_server,
+      srv = ServerProcess(dispatchers=nd, readers=nr, lanes=nl, binary=a.binary, walkers=nw, stream=strm, verbose=a.verbose_server, shm_pollers=a.shm_pollers,
                           env=dict(([("GPU_MAX_HW_QUEUES", str(a.hwq))] if a.hwq else []) +
                                    [tuple(kv.split("=", 1)) for kv in a.server_env.split(",") if "=" in kv]) or None)
       with srv:
@@ -167,7 +168,7 @@ def main():
               print(f"# parity: {same}/{ncheck} sampled hnsw_search() answers identical to the {kind} on the exported graph", flush=True)
               del cpu
           st = c.stats()
-          print("# server totals:", json.dumps({k: st[k] for k in ("connections", "searches", "batches", "max_batch", "search_errors")}))
+          print("# server totals:", json.dumps({k: st[k] for k in ("connections", "searches", "shm_searches", "batches", "max_batch", "search_errors")}))
           c.close()
           table += [(nd, nl, nr, nw, strm, r) for r in rows]
     print("\n| dispatchers x lanes (readers, walkers) | backends | queries/s | mean batch | ms per batch (host) | kernel ms per batch | round trip ms | in server: queue + walk + answer ms |\n|---|---|---|---|---|---|---|---|")

@@ -20,20 +20,24 @@ from pg_embedding_amd.datasets import gmm
 from pg_embedding_amd.server import HGS_ERR_NOKEY, HGS_ERR_STALE, RemoteClient, RemoteError, ServerProcess
 import server_util as SU
 
+os.environ["PG_EMBEDDING_GPU_SHM"] = "1"      # the backends of this module post their searches in mailboxes when the server polls them
+
 
 @pytest.fixture(scope="module")
 def double_bin():
     return SU.build_double_server()
 
 
-@pytest.fixture(params=[(2, False), (0, False), (2, True)], ids=["streamed", "blocking", "resident"])
+@pytest.fixture(params=[(2, False, 2), (0, False, 2), (2, True, 2), (2, False, 0)], ids=["streamed", "blocking", "resident", "socket-only"])
 def srv(double_bin, request):
     """The dispatcher forms: streamed completion (2 launches in flight per dispatcher, answers leave as
     their walks end), one blocking launch at a time, and --stream 1: searches through one resident launch
     per (mirror, efsearch) fed through a ring (the engine double plays the launch with threads that take
     tickets and answer ring slots out of order, tests/double/engine_double.c) — the smallest ring the server accepts (256 slots)."""
-    lanes, stream = request.param
-    with ServerProcess(binary=double_bin, lanes=lanes, stream=stream, ring=256) as s:
+    lanes, stream, pollers = request.param
+    # (searches travel through the backends' shared-memory mailboxes, HGS_OP_SHM: --shm-pollers 2 + PG_EMBEDDING_GPU_SHM=1 above;
+    # "socket-only" = the server's default, no pollers: it refuses mailboxes and every request stays on the socket)
+    with ServerProcess(binary=double_bin, lanes=lanes, stream=stream, ring=256, shm_pollers=pollers) as s:
         yield s
 
 
@@ -188,7 +192,8 @@ def test_many_backends_through_a_resident_launch(double_bin, tmp_path, walkers):
     port, X = port_index(n, dim, m, 24, efs, pg.DIST_L2, seed=23)
     meta = pg.make_meta(dim, m, 24, efs, pg.DIST_L2)
     Q = gmm(960, dim, k=20, seed=23, stream=1)
-    with ServerProcess(binary=double_bin, lanes=2, stream=True, ring=256, walkers=walkers, env={"HGS_DOUBLE_SLEEP_US": "2000"}) as s:
+    with ServerProcess(binary=double_bin, lanes=2, stream=True, ring=256, walkers=walkers, shm_pollers=2 if walkers else None,
+                       env={"HGS_DOUBLE_SLEEP_US": "2000"}) as s:
         c = RemoteClient(s.socket_path)
         c.upload(meta, 78, 3, port.raw(), n)
         info, labels, counts = run_clients(s.socket_path, 78, 3, dim, m, 24, efs, pg.DIST_L2, Q, 48, tmp_path)
@@ -244,7 +249,7 @@ def test_the_servers_threads_are_race_free(tmp_path, stream):
     log = str(tmp_path / "tsan")
     env = {"TSAN_OPTIONS": f"log_path={log} exitcode=0 halt_on_error=0", "HGS_DOUBLE_SLEEP_US": "500"}
     bad = []
-    with ServerProcess(binary=binary, lanes=2, stream=stream, ring=256, env=env) as s:
+    with ServerProcess(binary=binary, lanes=2, stream=stream, ring=256, shm_pollers=2, env=env) as s:
         c0 = RemoteClient(s.socket_path)
         c0.upload(pg.make_meta(dim, m, 16, efs, pg.DIST_L2), 5, 1, port.raw(), n)
 
@@ -271,6 +276,77 @@ def test_the_servers_threads_are_race_free(tmp_path, stream):
     assert st["searches"] == 12 * len(Q) and st["search_errors"] == 0, st
     reports = "".join(open(f).read() for f in glob.glob(log + "*"))
     assert "ThreadSanitizer" not in reports, reports[:4000]
+
+
+def test_searches_travel_through_mailboxes_and_fall_back_to_the_socket(double_bin, tmp_path):
+    """HGS_OP_SHM (include/hnsw_gpu_server.h): a connection's searches are posted in its shared-memory mailbox — the server counts them
+    (hgs_stats.shm_searches) — and equal the socket's answers bit for bit; what does not fit a mailbox (a beam of more than 1 024
+    results here), a client that did not ask (PG_EMBEDDING_GPU_SHM unset or 0, separate processes) and a server without pollers (the
+    default) go through the socket, same arrays."""
+    dim, m, n, efs = 24, 4, 900, 16
+    port, X = port_index(n, dim, m, 16, efs, pg.DIST_L2, seed=61)
+    meta = pg.make_meta(dim, m, 16, efs, pg.DIST_L2)
+    Q = gmm(48, dim, k=20, seed=61, stream=1)
+    for pollers in (2, None):
+        with ServerProcess(binary=double_bin, lanes=2, shm_pollers=pollers) as s:
+            c = RemoteClient(s.socket_path)
+            c.upload(meta, 9, 1, port.raw(), n)
+            for q in Q:
+                for ef in (efs, 5):
+                    lab, dst = c.search(9, q, ef)
+                    wl, wd = port.search(q, ef)[:2]
+                    assert (lab == wl).all() and (bits(dst) == bits(wd)).all()
+            st = c.stats()
+            assert st["searches"] == 2 * len(Q) and st["shm_searches"] == (2 * len(Q) if pollers else 0), st
+            lab, dst = c.search(9, Q[0], 1500)                      # more results than the mailbox holds: this one on the socket
+            wl, wd = port.search(Q[0], 1500)[:2]
+            assert (lab == wl).all() and (bits(dst) == bits(wd)).all()
+            assert c.stats()["shm_searches"] == st["shm_searches"]
+            if pollers:
+                os.environ["PG_EMBEDDING_GPU_SHM"] = "0"            # (read when a connection is made: the C clients below make their own)
+                try:
+                    info, labels, counts = run_clients(s.socket_path, 9, 1, dim, m, 16, efs, pg.DIST_L2, Q, 4, tmp_path)
+                finally:
+                    os.environ["PG_EMBEDDING_GPU_SHM"] = "1"
+                want = port.search_many(Q, efs)
+                assert (counts == want["counts"]).all() and all((labels[i, :int(counts[i])] == want["labels"][i, :int(counts[i])]).all() for i in range(len(Q)))
+                assert c.stats()["shm_searches"] == st["shm_searches"]
+                info, labels, counts = run_clients(s.socket_path, 9, 1, dim, m, 16, efs, pg.DIST_L2, Q, 4, tmp_path)
+                assert (counts == want["counts"]).all() and all((labels[i, :int(counts[i])] == want["labels"][i, :int(counts[i])]).all() for i in range(len(Q)))
+                assert c.stats()["shm_searches"] == st["shm_searches"] + len(Q)
+            c.close()
+
+
+def test_a_backend_waiting_at_its_mailbox_notices_that_the_server_died(double_bin):
+    """A search posted in the mailbox sleeps in futex_wait; the server is killed meanwhile: the backend finds the socket closed at
+    its next look (100 ms), and fails (no server to reconnect to) instead of waiting for its time-out."""
+    dim, m, n, efs = 24, 4, 900, 16
+    port, X = port_index(n, dim, m, 16, efs, pg.DIST_L2, seed=63)
+    s = ServerProcess(binary=double_bin, lanes=0, shm_pollers=2, env={"HGS_DOUBLE_SLEEP_US": "999999"}).start()
+    try:
+        c = RemoteClient(s.socket_path)
+        c.upload(pg.make_meta(dim, m, 16, efs, pg.DIST_L2), 3, 1, port.raw(), n)
+        c.search(3, X[0], efs)                                       # the mailbox is set up and works
+        out = {}
+
+        def call():
+            t0 = time.time()
+            try:
+                for i in range(200):                                 # keeps searching until the server is gone
+                    c.search(3, X[i], efs)
+                out["result"] = "answered"
+            except RemoteError as ex:
+                out["result"] = repr(ex)
+            out["seconds"] = time.time() - t0
+
+        th = threading.Thread(target=call)
+        th.start()
+        time.sleep(0.3)
+        s.proc.kill()
+        th.join(20)
+        assert not th.is_alive() and out.get("result", "").startswith("RemoteError"), out
+    finally:
+        s.stop()
 
 
 def test_batches_never_mix_beams_or_mirrors(srv):
