@@ -2628,9 +2628,6 @@ extern "C" int hnsw_gpu_stream_open(hnsw_gpu_ctx *c, size_t ef, size_t ring, uns
 	if (!c || !out) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
 	if (ring < 64 || ring > ((size_t) 1 << 20) || (ring & (ring - 1))) return fail(HNSW_GPU_ERR_ARG, "ring must be a power of two in [64, 2^20]");
 	if (ef == 0 || ef > 512) return fail(HNSW_GPU_ERR_ARG, "a stream needs ef <= 512 (the team form of the beam kernel)");
-#ifdef PGEMB_SIMT_EMULATOR
-	return fail(HNSW_GPU_ERR_ARG, "streams need a device whose launches are asynchronous (not the emulator)");
-#endif
 	hnsw_gpu_index *ix = c->ix;
 	HIPCHK(hipSetDevice(ix->device));
 	if (!c->stream) HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
@@ -2660,6 +2657,9 @@ extern "C" int hnsw_gpu_stream_open(hnsw_gpu_ctx *c, size_t ef, size_t ring, uns
 		c->ws.done_next = s->F;
 		c->ws.stream_host_next = s->host_ctl; c->ws.stream_dev_next = s->dev_ctl;
 		c->ws.stream_ring_next = (uint32_t) ring; c->ws.stream_walkers_next = s->walkers;
+#ifdef PGEMB_SIMT_EMULATOR
+		simt::next_launch_is_resident();                         // (the CPU tier's emulator runs every other launch at the call)
+#endif
 		rc = launch_search(ix, &c->ws, s->Q, s->dim, ring, ef, 0, s->L, nullptr, s->D, s->C, nullptr, c->stream);
 		c->ws.done_next = nullptr; c->ws.stream_host_next = nullptr; c->ws.stream_dev_next = nullptr;
 	}

@@ -239,7 +239,10 @@ inline uint32_t mbcnt_hi(uint32_t mask, uint32_t base)
 // ---- launch -----------------------------------------------------------------------------------------------------------------
 struct Idx { uint32_t tid = 0, bid = 0, bdim = 0, gdim = 0; };
 
-inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body, unsigned char *lds0, unsigned char *lds1, size_t lds_cap)
+// Blocks [b_from, b_to) of the grid, one after the other (a block = its wavefronts as threads).  poison = false: the caller has
+// prepared the LDS image (resident launches: two block ranges run side by side over it, below).
+inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body, unsigned char *lds0, unsigned char *lds1, size_t lds_cap,
+				   uint32_t b_from = 0, uint32_t b_to = 0xFFFFFFFFu, bool poison = true)
 {
 	if (block.x % 64 || block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1) die("launch shape not modelled (1-D, whole waves)");
 	if (lds_bytes > lds_cap) die("more dynamic LDS than a CU has");
@@ -257,13 +260,16 @@ inline void launch(dim3 grid, dim3 block, size_t lds_bytes, const std::function<
 		waves[i]->stacks = (char *) aligned_alloc(4096, 64 * Wave::STACK);
 		if (!waves[i]->stacks) die("out of memory for lane stacks");
 	}
-	for (uint32_t b = 0; b < grid.x; b++)
+	for (uint32_t b = b_from; b < grid.x && b < b_to; b++)
 	{
 		Block blk;
 		blk.bx = b; blk.nblocks = grid.x; blk.nthreads = block.x;
 		pthread_barrier_init(&blk.bar, nullptr, nw);
-		memset(lds0, 0xA5, lds_bytes ? lds_bytes : 1);      // LDS is not zeroed on the device either
-		memset(lds1, 0xA5, lds_bytes ? lds_bytes : 1);
+		if (poison)
+		{
+			memset(lds0, 0xA5, lds_bytes ? lds_bytes : 1);      // LDS is not zeroed on the device either
+			memset(lds1, 0xA5, lds_bytes ? lds_bytes : 1);
+		}
 		std::vector<std::thread> th;
 		for (uint32_t i = 0; i < nw; i++)
 		{
@@ -311,7 +317,12 @@ namespace pgemb { alignas(16) static unsigned char smem[SIMT_LDS_BYTES]; }
 #define __builtin_amdgcn_ds_bpermute(a, v) simt::ds_bpermute((a), (v))
 #define __builtin_amdgcn_mbcnt_lo(m, b) simt::mbcnt_lo((m), (b))
 #define __builtin_amdgcn_mbcnt_hi(m, b) simt::mbcnt_hi((m), (b))
-#define __builtin_amdgcn_fence(order, scope) __atomic_thread_fence(__ATOMIC_SEQ_CST)
+// A fence is ONE instruction of the wave: what any lane stored before it is before it for every lane.  Lanes are not in lockstep
+// here, so a system-scope release — the one in front of a completion flag that the HOST polls while the launch runs (streams) — is also
+// a rendezvous: without it lane 0 could raise the flag while another lane's result store is still to come (found by the stream
+// scenario: the device's lockstep makes that impossible there).  All uses are in converged code.
+namespace simt { inline void fence(int order, const char *scope) { __atomic_thread_fence(__ATOMIC_SEQ_CST); if (order == __ATOMIC_RELEASE && scope[0] == 0) wave_barrier(); } }
+#define __builtin_amdgcn_fence(order, scope) simt::fence((order), (scope))
 // s_waitcnt: every outstanding memory operation of the WAVE (all lanes) has completed — lanes are not in lockstep here, so it
 // is a rendezvous (the kernels hand values from lane to lane through memory across it, e.g. beam_compact's scratch line)
 #define __builtin_amdgcn_s_waitcnt(x) simt::wave_barrier()
@@ -358,9 +369,12 @@ static inline float max(float a, float b) { return fmaxf(a, b); }
 typedef int hipError_t;
 enum { hipSuccess = 0, hipErrorOutOfMemory = 2, hipErrorNotReady = 600, hipErrorPeerAccessAlreadyEnabled = 704, hipErrorInvalidValue = 1,
 	   hipErrorInvalidResourceHandle = 400, hipErrorInvalidDevice = 101 };
-struct simt_stream { int dev; };
+// A stream runs its work at the call — except ONE kind of launch: a resident kernel that the host feeds while it runs (the library's
+// streams, hnsw_gpu_stream_open, which says so through simt::next_launch_is_resident()).  That launch runs on threads of its own
+// until it ends by itself; hipStreamQuery / hipEventQuery report hipErrorNotReady meanwhile, the ...Synchronize calls wait for it.
+struct simt_stream { int dev = 0; std::thread *resident = nullptr; std::atomic<int> running{0}; };
 typedef struct simt_stream *hipStream_t;
-struct simt_event { std::chrono::steady_clock::time_point t; int dev = 0; };
+struct simt_event { std::chrono::steady_clock::time_point t; int dev = 0; simt_stream *after = nullptr; };
 typedef simt_event *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocCoherent = 0x40000000 };
@@ -406,9 +420,41 @@ inline void protect_others(int dev, int prot)
 	for (const DevAlloc &a : allocs())
 		if (a.dev != dev && !peer_on()[dev][a.dev]) mprotect(a.p, a.bytes, prot);
 }
+inline thread_local bool resident_next = false;
+inline void next_launch_is_resident() { resident_next = true; }
+inline void wait_resident(simt_stream *s)
+{
+	if (s && s->resident)
+	{
+		s->resident->join();
+		delete s->resident;
+		s->resident = nullptr;
+	}
+}
 inline void launch_on(simt_stream *stream, dim3 grid, dim3 block, size_t lds_bytes, const std::function<void()> &body, unsigned char *lds0,
 					  unsigned char *lds1, size_t lds_cap)
 {
+	if (resident_next)
+	{
+		// A resident launch: block 0 is its doorbell and runs for as long as the launch does, so it cannot be "the first of the blocks, one
+		// after the other": it gets threads of its own next to the others (it never touches LDS: one wave that copies control words).  The
+		// walking blocks still run one after the other — the first takes every query until the host stops the stream, the rest find the
+		// stop word and leave: "as many blocks as the device holds at once" is one walking block here.
+		resident_next = false;
+		if (!stream || ndev() != 1 || grid.x < 2) die("a resident launch needs a stream, one device and a doorbell block + a walking block");
+		wait_resident(stream);
+		memset(lds0, 0xA5, lds_bytes ? lds_bytes : 1);
+		memset(lds1, 0xA5, lds_bytes ? lds_bytes : 1);
+		stream->running.store(1);
+		const std::function<void()> kernel = body;              // (the caller's lambda dies with the call)
+		stream->resident = new std::thread([=]() {
+			std::thread doorbell([&]() { launch(grid, block, lds_bytes, kernel, lds0, lds1, lds_cap, 0, 1, false); });
+			launch(grid, block, lds_bytes, kernel, lds0, lds1, lds_cap, 1, 0xFFFFFFFFu, false);
+			doorbell.join();
+			stream->running.store(0);
+		});
+		return;
+	}
 	if (ndev() == 1) { launch(grid, block, lds_bytes, body, lds0, lds1, lds_cap); return; }
 	if (stream && stream->dev != cur_dev) { last_error = 400; return; }          // hipErrorInvalidResourceHandle: nothing runs
 	std::lock_guard<std::mutex> g(rt_mu());
@@ -506,13 +552,13 @@ static inline hipError_t hipMemcpyPeerAsync(void *d, int ddev, const void *s, in
 }
 static inline hipError_t hipMemset(void *d, int v, size_t n) { memset(d, v, n); return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t = nullptr) { memset(d, v, n); return hipSuccess; }
-static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = (hipStream_t) malloc(sizeof(simt_stream)); (*s)->dev = simt::cur_dev; return hipSuccess; }
+static inline hipError_t hipStreamCreate(hipStream_t *s) { *s = new simt_stream(); (*s)->dev = simt::cur_dev; return hipSuccess; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { return hipStreamCreate(s); }
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { return hipStreamCreate(s); }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 1; *greatest = -1; return hipSuccess; }
-static inline hipError_t hipStreamDestroy(hipStream_t s) { free(s); return hipSuccess; }
-static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
-static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t s) { simt::wait_resident(s); delete s; return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t s) { simt::wait_resident(s); return hipSuccess; }
+static inline hipError_t hipStreamQuery(hipStream_t s) { return s && s->running.load() ? hipErrorNotReady : hipSuccess; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = new simt_event(); (*e)->dev = simt::cur_dev; return hipSuccess; }
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
@@ -521,10 +567,11 @@ static inline hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr)
 {
 	if (simt::ndev() > 1 && e->dev != (s ? s->dev : simt::cur_dev)) return hipErrorInvalidResourceHandle;   // event and stream of different devices
 	e->t = std::chrono::steady_clock::now();
+	e->after = s && s->running.load() ? s : nullptr;        // recorded behind a resident launch: reached when that launch has ended
 	return hipSuccess;
 }
-static inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
-static inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }
+static inline hipError_t hipEventSynchronize(hipEvent_t e) { while (e->after && e->after->running.load()) sched_yield(); return hipSuccess; }
+static inline hipError_t hipEventQuery(hipEvent_t e) { return e->after && e->after->running.load() ? hipErrorNotReady : hipSuccess; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b)
 {
 	*ms = std::chrono::duration<float, std::milli>(b->t - a->t).count();

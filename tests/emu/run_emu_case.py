@@ -429,5 +429,57 @@ def insert():
     return out
 
 
+def part(want, lo, hi):
+    return {k: want[k][lo:hi] for k in ("labels", "dists", "counts")}
+
+
+def stream():
+    """streams (include/hnsw_gpu.h): ONE resident launch fed from the host while it runs — the emulator runs that launch on threads of
+    its own (doorbell block next to the walking block).  Queries published a few at a time while others are still walking, a ring far
+    smaller than the number of queries, both completion forms, one and several walking waves per block, the stream closed and another
+    opened, ordinary launches on the mirror before, between and after: every answer == the oracle's"""
+    out = []
+    for dim, m, func, ef, walkers in ((32, 8, pg.DIST_L2, 24, 2), (100, 12, pg.DIST_COSINE, 40, 8), (200, 8, pg.DIST_MANHATTAN, 16, 1)):
+        n, nq, ring = 1200, int(os.environ.get("EMU_STREAM_QUERIES", "150")), 64
+        port, X = U.build_port(n, dim, m, 40, func, k=10, seed=dim)
+        Q = gmm(nq, dim, k=10, seed=dim + 3)
+        want = port.search_many(Q, ef, nthreads=4)
+        setenv({"SIMT_EMU_CUS": "2"})
+        ix = U.mirror(port, func, efs=ef)
+        bad_launch = wrong(ix.search(Q[:8], ef), part(want, 0, 8), 8)
+        ctx = pg.SearchContext(ix)
+        bad = 0
+        bad_by_round = [0, 0]
+        for round_ in range(2):
+            pg.config_set("HNSW_GPU_STREAM_LIGHT", None if round_ == 0 else 0)
+            st = pg.SearchStream(ctx, ef, ring=ring, walkers=walkers)
+            try:
+                alive_at_start = st.alive()
+                rng = np.random.default_rng(round_)
+                done, pending = 0, []
+                while done < nq or pending:
+                    inflight = sum(len(sl) for _, sl in pending)
+                    if done < nq and inflight <= ring // 2:
+                        k = int(min(nq - done, rng.integers(1, ring // 2 - 1), ring - inflight - 1))
+                        pending.append((done, st.submit(Q[done:done + k])))
+                        done += k
+                        continue
+                    first, slots = pending.pop(0)
+                    lab, dst, cnt = st.wait(slots, timeout=300.0)
+                    k = len(slots)
+                    w = wrong((lab, dst, cnt), part(want, first, first + k), k)
+                    bad += w
+                    bad_by_round[round_] += w
+            finally:
+                pg.config_set("HNSW_GPU_STREAM_LIGHT", None)
+                st.close()
+            bad_launch += wrong(ix.search(Q[8:16], ef), part(want, 8, 16), 8)     # the mirror's ordinary launches go on
+        out.append({"dim": dim, "func": int(func), "ef": ef, "walkers": walkers, "queries_through_streams": 2 * nq, "wrong": bad, "wrong_by_completion_form": bad_by_round,
+                    "wrong_in_ordinary_launches": bad_launch, "alive_while_open": bool(alive_at_start), "health": ix.health()})
+        ctx.close()
+        ix.close()
+    return out
+
+
 if __name__ == "__main__":
-    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced, "sharded": sharded, "moving_helpers": moving_helpers, "wide": wide, "reforder": reforder, "insert": insert}[sys.argv[1]]()))
+    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced, "sharded": sharded, "moving_helpers": moving_helpers, "wide": wide, "reforder": reforder, "insert": insert, "stream": stream}[sys.argv[1]]()))

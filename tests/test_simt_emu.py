@@ -172,6 +172,19 @@ def test_helpers_that_change_walks_inside_a_block(emu_lib):
     assert sum(r["health"]["slices_delivered"] for r in res) > 50, res
 
 
+@pytest.mark.parametrize("jitter", [None, "3"])
+def test_a_resident_launch_fed_from_the_host_answers_like_the_oracle(emu_lib, jitter):
+    """Streams (include/hnsw_gpu.h) on the CPU: the emulator runs the resident launch on threads of its own — doorbell block beside the
+    walking block — while this process publishes queries into the ring and polls the completion flags: ring reuse, 1 / 2 / 8 walking
+    waves per block, both completion forms, stream closed and reopened, ordinary launches in between; with and without shaken wave
+    schedules.  (On the device: tests/test_gpu_search.py::test_a_stream_answers_like_a_launch.)"""
+    res = run_case("stream", emu_lib, env={"SIMT_EMU_JITTER": jitter, "EMU_STREAM_QUERIES": "70"} if jitter else None)
+    assert len(res) == 3
+    for r in res:
+        assert r["wrong"] == 0 and r["wrong_in_ordinary_launches"] == 0 and r["alive_while_open"], r
+        assert r["health"]["package_timeouts"] == 0 and r["health"]["slice_timeouts"] == 0, r
+
+
 def test_wide_beam_form_equals_the_oracle(emu_lib):
     """device_search_wide.h on the CPU: every beam from 1 to beyond the index size, ties, vacuumed rows, the pop sequence"""
     res = run_case("wide", emu_lib, timeout=900)
