@@ -77,6 +77,23 @@ def build_double_server_tsan() -> str:
     return target
 
 
+def build_emu_server() -> str:
+    """The server's own source linked against the SIMT-EMULATED library (tests/emu: the product's kernel source on host threads) instead
+    of libhnsw_gpu.so: server, C API, host code and kernels of the product in one process of the CPU tier."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tests", "emu"))
+    import build_emu
+    lib = build_emu.build()
+    target = os.path.join(OUT, "hnsw_gpu_server_emu")
+    src = [os.path.join(CSRC, "server_main.cpp"), os.path.join(CSRC, "hgs_io.h"), os.path.join(INC, "hnsw_gpu_server.h"),
+           os.path.join(INC, "hnsw_gpu.h"), lib]
+    with _Lock():
+        if _stale(target, src):
+            _run(["g++", "-O2", "-std=c++17", "-Wall", "-I", INC, "-I", CSRC, src[0], "-o", target, "-L", os.path.dirname(lib),
+                  "-l" + os.path.basename(lib)[3:-3], "-Wl,-rpath," + os.path.dirname(lib), "-lpthread"])
+    return target
+
+
 def build_c_client(name: str, link_client_lib: bool = True) -> str:
     """tests/dropin_c/<name>.c + the flat host, linked against libembedding_gpuc.so (the four
     reference symbols as a client of the server)."""

@@ -185,6 +185,60 @@ def test_a_resident_launch_fed_from_the_host_answers_like_the_oracle(emu_lib, ji
         assert r["health"]["package_timeouts"] == 0 and r["health"]["slice_timeouts"] == 0, r
 
 
+@pytest.mark.parametrize("stream", [False, True], ids=["lanes", "resident"])
+def test_the_server_over_the_emulated_library(emu_lib, stream):
+    """hnsw_gpu_server's own source linked against the emulated library: backends' searches go through the real server — reader
+    threads, dispatcher lanes with streamed completion (kernel-written flags polled while nothing else runs) or a stream session
+    (lock-free producers, a RESIDENT launch of the product's kernel on emulator threads, answer threads) — into the product's C API,
+    host code and kernels, all in the CPU tier: every answer equals the oracle's, a writer (delete flag) interleaved."""
+    import threading
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle
+    import pg_embedding_amd as pg
+    import server_util as SU
+    from pg_embedding_amd.datasets import gmm
+    from pg_embedding_amd.server import RemoteClient, ServerProcess
+    binary = SU.build_emu_server()
+    dim, m, n, efs = 32, 8, 1200, 24
+    X = gmm(n, dim, k=10, seed=71)
+    port = oracle.PortIndex(dim, m, 40, efs, pg.DIST_L2)
+    port.add(X, np.arange(n, dtype=np.uint64) + 500)
+    Q = gmm(16, dim, k=10, seed=72)
+    want = [port.search(q, efs)[:2] for q in Q]
+    port.set_deleted(5, True)
+    want_del = [port.search(q, efs)[:2] for q in Q]
+    port.set_deleted(5, False)
+    bad = []
+    with ServerProcess(binary=binary, lanes=2, dispatchers=2, stream=stream, ring=256, env={"SIMT_EMU_CUS": "2"}, start_timeout=60) as s:
+        c0 = RemoteClient(s.socket_path)
+        c0.upload(pg.make_meta(dim, m, 40, efs, pg.DIST_L2), 7, 1, port.raw(), n)
+
+        def worker(t):
+            try:
+                c = RemoteClient(s.socket_path)
+                for i, q in enumerate(Q):
+                    lab, dst = c.search(7, q, efs)
+                    ok = any((lab == w[0]).all() and (dst.view(np.uint32) == w[1].view(np.uint32)).all() for w in (want[i], want_del[i]))
+                    if not ok:
+                        bad.append((t, i))
+                c.close()
+            except Exception as ex:            # noqa: BLE001
+                bad.append((t, repr(ex)))
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+        [t.start() for t in th]
+        for i in range(6):
+            c0.set_deleted(7, 5, i % 2 == 0)
+        [t.join() for t in th]
+        st = c0.stats()
+        c0.close()
+    assert not bad, bad
+    assert st["searches"] == 4 * len(Q) and st["search_errors"] == 0, st
+    if stream:
+        assert st["max_batch"] == 0 and st["batches"] >= 1, st          # sessions, not batches
+
+
 def test_wide_beam_form_equals_the_oracle(emu_lib):
     """device_search_wide.h on the CPU: every beam from 1 to beyond the index size, ties, vacuumed rows, the pop sequence"""
     res = run_case("wide", emu_lib, timeout=900)
