@@ -1173,6 +1173,14 @@ def pmc_traffic(args, kernel_name):
         return None, None
 
 
+def cpu_quota():
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if quota == "max" else float(quota) / float(period)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_baseline(args, ix, Q, gpu_labels, gpu_dists, func):
     """oracle/_ref (the unmodified reference distfunc.c + hnswalg.cpp) or, where that was
     not shipped, the C restatement, timed on this box's host cores over a bounded sample of
@@ -1211,6 +1219,9 @@ def cpu_baseline(args, ix, Q, gpu_labels, gpu_dists, func):
         "single_thread_qps": qps1,
         "eight_thread_qps": qps8,
         "host_cpus": ncores,
+        # CPU time the box actually grants this process tree (cgroup v2 cpu.max = quota / period; null = unlimited or unknown): the MI355X
+        # boxes of round 4 showed 256 CPUs and granted 16 — a 64-thread figure measured there is 16 CPUs' worth
+        "host_cpu_quota_cpus": cpu_quota(),
     }
     glab = gpu_labels[:nt].cpu().numpy().view(np.uint64)
     same = (rt["labels"] == glab).all(axis=1)
