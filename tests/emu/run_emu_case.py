@@ -268,8 +268,25 @@ def traced():
         rc = ix.L.hnsw_gpu_replay_roof(ix._h, ev.ctypes.data, cap, st.ctypes.data, nq, 8, 2, 4, C.byref(ms), C.byref(by), C.byref(ws))
         words = X.view(np.uint32).astype(np.uint64).sum(axis=1)
         want_sum = int(sum(int(words[ev[i, :st[i, 0]]].sum()) for i in range(nq)) % (1 << 64))
+        # the same trace cut into 2 / 4 pieces per query, each gathered by a wave of its own (hnsw_gpu_replay_roof_parts: the roof of a
+        # launch with fewer queries than resident waves): the same bytes, the same words
+        parts_ok = True
+        for parts in (2, 4):
+            ms2, by2, ws2 = C.c_float(0), C.c_double(0), C.c_uint64(0)
+            rc2 = ix.L.hnsw_gpu_replay_roof_parts(ix._h, ev.ctypes.data, cap, st.ctypes.data, nq, 8, 2, 4, parts, C.byref(ms2), C.byref(by2), C.byref(ws2))
+            parts_ok = parts_ok and rc2 == 0 and by2.value == by.value and int(ws2.value) == want_sum
+        # walking waves per block of a small team launch (hnsw_gpu_ctx_set_walkers, what the server's lanes say): nothing but the shape changes
+        walkers_ok = True
+        if env.get("HNSW_GPU_TEAM") == "1":
+            ctx = pg.SearchContext(ix)
+            wantq = port.search_many(Q, ef, nthreads=2)
+            for w in (0, 1, 3, 8):
+                ctx.set_walkers(w)
+                walkers_ok = walkers_ok and wrong(ctx.search_host(Q, ef), wantq, nq) == 0
+            ctx.close()
         out.append({"env": env, "kernel": ix.last_search_kernel(), "wrong": bad, "replay_rc": rc, "replay_bytes": by.value,
-                    "want_bytes": float(st[:, 0].sum()) * dim * 4, "word_sum_ok": int(ws.value) == want_sum})
+                    "want_bytes": float(st[:, 0].sum()) * dim * 4, "word_sum_ok": int(ws.value) == want_sum, "parts_ok": parts_ok,
+                    "walkers_ok": walkers_ok})
         ix.close()
     return out
 

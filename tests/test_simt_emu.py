@@ -134,6 +134,7 @@ def test_the_evaluation_trace_is_the_walk_and_the_replay_runs_over_it(emu_lib):
     res = run_case("traced", emu_lib, timeout=600)
     for r in res:
         assert r["wrong"] == 0 and r["replay_rc"] == 0 and r["replay_bytes"] == r["want_bytes"] and r["word_sum_ok"], r
+        assert r["parts_ok"] and r["walkers_ok"], r          # (round 4: the trace in pieces per query; walking waves per block by the caller's hint)
 
 
 @pytest.mark.parametrize("env", [{"SIMT_EMU_DEVICES": "3"}, {"SIMT_EMU_DEVICES": "3", "SIMT_EMU_PEER": "0"},
