@@ -768,11 +768,11 @@ void stream_answer_main(int k, int n)
 			const size_t ef = ss->ef;
 			const uint32_t c = ss->C[slot];
 			const size_t cnt = c <= ef ? c : 0;
+			g_cnt.searches++;                                   // (before the answer leaves: a backend that asks for STATS next finds itself counted)
 			if (c > ef) { g_cnt.search_errors++; r.c->respond(r.h, HNSW_GPU_ERR_INTERNAL); }
 			else r.c->respond(r.h, HGS_OK, cnt, 0, ss->L + (size_t) slot * ef, cnt * 8, r.h.a0 ? ss->D + (size_t) slot * ef : nullptr, cnt * 4, gen);
 			g_cnt.walk_ns += t_seen - ss->t_pub[slot];
 			g_cnt.answer_ns += now_ns() - t_seen;
-			g_cnt.searches++;
 			ss->busy[slot].store(0, std::memory_order_release);
 			ss->outstanding.fetch_sub(1, std::memory_order_relaxed);
 			ss->t_active.store(t_seen, std::memory_order_relaxed);

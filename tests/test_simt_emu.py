@@ -186,8 +186,8 @@ def test_a_resident_launch_fed_from_the_host_answers_like_the_oracle(emu_lib, ji
         assert r["health"]["package_timeouts"] == 0 and r["health"]["slice_timeouts"] == 0, r
 
 
-@pytest.mark.parametrize("stream", [False, True], ids=["lanes", "resident"])
-def test_the_server_over_the_emulated_library(emu_lib, stream):
+@pytest.mark.parametrize("stream,mailboxes", [(False, False), (True, False), (True, True)], ids=["lanes", "resident", "resident-mailboxes"])
+def test_the_server_over_the_emulated_library(emu_lib, stream, mailboxes, monkeypatch):
     """hnsw_gpu_server's own source linked against the emulated library: backends' searches go through the real server — reader
     threads, dispatcher lanes with streamed completion (kernel-written flags polled while nothing else runs) or a stream session
     (lock-free producers, a RESIDENT launch of the product's kernel on emulator threads, answer threads) — into the product's C API,
@@ -201,6 +201,8 @@ def test_the_server_over_the_emulated_library(emu_lib, stream):
     from pg_embedding_amd.datasets import gmm
     from pg_embedding_amd.server import RemoteClient, ServerProcess
     binary = SU.build_emu_server()
+    if mailboxes:
+        monkeypatch.setenv("PG_EMBEDDING_GPU_SHM", "1")          # the backends post their searches in shared-memory mailboxes (HGS_OP_SHM)
     dim, m, n, efs = 32, 8, 1200, 24
     X = gmm(n, dim, k=10, seed=71)
     port = oracle.PortIndex(dim, m, 40, efs, pg.DIST_L2)
@@ -211,7 +213,8 @@ def test_the_server_over_the_emulated_library(emu_lib, stream):
     want_del = [port.search(q, efs)[:2] for q in Q]
     port.set_deleted(5, False)
     bad = []
-    with ServerProcess(binary=binary, lanes=2, dispatchers=2, stream=stream, ring=256, env={"SIMT_EMU_CUS": "2"}, start_timeout=60) as s:
+    with ServerProcess(binary=binary, lanes=2, dispatchers=2, stream=stream, ring=256, shm_pollers=2 if mailboxes else None,
+                       env={"SIMT_EMU_CUS": "2"}, start_timeout=60) as s:
         c0 = RemoteClient(s.socket_path)
         c0.upload(pg.make_meta(dim, m, 40, efs, pg.DIST_L2), 7, 1, port.raw(), n)
 
@@ -238,6 +241,7 @@ def test_the_server_over_the_emulated_library(emu_lib, stream):
     assert st["searches"] == 4 * len(Q) and st["search_errors"] == 0, st
     if stream:
         assert st["max_batch"] == 0 and st["batches"] >= 1, st          # sessions, not batches
+    assert st["shm_searches"] == (st["searches"] if mailboxes else 0), st
 
 
 def test_wide_beam_form_equals_the_oracle(emu_lib):
