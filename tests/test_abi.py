@@ -228,3 +228,22 @@ def test_the_shipped_library_knows_only_the_documented_knobs():
     src = open(os.path.join(ROOT, "pg_embedding_amd", "csrc", "hnsw_gpu.hip")).read()
     body = src[src.index("static int launch_search("):src.index('extern "C" int hnsw_gpu_search_batch_dev(')]
     assert "getenv" not in body
+
+
+def test_every_api_name_in_the_documents_exists():
+    """DESIGN.md, INTEGRATION.md, README.md and profiles/README.md name functions, wire operations and knobs: each
+    hnsw_gpu_* / hgs_* / HGS_* / HNSW_GPU_* word they use is somewhere in the headers, the sources, the glue patch, the tests or the
+    scripts — a renamed or removed API cannot stay behind in the text."""
+    import glob
+    import re
+    words = set()
+    for doc in ("DESIGN.md", "INTEGRATION.md", "README.md", os.path.join("profiles", "README.md")):
+        words |= set(re.findall(r"\b(hnsw_gpu_[a-z_0-9]+|hgs_[a-z_0-9]+|HGS_[A-Z_0-9]+|HNSW_GPU_[A-Z_0-9]+)\b", open(os.path.join(ROOT, doc)).read()))
+    text = ""
+    for pat in ("include/*.h", "pg_embedding_amd/csrc/*", "pg_embedding_amd/*.py", "integration/*", "tests/*.py", "tests/*/*.py", "tests/*/*.c",
+                "scripts/*", "bench.py", "__graft_entry__.py"):
+        for f in glob.glob(os.path.join(ROOT, pat)):
+            if os.path.isfile(f):
+                text += open(f, errors="replace").read()
+    missing = sorted(w for w in words if w not in text)
+    assert not missing, missing
