@@ -77,6 +77,27 @@ def build_double_server_tsan() -> str:
     return target
 
 
+def build_double_server_asan() -> str:
+    """The double link under AddressSanitizer + UndefinedBehaviorSanitizer: heap misuse in the server's own code (a ring freed under a
+    producer, a connection freed under a mailbox poller, ...) ends the process with a report."""
+    target = DOUBLE_BIN + "_asan"
+    src = [os.path.join(CSRC, "server_main.cpp"), os.path.join(CSRC, "hgs_io.h"),
+           os.path.join(ROOT, "tests", "double", "engine_double.c"), os.path.join(ROOT, "oracle", "hnsw_port.c"),
+           os.path.join(INC, "hnsw_gpu_server.h"), os.path.join(INC, "hnsw_gpu.h")]
+    san = ["-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-g"]
+    with _Lock():
+        if _stale(target, src):
+            objs = []
+            for name, c, flags in (
+                    ("engine_double_asan.o", src[2], ["-O1", "-std=gnu11"] + san),
+                    ("hnsw_port_asan.o", src[3], ["-O2", "-mavx2", "-mfma", "-ffp-contract=off", "-fno-fast-math", "-std=gnu11"] + san)):
+                o = os.path.join(OUT, name)
+                _run(["gcc"] + flags + ["-I", INC, "-c", c, "-o", o])
+                objs.append(o)
+            _run(["g++", "-O1", "-std=c++17", "-Wall", "-I", INC, "-I", CSRC, src[0]] + san + objs + ["-o", target, "-lpthread", "-lm"])
+    return target
+
+
 def build_emu_server() -> str:
     """The server's own source linked against the SIMT-EMULATED library (tests/emu: the product's kernel source on host threads) instead
     of libhnsw_gpu.so: server, C API, host code and kernels of the product in one process of the CPU tier."""

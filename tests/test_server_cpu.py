@@ -349,6 +349,47 @@ def test_a_backend_waiting_at_its_mailbox_notices_that_the_server_died(double_bi
         s.stop()
 
 
+@pytest.mark.parametrize("stream,pollers", [(False, None), (True, 2)], ids=["lanes", "resident-mailboxes"])
+def test_the_servers_memory_use_is_clean(stream, pollers):
+    """The server's own source under AddressSanitizer + UndefinedBehaviorSanitizer: connections come and go while others search
+    (mailboxes registered and unregistered under the pollers' feet), two beams, a writer that closes stream sessions: no report
+    (a report ends the server with status 77), every request answered."""
+    binary = SU.build_double_server_asan()
+    dim, m, n, efs = 24, 4, 900, 16
+    port, X = port_index(n, dim, m, 16, efs, pg.DIST_L2, seed=71)
+    Q = gmm(20, dim, k=20, seed=71, stream=1)
+    env = {"ASAN_OPTIONS": "detect_leaks=0:abort_on_error=0:exitcode=77", "HGS_DOUBLE_SLEEP_US": "300"}
+    s = ServerProcess(binary=binary, lanes=2, stream=stream, ring=256, shm_pollers=pollers, env=env).start()
+    errs = []
+    try:
+        c0 = RemoteClient(s.socket_path)
+        c0.upload(pg.make_meta(dim, m, 16, efs, pg.DIST_L2), 5, 1, port.raw(), n)
+
+        def worker(t):
+            try:
+                for _ in range(3):
+                    c = RemoteClient(s.socket_path)
+                    for q in Q:
+                        c.search(5, q, efs if t % 2 else 8)
+                    c.close()
+            except Exception as ex:            # noqa: BLE001
+                errs.append(repr(ex))
+
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+        [t.start() for t in th]
+        for i in range(30):
+            c0.set_deleted(5, 3, i % 2 == 0)
+        [t.join() for t in th]
+        st = c0.stats()
+        c0.close()
+    finally:
+        rc = s.stop()
+    assert not errs, errs
+    assert rc == 0, f"the server ended with status {rc} (77 = a sanitizer report, see its stderr)"
+    assert st["searches"] == 8 * 3 * len(Q) and st["search_errors"] == 0, st
+    assert st["shm_searches"] == (st["searches"] if pollers else 0), st
+
+
 def test_batches_never_mix_beams_or_mirrors(srv):
     """Concurrent searches with different efSearch on two mirrors: batches are per (mirror, ef)."""
     dim, m, efs = 24, 4, 16
