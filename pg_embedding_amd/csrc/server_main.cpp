@@ -707,16 +707,26 @@ struct Session
 		t_pub[slot] = now;
 		req[slot] = std::move(r);
 		busy[slot].store(1, std::memory_order_release);
-		ready[slot].store(t + 1, std::memory_order_release);
-		// advance the published count over every ticket that is ready, in order; whoever is behind an unready ticket leaves the rest
-		// to that ticket's owner (it runs this loop after its own store)
-		uint32_t p = pub.load(std::memory_order_acquire);
-		bool moved = false;
-		while (ready[p & (ring - 1)].load(std::memory_order_acquire) == p + 1)
-			if (pub.compare_exchange_weak(p, p + 1, std::memory_order_acq_rel)) { p = p + 1; moved = true; }
-		if (moved) (void) hnsw_gpu_stream_publish(st, p);                  // (the library keeps the maximum: two advancers may arrive out of order)
+		// SEQUENTIALLY CONSISTENT, and so are the looks in advance(): "store my ticket's ready word, then look at my neighbour's" on two
+		// producers at once is the store-buffer pattern — with release / acquire BOTH may miss the other's store, both stop, and the later
+		// ticket stays unpublished until another producer comes by.  In a busy session that is a blip; at a session's close nobody comes
+		// by any more and the query was answered with an error after the close's patience ran out ("stream closed with 1 queries
+		// unanswered": twice at 2 048 backends on the device, once on the CPU tier's double — profiles/r4aj_mailboxes.txt blamed the
+		// capped host for it, wrongly).  The closing manager also advances by itself (close_session).
+		ready[slot].store(t + 1);
+		advance();
 		t_active.store(now, std::memory_order_relaxed);
 		return true;
+	}
+	// advance the published count over every ticket that is ready, in order; whoever is behind an unready ticket leaves the rest to
+	// that ticket's owner (it runs this after its own store)
+	void advance()
+	{
+		uint32_t p = pub.load();
+		bool moved = false;
+		while (ready[p & (ring - 1)].load() == p + 1)
+			if (pub.compare_exchange_weak(p, p + 1)) { p = p + 1; moved = true; }
+		if (moved) (void) hnsw_gpu_stream_publish(st, p);                  // (the library keeps the maximum: two advancers may arrive out of order)
 	}
 };
 using SessionP = std::shared_ptr<Session>;
@@ -793,10 +803,12 @@ void close_session(SessionP &ss, const char *why)
 		while (g_in_submit[i].s.load() == (const void *) ss.get() && now_ns() - t0 < 1000000000ull)
 			std::this_thread::yield();
 	// producers that were past the check finish their slot; then every claimed ticket is published and, walked, answered
-	// (2 s: on a host whose CPU time is capped the whole process is frozen for tens of milliseconds at a time — a bound of 0.2 s gave up
-	// on a straggler that was merely not running, and its backend got an error: profiles/r4aj_mailboxes.txt)
+	// (2 s of patience: on a host whose CPU time is capped the whole process may be frozen for tens of milliseconds at a time)
 	while ((ss->outstanding.load() > 0 || ss->pub.load() != ss->claim.load()) && now_ns() - t0 < 2000000000ull)
+	{
+		ss->advance();                      // (no producer will come by any more: a ready ticket that two of them left to each other is published here)
 		std::this_thread::sleep_for(std::chrono::microseconds(20));
+	}
 	set_session(nullptr);                   // the answer threads and readers let go of it at their next look ...
 	// ... (their thread-local copies: a reader that is idle keeps one until its next request, so the count cannot be waited on; what
 	// matters is that nobody is INSIDE the ring: producers have left (their marks, above) and none enters any more, and the answer
@@ -904,6 +916,7 @@ void stream_manager_main()
 				}
 				continue;
 			}
+			ss->advance();                  // (bounds the blip of a ready ticket that two producers left to each other: Session::submit)
 			if (g_q_waiting.load(std::memory_order_acquire) == 0) std::this_thread::sleep_for(std::chrono::microseconds(50));
 			continue;
 		}
