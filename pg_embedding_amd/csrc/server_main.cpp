@@ -809,6 +809,10 @@ void close_session(SessionP &ss, const char *why)
 		ss->advance();                      // (no producer will come by any more: a ready ticket that two of them left to each other is published here)
 		std::this_thread::sleep_for(std::chrono::microseconds(20));
 	}
+	const uint64_t t_drained = now_ns();
+	if (t_drained - t0 > 200000000ull)      // (a close is a millisecond or two: say so when it is not, with what it was waiting for)
+		logf("slow close (%s): %.0f ms until the ring had drained — outstanding %ld, claimed %u, published %u", why, (t_drained - t0) / 1e6,
+			 ss->outstanding.load(), ss->claim.load(), ss->pub.load());
 	set_session(nullptr);                   // the answer threads and readers let go of it at their next look ...
 	// ... (their thread-local copies: a reader that is idle keeps one until its next request, so the count cannot be waited on; what
 	// matters is that nobody is INSIDE the ring: producers have left (their marks, above) and none enters any more, and the answer
@@ -819,12 +823,21 @@ void close_session(SessionP &ss, const char *why)
 			while (g_answer_gen[k].load(std::memory_order_acquire) < gen && !g_stop.load() && now_ns() - t1 < 1000000000ull)
 				std::this_thread::sleep_for(std::chrono::microseconds(20));
 	}
+	const uint64_t t_let_go = now_ns();
 	const int rc = hnsw_gpu_stream_close(ss->st);
 	if (rc != HNSW_GPU_OK) logf("closing the stream: %s", hnsw_gpu_last_error());
+	if (now_ns() - t_drained > 200000000ull)
+		logf("slow close (%s): %.0f ms for the answer threads to let go, %.0f ms for the launch to end", why, (t_let_go - t_drained) / 1e6,
+			 (now_ns() - t_let_go) / 1e6);
 	long lost = 0;
 	for (uint32_t slot = 0; slot < ss->ring; slot++)
 		if (ss->busy[slot].load())
 		{
+			// (what such a slot looked like, for whoever has to find out why: a query that was never published shows ready != its ticket
+			// or published <= its ticket; one that was published and not walked shows flag 0; one that was walked and not answered flag 1)
+			logf("unanswered slot %u: flag %u, ready word %u, published %u, claimed %u, outstanding %ld, in the ring for %.1f ms, the drain took %.0f ms",
+				 slot, (unsigned) ss->F[slot], ss->ready[slot].load(), ss->pub.load(), ss->claim.load(), ss->outstanding.load(),
+				 (now_ns() - ss->t_pub[slot]) / 1e6, (t_drained - t0) / 1e6);
 			ss->req[slot].c->respond(ss->req[slot].h, HNSW_GPU_ERR_INTERNAL);
 			lost++;
 		}
