@@ -16,5 +16,5 @@ from .bindings import (  # noqa: F401
     DIST_L2, DIST_COSINE, DIST_MANHATTAN,
     PortIndex, RefIndex, FlatHostIndex,
     build_oracle, have_ref, port_dist, port_dist_many, ref_dist, ref_dist_many,
-    elem_size,
+    elem_size, lockstep_insert_compare,
 )

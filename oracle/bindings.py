@@ -96,6 +96,8 @@ def _port():
         L.port_set_dist_fn.argtypes = [C.c_void_p, C.c_void_p]
         L.port_set_dist2_fn.restype = None
         L.port_set_dist2_fn.argtypes = [C.c_void_p, C.c_void_p]
+        L.port_add_shadowed.restype = C.c_long
+        L.port_add_shadowed.argtypes = [C.c_void_p, _f32p, C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_float)]
         _port_lib = L
     return _port_lib
 
@@ -154,6 +156,23 @@ class PortIndex:
         n = self.count * self.elem_size
         buf = (C.c_uint8 * n).from_address(self.L.port_data(self.h))
         return np.frombuffer(buf, dtype=np.uint8).copy()
+
+    def raw_view(self) -> np.ndarray:
+        """The element image itself (writable; valid until the next add)."""
+        n = self.count * self.elem_size
+        buf = (C.c_uint8 * n).from_address(self.L.port_data(self.h))
+        return np.frombuffer(buf, dtype=np.uint8)
+
+    def add_shadowed(self, vec, label: int):
+        """One serial insert (hnsw_bind_point, hnswalg.cpp:117-232, 279-291) with its decision record under the shadow
+        arithmetic (shadow_reference_distances): (idx, div_kind, div_margin) — div_kind 0: the reference's arithmetic
+        builds the same lists from the same state."""
+        vec = _f32(vec)
+        kind, margin = C.c_int32(0), C.c_float(0)
+        r = self.L.port_add_shadowed(self.h, _ptr(vec, _f32p), int(label), C.byref(kind), C.byref(margin))
+        if r < 0:
+            raise RuntimeError(f"port_add_shadowed failed ({r})")
+        return int(r), int(kind.value), float(margin.value)
 
     def load_raw(self, raw: np.ndarray, n: int) -> None:
         raw = np.ascontiguousarray(raw, dtype=np.uint8)
@@ -443,3 +462,54 @@ class FlatHostIndex(_FlatIndexBase):
     def __init__(self, shim_path: str, *a, **k):
         self.L = _host(shim_path)
         super().__init__(*a, **k)
+
+
+def lockstep_insert_compare(dim: int, m: int, efc: int, func: int, X, labels=None, tol: float = 1e-5) -> dict:
+    """Insert-path parity of the canonical arithmetic against the COMPILED REFERENCE, insert by insert (hnswalg.cpp:117-232).
+
+    Two serial builds of the same rows run side by side: `R` = oracle/_ref (the reference's own hnsw_bind_point) and `P` = the
+    port in the canonical order with the reference's hnsw_dist_func as shadow arithmetic.  After every insert the lists the
+    insert may have written (the new element's and those of both sides' selected neighbours) are compared; where they differ,
+    P's lists are overwritten with R's, so that EVERY insert starts from the reference's own graph on both sides and each
+    difference is one insert's own: it must come with a recorded decision (walk, heuristic pair test, candidate or list order)
+    whose two values lie within `tol` relative in the canonical arithmetic — the north-star tolerance — and an insert without
+    such a decision must have written the reference's bytes.  Returns the counts and the unexplained inserts (expected: none)."""
+    X = _f32(X).reshape(-1, dim)
+    n = X.shape[0]
+    if labels is None:
+        labels = np.arange(n, dtype=np.uint64)
+    labels = np.ascontiguousarray(labels, dtype=np.uint64)
+    R = RefIndex(dim, m, efc, 64, func, n)
+    P = PortIndex(dim, m, efc, 64, func, n)
+    P.shadow_reference_distances(True)
+    esz, maxM = P.elem_size, 2 * m
+    lw = maxM + 1
+    differing, unexplained, margins, kinds = [], [], [], {}
+    same_state_claims_broken = []
+    for i in range(n):
+        R.add(X[i:i + 1], labels[i:i + 1])
+        _, kind, margin = P.add_shadowed(X[i], int(labels[i]))
+        rv = R.raw_view().reshape(i + 1, esz)
+        pv = P.raw_view().reshape(i + 1, esz)
+        rl = rv[i, :lw * 4].view(np.uint32)
+        pl = pv[i, :lw * 4].view(np.uint32)
+        touched = {i} | set(rl[1:1 + rl[0]].tolist()) | set(pl[1:1 + pl[0]].tolist())
+        bad = []
+        for e in touched:
+            a = rv[e, :lw * 4].view(np.uint32)
+            b = pv[e, :lw * 4].view(np.uint32)
+            if a[0] != b[0] or (a[1:1 + a[0]] != b[1:1 + a[0]]).any():
+                bad.append(e)
+        if bad:
+            differing.append(i)
+            kinds[kind] = kinds.get(kind, 0) + 1
+            margins.append(margin)
+            if kind == 0:
+                same_state_claims_broken.append(i)
+            elif not margin <= tol:
+                unexplained.append((i, kind, margin))
+            for e in touched:                                  # both sides go on from the reference's graph
+                pv[e, :lw * 4] = rv[e, :lw * 4]
+    return {"inserts": n, "inserts_with_differing_lists": len(differing), "first_differing": differing[:8],
+            "decision_kinds": kinds, "largest_margin": max(margins) if margins else 0.0,
+            "unexplained": unexplained, "no_decision_but_different": same_state_claims_broken}

@@ -531,8 +531,12 @@ int port_search(PortIndex *ix, const float *q, size_t ef, uint64_t *label_out, f
 /* ------------------------------------------------------------------------- */
 
 /* getNeighborsByHeuristic, hnswalg.cpp:117-153.  `top` is a max-heap on
- * (dist, idx); on return it holds at most NN survivors. */
-static void port_neighbors_by_heuristic(const PortIndex *ix, Heap *top, size_t NN, PortStats *st)
+ * (dist, idx); on return it holds at most NN survivors.
+ * sh: NULL, or the shadow arithmetic's distance of every element of `top` to the same centre, indexed by element
+ * number (port_set_dist2_fn): the first decision it would take differently is recorded in st->div_* — 6 which
+ * candidate is considered next (:130-134), 7 the pair test (:144), [8 = the order of a written list, in
+ * port_mutually_connect]. */
+static void port_neighbors_by_heuristic(const PortIndex *ix, Heap *top, size_t NN, PortStats *st, const float *sh)
 {
 	if (top->n < NN)                                         /* :119-120 */
 		return;
@@ -551,6 +555,15 @@ static void port_neighbors_by_heuristic(const PortIndex *ix, Heap *top, size_t N
 		if (nret >= NN)                                      /* :131-132 */
 			break;
 		HPair cur = heap_top(&rs);
+		if (sh)                                              /* would the shadow look at another candidate now? */
+		{
+			HPair mine = { -sh[cur.k], cur.k };
+			for (size_t i = 1; i < rs.n; i++)
+			{
+				HPair o = { -sh[rs.a[i].k], rs.a[i].k };
+				if (pair_less(mine, o)) { note_div(st, 6, cur.d, rs.a[i].d); break; }
+			}
+		}
 		float dist_to_query = -cur.d;
 		heap_pop(&rs);
 		bool good = true;
@@ -559,6 +572,11 @@ static void port_neighbors_by_heuristic(const PortIndex *ix, Heap *top, size_t N
 			float curdist = ix->dist(ix->func, el_vec(ix, (uint32_t) ret[i].k),
 									  el_vec(ix, (uint32_t) cur.k), ix->dim);
 			st->evals++;
+			if (sh)
+			{
+				float curdist2 = ix->dist2(ix->func, el_vec(ix, (uint32_t) ret[i].k), el_vec(ix, (uint32_t) cur.k), ix->dim);
+				if ((curdist < dist_to_query) != (curdist2 < sh[cur.k])) note_div(st, 7, curdist, dist_to_query);
+			}
 			if (curdist < dist_to_query) { good = false; break; }
 		}
 		if (good) ret[nret++] = cur;                         /* :149 */
@@ -569,14 +587,35 @@ static void port_neighbors_by_heuristic(const PortIndex *ix, Heap *top, size_t N
 	heap_free(&rs);
 }
 
-/* mutuallyConnectNewElement, hnswalg.cpp:155-223.  Returns 0, or -1 where the
- * reference throws. */
-static int port_mutually_connect(PortIndex *ix, uint32_t cur_c, Heap *top, PortStats *st)
+/* pops `h` (max-heap on (dist, idx)) into out[] farthest first, as :164-167 and :214-219 do; with a shadow
+ * arithmetic, notes where ITS (dist, idx) order of the same elements would differ (kind 8) */
+static size_t drain_farthest_first(Heap *h, uint32_t *out, PortStats *st, const float *sh)
 {
-	port_neighbors_by_heuristic(ix, top, ix->M, st);          /* :158 */
-	size_t nres = 0;
+	size_t n = 0;
+	HPair prev = { 0, 0 };
+	while (h->n)
+	{
+		HPair p = heap_top(h);
+		if (sh && n > 0)
+		{
+			HPair p2 = { sh[p.k], p.k }, prev2 = { sh[prev.k], prev.k };
+			if (pair_less(prev2, p2)) note_div(st, 8, p.d, prev.d);
+		}
+		out[n++] = (uint32_t) p.k;
+		prev = p;
+		heap_pop(h);
+	}
+	return n;
+}
+
+/* mutuallyConnectNewElement, hnswalg.cpp:155-223.  Returns 0, or -1 where the
+ * reference throws.  d2q / d2n: NULL, or two arrays of ix->n floats for the shadow arithmetic — d2q holds its
+ * distances to the new point for every element the walk scored, d2n is scratch for the re-selections. */
+static int port_mutually_connect(PortIndex *ix, uint32_t cur_c, Heap *top, PortStats *st, const float *d2q, float *d2n)
+{
+	port_neighbors_by_heuristic(ix, top, ix->M, st, d2q);     /* :158 */
 	uint32_t *res = (uint32_t *) malloc((top->n ? top->n : 1) * 4);
-	while (top->n) { res[nres++] = (uint32_t) heap_top(top).k; heap_pop(top); }   /* :164-167: farthest first */
+	size_t nres = drain_farthest_first(top, res, st, d2q);    /* :164-167: farthest first */
 
 	uint32_t *mine = el_links(ix, cur_c);                     /* :169-181 */
 	if (mine[0]) { free(res); return -1; }                    /* "Should be blank" */
@@ -603,23 +642,18 @@ static int port_mutually_connect(PortIndex *ix, uint32_t cur_c, Heap *top, PortS
 			Heap cands;
 			heap_init(&cands);
 			float d_max = ix->dist(ix->func, el_vec(ix, cur_c), pc, ix->dim);    /* :200 */
+			if (d2n) d2n[cur_c] = ix->dist2(ix->func, el_vec(ix, cur_c), pc, ix->dim);
 			st->evals++;
 			heap_push(&cands, d_max, cur_c);                                      /* :204 */
 			for (uint32_t j = 0; j < sz; j++)                                     /* :206-211 */
 			{
 				uint32_t o = other[1 + j];
 				heap_push(&cands, ix->dist(ix->func, el_vec(ix, o), pc, ix->dim), o);
+				if (d2n) d2n[o] = ix->dist2(ix->func, el_vec(ix, o), pc, ix->dim);
 				st->evals++;
 			}
-			port_neighbors_by_heuristic(ix, &cands, ix->maxM, st);                /* :212 */
-			uint32_t k = 0;
-			while (cands.n)                                                       /* :214-219 */
-			{
-				other[1 + k] = (uint32_t) heap_top(&cands).k;
-				heap_pop(&cands);
-				k++;
-			}
-			other[0] = k;
+			port_neighbors_by_heuristic(ix, &cands, ix->maxM, st, d2n);           /* :212 */
+			other[0] = (uint32_t) drain_farthest_first(&cands, other + 1, st, d2n);   /* :214-219 */
 			heap_free(&cands);
 		}
 	}
@@ -627,21 +661,37 @@ static int port_mutually_connect(PortIndex *ix, uint32_t cur_c, Heap *top, PortS
 	return 0;
 }
 
-/* bindPoint / hnsw_bind_point, hnswalg.cpp:225-232, 279-291. */
-int port_bind_point(PortIndex *ix, const float *point, uint32_t cur_c)
+/* bindPoint / hnsw_bind_point, hnswalg.cpp:225-232, 279-291.  st_out: NULL, or where the insert's decision record goes
+ * (div_kind / div_margin under a shadow arithmetic: the first decision of the walk, the selections or the list orders that
+ * the second arithmetic would take differently — none: it builds the same bytes). */
+static int port_bind_point_st(PortIndex *ix, const float *point, uint32_t cur_c, PortStats *st_out)
 {
 	if (cur_c == 0)                                           /* :228 */
 		return 0;
 	Heap top;
 	PortStats st = PORT_STATS_INIT;
-	port_search_base_layer(ix, point, ix->efc, &top, &st, NULL);    /* :229 */
-	int rc = port_mutually_connect(ix, cur_c, &top, &st);     /* :230 */
+	float *d2q = NULL, *d2n = NULL;
+	if (ix->dist2)
+	{
+		d2q = (float *) malloc(ix->n * 4);
+		d2n = (float *) malloc(ix->n * 4);
+		if (!d2q || !d2n) { free(d2q); free(d2n); return -1; }
+	}
+	port_search_base_layer(ix, point, ix->efc, &top, &st, d2q);     /* :229 */
+	int rc = port_mutually_connect(ix, cur_c, &top, &st, d2q, d2n);  /* :230 */
 	heap_free(&top);
+	free(d2q); free(d2n);
+	if (st_out) *st_out = st;
 	return rc;
 }
 
+int port_bind_point(PortIndex *ix, const float *point, uint32_t cur_c)
+{
+	return port_bind_point_st(ix, point, cur_c, NULL);
+}
+
 /* hnsw_add_point minus paging (embedding.c:606-701): store zero-linked, then bind. */
-long port_add(PortIndex *ix, const float *vec, uint64_t label)
+static long port_add_st(PortIndex *ix, const float *vec, uint64_t label, PortStats *st_out)
 {
 	if (port_reserve(ix, ix->n + 1) != 0) return -1;
 	uint32_t idx = (uint32_t) ix->n;
@@ -650,8 +700,25 @@ long port_add(PortIndex *ix, const float *vec, uint64_t label)
 	memcpy(p + ix->off_data, vec, ix->dim * 4);
 	memcpy(p + ix->off_label, &label, 8);
 	ix->n++;
-	if (port_bind_point(ix, vec, idx) != 0) return -2;
+	if (port_bind_point_st(ix, vec, idx, st_out) != 0) return -2;
 	return (long) idx;
+}
+
+long port_add(PortIndex *ix, const float *vec, uint64_t label)
+{
+	return port_add_st(ix, vec, label, NULL);
+}
+
+/* One insert with its decision record under the shadow arithmetic (port_set_dist2_fn): div_kind 0 = the second arithmetic
+ * builds the same lists from the same state; else the kind of the first decision it takes differently (1-4 the walk,
+ * 6 / 7 getNeighborsByHeuristic, 8 the order of a written list) and the relative gap of the two values compared. */
+long port_add_shadowed(PortIndex *ix, const float *vec, uint64_t label, int32_t *div_kind, float *div_margin)
+{
+	PortStats st = PORT_STATS_INIT;
+	long r = port_add_st(ix, vec, label, &st);
+	if (div_kind) *div_kind = st.div_kind;
+	if (div_margin) *div_margin = st.div_margin;
+	return r;
 }
 
 long port_add_many(PortIndex *ix, const float *vecs, const uint64_t *labels, size_t n)

@@ -17,28 +17,39 @@
 // L2 uses |q|^2 + |x|^2 - 2 q.x, cosine 1 - q.x / sqrt(|q|^2 |x|^2) (distfunc.c:133-145);
 // Manhattan is not a contraction and is not offered here.
 //
-// Tiling: block = 4 waves, 128 queries x 128 rows per block, K in steps of 32 floats staged
-// through LDS k-major (operand reads are then unit-stride across lanes: conflict-free
-// ds_read_b32), each wave owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles (64 accumulator VGPRs).
-// blockIdx is remapped so that all query tiles of one row tile run on the same XCD
-// (block b -> XCD b % 8) and the row tile is fetched from HBM once per XCD L2.
+// Tiling (round 5): block = 4 waves, 128 queries x 128 rows per block, K in steps of 32 floats.  Global loads are whole
+// 128-byte lines (8 lanes x float4 per tile row: one wave instruction = 8 rows x 128 B) and go to LDS ROW-major with a padded
+// row stride of 36 floats, one ds_write_b128 per float4 — no transposition: a filter may sum a dot product in any k order as
+// long as both operands use the same one, so lane (col, kk) of an MFMA takes the four k of ONE ds_read_b128 (k = 8g + 4kk + s,
+// s = 0..3) and feeds them to four consecutive MFMAs.  Per 32-float K step a wave issues 16 ds_read_b128 for 64 MFMAs (round
+// 1-4: 64 ds_read_b32 + 32 ds_write_b32 per thread, and global loads that touched 64 different lines per instruction).  Two
+// LDS buffers: the stores of step ks + 1 go to the other buffer, ONE barrier per step.  Each wave owns a 64 x 64 sub-tile =
+// 2 x 2 MFMA tiles (64 accumulator registers).  blockIdx is remapped so that all query tiles of one row tile run on the same
+// XCD (block b -> XCD b % 8) and the row tile is fetched from HBM once per XCD L2.
 #pragma once
 #include "device_search.h"
 
 namespace pgemb {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx4 __attribute__((ext_vector_type(4)));       // (a first-class vector: HIP's float4 struct went through scratch here)
 
 constexpr int BF_TQ = 128, BF_TR = 128, BF_TK = 32;
+constexpr int BF_LS = BF_TK + 4;                     // LDS row stride in floats: 144 B, 8 consecutive rows x 16 B hit 8 distinct bank quads
+#ifndef BF_NBUF
+#define BF_NBUF 2
+#endif
+constexpr int BF_TILE_FLOATS = BF_TQ * BF_LS;        // one operand tile
+constexpr size_t BF_LDS_BYTES = (size_t) BF_NBUF * 2 * BF_TILE_FLOATS * sizeof(float);
 
 struct BfArgs
 {
-	const float *queries;      // [nq_pad][stride] zero padded copy
+	const float *queries;      // [nq][qstride] copy, zero padded to whole K steps (qstride = round_up(stride, BF_TK))
 	const float *qnorm;        // |q|^2
 	const float *qbound;       // L2: squared bound; cosine: threshold on dot / sqrt(|x|^2)
 	const float *vec;          // [n][stride]
 	const float *xnorm;        // |x|^2
-	uint32_t nq, n, stride, ksteps;
+	uint32_t nq, n, stride, qstride, ksteps;
 	int func;
 	uint32_t *cand;            // [nq][cap]
 	uint32_t *cand_cnt;        // [nq]
@@ -46,10 +57,9 @@ struct BfArgs
 	uint32_t nqt, nrt;         // tiles
 };
 
-__global__ __launch_bounds__(256) void bf_mfma_filter_kernel(const BfArgs a)
+__global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 {
-	__shared__ float As[BF_TK * BF_TQ];      // [k][q]
-	__shared__ float Bs[BF_TK * BF_TR];      // [k][r]
+	extern __shared__ __attribute__((aligned(16))) float bf_lds[];      // [buf][A | B][row][BF_LS]
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	// XCD-aware tile order: the nqt query tiles of one row tile share b % 8
 	const uint32_t b = blockIdx.x;
@@ -59,12 +69,17 @@ __global__ __launch_bounds__(256) void bf_mfma_filter_kernel(const BfArgs a)
 	if (rt >= a.nrt) return;
 	const uint32_t q0 = qt * BF_TQ, r0 = rt * BF_TR;
 
-	// staging role: thread owns one tile row (query or index row) and half of the K step
-	const uint32_t srow = t & 127, shalf = t >> 7;
-	const uint32_t qrow = min(q0 + srow, a.nq - 1), xrow = min(r0 + srow, a.n - 1);
-	const float4 *qsrc = reinterpret_cast<const float4 *>(a.queries + (size_t) qrow * a.stride);
-	const float4 *xsrc = reinterpret_cast<const float4 *>(a.vec + (size_t) xrow * a.stride);
+	// staging role: thread owns float4 chunk `sch` (of the 8 of a K step) of tile rows srow + 32 j: a wave instruction reads
+	// 8 rows x 128 contiguous bytes
+	const uint32_t sch = t & 7, srow = t >> 3;
 	const uint32_t nchunks = a.stride / 4;
+	const floatx4 *qsrc[4], *xsrc[4];
+#pragma unroll
+	for (int j = 0; j < 4; j++)
+	{
+		qsrc[j] = reinterpret_cast<const floatx4 *>(a.queries + (size_t) min(q0 + srow + 32 * j, a.nq - 1) * a.qstride);
+		xsrc[j] = reinterpret_cast<const floatx4 *>(a.vec + (size_t) min(r0 + srow + 32 * j, a.n - 1) * a.stride);
+	}
 
 	floatx16 acc[2][2];
 #pragma unroll
@@ -76,49 +91,71 @@ __global__ __launch_bounds__(256) void bf_mfma_filter_kernel(const BfArgs a)
 	const uint32_t wm = wave >> 1, wn = wave & 1;          // 2 x 2 waves over the block tile
 	const uint32_t kk = lane >> 5, col = lane & 31;
 
-	// Software pipeline: the global loads of K-step ks+1 are issued before the MFMAs of step ks, so
-	// their latency is covered by 64 MFMAs per wave instead of being exposed between two barriers.
-	float4 qa[4], xb[4];
+	floatx4 qa[4], xb[4];
+	// No select on a loaded value (it would pull the wait for the loads in front of the MFMAs): the query copy is zero padded
+	// to whole K steps, and a row chunk beyond the row's end re-reads the row's last chunk (times zero: nothing).
 	auto fetch = [&](uint32_t ks)
 	{
+		const uint32_t c = ks * 8 + sch;                          // float4 chunk along K
+		const uint32_t cc = min(c, nchunks - 1);
+#pragma unroll
+		for (int j = 0; j < 4; j++) { qa[j] = qsrc[j][c]; xb[j] = xsrc[j][cc]; }
+	};
+	auto stage = [&](uint32_t buf)
+	{
+		float *As = bf_lds + (size_t) buf * 2 * BF_TILE_FLOATS, *Bs = As + BF_TILE_FLOATS;
 #pragma unroll
 		for (int j = 0; j < 4; j++)
 		{
-			const uint32_t c = ks * 8 + shalf * 4 + j;              // float4 chunk along K
-			const uint32_t cc = c < nchunks ? c : nchunks - 1;       // unconditional loads, then select
-			const float4 tq = qsrc[cc], tx = xsrc[cc];
-			qa[j] = c < nchunks ? tq : make_float4(0.f, 0.f, 0.f, 0.f);
-			xb[j] = c < nchunks ? tx : make_float4(0.f, 0.f, 0.f, 0.f);
+			*reinterpret_cast<floatx4 *>(As + (srow + 32 * j) * BF_LS + sch * 4) = qa[j];
+			*reinterpret_cast<floatx4 *>(Bs + (srow + 32 * j) * BF_LS + sch * 4) = xb[j];
 		}
 	};
+	auto contract = [&](uint32_t buf)
+	{
+		const float *As = bf_lds + (size_t) buf * 2 * BF_TILE_FLOATS + (wm * 64 + col) * BF_LS + kk * 4;
+		const float *Bs = bf_lds + (size_t) buf * 2 * BF_TILE_FLOATS + BF_TILE_FLOATS + (wn * 64 + col) * BF_LS + kk * 4;
+#pragma unroll
+		for (int g = 0; g < BF_TK / 8; g++)
+		{
+			const floatx4 a0 = *reinterpret_cast<const floatx4 *>(As + g * 8);
+			const floatx4 a1 = *reinterpret_cast<const floatx4 *>(As + 32 * BF_LS + g * 8);
+			const floatx4 b0 = *reinterpret_cast<const floatx4 *>(Bs + g * 8);
+			const floatx4 b1 = *reinterpret_cast<const floatx4 *>(Bs + 32 * BF_LS + g * 8);
+#define BF_STEP(C)                                                                          \
+			acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.C, b0.C, acc[0][0], 0, 0, 0);    \
+			acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.C, b1.C, acc[0][1], 0, 0, 0);    \
+			acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.C, b0.C, acc[1][0], 0, 0, 0);    \
+			acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.C, b1.C, acc[1][1], 0, 0, 0);
+			BF_STEP(x) BF_STEP(y) BF_STEP(z) BF_STEP(w)
+#undef BF_STEP
+		}
+	};
+
+	// Software pipeline: the global loads of K step ks + 1 are issued before the 64 MFMAs of step ks and stored behind them.
 	fetch(0);
+#if BF_NBUF == 2
+	stage(0);
+	__syncthreads();
+	for (uint32_t ks = 0; ks < a.ksteps; ks++)
+	{
+		fetch(min(ks + 1, a.ksteps - 1));                          // (branch-free: the last step re-reads itself into the idle buffer)
+		__builtin_amdgcn_sched_barrier(0);                         // the loads are ISSUED here, not sunk behind the MFMAs
+		contract(ks & 1);
+		__builtin_amdgcn_sched_barrier(0);
+		stage((ks + 1) & 1);                                       // the other buffer: its readers passed the previous barrier
+		__syncthreads();
+	}
+#else
 	for (uint32_t ks = 0; ks < a.ksteps; ks++)
 	{
 		__syncthreads();                                            // previous step's operand reads are done
-#pragma unroll
-		for (int j = 0; j < 4; j++)
-		{
-			const uint32_t k = shalf * 16 + j * 4;
-			As[(k + 0) * BF_TQ + srow] = qa[j].x; As[(k + 1) * BF_TQ + srow] = qa[j].y;
-			As[(k + 2) * BF_TQ + srow] = qa[j].z; As[(k + 3) * BF_TQ + srow] = qa[j].w;
-			Bs[(k + 0) * BF_TR + srow] = xb[j].x; Bs[(k + 1) * BF_TR + srow] = xb[j].y;
-			Bs[(k + 2) * BF_TR + srow] = xb[j].z; Bs[(k + 3) * BF_TR + srow] = xb[j].w;
-		}
+		stage(0);
 		__syncthreads();
 		if (ks + 1 < a.ksteps) fetch(ks + 1);                       // in flight during the MFMAs below
-#pragma unroll
-		for (int k2 = 0; k2 < BF_TK; k2 += 2)
-		{
-			const float a0 = As[(k2 + kk) * BF_TQ + wm * 64 + col];
-			const float a1 = As[(k2 + kk) * BF_TQ + wm * 64 + 32 + col];
-			const float b0 = Bs[(k2 + kk) * BF_TR + wn * 64 + col];
-			const float b1 = Bs[(k2 + kk) * BF_TR + wn * 64 + 32 + col];
-			acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-			acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-			acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-			acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-		}
+		contract(0);
 	}
+#endif
 
 	// epilogue: C[q][r]; lane holds column r = lane & 31, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
 #pragma unroll

@@ -1780,7 +1780,8 @@ extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d
 	const size_t sample = std::min<size_t>(ix->n, std::max<size_t>(8192, (size_t) k * ix->n / 2048));
 	// scratch carve
 	const size_t o_q = 0;
-	const size_t o_qn = o_q + round_up(nq * stride * 4, 256);
+	const uint32_t qstride = (uint32_t) round_up(stride, BF_TK);        // the filter's query copy: zero padded to whole K steps
+	const size_t o_qn = o_q + round_up(nq * qstride * 4, 256);
 	const size_t o_sidx = o_qn + round_up(nq * 4, 256);
 	const size_t o_sdist = o_sidx + round_up(nq * k * 4, 256);
 	const size_t o_bound = o_sdist + round_up(nq * k * 4, 256);
@@ -1802,9 +1803,9 @@ extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d
 	// 1. bound per query from a canonical scan of the sample rows
 	int rc = bruteforce_prefix(ix, sample, d_queries, nq, k, sidx, sdist, s);
 	if (rc) return rc;
-	const size_t qtot = nq * (size_t) stride;
-	hipLaunchKernelGGL(pad_queries_kernel, dim3((uint32_t) ((qtot + 255) / 256)), dim3(256), 0, s, d_queries, (uint32_t) nq, dim, stride, qpad);
-	hipLaunchKernelGGL(row_norm2_kernel, dim3((uint32_t) ((nq + 3) / 4)), dim3(256), 0, s, qpad, (uint32_t) nq, stride, qn);
+	const size_t qtot = nq * (size_t) qstride;
+	hipLaunchKernelGGL(pad_queries_kernel, dim3((uint32_t) ((qtot + 255) / 256)), dim3(256), 0, s, d_queries, (uint32_t) nq, dim, qstride, qpad);
+	hipLaunchKernelGGL(row_norm2_kernel, dim3((uint32_t) ((nq + 3) / 4)), dim3(256), 0, s, qpad, (uint32_t) nq, qstride, qn);
 	// tau_q = sdist[q*k + k-1]: gather with a strided view
 	{
 		// reuse make_bounds on a compacted tau array: write tau into `bound` first
@@ -1818,14 +1819,16 @@ extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d
 	BfArgs a;
 	memset(&a, 0, sizeof(a));
 	a.queries = qpad; a.qnorm = qn; a.qbound = bound; a.vec = ix->vec; a.xnorm = ix->xnorm;
-	a.nq = (uint32_t) nq; a.n = n; a.stride = stride; a.ksteps = (stride + BF_TK - 1) / BF_TK; a.func = func;
+	a.nq = (uint32_t) nq; a.n = n; a.stride = stride; a.qstride = qstride; a.ksteps = qstride / BF_TK; a.func = func;
 	a.cand = cand; a.cand_cnt = cnt; a.cap = cap;
 	a.nqt = (uint32_t) ((nq + BF_TQ - 1) / BF_TQ); a.nrt = (n + BF_TR - 1) / BF_TR;
 	const uint32_t rgroups = (a.nrt + 7) / 8;
 	if (!ix->bf_e0) { HIPCHK(hipEventCreate(&ix->bf_e0)); HIPCHK(hipEventCreate(&ix->bf_e1)); }
 	hipEvent_t e0 = ix->bf_e0, e1 = ix->bf_e1;
 	HIPCHK(hipEventRecord(e0, s));
-	hipLaunchKernelGGL(bf_mfma_filter_kernel, dim3(rgroups * a.nqt * 8), dim3(256), 0, s, a);
+	// two operand tiles of 128 x 36 floats, twice: 72 KB of LDS per block (set per call: the attribute is per device)
+	HIPCHK(hipFuncSetAttribute((const void *) bf_mfma_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) BF_LDS_BYTES));
+	hipLaunchKernelGGL(bf_mfma_filter_kernel, dim3(rgroups * a.nqt * 8), dim3(256), BF_LDS_BYTES, s, a);
 	HIPCHK(hipEventRecord(e1, s));
 
 	// 3. canonical re-score of the survivors

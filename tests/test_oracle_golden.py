@@ -174,3 +174,22 @@ def test_fixture_file_is_current():
         ref2.add(X[:300])
         assert (ref2.raw() == ref.raw()).all()
         assert links[0, 0] <= 2 * m
+
+
+@pytest.mark.skipif(not oracle.have_ref(), reason="oracle/_ref not built")
+@pytest.mark.parametrize("func", [oracle.DIST_L2, oracle.DIST_COSINE, oracle.DIST_MANHATTAN])
+def test_insert_path_against_the_compiled_reference_insert_by_insert(func):
+    """hnswalg.cpp:117-232 at the bench's build configuration (m = 16, efconstruction = 200), small enough for this tier: the
+    port's serial inserts against the compiled reference's, every insert starting from the reference's own graph
+    (oracle.lockstep_insert_compare; the full sizes run in tests/test_gpu_insert_fullsize.py).  An insert that writes other lists
+    carries a recorded decision within 1e-5; one without a diverging decision writes the reference's bytes."""
+    dim, n = 128, 4000
+    X = gmm(n, dim, k=40, seed=31 + func)
+    res = oracle.lockstep_insert_compare(dim, 16, 200, func, X, tol=REL_TOL)
+    assert res["unexplained"] == [] and res["no_decision_but_different"] == [], res
+    assert res["inserts_with_differing_lists"] <= n // 100, res
+    # integer-valued rows: both arithmetics are exact, so every insert must write the reference's bytes
+    Xi = np.round(X * 3).astype(np.float32)
+    if func != oracle.DIST_COSINE:
+        res = oracle.lockstep_insert_compare(dim, 16, 200, func, Xi[:1500], tol=REL_TOL)
+        assert res["inserts_with_differing_lists"] == 0, res
