@@ -299,6 +299,8 @@ int  hnsw_gpu_ctx_idle(hnsw_gpu_ctx *ctx);
  *   hnsw_gpu_stream_close   stop: every wave leaves at its next look (a walking wave after its query); waits for the launch to end
  *                           (a launch that does not end within 2 s is asked through its abort word), frees the ring.  Queries
  *                           published but not yet started are dropped: close a stream when nothing is outstanding.
+ *   hnsw_gpu_stream_abandon the same stop, but the ring is NOT freed (leaked on purpose): for a host that had to give a stream up while
+ *                           it could not prove that none of its own threads was still inside the ring.
  * Results do not depend on the mode: a query's walk is the same walk in a plain launch, a team launch or a stream. */
 typedef struct hnsw_gpu_stream hnsw_gpu_stream;
 int  hnsw_gpu_stream_open(hnsw_gpu_ctx *ctx, size_t ef, size_t ring, unsigned walkers, hnsw_gpu_stream **out);
@@ -306,6 +308,7 @@ int  hnsw_gpu_stream_buffers(hnsw_gpu_stream *s, coord_t **queries, label_t **la
 int  hnsw_gpu_stream_publish(hnsw_gpu_stream *s, uint32_t published_total);
 int  hnsw_gpu_stream_alive(hnsw_gpu_stream *s);
 int  hnsw_gpu_stream_close(hnsw_gpu_stream *s);
+int  hnsw_gpu_stream_abandon(hnsw_gpu_stream *s);
 
 /* One query together with its walk: the results of hnsw_gpu_search_batch plus the sequence of elements the walk expanded
  * (candidateSet pops, hnswalg.cpp:73; *npops of them, the first min(*npops, pops_cap) stored) and the number of distance
@@ -357,6 +360,8 @@ int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d_queries, s
 /* Device milliseconds of the GEMM/filter kernel of the last call above (MFMA roofline figure:
  * 2*nq*n*stride flops). */
 float hnsw_gpu_last_bruteforce_gemm_ms(void);
+/* shader clock (MHz) a block of that kernel saw over its K loop: shader-clock ticks / constant-clock ticks (measurement only) */
+double hnsw_gpu_last_bruteforce_clock_mhz(void);
 
 /* ----------------------------------------------------------------- multi-shard */
 

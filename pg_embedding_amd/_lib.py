@@ -156,6 +156,7 @@ def gpu_lib():
     L.hnsw_gpu_bruteforce_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp]
     L.hnsw_gpu_bruteforce_mfma_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp]
     L.hnsw_gpu_last_bruteforce_gemm_ms.restype = C.c_float
+    L.hnsw_gpu_last_bruteforce_clock_mhz.restype = C.c_double
     L.hnsw_gpu_merge_topk_dev.argtypes = [i32, vp, vp, sz, sz, sz, vp, vp, vp, vp]
     L.hnsw_gpu_merge_topk_strided_dev.argtypes = [i32, vp, sz, vp, sz, sz, sz, sz, vp, vp, vp, vp]
     L.hnsw_gpu_last_search_kernel.argtypes = [vp, C.c_char_p, sz]
@@ -177,6 +178,7 @@ def gpu_lib():
     L.hnsw_gpu_stream_publish.argtypes = [vp, C.c_uint32]
     L.hnsw_gpu_stream_alive.argtypes = [vp]
     L.hnsw_gpu_stream_close.argtypes = [vp]
+    L.hnsw_gpu_stream_abandon.argtypes = [vp]
     L.hnsw_gpu_config_set.argtypes = [C.c_char_p, C.c_char_p]
     L.hnsw_gpu_config_get.argtypes = [C.c_char_p, C.POINTER(C.c_longlong)]
     L.hnsw_gpu_config_reload.restype = None

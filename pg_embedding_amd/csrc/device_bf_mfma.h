@@ -35,12 +35,20 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));       // (a first-class vector: HIP's float4 struct went through scratch here)
 
 constexpr int BF_TQ = 128, BF_TR = 128, BF_TK = 32;
-constexpr int BF_LS = BF_TK + 4;                     // LDS row stride in floats: 144 B, 8 consecutive rows x 16 B hit 8 distinct bank quads
+#ifndef BF_GLDS
+#define BF_GLDS 1                                    // 1: tiles go global -> LDS directly (global_load_lds_dwordx4), 0: through registers
+#endif
 #ifndef BF_NBUF
 #define BF_NBUF 2
 #endif
+#if BF_GLDS
+constexpr int BF_LS = BF_TK;                         // lane-linear LDS image: 128-byte rows, chunk c of row r at slot c ^ ((r >> 1) & 7)
+#else
+constexpr int BF_LS = BF_TK + 4;                     // padded rows: 144 B, 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte slots
+#endif
 constexpr int BF_TILE_FLOATS = BF_TQ * BF_LS;        // one operand tile
-constexpr size_t BF_LDS_BYTES = (size_t) BF_NBUF * 2 * BF_TILE_FLOATS * sizeof(float);
+constexpr int BF_EPI_FLOATS = 2 * BF_TQ;              // the tile's per-query bound and |q|^2, staged for the epilogue
+constexpr size_t BF_LDS_BYTES = ((size_t) BF_NBUF * 2 * BF_TILE_FLOATS + BF_EPI_FLOATS) * sizeof(float);
 
 struct BfArgs
 {
@@ -55,11 +63,13 @@ struct BfArgs
 	uint32_t *cand_cnt;        // [nq]
 	uint32_t cap;
 	uint32_t nqt, nrt;         // tiles
+	unsigned long long *clocks; // NULL, or 2 words: shader-clock and constant-clock ticks one block spent in its K loop (measurement only)
 };
 
 __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 {
-	extern __shared__ __attribute__((aligned(16))) float bf_lds[];      // [buf][A | B][row][BF_LS]
+	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+	float *bf_lds = reinterpret_cast<float *>(smem);                    // [buf][A | B][row][BF_LS], then the epilogue's bounds
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	// XCD-aware tile order: the nqt query tiles of one row tile share b % 8
 	const uint32_t b = blockIdx.x;
@@ -69,7 +79,7 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 	if (rt >= a.nrt) return;
 	const uint32_t q0 = qt * BF_TQ, r0 = rt * BF_TR;
 
-	// staging role: thread owns float4 chunk `sch` (of the 8 of a K step) of tile rows srow + 32 j: a wave instruction reads
+	// staging role: thread owns one 16-byte slot `sch` (of the 8 of a K step) of tile rows srow + 32 j: a wave instruction reads
 	// 8 rows x 128 contiguous bytes
 	const uint32_t sch = t & 7, srow = t >> 3;
 	const uint32_t nchunks = a.stride / 4;
@@ -91,9 +101,52 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 	const uint32_t wm = wave >> 1, wn = wave & 1;          // 2 x 2 waves over the block tile
 	const uint32_t kk = lane >> 5, col = lane & 31;
 
-	floatx4 qa[4], xb[4];
+	// What the epilogue compares with is fetched NOW, behind the K loop: every block of a launch takes the same time, so the blocks of
+	// a CU reach their epilogues together, and an epilogue that loads its 32 bounds per lane one dependent L2 round trip after the
+	// other (rounds 1-4) leaves the matrix pipe idle for a tenth of every round.  The tile's 128 bounds and |q|^2 go to LDS (read back
+	// four at a time), the two |x|^2 of the lane's columns to registers.
+	float *epi = bf_lds + (size_t) BF_NBUF * 2 * BF_TILE_FLOATS;
+	if (t < BF_TQ)
+	{
+		const uint32_t qi = min(q0 + (uint32_t) t, a.nq - 1);
+		epi[t] = a.qbound[qi];
+		epi[BF_TQ + t] = a.qnorm[qi];
+	}
+	float xs2[2];
+#pragma unroll
+	for (int j = 0; j < 2; j++)
+	{
+		const float xn = a.xnorm[min(r0 + wn * 64 + j * 32 + col, a.n - 1)];
+		xs2[j] = (a.func == F_COSINE) ? __builtin_sqrtf(xn) : xn;
+	}
+
 	// No select on a loaded value (it would pull the wait for the loads in front of the MFMAs): the query copy is zero padded
 	// to whole K steps, and a row chunk beyond the row's end re-reads the row's last chunk (times zero: nothing).
+#if BF_GLDS
+	// The LDS image is what the hardware writes: wave-uniform base + lane * 16, i.e. 8 rows x 128 B per instruction, no padding.
+	// Bank conflicts are avoided on the SOURCE side: slot p of row r holds chunk p ^ ((r >> 1) & 7) — still whole 128-byte lines per
+	// row from memory, and the 16 lanes of every ds_read_b128 group ((r & 1), (r >> 1) & 7 all distinct) land on 16 distinct slots.
+	const uint32_t gch = sch ^ ((srow >> 1) & 7);              // the chunk this lane fetches ((srow + 32 j) >> 1) & 7 == (srow >> 1) & 7
+	auto fetch = [&](uint32_t ks, uint32_t buf)
+	{
+		const uint32_t c = ks * 8 + gch;
+		const uint32_t cc = min(c, nchunks - 1);
+		float *As = bf_lds + (size_t) buf * 2 * BF_TILE_FLOATS + (wave * 8) * BF_LS, *Bs = As + BF_TILE_FLOATS;
+#pragma unroll
+		for (int j = 0; j < 4; j++)
+		{
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (qsrc[j] + c),
+											 (__attribute__((address_space(3))) void *) (As + 32 * j * BF_LS), 16, 0, 0);
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (xsrc[j] + cc),
+											 (__attribute__((address_space(3))) void *) (Bs + 32 * j * BF_LS), 16, 0, 0);
+		}
+	};
+	const uint32_t swz = (col >> 1) & 7;
+	uint32_t roff[BF_TK / 8];                                  // float offset of k-group g's slot in this lane's row
+#pragma unroll
+	for (int g = 0; g < BF_TK / 8; g++) roff[g] = ((2 * g + kk) ^ swz) * 4;
+#else
+	floatx4 qa[4], xb[4];
 	auto fetch = [&](uint32_t ks)
 	{
 		const uint32_t c = ks * 8 + sch;                          // float4 chunk along K
@@ -111,17 +164,23 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 			*reinterpret_cast<floatx4 *>(Bs + (srow + 32 * j) * BF_LS + sch * 4) = xb[j];
 		}
 	};
+#endif
 	auto contract = [&](uint32_t buf)
 	{
-		const float *As = bf_lds + (size_t) buf * 2 * BF_TILE_FLOATS + (wm * 64 + col) * BF_LS + kk * 4;
-		const float *Bs = bf_lds + (size_t) buf * 2 * BF_TILE_FLOATS + BF_TILE_FLOATS + (wn * 64 + col) * BF_LS + kk * 4;
+		const float *As = bf_lds + (size_t) buf * 2 * BF_TILE_FLOATS + (wm * 64 + col) * BF_LS;
+		const float *Bs = bf_lds + (size_t) buf * 2 * BF_TILE_FLOATS + BF_TILE_FLOATS + (wn * 64 + col) * BF_LS;
 #pragma unroll
 		for (int g = 0; g < BF_TK / 8; g++)
 		{
-			const floatx4 a0 = *reinterpret_cast<const floatx4 *>(As + g * 8);
-			const floatx4 a1 = *reinterpret_cast<const floatx4 *>(As + 32 * BF_LS + g * 8);
-			const floatx4 b0 = *reinterpret_cast<const floatx4 *>(Bs + g * 8);
-			const floatx4 b1 = *reinterpret_cast<const floatx4 *>(Bs + 32 * BF_LS + g * 8);
+#if BF_GLDS
+			const uint32_t o = roff[g];
+#else
+			const uint32_t o = g * 8 + kk * 4;
+#endif
+			const floatx4 a0 = *reinterpret_cast<const floatx4 *>(As + o);
+			const floatx4 a1 = *reinterpret_cast<const floatx4 *>(As + 32 * BF_LS + o);
+			const floatx4 b0 = *reinterpret_cast<const floatx4 *>(Bs + o);
+			const floatx4 b1 = *reinterpret_cast<const floatx4 *>(Bs + 32 * BF_LS + o);
 #define BF_STEP(C)                                                                          \
 			acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.C, b0.C, acc[0][0], 0, 0, 0);    \
 			acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.C, b1.C, acc[0][1], 0, 0, 0);    \
@@ -132,9 +191,29 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 		}
 	};
 
-	// Software pipeline: the global loads of K step ks + 1 are issued before the 64 MFMAs of step ks and stored behind them.
+	unsigned long long c0 = 0, r0c = 0;
+	if (a.clocks) { c0 = __builtin_readcyclecounter(); r0c = wall_clock64(); }
+	// Software pipeline: the loads of K step ks + 1 are issued before the 64 MFMAs of step ks.
+#if BF_GLDS && BF_NBUF == 2
+	fetch(0, 0);
+	__syncthreads();                                            // (hipcc drains the LDS-bound loads, vmcnt(0), in front of the barrier)
+	for (uint32_t ks = 0; ks < a.ksteps; ks++)
+	{
+		fetch(min(ks + 1, a.ksteps - 1), (ks + 1) & 1);            // the other buffer: its readers passed the previous barrier
+		__builtin_amdgcn_sched_barrier(0);
+		contract(ks & 1);
+		__syncthreads();
+	}
+#elif BF_GLDS
+	for (uint32_t ks = 0; ks < a.ksteps; ks++)
+	{
+		__syncthreads();                                            // previous step's operand reads are done
+		fetch(ks, 0);
+		__syncthreads();
+		contract(0);
+	}
+#elif BF_NBUF == 2
 	fetch(0);
-#if BF_NBUF == 2
 	stage(0);
 	__syncthreads();
 	for (uint32_t ks = 0; ks < a.ksteps; ks++)
@@ -147,6 +226,7 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 		__syncthreads();
 	}
 #else
+	fetch(0);
 	for (uint32_t ks = 0; ks < a.ksteps; ks++)
 	{
 		__syncthreads();                                            // previous step's operand reads are done
@@ -156,35 +236,45 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 		contract(0);
 	}
 #endif
+	if (a.clocks && blockIdx.x == gridDim.x / 2 && t == 0)             // a block from the middle of the launch
+	{
+		a.clocks[0] = __builtin_readcyclecounter() - c0;
+		a.clocks[1] = wall_clock64() - r0c;
+	}
 
 	// epilogue: C[q][r]; lane holds column r = lane & 31, rows (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+	// (the K loop's barriers lie between the stores of `epi` and these reads)
 #pragma unroll
-	for (int j = 0; j < 2; j++)
-	{
-		const uint32_t r = r0 + wn * 64 + j * 32 + col;
-		const bool rok = r < a.n;
-		const float xn = a.xnorm[rok ? r : 0];
-		const float xs = (a.func == F_COSINE) ? __builtin_sqrtf(xn) : xn;
+	for (int i = 0; i < 2; i++)
 #pragma unroll
-		for (int i = 0; i < 2; i++)
+		for (int e4 = 0; e4 < 4; e4++)
+		{
+			const uint32_t ql = wm * 64 + i * 32 + 8 * e4 + 4 * kk;          // four consecutive queries of the tile
+			const floatx4 qb = *reinterpret_cast<const floatx4 *>(epi + ql);
+			const floatx4 qn = *reinterpret_cast<const floatx4 *>(epi + BF_TQ + ql);
 #pragma unroll
-			for (int e = 0; e < 16; e++)
+			for (int j = 0; j < 2; j++)
 			{
-				const uint32_t q = q0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-				if (!rok || q >= a.nq) continue;
-				const float dot = acc[i][j][e];
-				bool pass;
-				if (a.func == F_COSINE)
-					pass = dot >= a.qbound[q] * xs;                  // 1 - dot/sqrt(nq nx) <= tau (+margin)
-				else
-					pass = a.qnorm[q] + xs - 2.f * dot <= a.qbound[q];   // |q-x|^2 <= tau^2 (+margin)
-				if (pass)
+				const uint32_t r = r0 + wn * 64 + j * 32 + col;
+				const bool rok = r < a.n;
+#pragma unroll
+				for (int e1 = 0; e1 < 4; e1++)
 				{
-					const uint32_t pos = atomicAdd(&a.cand_cnt[q], 1u);
-					if (pos < a.cap) a.cand[(size_t) q * a.cap + pos] = r;
+					const uint32_t q = q0 + ql + e1;
+					const float dot = acc[i][j][e4 * 4 + e1];
+					bool pass;
+					if (a.func == F_COSINE)
+						pass = dot >= qb[e1] * xs2[j];                   // 1 - dot/sqrt(nq nx) <= tau (+margin)
+					else
+						pass = qn[e1] + xs2[j] - 2.f * dot <= qb[e1];    // |q-x|^2 <= tau^2 (+margin)
+					if (pass && rok && q < a.nq)
+					{
+						const uint32_t pos = atomicAdd(&a.cand_cnt[q], 1u);
+						if (pos < a.cap) a.cand[(size_t) q * a.cap + pos] = r;
+					}
 				}
 			}
-	}
+		}
 }
 
 // |row|^2 for every row (plain accumulation; only used by the filter and its margin)

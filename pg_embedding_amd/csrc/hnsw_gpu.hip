@@ -1744,6 +1744,7 @@ extern "C" int hnsw_gpu_bruteforce_dev(hnsw_gpu_index *ix, const coord_t *d_quer
 // exhaustive k-NN with the dense part on the matrix cores (device_bf_mfma.h)
 // ------------------------------------------------------------------------------------
 static float g_last_bf_gemm_ms = 0.f;
+static unsigned long long g_last_bf_clocks[2] = { 0, 0 };
 
 extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t k,
 											idx_t *d_idx, dist_t *d_dists, void *stream_)
@@ -1787,7 +1788,8 @@ extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d
 	const size_t o_bound = o_sdist + round_up(nq * k * 4, 256);
 	const size_t o_cnt = o_bound + round_up(nq * 4, 256);
 	const size_t o_cand = o_cnt + round_up(nq * 4 + 64, 256);
-	const size_t total = o_cand + round_up(nq * (size_t) cap * 4, 256);
+	const size_t o_clk = o_cand + round_up(nq * (size_t) cap * 4, 256);
+	const size_t total = o_clk + 256;
 	if (total > ix->bf_bytes)
 	{
 		if (ix->bf) (void) hipFree(ix->bf);
@@ -1820,7 +1822,7 @@ extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d
 	memset(&a, 0, sizeof(a));
 	a.queries = qpad; a.qnorm = qn; a.qbound = bound; a.vec = ix->vec; a.xnorm = ix->xnorm;
 	a.nq = (uint32_t) nq; a.n = n; a.stride = stride; a.qstride = qstride; a.ksteps = qstride / BF_TK; a.func = func;
-	a.cand = cand; a.cand_cnt = cnt; a.cap = cap;
+	a.cand = cand; a.cand_cnt = cnt; a.cap = cap; a.clocks = (unsigned long long *) (B + o_clk);
 	a.nqt = (uint32_t) ((nq + BF_TQ - 1) / BF_TQ); a.nrt = (n + BF_TR - 1) / BF_TR;
 	const uint32_t rgroups = (a.nrt + 7) / 8;
 	if (!ix->bf_e0) { HIPCHK(hipEventCreate(&ix->bf_e0)); HIPCHK(hipEventCreate(&ix->bf_e1)); }
@@ -1844,6 +1846,7 @@ extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d
 	HIPCHK(hipGetLastError());
 	uint32_t ovf = 0;
 	HIPCHK(hipMemcpyAsync(&ovf, overflow, 4, hipMemcpyDeviceToHost, s));
+	HIPCHK(hipMemcpyAsync(g_last_bf_clocks, a.clocks, 16, hipMemcpyDeviceToHost, s));
 	HIPCHK(hipStreamSynchronize(s));
 	(void) hipEventElapsedTime(&g_last_bf_gemm_ms, e0, e1);
 	if (ovf)      // a candidate list overflowed (bound far too loose for some query): canonical scan instead
@@ -1853,6 +1856,16 @@ extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d
 
 /* device time of the MFMA filter kernel of the most recent hnsw_gpu_bruteforce_mfma_dev call */
 extern "C" float hnsw_gpu_last_bruteforce_gemm_ms(void) { return g_last_bf_gemm_ms; }
+
+/* shader-clock MHz during that kernel: ticks of the shader clock over ticks of the constant 100 MHz clock, both taken by block 0
+ * around its K loop — what the matrix roof has to be priced at when the device does not hold its nominal clock under this load */
+extern "C" double hnsw_gpu_last_bruteforce_clock_mhz(void)
+{
+	int khz = 0, dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0)
+		khz = 100000;
+	return g_last_bf_clocks[1] ? khz * 1e-3 * (double) g_last_bf_clocks[0] / (double) g_last_bf_clocks[1] : 0.0;
+}
 
 // ------------------------------------------------------------------------------------
 // multi-shard merge: nlists x (dist,label) lists per query -> ef best by (dist, label)
@@ -2589,6 +2602,9 @@ extern "C" int hnsw_gpu_search_batch_ctx_host(hnsw_gpu_ctx *c, const coord_t *qu
 	if (dists) HIPCHK(hipMemcpyAsync(dists, dd, nq * ef * 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipMemcpyAsync(counts, dc, nq * 4, hipMemcpyDeviceToHost, c->stream));
 	HIPCHK(hipStreamSynchronize(c->stream));
+	for (size_t i = 0; i < nq; i++)                            // (as hnsw_gpu_search_batch: an interrupted launch is an error of a host-pointer call)
+		if (counts[i] == ABORTED_COUNT)
+			return fail(HNSW_GPU_ERR_INTERNAL, "the search launch was asked to end early (abort word): query %zu has no result", i);
 	return HNSW_GPU_OK;
 }
 
@@ -2706,7 +2722,13 @@ extern "C" int hnsw_gpu_stream_alive(hnsw_gpu_stream *s)
 	return idle < 0 ? idle : (idle ? 0 : 1);
 }
 
-extern "C" int hnsw_gpu_stream_close(hnsw_gpu_stream *s)
+static int stream_end(hnsw_gpu_stream *s, bool keep_buffers);
+extern "C" int hnsw_gpu_stream_close(hnsw_gpu_stream *s) { return stream_end(s, false); }
+/* the same stop, but the ring stays allocated (leaked on purpose): for a host that could not prove that none of its threads is
+ * still reading or writing the ring it was given (hnsw_gpu_stream_buffers) when it had to give the stream up */
+extern "C" int hnsw_gpu_stream_abandon(hnsw_gpu_stream *s) { return stream_end(s, true); }
+
+static int stream_end(hnsw_gpu_stream *s, bool keep_buffers)
 {
 	if (!s) return HNSW_GPU_OK;
 	hnsw_gpu_ctx *c = s->ctx;
@@ -2729,7 +2751,7 @@ extern "C" int hnsw_gpu_stream_close(hnsw_gpu_stream *s)
 		std::this_thread::sleep_for(std::chrono::microseconds(20));
 	}
 	(void) hipGetLastError();
-	if (rc == HNSW_GPU_OK)
+	if (rc == HNSW_GPU_OK && !keep_buffers)
 	{
 		(void) hipHostFree(s->pin);
 		(void) hipFree(s->dev_ctl);

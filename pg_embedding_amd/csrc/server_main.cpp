@@ -308,6 +308,17 @@ std::condition_variable g_q_cv;
 std::deque<SReq> g_q;
 std::atomic<long> g_q_waiting{0};          // stream mode: requests in g_q (the readers' "is anything queued" without the lock)
 
+// Stream mode: control work that needs the DEVICE — a mirror destroyed (hipFree), an upload's build or link kernels, a staging
+// re-allocation, a hipDeviceSynchronize — can wait for ever behind a resident launch, which holds every block slot and never ends by
+// itself while searches keep coming (the session only ever yielded to a writer on ITS OWN mirror).  The control thread counts itself
+// in here around such work; the stream manager closes the open session while the count is up and opens none until it is down.
+std::atomic<int> g_device_wanted{0};
+struct DeviceWanted
+{
+	DeviceWanted() { g_device_wanted.fetch_add(1); }
+	~DeviceWanted() { g_device_wanted.fetch_sub(1); }
+};
+
 struct CReq            // a control request
 {
 	ConnP c;
@@ -376,6 +387,12 @@ void run_batch(int d, std::vector<SReq> &batch, Pinned &pin)
 		SReq &r = batch[i];
 		if (rc != HNSW_GPU_OK) { r.c->respond(r.h, rc); continue; }
 		const size_t cnt = C[i];
+		if (cnt > ef)                                          // never a result count (an interrupted launch marks unanswered queries 0xFFFFFFFF)
+		{
+			g_cnt.search_errors++;
+			r.c->respond(r.h, HNSW_GPU_ERR_INTERNAL);
+			continue;
+		}
 		r.c->respond(r.h, HGS_OK, cnt, 0, L + i * ef, cnt * 8, r.h.a0 ? D + i * ef : nullptr, cnt * 4, e->gen.load());
 	}
 }
@@ -699,7 +716,12 @@ struct Session
 		const uint32_t t = claim.fetch_add(1, std::memory_order_acq_rel);
 		const uint32_t slot = t & (ring - 1);
 		for (unsigned spin = 0; busy[slot].load(std::memory_order_acquire); spin++)     // its occupant of a ring ago is being answered right now
+		{
+			// ... or is a walk that hangs: then the session is closed over it (stream_manager_main), and this request queues instead of
+			// spinning inside a ring that is going away.  The ticket stays unpublished; the closer does not wait for it for ever.
+			if (spin > 1000 && !accepting.load(std::memory_order_acquire)) { outstanding.fetch_sub(1, std::memory_order_acq_rel); return false; }
 			if (spin > 1000) std::this_thread::yield(); else __builtin_ia32_pause();
+		}
 		memcpy(Q + (size_t) slot * dim, r.q.data(), dim * 4);
 		F[slot] = 0;
 		const uint64_t now = now_ns();
@@ -734,7 +756,10 @@ std::mutex g_sess_mu;
 SessionP g_sess;                            // the open session, if any (g_sess_mu)
 std::atomic<uint64_t> g_sess_gen{0};        // bumped at every change of g_sess: the hot paths keep a thread-local copy and look at this word only
 
-std::atomic<uint64_t> g_answer_gen[64];     // per answer thread: the session generation it has refreshed to
+constexpr int MAX_ANSWER_THREADS = 64;      // (main() refuses --stream 1 with more dispatchers)
+std::atomic<uint64_t> g_answer_gen[MAX_ANSWER_THREADS];     // per answer thread: the session generation it has refreshed to
+std::atomic<bool> g_answer_exited[MAX_ANSWER_THREADS];      // per answer thread: it has returned (it holds nothing any more)
+std::atomic<bool> g_sessions_over{false};   // shutdown: the manager has closed the last session — only then do the answer threads leave
 
 void set_session(const SessionP &ss)
 {
@@ -762,7 +787,9 @@ void stream_answer_main(int k, int n)
 {
 	pthread_setname_np(pthread_self(), "hgs-answer");
 	unsigned idle = 0;
-	while (!g_stop.load())
+	// (until the manager has closed the last session, not just until g_stop: the walks that are outstanding at shutdown are answered,
+	// not left to the close's patience)
+	while (!g_sessions_over.load(std::memory_order_acquire))
 	{
 		SessionP ss = current_session();
 		g_answer_gen[k].store(g_sess_gen.load(std::memory_order_acquire), std::memory_order_release);   // "I hold nothing older than this"
@@ -792,16 +819,21 @@ void stream_answer_main(int k, int n)
 		else if (++idle > 256) std::this_thread::yield();
 		else __builtin_ia32_pause();
 	}
+	g_answer_exited[k].store(true);
 }
 
 // Close the session: no new queries, let the walks in flight finish (bounded), stop the launch, release the mirror.
-void close_session(SessionP &ss, const char *why)
+void close_session(SessionP &ss, const char *why, int unanswered_rc = HNSW_GPU_ERR_INTERNAL)
 {
 	ss->accepting.store(false);             // (sequentially consistent, as the producers' marks: Session::submit)
 	const uint64_t t0 = now_ns();
+	bool somebody_inside = false;           // a thread of ours may still touch the ring: it is then given up, not freed
 	for (int i = 0, n = std::min(g_producers.load(), MAX_PRODUCERS); i < n; i++)        // producers inside submit finish their slot and leave
+	{
 		while (g_in_submit[i].s.load() == (const void *) ss.get() && now_ns() - t0 < 1000000000ull)
 			std::this_thread::yield();
+		if (g_in_submit[i].s.load() == (const void *) ss.get()) somebody_inside = true;
+	}
 	// producers that were past the check finish their slot; then every claimed ticket is published and, walked, answered
 	// (2 s of patience: on a host whose CPU time is capped the whole process may be frozen for tens of milliseconds at a time)
 	while ((ss->outstanding.load() > 0 || ss->pub.load() != ss->claim.load()) && now_ns() - t0 < 2000000000ull)
@@ -819,12 +851,16 @@ void close_session(SessionP &ss, const char *why)
 	// threads have refreshed once every one of them has passed the generation check)
 	{
 		const uint64_t t1 = now_ns(), gen = g_sess_gen.load();
-		for (int k = 0; k < g_opt.dispatchers && k < 64; k++)
-			while (g_answer_gen[k].load(std::memory_order_acquire) < gen && !g_stop.load() && now_ns() - t1 < 1000000000ull)
+		for (int k = 0; k < g_opt.dispatchers && k < MAX_ANSWER_THREADS; k++)
+		{
+			while (g_answer_gen[k].load(std::memory_order_acquire) < gen && !g_answer_exited[k].load() && now_ns() - t1 < 1000000000ull)
 				std::this_thread::sleep_for(std::chrono::microseconds(20));
+			if (g_answer_gen[k].load(std::memory_order_acquire) < gen && !g_answer_exited[k].load()) somebody_inside = true;
+		}
 	}
 	const uint64_t t_let_go = now_ns();
-	const int rc = hnsw_gpu_stream_close(ss->st);
+	if (somebody_inside) logf("closing the stream (%s): a thread did not leave the ring within its second: the ring is given up, not freed", why);
+	const int rc = somebody_inside ? hnsw_gpu_stream_abandon(ss->st) : hnsw_gpu_stream_close(ss->st);
 	if (rc != HNSW_GPU_OK) logf("closing the stream: %s", hnsw_gpu_last_error());
 	if (now_ns() - t_drained > 200000000ull)
 		logf("slow close (%s): %.0f ms for the answer threads to let go, %.0f ms for the launch to end", why, (t_let_go - t_drained) / 1e6,
@@ -838,7 +874,8 @@ void close_session(SessionP &ss, const char *why)
 			logf("unanswered slot %u: flag %u, ready word %u, published %u, claimed %u, outstanding %ld, in the ring for %.1f ms, the drain took %.0f ms",
 				 slot, (unsigned) ss->F[slot], ss->ready[slot].load(), ss->pub.load(), ss->claim.load(), ss->outstanding.load(),
 				 (now_ns() - ss->t_pub[slot]) / 1e6, (t_drained - t0) / 1e6);
-			ss->req[slot].c->respond(ss->req[slot].h, HNSW_GPU_ERR_INTERNAL);
+			ss->req[slot].c->respond(ss->req[slot].h, unanswered_rc);
+			ss->busy[slot].store(0, std::memory_order_release);
 			lost++;
 		}
 	if (lost) { g_cnt.search_errors += (uint64_t) lost; logf("stream closed (%s) with %ld queries unanswered", why, lost); }
@@ -876,6 +913,8 @@ SessionP open_session(const EntryP &e, size_t ef, size_t backlog)
 	return ss;
 }
 
+const uint64_t STREAM_WALK_TIMEOUT_NS = 60ull * 1000000000ull;   // (as LANE_TIMEOUT_NS of the lanes: a walk is a millisecond)
+
 void stream_manager_main()
 {
 	pthread_setname_np(pthread_self(), "hgs-manager");
@@ -901,7 +940,24 @@ void stream_manager_main()
 			}
 			const char *why = nullptr;
 			size_t hint = 0;
-			if (ss->e->writer_wants()) why = "a writer wants the mirror";
+			// liveness of the resident launch (the library's watchdog does not cover it): a launch that has left the device (abort, fault)
+			// or a walk that has been in the ring longer than any walk takes — checked every 100 ms — ends the session; close_session
+			// answers what is unanswered with an error and the next request opens a new one
+			static thread_local uint64_t t_scan = 0;
+			bool dead = false, overdue = false;
+			if (now - t_scan > 100000000ull)
+			{
+				t_scan = now;
+				dead = hnsw_gpu_stream_alive(ss->st) != 1;
+				if (!dead && out > 0)
+					for (uint32_t slot = 0; slot < ss->ring && !overdue; slot++)
+						if (ss->busy[slot].load(std::memory_order_acquire) && now > ss->t_pub[slot] && now - ss->t_pub[slot] > STREAM_WALK_TIMEOUT_NS)
+							overdue = true;
+			}
+			if (dead) why = "the resident launch has left the device";
+			else if (overdue) why = "a walk has been in the ring for longer than the time-out";
+			else if (ss->e->writer_wants()) why = "a writer wants the mirror";
+			else if (g_device_wanted.load() > 0) why = "control work needs the device";
 			else if (out == 0 && now - ss->t_active.load() > IDLE_NS) why = "idle";
 			else if (ss->t_crowded.load() && now - ss->t_crowded.load() > CROWDED_NS) { why = "more walking waves per block needed"; hint = (size_t) (out + out / 8 + 1); }
 			else if (ss->t_roomy.load() && now - ss->t_roomy.load() > ROOMY_NS) { why = "fewer walking waves per block suffice"; hint = (size_t) std::max<long>(out + out / 4, 1); }
@@ -934,6 +990,7 @@ void stream_manager_main()
 			continue;
 		}
 		// no session: wait for work, open one for the oldest request's (mirror, ef)
+		if (g_device_wanted.load() > 0) { std::this_thread::sleep_for(std::chrono::microseconds(50)); continue; }   // (control work first: it cannot run beside a resident launch)
 		batch.clear();
 		EntryP e;
 		size_t ef = 0, backlog = 0;
@@ -961,7 +1018,8 @@ void stream_manager_main()
 		if (!batch.empty()) run_batch(0, batch, pin);
 	}
 	SessionP ss = current_session();
-	if (ss) close_session(ss, "shutdown");
+	if (ss) close_session(ss, "shutdown", HGS_ERR_SHUTDOWN);           // (the answer threads are still at work: outstanding walks get their answers)
+	g_sessions_over.store(true, std::memory_order_release);             // now they may leave
 	answer_leftovers();
 }
 
@@ -1185,6 +1243,9 @@ void do_bind(CReq &r)
 
 void do_control(CReq &r)
 {
+	// (everything here may free or allocate device memory, launch kernels or wait for the device; a dropped mirror dies where its
+	// last reference goes, which is inside this function)
+	DeviceWanted wanted;
 	switch (r.h.op)
 	{
 	case HGS_OP_UPLOAD: do_upload(r); break;
@@ -1647,6 +1708,12 @@ int main(int argc, char **argv)
 	if (g_opt.path.empty() || g_opt.dispatchers < 1 || g_opt.readers < 1 || g_opt.max_batch < 1 || g_opt.lanes < 0 || g_opt.lanes > 16) { usage(); return 2; }
 	// (the ring keeps a margin of 64 slots, Session::submit: a 64-slot ring would take nothing at all and every request would queue for ever —
 	// what the CPU tier's first resident-launch run did; 256 is the smallest ring the server accepts)
+	// (stream mode keeps one word per answer thread and one mark per producer thread — readers, mailbox pollers, the manager — in fixed tables)
+	if (g_opt.stream && (g_opt.dispatchers > MAX_ANSWER_THREADS || g_opt.readers + g_opt.shm_pollers + 1 > MAX_PRODUCERS))
+	{
+		logf("--stream 1 takes at most %d dispatchers and %d readers + mailbox pollers", MAX_ANSWER_THREADS, MAX_PRODUCERS - 1);
+		return 2;
+	}
 	if (g_opt.stream && (g_opt.ring < 256 || g_opt.ring > ((size_t) 1 << 20) || (g_opt.ring & (g_opt.ring - 1)))) { usage(); return 2; }
 	if (g_opt.path.size() >= sizeof(((struct sockaddr_un *) nullptr)->sun_path)) { logf("socket path too long"); return 2; }
 

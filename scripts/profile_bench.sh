@@ -8,7 +8,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-BENCH="python $R/bench.py --no-cpu --no-side-configs --hostile-rows 0 --steps 3 $*"
+BENCH="python $R/bench.py --no-cpu --no-side-configs --hostile-rows 0 --serial-rows 0 --steps 3 $*"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1
 grep '^{' $OUT/trace.log | tail -1 > $OUT/bench_line.json
 for PASS in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" \

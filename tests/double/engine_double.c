@@ -411,16 +411,18 @@ int hnsw_gpu_stream_publish(hnsw_gpu_stream *s, uint32_t n)
 
 int hnsw_gpu_stream_alive(hnsw_gpu_stream *s) { return s && __atomic_load_n(&s->alive, __ATOMIC_ACQUIRE) > 0 && !s->stop; }
 
-int hnsw_gpu_stream_close(hnsw_gpu_stream *s)
+static int stream_end(hnsw_gpu_stream *s, int keep_buffers)
 {
 	if (!s) return HNSW_GPU_OK;
 	__atomic_store_n(&s->stop, 1, __ATOMIC_RELEASE);
 	for (int i = 0; i < s->nthreads; i++) pthread_join(s->th[i], NULL);
 	__atomic_store_n(&s->c->busy, 0, __ATOMIC_RELEASE);
-	free(s->Q); free(s->L); free(s->D); free(s->C); free(s->F);
+	if (!keep_buffers) { free(s->Q); free(s->L); free(s->D); free(s->C); free(s->F); }
 	free(s);
 	return HNSW_GPU_OK;
 }
+int hnsw_gpu_stream_close(hnsw_gpu_stream *s) { return stream_end(s, 0); }
+int hnsw_gpu_stream_abandon(hnsw_gpu_stream *s) { return stream_end(s, 1); }      /* (the ring stays allocated, as in the library) */
 int hnsw_gpu_device_blocks(int device) { (void) device; return 4; }   /* a tiny "device": the server's load policy is exercised with a handful of backends */
 
 static void *flags_worker(void *arg)

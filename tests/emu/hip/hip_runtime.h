@@ -331,6 +331,9 @@ namespace simt { inline void fence(int order, const char *scope) { __atomic_thre
 #define __builtin_amdgcn_s_memtime() ((uint64_t) __rdtsc())
 #define __builtin_amdgcn_s_memrealtime() ((uint64_t) (__rdtsc() >> 5))
 #define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) (simt::die("MFMA is not modelled"), (c))
+// the exhaustive scorer's tile loads (global -> LDS directly) belong to the same unmodelled kernel
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) simt::die("global_load_lds is not modelled")
+#define wall_clock64() ((unsigned long long) (__rdtsc() >> 5))
 
 #define __HIP_MEMORY_SCOPE_SINGLETHREAD 1
 #define __HIP_MEMORY_SCOPE_WAVEFRONT 2
@@ -379,7 +382,7 @@ typedef simt_event *hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
 enum { hipStreamNonBlocking = 1, hipEventDisableTiming = 2, hipHostMallocDefault = 0, hipHostMallocCoherent = 0x40000000 };
 enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
-enum hipDeviceAttribute_t { hipDeviceAttributeMaxSharedMemoryPerBlock = 1, hipDeviceAttributeMultiprocessorCount = 2 };
+enum hipDeviceAttribute_t { hipDeviceAttributeMaxSharedMemoryPerBlock = 1, hipDeviceAttributeMultiprocessorCount = 2, hipDeviceAttributeWallClockRate = 3 };
 struct hipDeviceProp_t { char name[256]; char gcnArchName[256]; int multiProcessorCount; size_t totalGlobalMem; };
 
 // ---- several emulated devices (SIMT_EMU_DEVICES=N > 1) ------------------------------------------------------------------------
@@ -492,7 +495,7 @@ static inline hipError_t hipGetDeviceProperties(hipDeviceProp_t *p, int)
 }
 static inline hipError_t hipDeviceGetAttribute(int *v, int attr, int)
 {
-	*v = attr == hipDeviceAttributeMaxSharedMemoryPerBlock ? (int) SIMT_LDS_BYTES : simt_num_cu();
+	*v = attr == hipDeviceAttributeMaxSharedMemoryPerBlock ? (int) SIMT_LDS_BYTES : attr == hipDeviceAttributeWallClockRate ? 100000 : simt_num_cu();
 	return hipSuccess;
 }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
