@@ -17,15 +17,13 @@
 // L2 uses |q|^2 + |x|^2 - 2 q.x, cosine 1 - q.x / sqrt(|q|^2 |x|^2) (distfunc.c:133-145);
 // Manhattan is not a contraction and is not offered here.
 //
-// Tiling (round 5): block = 4 waves, 128 queries x 128 rows per block, K in steps of 32 floats.  Global loads are whole
-// 128-byte lines (8 lanes x float4 per tile row: one wave instruction = 8 rows x 128 B) and go to LDS ROW-major with a padded
-// row stride of 36 floats, one ds_write_b128 per float4 — no transposition: a filter may sum a dot product in any k order as
-// long as both operands use the same one, so lane (col, kk) of an MFMA takes the four k of ONE ds_read_b128 (k = 8g + 4kk + s,
-// s = 0..3) and feeds them to four consecutive MFMAs.  Per 32-float K step a wave issues 16 ds_read_b128 for 64 MFMAs (round
-// 1-4: 64 ds_read_b32 + 32 ds_write_b32 per thread, and global loads that touched 64 different lines per instruction).  Two
-// LDS buffers: the stores of step ks + 1 go to the other buffer, ONE barrier per step.  Each wave owns a 64 x 64 sub-tile =
-// 2 x 2 MFMA tiles (64 accumulator registers).  blockIdx is remapped so that all query tiles of one row tile run on the same
-// XCD (block b -> XCD b % 8) and the row tile is fetched from HBM once per XCD L2.
+// Tiling (round 5): block = 4 waves, 128 queries x 128 rows per block, K in steps of BF_TK floats.  Tiles go from global memory
+// straight into LDS (global_load_lds_dwordx4) in whole 128-byte lines, bank-swizzled on the source side; operands are read with
+// ds_read_b128 (four k per read: a filter may sum in any k order), 16 reads per 64 MFMAs, conflict-free (SQ_LDS_BANK_CONFLICT 0); two
+// LDS buffers, one barrier per step; each wave owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles (64 accumulator registers); the epilogue's
+// operands are fetched behind the K loop.  blockIdx is remapped so that all query tiles of one row tile run on the same XCD
+// (block b -> XCD b % 8) and the row tile is fetched from HBM once per XCD L2.  (Rounds 1-4: K-major transposing ds_write_b32 staging
+// from loads that touched 64 lines per instruction, 64 ds_read_b32 per 64 MFMAs: 122 TFLOP/s; this form: 134-135, profiles/r5*.)
 #pragma once
 #include "device_search.h"
 
@@ -34,21 +32,28 @@ namespace pgemb {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef float floatx4 __attribute__((ext_vector_type(4)));       // (a first-class vector: HIP's float4 struct went through scratch here)
 
-constexpr int BF_TQ = 128, BF_TR = 128, BF_TK = 32;
-#ifndef BF_GLDS
-#define BF_GLDS 1                                    // 1: tiles go global -> LDS directly (global_load_lds_dwordx4), 0: through registers
+#ifndef BF_TK
+#define BF_TK 32                                     // floats of K per step (32 or 64)
 #endif
-#ifndef BF_NBUF
-#define BF_NBUF 2
+#define BF_NBUF 2                                    // LDS buffers: the loads of step ks + 1 fly during the MFMAs of step ks
+#ifndef BF_NJ
+#define BF_NJ 2                                      // 32-row MFMA tiles of index rows per wave (2: 64 x 64 per wave, 4: 64 x 128)
 #endif
-#if BF_GLDS
-constexpr int BF_LS = BF_TK;                         // lane-linear LDS image: 128-byte rows, chunk c of row r at slot c ^ ((r >> 1) & 7)
-#else
-constexpr int BF_LS = BF_TK + 4;                     // padded rows: 144 B, 16 lanes of a ds_read_b128 group hit 16 distinct 16-byte slots
-#endif
-constexpr int BF_TILE_FLOATS = BF_TQ * BF_LS;        // one operand tile
+constexpr int BF_TQ = 128, BF_TR = 64 * BF_NJ;       // block tile: 128 queries x 128 (or 256) rows, 2 x 2 waves
+constexpr int BF_CH = BF_TK / 4;                     // 16-byte chunks of a tile row per K step (8 or 16)
+constexpr int BF_RPI = 64 / BF_CH;                   // tile rows one wave instruction fills (8 x 128 B or 4 x 256 B: whole lines either way)
+constexpr int BF_PASSES = BF_TQ / (4 * BF_RPI);      // load instructions per query tile, thread and K step
+constexpr int BF_PASSES_R = BF_TR / (4 * BF_RPI);    // ... per row tile
+constexpr int BF_LS = BF_TK;                         // lane-linear LDS image, no padding: chunk c of row r at slot c ^ swizzle(r)
+constexpr int BF_TILE_FLOATS = BF_TQ * BF_LS;        // the query tile
+constexpr int BF_BUF_FLOATS = (BF_TQ + BF_TR) * BF_LS;   // one buffer: query tile, then row tile
 constexpr int BF_EPI_FLOATS = 2 * BF_TQ;              // the tile's per-query bound and |q|^2, staged for the epilogue
-constexpr size_t BF_LDS_BYTES = ((size_t) BF_NBUF * 2 * BF_TILE_FLOATS + BF_EPI_FLOATS) * sizeof(float);
+constexpr int BF_PASS_CAP = 508;                     // (query, row) pairs of a block that passed the filter, collected in LDS (+ 4 words of counter: 4 KB)
+constexpr size_t BF_LDS_BYTES = ((size_t) BF_NBUF * BF_BUF_FLOATS + BF_EPI_FLOATS + 4 + 2 * BF_PASS_CAP) * sizeof(float);
+// bank swizzle of a tile row: a ds_read_b128 serves 16 lanes per cycle over a 256-byte bank row.  128-byte rows (BF_TK 32) put two
+// rows in a bank row: slot = c ^ ((r >> 1) & 7) makes (r & 1, (r >> 1) & 7) — all distinct within a lane group — pick 16 distinct
+// slots; 256-byte rows (BF_TK 64) fill one: slot = c ^ (r & 15).
+__device__ __forceinline__ uint32_t bf_swz(uint32_t r) { return BF_TK == 32 ? ((r >> 1) & 7u) : (r & 15u); }
 
 struct BfArgs
 {
@@ -79,23 +84,22 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 	if (rt >= a.nrt) return;
 	const uint32_t q0 = qt * BF_TQ, r0 = rt * BF_TR;
 
-	// staging role: thread owns one 16-byte slot `sch` (of the 8 of a K step) of tile rows srow + 32 j: a wave instruction reads
-	// 8 rows x 128 contiguous bytes
-	const uint32_t sch = t & 7, srow = t >> 3;
+	// staging role: thread owns 16-byte slot `sch` of tile rows srow + 4 * BF_RPI * j; a wave instruction moves whole 128-byte lines
+	const uint32_t sch = t & (BF_CH - 1), srow = t / BF_CH;
 	const uint32_t nchunks = a.stride / 4;
-	const floatx4 *qsrc[4], *xsrc[4];
+	const floatx4 *qsrc[BF_PASSES], *xsrc[BF_PASSES_R];
 #pragma unroll
-	for (int j = 0; j < 4; j++)
-	{
-		qsrc[j] = reinterpret_cast<const floatx4 *>(a.queries + (size_t) min(q0 + srow + 32 * j, a.nq - 1) * a.qstride);
-		xsrc[j] = reinterpret_cast<const floatx4 *>(a.vec + (size_t) min(r0 + srow + 32 * j, a.n - 1) * a.stride);
-	}
+	for (int j = 0; j < BF_PASSES; j++)
+		qsrc[j] = reinterpret_cast<const floatx4 *>(a.queries + (size_t) min(q0 + srow + 4 * BF_RPI * j, a.nq - 1) * a.qstride);
+#pragma unroll
+	for (int j = 0; j < BF_PASSES_R; j++)
+		xsrc[j] = reinterpret_cast<const floatx4 *>(a.vec + (size_t) min(r0 + srow + 4 * BF_RPI * j, a.n - 1) * a.stride);
 
-	floatx16 acc[2][2];
+	floatx16 acc[2][BF_NJ];
 #pragma unroll
 	for (int i = 0; i < 2; i++)
 #pragma unroll
-		for (int j = 0; j < 2; j++)
+		for (int j = 0; j < BF_NJ; j++)
 #pragma unroll
 			for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 	const uint32_t wm = wave >> 1, wn = wave & 1;          // 2 x 2 waves over the block tile
@@ -103,139 +107,92 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 
 	// What the epilogue compares with is fetched NOW, behind the K loop: every block of a launch takes the same time, so the blocks of
 	// a CU reach their epilogues together, and an epilogue that loads its 32 bounds per lane one dependent L2 round trip after the
-	// other (rounds 1-4) leaves the matrix pipe idle for a tenth of every round.  The tile's 128 bounds and |q|^2 go to LDS (read back
-	// four at a time), the two |x|^2 of the lane's columns to registers.
-	float *epi = bf_lds + (size_t) BF_NBUF * 2 * BF_TILE_FLOATS;
+	// other (rounds 1-4) leaves the matrix pipe idle.  The tile's 128 bounds and |q|^2 go to LDS (read back four at a time), the two
+	// |x|^2 of the lane's columns to registers.
+	float *epi = bf_lds + (size_t) BF_NBUF * BF_BUF_FLOATS;
+	// Rows that pass the filter (about twenty per block) are collected in LDS and appended to their queries' candidate lists by the
+	// whole block at once: in rounds 1-4 every passing element was a returning global atomic behind its own `s_waitcnt vmcnt(0)` inside
+	// a divergent branch — a handful of dependent L2 round trips per wave at the end of every block, with the matrix pipe idle.
+	uint32_t *pass_cnt = reinterpret_cast<uint32_t *>(epi + BF_EPI_FLOATS);
+	uint2 *pass_list = reinterpret_cast<uint2 *>(epi + BF_EPI_FLOATS + 4);
+	if (t == 0) *pass_cnt = 0u;
 	if (t < BF_TQ)
 	{
 		const uint32_t qi = min(q0 + (uint32_t) t, a.nq - 1);
 		epi[t] = a.qbound[qi];
 		epi[BF_TQ + t] = a.qnorm[qi];
 	}
-	float xs2[2];
+	float xs2[BF_NJ];
 #pragma unroll
-	for (int j = 0; j < 2; j++)
+	for (int j = 0; j < BF_NJ; j++)
 	{
-		const float xn = a.xnorm[min(r0 + wn * 64 + j * 32 + col, a.n - 1)];
+		const float xn = a.xnorm[min(r0 + wn * (32 * BF_NJ) + j * 32 + col, a.n - 1)];
 		xs2[j] = (a.func == F_COSINE) ? __builtin_sqrtf(xn) : xn;
 	}
 
-	// No select on a loaded value (it would pull the wait for the loads in front of the MFMAs): the query copy is zero padded
-	// to whole K steps, and a row chunk beyond the row's end re-reads the row's last chunk (times zero: nothing).
-#if BF_GLDS
-	// The LDS image is what the hardware writes: wave-uniform base + lane * 16, i.e. 8 rows x 128 B per instruction, no padding.
-	// Bank conflicts are avoided on the SOURCE side: slot p of row r holds chunk p ^ ((r >> 1) & 7) — still whole 128-byte lines per
-	// row from memory, and the 16 lanes of every ds_read_b128 group ((r & 1), (r >> 1) & 7 all distinct) land on 16 distinct slots.
-	const uint32_t gch = sch ^ ((srow >> 1) & 7);              // the chunk this lane fetches ((srow + 32 j) >> 1) & 7 == (srow >> 1) & 7
+	// Tiles go global -> LDS directly (global_load_lds_dwordx4: no staging registers, no ds_write).  The LDS image is what the hardware
+	// writes — wave-uniform base + lane * 16: BF_RPI rows of whole lines per instruction, no padding — so bank conflicts are avoided on
+	// the SOURCE side: the lane that fills slot p of row r fetches chunk p ^ swizzle(r).  No select on a loaded value either: the query
+	// copy is zero padded to whole K steps, and a row chunk beyond the row's end re-reads the row's last chunk (times zero: nothing).
+	const uint32_t gch = sch ^ bf_swz(srow);                    // (swizzle(srow + 4 * BF_RPI * j) == swizzle(srow): the step is a multiple of 16)
 	auto fetch = [&](uint32_t ks, uint32_t buf)
 	{
-		const uint32_t c = ks * 8 + gch;
+		const uint32_t c = ks * BF_CH + gch;
 		const uint32_t cc = min(c, nchunks - 1);
-		float *As = bf_lds + (size_t) buf * 2 * BF_TILE_FLOATS + (wave * 8) * BF_LS, *Bs = As + BF_TILE_FLOATS;
+		float *As = bf_lds + (size_t) buf * BF_BUF_FLOATS + (wave * BF_RPI) * BF_LS, *Bs = As + BF_TILE_FLOATS;
 #pragma unroll
-		for (int j = 0; j < 4; j++)
-		{
+		for (int j = 0; j < BF_PASSES; j++)
 			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (qsrc[j] + c),
-											 (__attribute__((address_space(3))) void *) (As + 32 * j * BF_LS), 16, 0, 0);
+											 (__attribute__((address_space(3))) void *) (As + 4 * BF_RPI * j * BF_LS), 16, 0, 0);
+#pragma unroll
+		for (int j = 0; j < BF_PASSES_R; j++)
 			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (xsrc[j] + cc),
-											 (__attribute__((address_space(3))) void *) (Bs + 32 * j * BF_LS), 16, 0, 0);
-		}
+											 (__attribute__((address_space(3))) void *) (Bs + 4 * BF_RPI * j * BF_LS), 16, 0, 0);
 	};
-	const uint32_t swz = (col >> 1) & 7;
+	// An MFMA may sum a dot product in any k order as long as both operands use the same one: lane (col, kk) takes the four k of ONE
+	// ds_read_b128 (chunk 2g + kk of its row) and feeds them to four consecutive MFMAs — 16 ds_read_b128 per 64 MFMAs.
+	const uint32_t swz = bf_swz(col);                           // (the tile rows of this lane are col + 32 * i + 64 * wm: same swizzle)
 	uint32_t roff[BF_TK / 8];                                  // float offset of k-group g's slot in this lane's row
 #pragma unroll
 	for (int g = 0; g < BF_TK / 8; g++) roff[g] = ((2 * g + kk) ^ swz) * 4;
-#else
-	floatx4 qa[4], xb[4];
-	auto fetch = [&](uint32_t ks)
-	{
-		const uint32_t c = ks * 8 + sch;                          // float4 chunk along K
-		const uint32_t cc = min(c, nchunks - 1);
-#pragma unroll
-		for (int j = 0; j < 4; j++) { qa[j] = qsrc[j][c]; xb[j] = xsrc[j][cc]; }
-	};
-	auto stage = [&](uint32_t buf)
-	{
-		float *As = bf_lds + (size_t) buf * 2 * BF_TILE_FLOATS, *Bs = As + BF_TILE_FLOATS;
-#pragma unroll
-		for (int j = 0; j < 4; j++)
-		{
-			*reinterpret_cast<floatx4 *>(As + (srow + 32 * j) * BF_LS + sch * 4) = qa[j];
-			*reinterpret_cast<floatx4 *>(Bs + (srow + 32 * j) * BF_LS + sch * 4) = xb[j];
-		}
-	};
-#endif
 	auto contract = [&](uint32_t buf)
 	{
-		const float *As = bf_lds + (size_t) buf * 2 * BF_TILE_FLOATS + (wm * 64 + col) * BF_LS;
-		const float *Bs = bf_lds + (size_t) buf * 2 * BF_TILE_FLOATS + BF_TILE_FLOATS + (wn * 64 + col) * BF_LS;
+		const float *As = bf_lds + (size_t) buf * BF_BUF_FLOATS + (wm * 64 + col) * BF_LS;
+		const float *Bs = bf_lds + (size_t) buf * BF_BUF_FLOATS + BF_TILE_FLOATS + (wn * (32 * BF_NJ) + col) * BF_LS;
 #pragma unroll
 		for (int g = 0; g < BF_TK / 8; g++)
 		{
-#if BF_GLDS
 			const uint32_t o = roff[g];
-#else
-			const uint32_t o = g * 8 + kk * 4;
-#endif
-			const floatx4 a0 = *reinterpret_cast<const floatx4 *>(As + o);
-			const floatx4 a1 = *reinterpret_cast<const floatx4 *>(As + 32 * BF_LS + o);
-			const floatx4 b0 = *reinterpret_cast<const floatx4 *>(Bs + o);
-			const floatx4 b1 = *reinterpret_cast<const floatx4 *>(Bs + 32 * BF_LS + o);
-#define BF_STEP(C)                                                                          \
-			acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.C, b0.C, acc[0][0], 0, 0, 0);    \
-			acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.C, b1.C, acc[0][1], 0, 0, 0);    \
-			acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.C, b0.C, acc[1][0], 0, 0, 0);    \
-			acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.C, b1.C, acc[1][1], 0, 0, 0);
-			BF_STEP(x) BF_STEP(y) BF_STEP(z) BF_STEP(w)
-#undef BF_STEP
+			floatx4 av[2], bv[BF_NJ];
+#pragma unroll
+			for (int i = 0; i < 2; i++) av[i] = *reinterpret_cast<const floatx4 *>(As + i * 32 * BF_LS + o);
+#pragma unroll
+			for (int j = 0; j < BF_NJ; j++) bv[j] = *reinterpret_cast<const floatx4 *>(Bs + j * 32 * BF_LS + o);
+#pragma unroll
+			for (int c = 0; c < 4; c++)
+#pragma unroll
+				for (int i = 0; i < 2; i++)
+#pragma unroll
+					for (int j = 0; j < BF_NJ; j++)
+						acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][c], bv[j][c], acc[i][j], 0, 0, 0);
 		}
 	};
 
 	unsigned long long c0 = 0, r0c = 0;
 	if (a.clocks) { c0 = __builtin_readcyclecounter(); r0c = wall_clock64(); }
-	// Software pipeline: the loads of K step ks + 1 are issued before the 64 MFMAs of step ks.
-#if BF_GLDS && BF_NBUF == 2
+	// Software pipeline over two LDS buffers: the loads of K step ks + 1 are issued before the MFMAs of step ks, into the other buffer;
+	// one barrier per step.  (Measured and NOT kept, profiles/r5e_mfma_tile_variants.txt: a 64-float K step with one buffer 129 TFLOP/s,
+	// 64 x 128 wave tiles 128-130, operand reads written out one k-group ahead with counted lgkmcnt waits and the barrier in front of
+	// the last k-group — no LDS or memory round trip exposed inside the loop — 129; this plain form 134-136.)
 	fetch(0, 0);
 	__syncthreads();                                            // (hipcc drains the LDS-bound loads, vmcnt(0), in front of the barrier)
 	for (uint32_t ks = 0; ks < a.ksteps; ks++)
 	{
-		fetch(min(ks + 1, a.ksteps - 1), (ks + 1) & 1);            // the other buffer: its readers passed the previous barrier
+		fetch(min(ks + 1, a.ksteps - 1), (ks + 1) & 1);            // its readers passed the previous barrier (branch-free: the last step re-reads itself)
 		__builtin_amdgcn_sched_barrier(0);
 		contract(ks & 1);
 		__syncthreads();
 	}
-#elif BF_GLDS
-	for (uint32_t ks = 0; ks < a.ksteps; ks++)
-	{
-		__syncthreads();                                            // previous step's operand reads are done
-		fetch(ks, 0);
-		__syncthreads();
-		contract(0);
-	}
-#elif BF_NBUF == 2
-	fetch(0);
-	stage(0);
-	__syncthreads();
-	for (uint32_t ks = 0; ks < a.ksteps; ks++)
-	{
-		fetch(min(ks + 1, a.ksteps - 1));                          // (branch-free: the last step re-reads itself into the idle buffer)
-		__builtin_amdgcn_sched_barrier(0);                         // the loads are ISSUED here, not sunk behind the MFMAs
-		contract(ks & 1);
-		__builtin_amdgcn_sched_barrier(0);
-		stage((ks + 1) & 1);                                       // the other buffer: its readers passed the previous barrier
-		__syncthreads();
-	}
-#else
-	fetch(0);
-	for (uint32_t ks = 0; ks < a.ksteps; ks++)
-	{
-		__syncthreads();                                            // previous step's operand reads are done
-		stage(0);
-		__syncthreads();
-		if (ks + 1 < a.ksteps) fetch(ks + 1);                       // in flight during the MFMAs below
-		contract(0);
-	}
-#endif
 	if (a.clocks && blockIdx.x == gridDim.x / 2 && t == 0)             // a block from the middle of the launch
 	{
 		a.clocks[0] = __builtin_readcyclecounter() - c0;
@@ -253,9 +210,9 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 			const floatx4 qb = *reinterpret_cast<const floatx4 *>(epi + ql);
 			const floatx4 qn = *reinterpret_cast<const floatx4 *>(epi + BF_TQ + ql);
 #pragma unroll
-			for (int j = 0; j < 2; j++)
+			for (int j = 0; j < BF_NJ; j++)
 			{
-				const uint32_t r = r0 + wn * 64 + j * 32 + col;
+				const uint32_t r = r0 + wn * (32 * BF_NJ) + j * 32 + col;
 				const bool rok = r < a.n;
 #pragma unroll
 				for (int e1 = 0; e1 < 4; e1++)
@@ -269,12 +226,25 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 						pass = qn[e1] + xs2[j] - 2.f * dot <= qb[e1];    // |q-x|^2 <= tau^2 (+margin)
 					if (pass && rok && q < a.nq)
 					{
-						const uint32_t pos = atomicAdd(&a.cand_cnt[q], 1u);
-						if (pos < a.cap) a.cand[(size_t) q * a.cap + pos] = r;
+						const uint32_t slot = atomicAdd(pass_cnt, 1u);      // (LDS)
+						if (slot < (uint32_t) BF_PASS_CAP) pass_list[slot] = make_uint2(q, r);
+						else                                              // a block with more passes than the list holds: straight to the global list
+						{
+							const uint32_t pos = atomicAdd(&a.cand_cnt[q], 1u);
+							if (pos < a.cap) a.cand[(size_t) q * a.cap + pos] = r;
+						}
 					}
 				}
 			}
 		}
+	__syncthreads();
+	const uint32_t npass = min(*pass_cnt, (uint32_t) BF_PASS_CAP);
+	for (uint32_t i = (uint32_t) t; i < npass; i += 256)
+	{
+		const uint2 e = pass_list[i];
+		const uint32_t pos = atomicAdd(&a.cand_cnt[e.x], 1u);
+		if (pos < a.cap) a.cand[(size_t) e.x * a.cap + pos] = e.y;
+	}
 }
 
 // |row|^2 for every row (plain accumulation; only used by the filter and its margin)

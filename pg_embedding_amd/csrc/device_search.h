@@ -248,6 +248,7 @@ __device__ __forceinline__ uint64_t readlane_u64(uint64_t v, uint32_t l)
 	return ((uint64_t) hi << 32) | lo;
 }
 
+#ifdef HNSW_EXPERIMENT      // (helpers of the two-set register form: experiment builds only, see hnsw_search_kernel_reg)
 // value of lane-1 (lane 0 receives `fill`)
 __device__ __forceinline__ uint64_t wave_shr1_u64(uint64_t v, uint64_t fill)
 {
@@ -361,6 +362,8 @@ __device__ __forceinline__ uint64_t cand_max(const uint64_t (&ck)[C], uint32_t &
 }
 
 
+#endif
+
 // ---- exact visited set in LDS: open addressing, linear probing, lock-free insert ------------
 constexpr uint32_t HASH_EMPTY = 0xFFFFFFFFu;     // never a valid element number (LINK_NONE)
 
@@ -369,6 +372,7 @@ __device__ __forceinline__ uint32_t hash_slot(uint32_t id, uint32_t mask)
 	return ((id * 2654435761u) >> 7) & mask;
 }
 
+#ifdef HNSW_EXPERIMENT
 // true if `id` was not in the table (and is now); per-lane, lanes may collide on a slot
 __device__ __forceinline__ bool hash_test_and_set(uint32_t *tab, uint32_t mask, uint32_t id)
 {
@@ -393,6 +397,8 @@ __device__ __forceinline__ bool hash_contains(const uint32_t *tab, uint32_t mask
 		s = (s + 1) & mask;
 	}
 }
+
+#endif
 
 // ---- exact visited set in LDS, bucketed (beam form): 16-byte buckets of eight 16-bit tags ---------------
 // bucket = id % nb, tag = id / nb + 1 (0 = free slot): bucket and tag together ARE the id, so the set is
@@ -452,6 +458,11 @@ __device__ __forceinline__ bool tagset_contains(const uint32_t *tab, uint32_t nb
 	return tag_match(w, tag * 0x00010001u) != 0u;
 }
 
+// The two-set register form was the hot kernel of round 1; the beam form (further down) has dominated it since (40 % fewer VALU
+// instructions at 128 dims, 0.76 -> 0.62 ms for one query at 768 dims: profiles/r1i_beam_form.txt) and it had survived only as the
+// HNSW_GPU_BEAM=0 fallback and for mirrors of >= 2^31 elements.  Since round 5 those run the generic form below and this kernel is
+// compiled in experiment builds only (-DHNSW_EXPERIMENT): 30 instantiations fewer in the shipped library.
+#ifdef HNSW_EXPERIMENT
 template <int FUNC, typename SH, int RREG>
 __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(const SearchArgs a)
 {
@@ -753,6 +764,8 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 	if (aborted && lane == 0) atomicAdd(a.health + HEALTH_ABORTED_WAVES, 1u);
 }
 
+
+#endif      // HNSW_EXPERIMENT (two-set register form)
 
 // =====================================================================================
 // Generic form (any ef; used when ef > 256): both sets as UNSORTED arrays in LDS.

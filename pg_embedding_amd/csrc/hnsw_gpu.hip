@@ -806,8 +806,8 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	//     to ef = 512 for rows wider than 256 floats — those run at 2 waves/SIMD anyway, so 16 set registers
 	//     beat the LDS form there (+22-28 %, profiles/r1i_beam_form.txt); narrow rows keep the LDS form
 	//     above 256 (it holds 4 waves/SIMD).  Its prune packs the "expanded" bit into bit 31 of the idx.
-	//   two-set register form: HNSW_GPU_BEAM=0, or mirrors of >= 2^31 elements; ef <= 256.
-	//   LDS form: everything else (HNSW_GPU_FORCE_LDS_HEAPS=1 forces it).
+	//   LDS (generic) form: everything else — also HNSW_GPU_BEAM=0 and mirrors of >= 2^31 elements (HNSW_GPU_FORCE_LDS_HEAPS=1 forces it).
+	//   (two-set register form, round 1's hot kernel: experiment builds only since round 5.)
 	// The register forms use their LDS "res"/"cand" areas only as scratch of the emit step.
 	knobs_init();
 	const bool use_beam = knob(K_BEAM, 1) != 0 && ix->cap < 0x80000000ull;
@@ -831,7 +831,11 @@ static int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries
 	else if (ef > wide_min) rreg = 3;
 	else if (knob(K_FORCE_LDS_HEAPS, 0) > 0) rreg = 0;
 	else if (use_beam && (ef <= 256 || beam16)) rreg = ef <= 64 ? -2 : (ef <= 128 ? -4 : (ef <= 256 ? -8 : -16));
-	else rreg = ef <= 128 ? 2 : (ef <= 256 ? 4 : 0);
+#ifdef HNSW_EXPERIMENT
+	else rreg = ef <= 128 ? 2 : (ef <= 256 ? 4 : 0);         // two-set register form (experiment builds)
+#else
+	else rreg = 0;                                           // HNSW_GPU_BEAM=0, or a mirror of >= 2^31 elements: the generic form
+#endif
 	const size_t ucap = rreg < 0 ? (size_t) 64 * (size_t) -rreg : 0;      // beam form: slots of the accepted set
 	// Team form wanted for this launch?  (decided for good further down, once the LDS carve is known)
 	const int treq = (int) knob(K_TEAM, -1);

@@ -10,7 +10,8 @@ namespace pgemb {
 
 typedef void (*search_kernel_t)(const SearchArgs);
 
-// rreg: 0 = generic form, sets in LDS; 1 = generic form, sets in HBM (any ef); 2 / 4 = register form for ef <= 128 / 256,
+// rreg: 0 = generic form, sets in LDS; 1 = generic form, sets in HBM (any ef); 2 / 4 = two-set register form for ef <= 128 / 256
+//       (experiment builds only),
 //       -2 / -4 / -8 / -16 = beam form (counting acceptance) with that many set registers, ef <= 64 / 128 / 256 / 512
 template <typename SH, int RREG>
 inline search_kernel_t pick_search_kernel_f(int func, bool team)
@@ -56,6 +57,7 @@ inline search_kernel_t pick_search_kernel_f(int func, bool team)
 			case F_COSINE: return hnsw_search_kernel_lds<F_COSINE, SH, false>;
 			default:       return hnsw_search_kernel_lds<F_MANHATTAN, SH, false>;
 		}
+#ifdef HNSW_EXPERIMENT
 	constexpr int R = (RREG <= 1 || RREG == 3) ? 2 : RREG;
 	switch (func)
 	{
@@ -63,6 +65,9 @@ inline search_kernel_t pick_search_kernel_f(int func, bool team)
 		case F_COSINE: return hnsw_search_kernel_reg<F_COSINE, SH, R>;
 		default:       return hnsw_search_kernel_reg<F_MANHATTAN, SH, R>;
 	}
+#else
+	return nullptr;          // (the two-set register form exists in experiment builds only; the host never asks for it otherwise)
+#endif
 }
 
 template <typename SH>
@@ -70,8 +75,10 @@ inline search_kernel_t pick_search_kernel_s(int func, int rreg, bool team)
 {
 	switch (rreg)
 	{
+#ifdef HNSW_EXPERIMENT
 		case 2:  return pick_search_kernel_f<SH, 2>(func, false);
 		case 4:  return pick_search_kernel_f<SH, 4>(func, false);
+#endif
 		case -2: return pick_search_kernel_f<SH, -2>(func, team);
 		case -4: return pick_search_kernel_f<SH, -4>(func, team);
 		case -8: return pick_search_kernel_f<SH, -8>(func, team);

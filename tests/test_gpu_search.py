@@ -329,7 +329,7 @@ def test_many_queries_reuse_slots():
     {"HNSW_GPU_HASH_ENTRIES": "512"},        # tiny LDS visited set: most ids spill to the HBM bitmap
     {"HNSW_GPU_HASH_ENTRIES": "0"},          # bitmap only
     {"HNSW_GPU_FORCE_LDS_HEAPS": "1"},       # generic kernel (sorted arrays in LDS) at small ef
-    {"HNSW_GPU_BEAM": "0"},                  # two-set register form instead of the beam form
+    {"HNSW_GPU_BEAM": "0"},                  # no beam form: the generic kernel (the two-set register form lives in experiment builds only)
     {"HNSW_GPU_BEAM": "0", "HNSW_GPU_HASH_ENTRIES": "512"},
     {"HNSW_GPU_BEAM16": "0"},                # ef in (256, 512]: LDS form instead of 16 set registers
     {"HNSW_GPU_TEAM": "1"},                  # team form: idle waves of a block feed a sibling's walk from LDS caches
@@ -340,8 +340,8 @@ def test_many_queries_reuse_slots():
 ])
 def test_every_kernel_variant_is_exact(env, monkeypatch):
     """The visited set may live in LDS, spill to the bitmap half-way through a query, or be the
-    bitmap alone; the accepted set may be one counted set in registers (beam form), two sets in
-    registers, or sorted arrays in LDS: all must give the oracle's answer."""
+    bitmap alone; the accepted set may be one counted set in registers (beam form) or two unsorted
+    arrays in LDS (generic form): all must give the oracle's answer."""
     for k, v in env.items():
         monkeypatch.setenv(k, v)
     port, X = build_port(20000, 768, 16, 64, pg.DIST_L2, k=100, seed=77)
@@ -480,6 +480,60 @@ def test_a_stream_answers_like_a_launch(dim, m, func, walkers):
         assert_same_as_oracle(ix, port, Q[40:80], ef)            # an ordinary launch on the mirror after the stream has left
     ctx.close()
     ix.close()
+
+
+def test_a_plain_launch_issued_while_a_stream_is_open_runs_when_the_stream_lets_go(capsys):
+    """A stream's resident launch is sized to exactly the blocks the device holds (wide rows: 2 waves/SIMD, the register file is
+    full), so an ordinary launch on the same device has nowhere to run while the stream is open: it is queued BEHIND the stream — not
+    beside it, not lost — and runs the moment the stream closes; the stream keeps answering meanwhile.  That is why a stream owns its
+    device (include/hnsw_gpu.h "Streams", DESIGN.md 4.6: the server closes a session for writers, control work and after 2 ms without
+    searches).  The test states what happens with its numbers; both sides' answers must equal the oracle's either way."""
+    import time
+    import torch
+    n, dim, m, ef, nq = 20000, 768, 16, 64, 20000
+    port, X = build_port(n, dim, m, 48, pg.DIST_L2, k=40, seed=91)
+    Q = gmm(nq, dim, k=40, seed=91, stream=1)
+    want = port.search_many(Q[:512], ef, nthreads=8)
+    ix = mirror(port, pg.DIST_L2)
+    dq = torch.from_numpy(Q).cuda()
+    out = ix.search_torch(dq, ef)                              # (buffers; also the time of the launch on a free device)
+    torch.cuda.synchronize()
+    t_free = ix.last_search_ms()
+    ctx_s, ctx_p = pg.SearchContext(ix), pg.SearchContext(ix)
+    side = torch.cuda.Stream()
+    st = pg.SearchStream(ctx_s, ef, ring=256)
+    try:
+        slots = st.submit(Q[:64])                              # the stream is alive and answering
+        lab, dst, cnt = st.wait(slots)
+        assert (lab == want["labels"][:64]).all() and (bits(dst) == bits(want["dists"][:64])).all()
+        out["labels"].zero_()
+        ev = torch.cuda.Event()
+        t0 = time.perf_counter()
+        ctx_p.search_torch(dq, ef, out, stream=side)           # an ordinary launch of 20 000 queries, same device, another stream
+        ev.record(side)
+        beside = False
+        answered_meanwhile = 0
+        while time.perf_counter() - t0 < 1.0:                  # one second: forty times what the launch takes on a free device
+            if ev.query():
+                beside = True
+                break
+            slots = st.submit(Q[64 + answered_meanwhile:64 + answered_meanwhile + 32])
+            lab, dst, cnt = st.wait(slots)                     # the open stream still answers while that launch waits
+            assert (lab == want["labels"][64 + answered_meanwhile:96 + answered_meanwhile]).all()
+            answered_meanwhile = (answered_meanwhile + 32) % 384
+        t_waited = time.perf_counter() - t0
+    finally:
+        t1 = time.perf_counter()
+        st.close()
+    ev.synchronize()
+    t_after_close = time.perf_counter() - t1
+    got = out["labels"][:512].cpu().numpy()
+    assert (got == want["labels"]).all()                       # the queued launch ran, whole and exact
+    with capsys.disabled():
+        print(f"\n[stream + plain launch on one device] 20 000-query launch: {t_free:.2f} ms on a free device; issued while a stream was open it "
+              f"{'ran BESIDE the resident launch and ended after %.1f ms' % (t_waited * 1e3) if beside else 'had not ended after %.0f ms (the stream answered queries meanwhile)' % (t_waited * 1e3)}"
+              f"; it ended {t_after_close * 1e3:.1f} ms after the stream was closed")
+    ctx_s.close(); ctx_p.close(); ix.close()
 
 
 def _drive_stream(st, Q, want, nq, ring, round_):

@@ -38,7 +38,7 @@ def test_every_kernel_form_walks_and_emits_like_the_oracle(emu_lib):
     bad = [r for r in res if r["wrong"]]
     assert not bad, bad
     kernels = {r["kernel"] for r in res}
-    for needle in ("hnsw_search_kernel_beam<0, pgemb::Shape2x2, 2, false, true>", "hnsw_search_kernel_reg<", "hnsw_search_kernel_lds<",
+    for needle in ("hnsw_search_kernel_beam<0, pgemb::Shape2x2, 2, false, true>", "hnsw_search_kernel_lds<",
                    "Shape12x2, 2, true, false>", "Shape4x2", "kernel_beam<1,", "kernel_beam<2,"):
         assert any(needle in k for k in kernels), (needle, sorted(kernels))
 
