@@ -19,6 +19,6 @@ while IFS= read -r line; do
   timeout -k 10 $limit bash -c "$cmd" > $O/$name.txt 2>&1
   rc=$?
   echo "END   $name rc=$rc $((SECONDS - t0)) s" | tee -a $O/summary.txt
-  tail -4 $O/$name.txt
+  tail -6 $O/$name.txt
 done < "$2"
 cat $O/summary.txt
