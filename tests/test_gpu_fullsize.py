@@ -168,3 +168,65 @@ def test_reference_order_mode_equals_the_compiled_reference_for_every_query(cfg,
     same = (lab == r["labels"]).all(axis=1)
     print(f"\n[{cfg['name']}] reference-order mode: {int(same.sum())} of {nq} id lists equal the compiled reference's")
     assert same.all()
+
+
+REF_GRAPH = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref", "serial_graph_1000000x768_m16_efc200_l2.npy")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_GRAPH), reason="the reference's own serial 1M graph (tests/experiments/make_ref_serial_graph.py, 17 min on a host core) does not travel with this tree")
+def test_the_graph_the_reference_itself_built_is_searched_like_the_reference_searches_it(monkeypatch):
+    """Every other full-size test walks a graph the DEVICE built.  This one walks the headline table as oracle/_ref — the unmodified
+    hnswalg.cpp + distfunc.c — built it with 1 000 000 serial hnsw_bind_point calls (hnswalg.cpp:279-291; the link words travel in
+    oracle/_ref/, the rows are the seeded numpy generator's on every box): uploaded byte for byte, searched with 10 000 queries,
+      * device == port oracle bit-exactly (ids, distance bits, E_q, H_q),
+      * every id list that differs from the compiled reference's search of ITS OWN graph is a classified near-tie (<= 1e-5), none unexplained,
+      * in reference-order arithmetic every id list equals the compiled reference's directly,
+      * recall@10 of that graph passes the metric's gate."""
+    import torch
+    from pg_embedding_amd.datasets import gmm
+    dim, m, efc, ef, func, nq = 768, 16, 200, 128, pg.DIST_L2, 10_000
+    links = np.load(REF_GRAPH)
+    assert links.shape == (N, 2 * m + 1)
+    X = gmm(N, dim, k=1000, sigma=0.3, seed=42)
+    Qh = gmm(nq, dim, k=1000, sigma=0.3, seed=42, stream=1)
+    meta = pg.make_meta(dim, m, efc, ef, func)
+    raw = np.zeros((N, int(meta.size_data_per_element)), np.uint8)
+    raw[:, :int(meta.offset_data)] = links.view(np.uint8)
+    raw[:, int(meta.offset_data):int(meta.offset_label)] = X.view(np.uint8)
+    raw[:, int(meta.offset_label):] = np.arange(N, dtype=np.uint64)[:, None].view(np.uint8)
+    del X
+    raw = raw.reshape(-1)
+    ix = pg.GpuIndex.from_flat(meta, raw, N)
+    Q = torch.from_numpy(Qh).cuda()
+    out = ix.search_torch(Q, ef, stats=True)
+    torch.cuda.synchronize()
+    dev_labels = out["labels"].cpu().numpy().view(np.uint64)
+    dev_dists = out["dists"].cpu().numpy()
+    st = out["stats"].cpu().numpy().astype(np.uint32)
+    truth, _ = ix.bruteforce_torch(Q[:500].contiguous(), 10, mfma=True)
+    rec = recall_at_k(dev_labels[:500], truth.cpu().numpy(), 10)
+    ref = oracle.RefIndex(dim, m, efc, ef, func, capacity=N)
+    ref.load_raw(raw, N)
+    r = ref.search_many(Qh, ef, nthreads=THREADS)
+    port = oracle.PortIndex(dim, m, efc, ef, func, capacity=N)
+    port.load_raw(raw, N)
+    want = classify_against_reference(port, Qh, ef, r["labels"], nthreads=THREADS)
+    c = want["classification"]
+    monkeypatch.setenv("HNSW_GPU_REF_ORDER", "1")
+    o2 = ix.search_torch(Q, ef)
+    torch.cuda.synchronize()
+    monkeypatch.delenv("HNSW_GPU_REF_ORDER")
+    same = (o2["labels"].cpu().numpy().view(np.uint64) == r["labels"]).all(axis=1)
+    print(f"\n[the reference's own serial graph, 1M x 768] E_q {st[:, 0].mean():.1f} H_q {st[:, 1].mean():.1f} recall@10 {rec:.4f}; vs the compiled reference: {c}; "
+          f"reference-order mode: {int(same.sum())} of {nq} id lists equal")
+    assert (dev_labels == want["labels"]).all()
+    assert (bits(dev_dists) == bits(want["dists"])).all()
+    assert (st[:, 0] == want["evals"]).all() and (st[:, 1] == want["hops"]).all()
+    assert c["mismatch_unexplained"] == 0 and c["identical_ids"] >= 0.9 * nq
+    if same.all() is False or not same.all():
+        X0 = np.ascontiguousarray(raw.reshape(N, -1)[o2["labels"][0].cpu().numpy().astype(np.int64), int(meta.offset_data):int(meta.offset_label)]).view(np.float32)
+        if not (bits(o2["dists"][0].cpu().numpy()) == bits(oracle.ref_dist_many(func, Qh[0], X0))).all():
+            foreign_toolchain("the distance bits of the first query differ between HNSW_GPU_REF_ORDER=1 and oracle/_ref")
+    assert same.all()
+    assert rec >= 0.95, rec
+    ix.close()
