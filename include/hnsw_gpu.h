@@ -382,6 +382,19 @@ int hnsw_gpu_merge_topk_strided_dev(int device, const label_t *d_in_labels, size
 									size_t nq, size_t ef, label_t *d_out_labels, dist_t *d_out_dists,
 									uint32_t *d_out_counts, void *stream);
 
+/* A device buffer shared between PROCESSES — the exchange buffer of a row-sharded search whose shards live in different
+ * processes (one GPU-owning server per GPU; SURVEY.md §8e "direct P2P stores into rank-0 memory").  The merging process
+ * allocates it and hands the 64-byte handle to the others over whatever channel they share; they map it
+ * (hnsw_gpu_shared_open: on another GPU their stores into it cross xGMI as peer stores), run hnsw_gpu_search_batch_dev
+ * on their shard with the output pointers inside it — list r = the r-th [nq][ef] block — and tell the owner when their
+ * stream has drained; the owner merges with hnsw_gpu_merge_topk[_strided]_dev.  No staging copy, no collective library.
+ * (HSA_ENABLE_IPC_MODE_LEGACY=0 where the host driver only supports dmabuf IPC.) */
+typedef struct hnsw_gpu_ipc_handle { unsigned char bytes[64]; } hnsw_gpu_ipc_handle;
+int hnsw_gpu_shared_alloc(int device, size_t bytes, void **d_ptr, hnsw_gpu_ipc_handle *handle);     /* owner */
+int hnsw_gpu_shared_open(int device, const hnsw_gpu_ipc_handle *handle, void **d_ptr);            /* another process */
+int hnsw_gpu_shared_close(int device, void *d_ptr);                                                /* that process, when done */
+int hnsw_gpu_shared_free(int device, void *d_ptr);                                                 /* owner */
+
 /* A row-sharded index inside ONE process (an index larger than one GPU behind a C host; the reference has no
  * counterpart: embedding.c:982 amcanparallel = false).  `shards` are mirrors the caller built — one graph per
  * contiguous row range, labels globally unique (SURVEY.md §8e mode 2) — on one or several devices; they are

@@ -157,6 +157,10 @@ def gpu_lib():
     L.hnsw_gpu_bruteforce_mfma_dev.argtypes = [vp, vp, sz, sz, vp, vp, vp]
     L.hnsw_gpu_last_bruteforce_gemm_ms.restype = C.c_float
     L.hnsw_gpu_last_bruteforce_clock_mhz.restype = C.c_double
+    L.hnsw_gpu_shared_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(vp), C.c_char_p]
+    L.hnsw_gpu_shared_open.argtypes = [C.c_int, C.c_char_p, C.POINTER(vp)]
+    L.hnsw_gpu_shared_close.argtypes = [C.c_int, vp]
+    L.hnsw_gpu_shared_free.argtypes = [C.c_int, vp]
     L.hnsw_gpu_merge_topk_dev.argtypes = [i32, vp, vp, sz, sz, sz, vp, vp, vp, vp]
     L.hnsw_gpu_merge_topk_strided_dev.argtypes = [i32, vp, sz, vp, sz, sz, sz, sz, vp, vp, vp, vp]
     L.hnsw_gpu_last_search_kernel.argtypes = [vp, C.c_char_p, sz]

@@ -2776,6 +2776,66 @@ extern "C" int hnsw_gpu_ctx_idle(hnsw_gpu_ctx *c)
 	return fail(HNSW_GPU_ERR_HIP, "hipEventQuery failed: %s", hipGetErrorString(e));
 }
 
+// ------------------------------------------------------------------------------------
+// A device buffer shared between PROCESSES: the exchange buffer of a row-sharded search whose shards live in different
+// processes (one GPU-owning server per GPU).  Every process searches its shard with its output pointers inside the buffer
+// (hnsw_gpu_search_batch_dev: slot r = the r-th [nq][ef] block), the owner merges (hnsw_gpu_merge_topk_strided_dev) once the
+// others have told it — over whatever channel they already share — that their launches are complete.  With the importer on
+// another GPU its stores cross xGMI as peer stores, exactly like the one-process form (hnsw_gpu_sharded_search_dev); no
+// staging copy, no collective library in a C host.
+// ------------------------------------------------------------------------------------
+static_assert(sizeof(hipIpcMemHandle_t) <= sizeof(hnsw_gpu_ipc_handle), "the ABI's handle must hold a HIP IPC handle");
+
+extern "C" int hnsw_gpu_shared_alloc(int device, size_t bytes, void **d_ptr, hnsw_gpu_ipc_handle *handle)
+{
+	if (!d_ptr || !handle || bytes == 0) return fail(HNSW_GPU_ERR_ARG, "NULL argument or empty buffer");
+	HIPCHK(hipSetDevice(device));
+	void *p = nullptr;
+	hipError_t e = hipMalloc(&p, bytes);
+	if (e != hipSuccess) { (void) hipGetLastError(); return fail(e == hipErrorOutOfMemory ? HNSW_GPU_ERR_NOMEM : HNSW_GPU_ERR_HIP, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+	hipIpcMemHandle_t h;
+	e = hipIpcGetMemHandle(&h, p);
+	if (e != hipSuccess)
+	{
+		(void) hipGetLastError();
+		(void) hipFree(p);
+		return fail(HNSW_GPU_ERR_HIP, "hipIpcGetMemHandle: %s (is HSA_ENABLE_IPC_MODE_LEGACY=0 set where the driver only has dmabuf IPC?)", hipGetErrorString(e));
+	}
+	memset(handle, 0, sizeof(*handle));
+	memcpy(handle->bytes, &h, sizeof(h));
+	*d_ptr = p;
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_shared_open(int device, const hnsw_gpu_ipc_handle *handle, void **d_ptr)
+{
+	if (!d_ptr || !handle) return fail(HNSW_GPU_ERR_ARG, "NULL argument");
+	HIPCHK(hipSetDevice(device));
+	hipIpcMemHandle_t h;
+	memcpy(&h, handle->bytes, sizeof(h));
+	void *p = nullptr;
+	const hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+	if (e != hipSuccess) { (void) hipGetLastError(); return fail(HNSW_GPU_ERR_HIP, "hipIpcOpenMemHandle: %s", hipGetErrorString(e)); }
+	*d_ptr = p;
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_shared_close(int device, void *d_ptr)
+{
+	if (!d_ptr) return HNSW_GPU_OK;
+	HIPCHK(hipSetDevice(device));
+	HIPCHK(hipIpcCloseMemHandle(d_ptr));
+	return HNSW_GPU_OK;
+}
+
+extern "C" int hnsw_gpu_shared_free(int device, void *d_ptr)
+{
+	if (!d_ptr) return HNSW_GPU_OK;
+	HIPCHK(hipSetDevice(device));
+	HIPCHK(hipFree(d_ptr));
+	return HNSW_GPU_OK;
+}
+
 // Pinned host memory for the host-pointer entry points (NULL when there is no device / no memory).
 extern "C" void *hnsw_gpu_host_alloc(size_t bytes)
 {

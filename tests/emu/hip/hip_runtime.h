@@ -499,6 +499,12 @@ static inline hipError_t hipDeviceGetAttribute(int *v, int attr, int)
 	return hipSuccess;
 }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+// memory shared between processes: not modelled (one process is the whole "device" here)
+struct hipIpcMemHandle_t { char reserved[64]; };
+enum { hipIpcMemLazyEnablePeerAccess = 1 };
+static inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t *, void *) { return hipErrorInvalidValue; }
+static inline hipError_t hipIpcOpenMemHandle(void **, hipIpcMemHandle_t, unsigned) { return hipErrorInvalidValue; }
+static inline hipError_t hipIpcCloseMemHandle(void *) { return hipErrorInvalidValue; }
 static inline hipError_t hipDeviceCanAccessPeer(int *can, int dev, int peer) { *can = simt::ndev() > 1 && simt::peer_hw() && dev != peer; return hipSuccess; }
 static inline hipError_t hipDeviceEnablePeerAccess(int peer, unsigned)
 {

@@ -178,3 +178,64 @@ def test_two_processes_one_collective(tmp_path):
         order = np.lexsort((l, d))[:ef]
         assert (got["labels"][q].view(np.uint64) == l[order]).all()
         assert (got["dists"][q].view(np.uint32) == d[order].view(np.uint32)).all()
+
+
+def test_shards_in_two_processes_meet_in_one_shared_buffer():
+    """Row shards that live in DIFFERENT processes (one GPU-owning server per GPU): the merging process allocates the exchange buffer
+    (hnsw_gpu_shared_alloc), the other maps it from the 64-byte IPC handle (hnsw_gpu_shared_open) and searches its shard with the
+    output pointers inside it; one merge kernel on the owner == oracle per shard + CPU merge.  Both processes share device 0 here
+    (the IPC mapping is the same call that crosses xGMI between two GPUs); no torch.distributed, no collective library."""
+    import ctypes as C
+    import os
+    import subprocess
+    import sys
+    import torch
+    from pg_embedding_amd._lib import check, gpu_lib
+    n, dim, m, efc, ef, nq, seed, nshards = 8000, 64, 8, 48, 32, 256, 53, 2
+    X = gmm(n, dim, k=40, seed=seed)
+    Q = gmm(nq, dim, k=40, seed=seed, stream=1)
+    L = gpu_lib()
+    lab_bytes, dst_bytes, cnt_bytes = nshards * nq * ef * 8, nshards * nq * ef * 4, nshards * nq * 4
+    base, handle = C.c_void_p(), C.create_string_buffer(64)
+    check(L.hnsw_gpu_shared_alloc(0, lab_bytes + dst_bytes + cnt_bytes, C.byref(base), handle), "hnsw_gpu_shared_alloc")
+    peer = subprocess.Popen([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "shared_gather_peer.py"), handle.raw.hex(), "1",
+                             str(nshards), str(n), str(dim), str(m), str(efc), str(ef), str(nq), str(seed)],
+                            stdin=subprocess.PIPE, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        per = []
+        meta = pg.make_meta(dim, m, efc, ef, pg.DIST_L2)
+        for r in range(nshards):
+            lo, hi = shard_range(n, nshards, r)
+            port = oracle.PortIndex(dim, m, efc, ef, pg.DIST_L2)
+            port.add(X[lo:hi], np.arange(lo, hi, dtype=np.uint64))
+            per.append(port.search_many(Q, ef))
+            if r == 0:                                           # my own shard: list 0 of the buffer
+                ix = pg.GpuIndex.from_flat(meta, port.raw(), hi - lo)
+                dq = torch.from_numpy(Q).cuda()
+                check(L.hnsw_gpu_search_batch_dev(ix._h, dq.data_ptr(), nq, ef, base.value, base.value + lab_bytes,
+                                                  base.value + lab_bytes + dst_bytes, None, None), "hnsw_gpu_search_batch_dev")
+                torch.cuda.synchronize()
+        line = peer.stdout.readline().strip()                    # the other process's launch has drained
+        assert line == "STORED", (line, peer.stderr.read()[-2000:] if peer.poll() is not None else "")
+        ol = torch.empty((nq, ef), dtype=torch.int64, device="cuda")
+        od = torch.empty((nq, ef), dtype=torch.float32, device="cuda")
+        oc = torch.empty((nq,), dtype=torch.int32, device="cuda")
+        check(L.hnsw_gpu_merge_topk_dev(0, base.value, base.value + lab_bytes, nshards, nq, ef, ol.data_ptr(), od.data_ptr(), oc.data_ptr(), None),
+              "hnsw_gpu_merge_topk_dev")
+        torch.cuda.synchronize()
+        peer.stdin.write("MERGED\n"); peer.stdin.flush()
+        assert peer.stdout.readline().strip() == "CLOSED"
+        assert peer.wait(timeout=60) == 0
+    finally:
+        if peer.poll() is None:
+            peer.kill()
+    ml, md, mc = ol.cpu().numpy().view(np.uint64), od.cpu().numpy(), oc.cpu().numpy().view(np.uint32)
+    for q in range(nq):
+        l = np.concatenate([p["labels"][q, :p["counts"][q]] for p in per])
+        d = np.concatenate([p["dists"][q, :p["counts"][q]] for p in per])
+        order = np.lexsort((l, d))[:ef]
+        assert mc[q] == order.size
+        assert (ml[q, :order.size] == l[order]).all()
+        assert (md[q, :order.size].view(np.uint32) == d[order].view(np.uint32)).all()
+    ix.close()
+    check(L.hnsw_gpu_shared_free(0, base), "hnsw_gpu_shared_free")
