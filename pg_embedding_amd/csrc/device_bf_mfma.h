@@ -36,14 +36,22 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));       // (a first-cla
 #define BF_TK 32                                     // floats of K per step (32 or 64)
 #endif
 #define BF_NBUF 2                                    // LDS buffers: the loads of step ks + 1 fly during the MFMAs of step ks
+#ifndef BF_ABLATE
+#define BF_ABLATE 0                                  // 0 = the product.  1: no barrier in the K loop; 2: one operand read per K step; 3: no tile loads after the first
+#endif
 #ifndef BF_NJ
 #define BF_NJ 2                                      // 32-row MFMA tiles of index rows per wave (2: 64 x 64 per wave, 4: 64 x 128)
 #endif
-constexpr int BF_TQ = 128, BF_TR = 64 * BF_NJ;       // block tile: 128 queries x 128 (or 256) rows, 2 x 2 waves
+#ifndef BF_WM
+#define BF_WM 2                                      // waves along the queries (2: 128-query tiles, 4 waves; 4: 256-query tiles, 8 waves)
+#endif
+constexpr int BF_WAVES = 2 * BF_WM, BF_THREADS = 64 * BF_WAVES;
+constexpr int BF_TQ = 64 * BF_WM, BF_TR = 64 * BF_NJ; // block tile: BF_WM x 2 waves of 64 x (32 BF_NJ) each
 constexpr int BF_CH = BF_TK / 4;                     // 16-byte chunks of a tile row per K step (8 or 16)
 constexpr int BF_RPI = 64 / BF_CH;                   // tile rows one wave instruction fills (8 x 128 B or 4 x 256 B: whole lines either way)
-constexpr int BF_PASSES = BF_TQ / (4 * BF_RPI);      // load instructions per query tile, thread and K step
-constexpr int BF_PASSES_R = BF_TR / (4 * BF_RPI);    // ... per row tile
+constexpr int BF_RPP = BF_WAVES * BF_RPI;             // tile rows the block fills per pass
+constexpr int BF_PASSES = BF_TQ / BF_RPP;            // load instructions per query tile, thread and K step
+constexpr int BF_PASSES_R = BF_TR / BF_RPP;          // ... per row tile
 constexpr int BF_LS = BF_TK;                         // lane-linear LDS image, no padding: chunk c of row r at slot c ^ swizzle(r)
 constexpr int BF_TILE_FLOATS = BF_TQ * BF_LS;        // the query tile
 constexpr int BF_BUF_FLOATS = (BF_TQ + BF_TR) * BF_LS;   // one buffer: query tile, then row tile
@@ -71,7 +79,7 @@ struct BfArgs
 	unsigned long long *clocks; // NULL, or 2 words: shader-clock and constant-clock ticks one block spent in its K loop (measurement only)
 };
 
-__global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
+__global__ __launch_bounds__(BF_THREADS, BF_WM == 2 ? 2 : 1) void bf_mfma_filter_kernel(const BfArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	float *bf_lds = reinterpret_cast<float *>(smem);                    // [buf][A | B][row][BF_LS], then the epilogue's bounds
@@ -84,16 +92,16 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 	if (rt >= a.nrt) return;
 	const uint32_t q0 = qt * BF_TQ, r0 = rt * BF_TR;
 
-	// staging role: thread owns 16-byte slot `sch` of tile rows srow + 4 * BF_RPI * j; a wave instruction moves whole 128-byte lines
+	// staging role: thread owns 16-byte slot `sch` of tile rows srow + BF_RPP * j; a wave instruction moves whole 128-byte lines
 	const uint32_t sch = t & (BF_CH - 1), srow = t / BF_CH;
 	const uint32_t nchunks = a.stride / 4;
 	const floatx4 *qsrc[BF_PASSES], *xsrc[BF_PASSES_R];
 #pragma unroll
 	for (int j = 0; j < BF_PASSES; j++)
-		qsrc[j] = reinterpret_cast<const floatx4 *>(a.queries + (size_t) min(q0 + srow + 4 * BF_RPI * j, a.nq - 1) * a.qstride);
+		qsrc[j] = reinterpret_cast<const floatx4 *>(a.queries + (size_t) min(q0 + srow + BF_RPP * j, a.nq - 1) * a.qstride);
 #pragma unroll
 	for (int j = 0; j < BF_PASSES_R; j++)
-		xsrc[j] = reinterpret_cast<const floatx4 *>(a.vec + (size_t) min(r0 + srow + 4 * BF_RPI * j, a.n - 1) * a.stride);
+		xsrc[j] = reinterpret_cast<const floatx4 *>(a.vec + (size_t) min(r0 + srow + BF_RPP * j, a.n - 1) * a.stride);
 
 	floatx16 acc[2][BF_NJ];
 #pragma unroll
@@ -134,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 	// writes — wave-uniform base + lane * 16: BF_RPI rows of whole lines per instruction, no padding — so bank conflicts are avoided on
 	// the SOURCE side: the lane that fills slot p of row r fetches chunk p ^ swizzle(r).  No select on a loaded value either: the query
 	// copy is zero padded to whole K steps, and a row chunk beyond the row's end re-reads the row's last chunk (times zero: nothing).
-	const uint32_t gch = sch ^ bf_swz(srow);                    // (swizzle(srow + 4 * BF_RPI * j) == swizzle(srow): the step is a multiple of 16)
+	const uint32_t gch = sch ^ bf_swz(srow);                    // (swizzle(srow + BF_RPP * j) == swizzle(srow): the step is a multiple of 16)
 	auto fetch = [&](uint32_t ks, uint32_t buf)
 	{
 		const uint32_t c = ks * BF_CH + gch;
@@ -143,11 +151,11 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 #pragma unroll
 		for (int j = 0; j < BF_PASSES; j++)
 			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (qsrc[j] + c),
-											 (__attribute__((address_space(3))) void *) (As + 4 * BF_RPI * j * BF_LS), 16, 0, 0);
+											 (__attribute__((address_space(3))) void *) (As + BF_RPP * j * BF_LS), 16, 0, 0);
 #pragma unroll
 		for (int j = 0; j < BF_PASSES_R; j++)
 			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (xsrc[j] + cc),
-											 (__attribute__((address_space(3))) void *) (Bs + 4 * BF_RPI * j * BF_LS), 16, 0, 0);
+											 (__attribute__((address_space(3))) void *) (Bs + BF_RPP * j * BF_LS), 16, 0, 0);
 	};
 	// An MFMA may sum a dot product in any k order as long as both operands use the same one: lane (col, kk) takes the four k of ONE
 	// ds_read_b128 (chunk 2g + kk of its row) and feeds them to four consecutive MFMAs — 16 ds_read_b128 per 64 MFMAs.
@@ -162,7 +170,7 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 #pragma unroll
 		for (int g = 0; g < BF_TK / 8; g++)
 		{
-			const uint32_t o = roff[g];
+			const uint32_t o = roff[BF_ABLATE == 2 ? 0 : g];
 			floatx4 av[2], bv[BF_NJ];
 #pragma unroll
 			for (int i = 0; i < 2; i++) av[i] = *reinterpret_cast<const floatx4 *>(As + i * 32 * BF_LS + o);
@@ -188,10 +196,16 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 	__syncthreads();                                            // (hipcc drains the LDS-bound loads, vmcnt(0), in front of the barrier)
 	for (uint32_t ks = 0; ks < a.ksteps; ks++)
 	{
+#if BF_ABLATE != 3                                              // (ablation builds — wrong answers, timing only: profiles/r5l_mfma_ablation.txt)
 		fetch(min(ks + 1, a.ksteps - 1), (ks + 1) & 1);            // its readers passed the previous barrier (branch-free: the last step re-reads itself)
+#endif
 		__builtin_amdgcn_sched_barrier(0);
 		contract(ks & 1);
+#if BF_ABLATE == 1
+		__builtin_amdgcn_s_waitcnt(0);                             // the loads are still waited for; only the rendezvous of the four waves is gone
+#else
 		__syncthreads();
+#endif
 	}
 	if (a.clocks && blockIdx.x == gridDim.x / 2 && t == 0)             // a block from the middle of the launch
 	{
@@ -224,6 +238,7 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 						pass = dot >= qb[e1] * xs2[j];                   // 1 - dot/sqrt(nq nx) <= tau (+margin)
 					else
 						pass = qn[e1] + xs2[j] - 2.f * dot <= qb[e1];    // |q-x|^2 <= tau^2 (+margin)
+					if (BF_ABLATE) pass = pass && dot == 12345.678f;      // (timing-only builds compute garbage: keep it out of the lists)
 					if (pass && rok && q < a.nq)
 					{
 						const uint32_t slot = atomicAdd(pass_cnt, 1u);      // (LDS)
@@ -239,7 +254,7 @@ __global__ __launch_bounds__(256, 2) void bf_mfma_filter_kernel(const BfArgs a)
 		}
 	__syncthreads();
 	const uint32_t npass = min(*pass_cnt, (uint32_t) BF_PASS_CAP);
-	for (uint32_t i = (uint32_t) t; i < npass; i += 256)
+	for (uint32_t i = (uint32_t) t; i < npass; i += BF_THREADS)
 	{
 		const uint2 e = pass_list[i];
 		const uint32_t pos = atomicAdd(&a.cand_cnt[e.x], 1u);

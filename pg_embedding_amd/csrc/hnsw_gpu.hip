@@ -1834,7 +1834,7 @@ extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d
 	HIPCHK(hipEventRecord(e0, s));
 	// two operand tiles of 128 x 36 floats, twice: 72 KB of LDS per block (set per call: the attribute is per device)
 	HIPCHK(hipFuncSetAttribute((const void *) bf_mfma_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) BF_LDS_BYTES));
-	hipLaunchKernelGGL(bf_mfma_filter_kernel, dim3(rgroups * a.nqt * 8), dim3(256), BF_LDS_BYTES, s, a);
+	hipLaunchKernelGGL(bf_mfma_filter_kernel, dim3(rgroups * a.nqt * 8), dim3(BF_THREADS), BF_LDS_BYTES, s, a);
 	HIPCHK(hipEventRecord(e1, s));
 
 	// 3. canonical re-score of the survivors
