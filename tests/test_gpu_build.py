@@ -105,7 +105,10 @@ def test_bruteforce_is_exact(func):
 
 
 @pytest.mark.parametrize("func", [pg.DIST_L2, pg.DIST_COSINE])
-@pytest.mark.parametrize("n,dim,nq,k", [(50000, 200, 300, 10), (20000, 768, 129, 32), (9000, 30, 64, 5)])
+@pytest.mark.parametrize("n,dim,nq,k", [(50000, 200, 300, 10), (20000, 768, 129, 32), (9000, 30, 64, 5),
+                                        # rows that end inside a K step (100 floats: the query copy is zero padded to 128, the row's last chunk re-read times zero),
+                                        # one query, a table one row past a tile, k = 1; 1536 floats with more queries than one 128-query tile
+                                        (4097, 100, 1, 1), (70001, 100, 257, 10), (12000, 1536, 200, 10)])
 def test_mfma_exhaustive_scorer_equals_canonical_scan(func, n, dim, nq, k):
     """The dense MFMA pass is only a filter; the answer must equal the canonical brute force
     bit for bit (ids, and distances from the canonical code)."""
