@@ -526,10 +526,12 @@ HEADLINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per
 
 
 def emit(result):
-    """Two JSON lines on stdout: every extra leg FIRST (one long line, `"extras_of": <metric>`), the compact headline LAST — the line
-    the contract describes, short enough that the tail of a captured stdout holds it whole.  The headline carries, as plain scalars
-    inside `config` / `roofline` / `cpu_baseline` (the objects a record keeps), everything the metric's claim rests on: the recall
-    gate, the one-query latency, the HBM-only fraction, traffic over algorithmic bytes, and the other configs' fractions."""
+    """ONE JSON line on stdout — the line the contract describes, compact enough that the tail of a captured stdout holds it whole — and,
+    BEFORE it, every extra leg as one long JSON line (`"extras_of": <metric>`) on stderr (also written to gpurun_out/bench_extras.json):
+    whoever captures the two streams together sees the extras first and the headline last, whoever parses stdout finds exactly one
+    line.  The headline carries, as plain scalars inside `config` / `roofline` / `cpu_baseline` (the objects a record keeps),
+    everything the metric's claim rests on: the recall gate, the one-query latency, the HBM-only fraction, traffic over algorithmic
+    bytes, and the other configs' fractions."""
     def get(d, *path):
         for k in path:
             if not isinstance(d, dict) or k not in d:
@@ -574,7 +576,15 @@ def emit(result):
         head["cpu_baseline"] = {k: v for k, v in head["cpu_baseline"].items() if not isinstance(v, (dict, list))}
     extras = {"extras_of": result.get("metric"), "note": "every extra leg of this run; the headline line follows as the LAST line"}
     extras.update({k: v for k, v in result.items() if k not in ("metric", "value", "unit")})
-    sys.stdout.write(json.dumps(extras) + "\n")
+    line = json.dumps(extras)
+    sys.stderr.write(line + "\n")
+    sys.stderr.flush()
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "bench_extras.json"), "w") as f:
+            f.write(line + "\n" + json.dumps(head) + "\n")
+    except OSError:
+        pass
     sys.stdout.write(json.dumps(head) + "\n")
     sys.stdout.flush()
 
