@@ -36,6 +36,9 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));       // (a first-cla
 #define BF_TK 32                                     // floats of K per step (32 or 64)
 #endif
 #define BF_NBUF 2                                    // LDS buffers: the loads of step ks + 1 fly during the MFMAs of step ks
+#ifndef BF_INTERLEAVE
+#define BF_INTERLEAVE 0                              // 1: the next step's tile loads are issued a pass at a time between the MFMAs of this step
+#endif
 #ifndef BF_ABLATE
 #define BF_ABLATE 0                                  // 0 = the product.  1: no barrier in the K loop; 2: one operand read per K step; 3: no tile loads after the first
 #endif
@@ -163,8 +166,23 @@ __global__ __launch_bounds__(BF_THREADS, BF_WM == 2 ? 2 : 1) void bf_mfma_filter
 	uint32_t roff[BF_TK / 8];                                  // float offset of k-group g's slot in this lane's row
 #pragma unroll
 	for (int g = 0; g < BF_TK / 8; g++) roff[g] = ((2 * g + kk) ^ swz) * 4;
-	auto contract = [&](uint32_t buf)
+	// one pass of the next step's tile loads (query tile passes first, then row tile passes): issued BETWEEN the MFMAs of the current step
+	// (BF_INTERLEAVE), so that a wave's load issue runs under its own MFMAs instead of in front of them
+	auto fetch_pass = [&](uint32_t ks, uint32_t buf, int p)
 	{
+		const uint32_t c = ks * BF_CH + gch;
+		const uint32_t cc = min(c, nchunks - 1);
+		float *As = bf_lds + (size_t) buf * BF_BUF_FLOATS + (wave * BF_RPI) * BF_LS, *Bs = As + BF_TILE_FLOATS;
+		if (p < BF_PASSES)
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (qsrc[p] + c),
+											 (__attribute__((address_space(3))) void *) (As + BF_RPP * p * BF_LS), 16, 0, 0);
+		else if (p < BF_PASSES + BF_PASSES_R)
+			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (xsrc[p - BF_PASSES] + cc),
+											 (__attribute__((address_space(3))) void *) (Bs + BF_RPP * (p - BF_PASSES) * BF_LS), 16, 0, 0);
+	};
+	auto contract = [&](uint32_t buf, uint32_t ks_next, uint32_t buf_next)
+	{
+		(void) ks_next; (void) buf_next;
 		const float *As = bf_lds + (size_t) buf * BF_BUF_FLOATS + (wm * 64 + col) * BF_LS;
 		const float *Bs = bf_lds + (size_t) buf * BF_BUF_FLOATS + BF_TILE_FLOATS + (wn * (32 * BF_NJ) + col) * BF_LS;
 #pragma unroll
@@ -178,11 +196,28 @@ __global__ __launch_bounds__(BF_THREADS, BF_WM == 2 ? 2 : 1) void bf_mfma_filter
 			for (int j = 0; j < BF_NJ; j++) bv[j] = *reinterpret_cast<const floatx4 *>(Bs + j * 32 * BF_LS + o);
 #pragma unroll
 			for (int c = 0; c < 4; c++)
+			{
 #pragma unroll
 				for (int i = 0; i < 2; i++)
 #pragma unroll
 					for (int j = 0; j < BF_NJ; j++)
 						acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][c], bv[j][c], acc[i][j], 0, 0, 0);
+#if BF_INTERLEAVE
+				// loads of the next step, a pass at a time, behind each quarter of this k-group's MFMAs
+				{
+					constexpr int NP = BF_PASSES + BF_PASSES_R, SLOTS = 4 * (BF_TK / 8), PER = (NP + SLOTS - 1) / SLOTS;
+					__builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+					for (int q = 0; q < PER; q++)
+					{
+						const int slot = g * 4 + c;
+						if (BF_INTERLEAVE == 2 && NP * 2 <= SLOTS) { if (slot % 2 == 1) fetch_pass(ks_next, buf_next, slot / 2); }   // spread over the whole step
+						else fetch_pass(ks_next, buf_next, slot * PER + q);
+					}
+					__builtin_amdgcn_sched_barrier(0);
+				}
+#endif
+			}
 		}
 	};
 
@@ -196,11 +231,11 @@ __global__ __launch_bounds__(BF_THREADS, BF_WM == 2 ? 2 : 1) void bf_mfma_filter
 	__syncthreads();                                            // (hipcc drains the LDS-bound loads, vmcnt(0), in front of the barrier)
 	for (uint32_t ks = 0; ks < a.ksteps; ks++)
 	{
-#if BF_ABLATE != 3                                              // (ablation builds — wrong answers, timing only: profiles/r5l_mfma_ablation.txt)
+#if BF_ABLATE != 3 && !BF_INTERLEAVE                            // (ablation builds — wrong answers, timing only: profiles/r5l_mfma_ablation.txt)
 		fetch(min(ks + 1, a.ksteps - 1), (ks + 1) & 1);            // its readers passed the previous barrier (branch-free: the last step re-reads itself)
 #endif
 		__builtin_amdgcn_sched_barrier(0);
-		contract(ks & 1);
+		contract(ks & 1, min(ks + 1, a.ksteps - 1), (ks + 1) & 1);
 #if BF_ABLATE == 1
 		__builtin_amdgcn_s_waitcnt(0);                             // the loads are still waited for; only the rendezvous of the four waves is gone
 #else
