@@ -815,7 +815,7 @@ def side_configs(args, dev, local):
                 best_ms = min(best_ms, float(gl.hnsw_gpu_last_bruteforce_gemm_ms()))
             flops = 2.0 * nq * n * ((dim + 3) // 4 * 4)
             si, sd = ix.bruteforce_torch(Q[:64].contiguous(), 10)          # the canonical scan on a slice
-            mfma = {"queries": nq, "gemm_kernel_ms": best_ms, "tflops": flops / best_ms / 1e9, "peak_f32_mfma_tflops": 157.3,
+            mfma = {"queries": nq, "block_tile": int(gl.hnsw_gpu_last_bruteforce_tile()), "gemm_kernel_ms": best_ms, "tflops": flops / best_ms / 1e9, "peak_f32_mfma_tflops": 157.3,
                     "frac": flops / best_ms / 1e9 / 157.3, "whole_call_ms": best_total,
                     "identical_to_canonical_scan": bool((si == ti[:64]).all().item() and
                                                         (sd.view(torch.int32) == td[:64].view(torch.int32)).all().item())}

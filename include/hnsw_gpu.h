@@ -362,6 +362,8 @@ int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d_queries, s
 float hnsw_gpu_last_bruteforce_gemm_ms(void);
 /* shader clock (MHz) a block of that kernel saw over its K loop: shader-clock ticks / constant-clock ticks (measurement only) */
 double hnsw_gpu_last_bruteforce_clock_mhz(void);
+/* queries (= rows) per block tile of that launch: 128 or 256 (256 x 256 tiles are picked for launches with thousands of tiles) */
+int hnsw_gpu_last_bruteforce_tile(void);
 
 /* ----------------------------------------------------------------- multi-shard */
 

@@ -161,6 +161,8 @@ def build_variant(tag: str, defines) -> str:
     host_only = ("hgs_io.h", "host_walk.h", "host_dist.h", "shim_cache.h")
     gpu_src = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) and f not in host_only] + hdrs
     _build_gpu_lib(out, gpu_src, defines)
+    import shutil
+    shutil.rmtree(os.path.join(LIBDIR, "obj", os.path.basename(out)), ignore_errors=True)   # (9 MB of objects per variant, and they travel to the GPU box)
     return out
 
 

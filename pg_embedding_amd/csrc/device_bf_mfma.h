@@ -17,7 +17,8 @@
 // L2 uses |q|^2 + |x|^2 - 2 q.x, cosine 1 - q.x / sqrt(|q|^2 |x|^2) (distfunc.c:133-145);
 // Manhattan is not a contraction and is not offered here.
 //
-// Tiling (round 5): block = 4 waves, 128 queries x 128 rows per block, K in steps of BF_TK floats.  Tiles go from global memory
+// Tiling (round 5): block = 4 waves, 128 queries x 128 rows per block (8 waves and 256 x 256 for launches with tiles enough: BfTile below), K in
+// steps of BF_TK floats.  Tiles go from global memory
 // straight into LDS (global_load_lds_dwordx4) in whole 128-byte lines, bank-swizzled on the source side; operands are read with
 // ds_read_b128 (four k per read: a filter may sum in any k order), 16 reads per 64 MFMAs, conflict-free (SQ_LDS_BANK_CONFLICT 0); two
 // LDS buffers, one barrier per step; each wave owns a 64 x 64 sub-tile = 2 x 2 MFMA tiles (64 accumulator registers); the epilogue's
@@ -35,9 +36,14 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));       // (a first-cla
 #ifndef BF_TK
 #define BF_TK 32                                     // floats of K per step (32 or 64)
 #endif
-#define BF_NBUF 2                                    // LDS buffers: the loads of step ks + 1 fly during the MFMAs of step ks
+#ifndef BF_NBUF
+#define BF_NBUF 2                                    // LDS buffers: the loads of step ks + 1 fly during the MFMAs of step ks (3: those of ks + 2 as well, counted vmcnt)
+#endif
 #ifndef BF_INTERLEAVE
 #define BF_INTERLEAVE 0                              // 1: the next step's tile loads are issued a pass at a time between the MFMAs of this step
+#endif
+#ifndef BF_SETPRIO
+#define BF_SETPRIO 0                                 // 1: s_setprio(1) around every k-group's MFMAs
 #endif
 #ifndef BF_ABLATE
 #define BF_ABLATE 0                                  // 0 = the product.  1: no barrier in the K loop; 2: one operand read per K step; 3: no tile loads after the first
@@ -48,19 +54,28 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));       // (a first-cla
 #ifndef BF_WM
 #define BF_WM 2                                      // waves along the queries (2: 128-query tiles, 4 waves; 4: 256-query tiles, 8 waves)
 #endif
-constexpr int BF_WAVES = 2 * BF_WM, BF_THREADS = 64 * BF_WAVES;
-constexpr int BF_TQ = 64 * BF_WM, BF_TR = 64 * BF_NJ; // block tile: BF_WM x 2 waves of 64 x (32 BF_NJ) each
+#ifndef BF_BIG
+#define BF_BIG 1                                     // 1: launches with enough tiles use 256 x 256 block tiles (8 waves, 64 x 128 per wave, one block per CU)
+#endif
 constexpr int BF_CH = BF_TK / 4;                     // 16-byte chunks of a tile row per K step (8 or 16)
 constexpr int BF_RPI = 64 / BF_CH;                   // tile rows one wave instruction fills (8 x 128 B or 4 x 256 B: whole lines either way)
-constexpr int BF_RPP = BF_WAVES * BF_RPI;             // tile rows the block fills per pass
-constexpr int BF_PASSES = BF_TQ / BF_RPP;            // load instructions per query tile, thread and K step
-constexpr int BF_PASSES_R = BF_TR / BF_RPP;          // ... per row tile
 constexpr int BF_LS = BF_TK;                         // lane-linear LDS image, no padding: chunk c of row r at slot c ^ swizzle(r)
-constexpr int BF_TILE_FLOATS = BF_TQ * BF_LS;        // the query tile
-constexpr int BF_BUF_FLOATS = (BF_TQ + BF_TR) * BF_LS;   // one buffer: query tile, then row tile
-constexpr int BF_EPI_FLOATS = 2 * BF_TQ;              // the tile's per-query bound and |q|^2, staged for the epilogue
 constexpr int BF_PASS_CAP = 508;                     // (query, row) pairs of a block that passed the filter, collected in LDS (+ 4 words of counter: 4 KB)
-constexpr size_t BF_LDS_BYTES = ((size_t) BF_NBUF * BF_BUF_FLOATS + BF_EPI_FLOATS + 4 + 2 * BF_PASS_CAP) * sizeof(float);
+// One block tile: WM x 2 waves of 64 queries x (32 NJ) rows each.  Two are instantiated: <BF_WM, BF_NJ> = 128 x 128 (4 waves, two blocks per
+// CU) and <4, 4> = 256 x 256 (8 waves, one block per CU: half the tile loads per flop — 138 against 136 TFLOP/s — for launches with enough tiles).
+template <int WM, int NJ>
+struct BfTile
+{
+	static constexpr int WAVES = 2 * WM, THREADS = 64 * WAVES;
+	static constexpr int TQ = 64 * WM, TR = 64 * NJ;        // block tile
+	static constexpr int RPP = WAVES * BF_RPI;              // tile rows the block fills per pass
+	static constexpr int PASSES = TQ / RPP;                 // load instructions per query tile, thread and K step
+	static constexpr int PASSES_R = TR / RPP;               // ... per row tile
+	static constexpr int TILE_FLOATS = TQ * BF_LS;          // the query tile
+	static constexpr int BUF_FLOATS = (TQ + TR) * BF_LS;    // one buffer: query tile, then row tile
+	static constexpr int EPI_FLOATS = 2 * TQ;               // the tile's per-query bound and |q|^2, staged for the epilogue
+	static constexpr size_t LDS_BYTES = ((size_t) BF_NBUF * BUF_FLOATS + EPI_FLOATS + 4 + 2 * BF_PASS_CAP) * sizeof(float);
+};
 // bank swizzle of a tile row: a ds_read_b128 serves 16 lanes per cycle over a 256-byte bank row.  128-byte rows (BF_TK 32) put two
 // rows in a bank row: slot = c ^ ((r >> 1) & 7) makes (r & 1, (r >> 1) & 7) — all distinct within a lane group — pick 16 distinct
 // slots; 256-byte rows (BF_TK 64) fill one: slot = c ^ (r & 15).
@@ -82,8 +97,12 @@ struct BfArgs
 	unsigned long long *clocks; // NULL, or 2 words: shader-clock and constant-clock ticks one block spent in its K loop (measurement only)
 };
 
-__global__ __launch_bounds__(BF_THREADS, BF_WM == 2 ? 2 : 1) void bf_mfma_filter_kernel(const BfArgs a)
+template <int WM, int NJ>
+__global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void bf_mfma_filter_kernel(const BfArgs a)
 {
+	using T = BfTile<WM, NJ>;
+	constexpr int BF_THREADS = T::THREADS, BF_TQ = T::TQ, BF_TR = T::TR, BF_RPP = T::RPP, BF_PASSES = T::PASSES, BF_PASSES_R = T::PASSES_R;
+	constexpr int BF_TILE_FLOATS = T::TILE_FLOATS, BF_BUF_FLOATS = T::BUF_FLOATS, BF_EPI_FLOATS = T::EPI_FLOATS;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	float *bf_lds = reinterpret_cast<float *>(smem);                    // [buf][A | B][row][BF_LS], then the epilogue's bounds
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -106,11 +125,11 @@ __global__ __launch_bounds__(BF_THREADS, BF_WM == 2 ? 2 : 1) void bf_mfma_filter
 	for (int j = 0; j < BF_PASSES_R; j++)
 		xsrc[j] = reinterpret_cast<const floatx4 *>(a.vec + (size_t) min(r0 + srow + BF_RPP * j, a.n - 1) * a.stride);
 
-	floatx16 acc[2][BF_NJ];
+	floatx16 acc[2][NJ];
 #pragma unroll
 	for (int i = 0; i < 2; i++)
 #pragma unroll
-		for (int j = 0; j < BF_NJ; j++)
+		for (int j = 0; j < NJ; j++)
 #pragma unroll
 			for (int e = 0; e < 16; e++) acc[i][j][e] = 0.f;
 	const uint32_t wm = wave >> 1, wn = wave & 1;          // 2 x 2 waves over the block tile
@@ -133,11 +152,11 @@ __global__ __launch_bounds__(BF_THREADS, BF_WM == 2 ? 2 : 1) void bf_mfma_filter
 		epi[t] = a.qbound[qi];
 		epi[BF_TQ + t] = a.qnorm[qi];
 	}
-	float xs2[BF_NJ];
+	float xs2[NJ];
 #pragma unroll
-	for (int j = 0; j < BF_NJ; j++)
+	for (int j = 0; j < NJ; j++)
 	{
-		const float xn = a.xnorm[min(r0 + wn * (32 * BF_NJ) + j * 32 + col, a.n - 1)];
+		const float xn = a.xnorm[min(r0 + wn * (32 * NJ) + j * 32 + col, a.n - 1)];
 		xs2[j] = (a.func == F_COSINE) ? __builtin_sqrtf(xn) : xn;
 	}
 
@@ -184,23 +203,26 @@ __global__ __launch_bounds__(BF_THREADS, BF_WM == 2 ? 2 : 1) void bf_mfma_filter
 	{
 		(void) ks_next; (void) buf_next;
 		const float *As = bf_lds + (size_t) buf * BF_BUF_FLOATS + (wm * 64 + col) * BF_LS;
-		const float *Bs = bf_lds + (size_t) buf * BF_BUF_FLOATS + BF_TILE_FLOATS + (wn * (32 * BF_NJ) + col) * BF_LS;
+		const float *Bs = bf_lds + (size_t) buf * BF_BUF_FLOATS + BF_TILE_FLOATS + (wn * (32 * NJ) + col) * BF_LS;
 #pragma unroll
 		for (int g = 0; g < BF_TK / 8; g++)
 		{
 			const uint32_t o = roff[BF_ABLATE == 2 ? 0 : g];
-			floatx4 av[2], bv[BF_NJ];
+			floatx4 av[2], bv[NJ];
 #pragma unroll
 			for (int i = 0; i < 2; i++) av[i] = *reinterpret_cast<const floatx4 *>(As + i * 32 * BF_LS + o);
 #pragma unroll
-			for (int j = 0; j < BF_NJ; j++) bv[j] = *reinterpret_cast<const floatx4 *>(Bs + j * 32 * BF_LS + o);
+			for (int j = 0; j < NJ; j++) bv[j] = *reinterpret_cast<const floatx4 *>(Bs + j * 32 * BF_LS + o);
+#if BF_SETPRIO
+			__builtin_amdgcn_s_setprio(1);                          // (measurement build: the wave entering its MFMAs outranks the one issuing loads / LDS reads)
+#endif
 #pragma unroll
 			for (int c = 0; c < 4; c++)
 			{
 #pragma unroll
 				for (int i = 0; i < 2; i++)
 #pragma unroll
-					for (int j = 0; j < BF_NJ; j++)
+					for (int j = 0; j < NJ; j++)
 						acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][c], bv[j][c], acc[i][j], 0, 0, 0);
 #if BF_INTERLEAVE
 				// loads of the next step, a pass at a time, behind each quarter of this k-group's MFMAs
@@ -218,6 +240,9 @@ __global__ __launch_bounds__(BF_THREADS, BF_WM == 2 ? 2 : 1) void bf_mfma_filter
 				}
 #endif
 			}
+#if BF_SETPRIO
+			__builtin_amdgcn_s_setprio(0);
+#endif
 		}
 	};
 
@@ -227,6 +252,31 @@ __global__ __launch_bounds__(BF_THREADS, BF_WM == 2 ? 2 : 1) void bf_mfma_filter
 	// one barrier per step.  (Measured and NOT kept, profiles/r5e_mfma_tile_variants.txt: a 64-float K step with one buffer 129 TFLOP/s,
 	// 64 x 128 wave tiles 128-130, operand reads written out one k-group ahead with counted lgkmcnt waits and the barrier in front of
 	// the last k-group — no LDS or memory round trip exposed inside the loop — 129; this plain form 134-136.)
+#if BF_NBUF == 3
+	// Three buffers (measurement build): the loads of steps ks + 1 AND ks + 2 are in flight during the MFMAs of step ks — twice the time for
+	// a slow line to arrive.  hipcc's own wait in front of a barrier is vmcnt(0), so the wait is written out: all but the newest step's
+	// loads (BF_PASSES + BF_PASSES_R per thread) have landed, then a raw barrier (everybody's loads of step ks are in LDS, and everybody is
+	// done reading the buffer the next fetch overwrites).
+	{
+		const uint32_t last = a.ksteps - 1;
+		fetch(0, 0);
+		fetch(min(1u, last), 1);
+		uint32_t cur = 0, nxt2 = 2;
+		for (uint32_t ks = 0; ks < a.ksteps; ks++)
+		{
+			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BF_PASSES + BF_PASSES_R) : "memory");
+			__builtin_amdgcn_s_barrier();
+			asm volatile("" ::: "memory");
+			fetch(min(ks + 2, last), nxt2);
+			__builtin_amdgcn_sched_barrier(0);
+			contract(cur, 0, 0);
+			cur = cur == 2 ? 0 : cur + 1;
+			nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
+		}
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // nothing may still be writing this block's LDS when the block ends
+		__syncthreads();
+	}
+#else
 	fetch(0, 0);
 	__syncthreads();                                            // (hipcc drains the LDS-bound loads, vmcnt(0), in front of the barrier)
 	for (uint32_t ks = 0; ks < a.ksteps; ks++)
@@ -242,6 +292,7 @@ __global__ __launch_bounds__(BF_THREADS, BF_WM == 2 ? 2 : 1) void bf_mfma_filter
 		__syncthreads();
 #endif
 	}
+#endif
 	if (a.clocks && blockIdx.x == gridDim.x / 2 && t == 0)             // a block from the middle of the launch
 	{
 		a.clocks[0] = __builtin_readcyclecounter() - c0;
@@ -259,9 +310,9 @@ __global__ __launch_bounds__(BF_THREADS, BF_WM == 2 ? 2 : 1) void bf_mfma_filter
 			const floatx4 qb = *reinterpret_cast<const floatx4 *>(epi + ql);
 			const floatx4 qn = *reinterpret_cast<const floatx4 *>(epi + BF_TQ + ql);
 #pragma unroll
-			for (int j = 0; j < BF_NJ; j++)
+			for (int j = 0; j < NJ; j++)
 			{
-				const uint32_t r = r0 + wn * (32 * BF_NJ) + j * 32 + col;
+				const uint32_t r = r0 + wn * (32 * NJ) + j * 32 + col;
 				const bool rok = r < a.n;
 #pragma unroll
 				for (int e1 = 0; e1 < 4; e1++)

@@ -73,7 +73,7 @@ enum Knob : int
 	K_BEAM, K_FORCE_LDS_HEAPS, K_TEAM, K_TEAM_MAX_NQ, K_WIDE_EF_MIN, K_REF_ORDER, K_NO_POLL, K_POLL_LIMIT_S, K_INSERT_FUSED,
 	K_BLOCKS_PER_CU, K_STREAM_LIGHT,
 	// test knobs (hnsw_gpu_config_set only)
-	K_BEAM16, K_NARROW5, K_LEAN, K_HASH_ENTRIES, K_LDS_SET_MIN_WAVES, K_TEAM_SPEC, K_TEAM_WPB, K_MAX_BLOCKS, K_SHARDED_NO_PEER,
+	K_BEAM16, K_NARROW5, K_LEAN, K_HASH_ENTRIES, K_LDS_SET_MIN_WAVES, K_TEAM_SPEC, K_TEAM_WPB, K_MAX_BLOCKS, K_SHARDED_NO_PEER, K_BF_BIG_MIN_BLOCKS,
 #ifdef HNSW_EXPERIMENT
 	K_WIDE_WAVES, K_SHAPE_12X1, K_TEAM_MAINS, K_TEAM_COUNTERS,
 #endif
@@ -86,6 +86,7 @@ static const KnobDef g_knob_def[K_COUNT] = {
 	{ "HNSW_GPU_INSERT_FUSED", true }, { "HNSW_GPU_BLOCKS_PER_CU", true }, { "HNSW_GPU_STREAM_LIGHT", true },
 	{ "HNSW_GPU_BEAM16", false }, { "HNSW_GPU_NARROW5", false }, { "HNSW_GPU_LEAN", false }, { "HNSW_GPU_HASH_ENTRIES", false }, { "HNSW_GPU_LDS_SET_MIN_WAVES", false },
 	{ "HNSW_GPU_TEAM_SPEC", false }, { "HNSW_GPU_TEAM_WPB", false }, { "HNSW_GPU_MAX_BLOCKS", false }, { "HNSW_GPU_SHARDED_NO_PEER", false },
+	{ "HNSW_GPU_BF_BIG_MIN_BLOCKS", false },
 #ifdef HNSW_EXPERIMENT
 	{ "HNSW_GPU_WIDE_WAVES", false }, { "HNSW_GPU_SHAPE_12X1", false }, { "HNSW_GPU_TEAM_MAINS", false }, { "HNSW_GPU_TEAM_COUNTERS", false },
 #endif
@@ -1749,6 +1750,20 @@ extern "C" int hnsw_gpu_bruteforce_dev(hnsw_gpu_index *ix, const coord_t *d_quer
 // ------------------------------------------------------------------------------------
 static float g_last_bf_gemm_ms = 0.f;
 static unsigned long long g_last_bf_clocks[2] = { 0, 0 };
+static int g_last_bf_tile = 0;
+
+// the filter launch for one tile shape (LDS per block: 69 KB for 128 x 128 tiles, 134 KB for 256 x 256; set per call: the attribute is per device)
+template <int WM, int NJ>
+static int bf_filter_launch(BfArgs &a, uint32_t nq, uint32_t n, hipStream_t s)
+{
+	using T = BfTile<WM, NJ>;
+	a.nqt = (nq + T::TQ - 1) / T::TQ;
+	a.nrt = (n + T::TR - 1) / T::TR;
+	const uint32_t rgroups = (a.nrt + 7) / 8;
+	HIPCHK(hipFuncSetAttribute((const void *) bf_mfma_filter_kernel<WM, NJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) T::LDS_BYTES));
+	hipLaunchKernelGGL((bf_mfma_filter_kernel<WM, NJ>), dim3(rgroups * a.nqt * 8), dim3(T::THREADS), T::LDS_BYTES, s, a);
+	return HNSW_GPU_OK;
+}
 
 extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t k,
 											idx_t *d_idx, dist_t *d_dists, void *stream_)
@@ -1827,14 +1842,23 @@ extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d
 	a.queries = qpad; a.qnorm = qn; a.qbound = bound; a.vec = ix->vec; a.xnorm = ix->xnorm;
 	a.nq = (uint32_t) nq; a.n = n; a.stride = stride; a.qstride = qstride; a.ksteps = qstride / BF_TK; a.func = func;
 	a.cand = cand; a.cand_cnt = cnt; a.cap = cap; a.clocks = (unsigned long long *) (B + o_clk);
-	a.nqt = (uint32_t) ((nq + BF_TQ - 1) / BF_TQ); a.nrt = (n + BF_TR - 1) / BF_TR;
-	const uint32_t rgroups = (a.nrt + 7) / 8;
 	if (!ix->bf_e0) { HIPCHK(hipEventCreate(&ix->bf_e0)); HIPCHK(hipEventCreate(&ix->bf_e1)); }
 	hipEvent_t e0 = ix->bf_e0, e1 = ix->bf_e1;
 	HIPCHK(hipEventRecord(e0, s));
-	// two operand tiles of 128 x 36 floats, twice: 72 KB of LDS per block (set per call: the attribute is per device)
-	HIPCHK(hipFuncSetAttribute((const void *) bf_mfma_filter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int) BF_LDS_BYTES));
-	hipLaunchKernelGGL(bf_mfma_filter_kernel, dim3(rgroups * a.nqt * 8), dim3(BF_THREADS), BF_LDS_BYTES, s, a);
+	// 256 x 256 tiles when they compute no more padding than 128 x 128 tiles would (an even number of 128-query tiles) and there are
+	// tiles enough to fill the device several times over; the same dot products in the same k order either way: the same survivors
+	{
+		using Big = BfTile<4, 4>;
+		const uint64_t nqt_s = (nq + BfTile<BF_WM, BF_NJ>::TQ - 1) / BfTile<BF_WM, BF_NJ>::TQ;
+		const uint64_t big_blocks = ((nq + Big::TQ - 1) / Big::TQ) * ((n + Big::TR - 1) / Big::TR);
+		// (test knob: 0 = never, < 0 = always, n = at least n blocks; the tests run every case through both tiles)
+		const long long min_blocks = knob(K_BF_BIG_MIN_BLOCKS, 2048);
+		const bool big = BF_BIG && BF_WM == 2 && BF_NJ == 2 && min_blocks != 0 &&
+						 (min_blocks < 0 || (nqt_s % 2 == 0 && big_blocks >= (uint64_t) min_blocks));
+		rc = big ? bf_filter_launch<4, 4>(a, (uint32_t) nq, n, s) : bf_filter_launch<BF_WM, BF_NJ>(a, (uint32_t) nq, n, s);
+		if (rc) return rc;
+		g_last_bf_tile = big ? Big::TQ : BfTile<BF_WM, BF_NJ>::TQ;
+	}
 	HIPCHK(hipEventRecord(e1, s));
 
 	// 3. canonical re-score of the survivors
@@ -1857,6 +1881,8 @@ extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d
 		return hnsw_gpu_bruteforce_dev(ix, d_queries, nq, k, d_idx, d_dists, stream_);
 	return HNSW_GPU_OK;
 }
+
+extern "C" int hnsw_gpu_last_bruteforce_tile(void) { return g_last_bf_tile; }
 
 /* device time of the MFMA filter kernel of the most recent hnsw_gpu_bruteforce_mfma_dev call */
 extern "C" float hnsw_gpu_last_bruteforce_gemm_ms(void) { return g_last_bf_gemm_ms; }

@@ -16,7 +16,8 @@ for rep in range(3):
     gemm_ms = gpu_lib().hnsw_gpu_last_bruteforce_gemm_ms()
     flops = 2.0 * nq * n * ((dim + 3) // 4 * 4)
     mhz = gpu_lib().hnsw_gpu_last_bruteforce_clock_mhz()
-    print(f"mfma path: total {t1*1e3:.1f} ms, GEMM/filter kernel {gemm_ms:.2f} ms = {flops/gemm_ms/1e9:.1f} TFLOP/s "
+    tile = gpu_lib().hnsw_gpu_last_bruteforce_tile()
+    print(f"mfma path ({tile} x {tile} tiles): total {t1*1e3:.1f} ms, GEMM/filter kernel {gemm_ms:.2f} ms = {flops/gemm_ms/1e9:.1f} TFLOP/s "
           f"({flops/gemm_ms/1e9/157.3:.3f} of the 157.3 TF f32 MFMA peak; shader clock in the kernel {mhz:.0f} MHz -> "
           f"{flops/gemm_ms/1e9/(157.3*mhz/2400.0):.3f} of the roof at that clock); {nq/t1:,.0f} exhaustive queries/s", flush=True)
 t = time.time(); i0, d0 = ix.bruteforce_torch(Q, k); torch.cuda.synchronize(); t0 = time.time() - t

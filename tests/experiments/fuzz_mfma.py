@@ -1,6 +1,6 @@
 """Randomised parity sweep of the exhaustive scorer: the MFMA filter + canonical re-score (csrc/device_bf_mfma.h) against the all-canonical
 scan, ids and distance bits, over random table sizes (around tile edges), dimensions (rows that end inside a K step), query counts (one to
-several 128-query tiles), k, L2 / cosine, exact ties and duplicate rows, queries equal to rows.  Prints one line per case; exits non-zero on
+several 128-query tiles), both block tiles, k, L2 / cosine, exact ties and duplicate rows, queries equal to rows.  Prints one line per case; exits non-zero on
 the first mismatch.   usage: fuzz_mfma.py <cases> [seed]"""
 import os
 import sys
@@ -36,11 +36,13 @@ def one_case(rng, idx):
     ix.append(X)
     dq = torch.from_numpy(Q).cuda()
     i0, d0 = ix.bruteforce_torch(dq, k)
+    tile = str(rng.choice(["128x128", "256x256"]))             # (the library picks 256 x 256 only for launches with thousands of tiles: forced here)
+    pg._lib.gpu_lib().hnsw_gpu_config_set(b"HNSW_GPU_BF_BIG_MIN_BLOCKS", b"0" if tile == "128x128" else b"-1")
     i1, d1 = ix.bruteforce_torch(dq, k, mfma=True)
     torch.cuda.synchronize()
     ok = bool((i0 == i1).all().item()) and bool((d0.view(torch.int32) == d1.view(torch.int32)).all().item())
     ix.close()
-    print(f"case {idx}: func {func} n {n} dim {dim} nq {nq} k {k}: {'ok' if ok else 'MISMATCH'}", flush=True)
+    print(f"case {idx}: func {func} n {n} dim {dim} nq {nq} k {k} tile {tile}: {'ok' if ok else 'MISMATCH'}", flush=True)
     return ok
 
 

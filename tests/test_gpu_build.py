@@ -109,9 +109,25 @@ def test_bruteforce_is_exact(func):
                                         # rows that end inside a K step (100 floats: the query copy is zero padded to 128, the row's last chunk re-read times zero),
                                         # one query, a table one row past a tile, k = 1; 1536 floats with more queries than one 128-query tile
                                         (4097, 100, 1, 1), (70001, 100, 257, 10), (12000, 1536, 200, 10)])
-def test_mfma_exhaustive_scorer_equals_canonical_scan(func, n, dim, nq, k):
+@pytest.mark.parametrize("tile", ["128x128", "256x256"])
+def test_mfma_exhaustive_scorer_equals_canonical_scan(func, n, dim, nq, k, tile):
     """The dense MFMA pass is only a filter; the answer must equal the canonical brute force
-    bit for bit (ids, and distances from the canonical code)."""
+    bit for bit (ids, and distances from the canonical code) — with either block tile (the library picks 256 x 256 only for launches
+    with thousands of tiles; the test knob forces each)."""
+    import torch
+    pg._lib.gpu_lib().hnsw_gpu_config_set(b"HNSW_GPU_BF_BIG_MIN_BLOCKS", b"0" if tile == "128x128" else b"-1")
+    try:
+        _mfma_case(func, n, dim, nq, k)
+    finally:
+        pg._lib.gpu_lib().hnsw_gpu_config_set(b"HNSW_GPU_BF_BIG_MIN_BLOCKS", None)
+
+
+def test_mfma_tile_choice_of_a_large_launch_is_exact():
+    """512 queries x 300 000 rows: the launch the library itself gives 256 x 256 tiles (an even number of 128-query tiles, > 2048 blocks)."""
+    _mfma_case(pg.DIST_L2, 300_000, 32, 512, 10)
+
+
+def _mfma_case(func, n, dim, nq, k):
     import torch
     X = gmm(n, dim, k=60, seed=19)
     X[100:140] = X[300:340]                  # exact duplicates: equal distances, tie by lower idx
