@@ -36,15 +36,7 @@ typedef float floatx4 __attribute__((ext_vector_type(4)));       // (a first-cla
 #ifndef BF_TK
 #define BF_TK 32                                     // floats of K per step (32 or 64)
 #endif
-#ifndef BF_NBUF
-#define BF_NBUF 2                                    // LDS buffers: the loads of step ks + 1 fly during the MFMAs of step ks (3: those of ks + 2 as well, counted vmcnt)
-#endif
-#ifndef BF_INTERLEAVE
-#define BF_INTERLEAVE 0                              // 1: the next step's tile loads are issued a pass at a time between the MFMAs of this step
-#endif
-#ifndef BF_SETPRIO
-#define BF_SETPRIO 0                                 // 1: s_setprio(1) around every k-group's MFMAs
-#endif
+#define BF_NBUF 2                                    // LDS buffers: the loads of step ks + 1 fly during the MFMAs of step ks
 #ifndef BF_ABLATE
 #define BF_ABLATE 0                                  // 0 = the product.  1: no barrier in the K loop; 2: one operand read per K step; 3: no tile loads after the first
 #endif
@@ -185,23 +177,8 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void bf_mfma_filter_kern
 	uint32_t roff[BF_TK / 8];                                  // float offset of k-group g's slot in this lane's row
 #pragma unroll
 	for (int g = 0; g < BF_TK / 8; g++) roff[g] = ((2 * g + kk) ^ swz) * 4;
-	// one pass of the next step's tile loads (query tile passes first, then row tile passes): issued BETWEEN the MFMAs of the current step
-	// (BF_INTERLEAVE), so that a wave's load issue runs under its own MFMAs instead of in front of them
-	auto fetch_pass = [&](uint32_t ks, uint32_t buf, int p)
+	auto contract = [&](uint32_t buf)
 	{
-		const uint32_t c = ks * BF_CH + gch;
-		const uint32_t cc = min(c, nchunks - 1);
-		float *As = bf_lds + (size_t) buf * BF_BUF_FLOATS + (wave * BF_RPI) * BF_LS, *Bs = As + BF_TILE_FLOATS;
-		if (p < BF_PASSES)
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (qsrc[p] + c),
-											 (__attribute__((address_space(3))) void *) (As + BF_RPP * p * BF_LS), 16, 0, 0);
-		else if (p < BF_PASSES + BF_PASSES_R)
-			__builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *) (xsrc[p - BF_PASSES] + cc),
-											 (__attribute__((address_space(3))) void *) (Bs + BF_RPP * (p - BF_PASSES) * BF_LS), 16, 0, 0);
-	};
-	auto contract = [&](uint32_t buf, uint32_t ks_next, uint32_t buf_next)
-	{
-		(void) ks_next; (void) buf_next;
 		const float *As = bf_lds + (size_t) buf * BF_BUF_FLOATS + (wm * 64 + col) * BF_LS;
 		const float *Bs = bf_lds + (size_t) buf * BF_BUF_FLOATS + BF_TILE_FLOATS + (wn * (32 * NJ) + col) * BF_LS;
 #pragma unroll
@@ -213,9 +190,6 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void bf_mfma_filter_kern
 			for (int i = 0; i < 2; i++) av[i] = *reinterpret_cast<const floatx4 *>(As + i * 32 * BF_LS + o);
 #pragma unroll
 			for (int j = 0; j < NJ; j++) bv[j] = *reinterpret_cast<const floatx4 *>(Bs + j * 32 * BF_LS + o);
-#if BF_SETPRIO
-			__builtin_amdgcn_s_setprio(1);                          // (measurement build: the wave entering its MFMAs outranks the one issuing loads / LDS reads)
-#endif
 #pragma unroll
 			for (int c = 0; c < 4; c++)
 			{
@@ -224,25 +198,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void bf_mfma_filter_kern
 #pragma unroll
 					for (int j = 0; j < NJ; j++)
 						acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][c], bv[j][c], acc[i][j], 0, 0, 0);
-#if BF_INTERLEAVE
-				// loads of the next step, a pass at a time, behind each quarter of this k-group's MFMAs
-				{
-					constexpr int NP = BF_PASSES + BF_PASSES_R, SLOTS = 4 * (BF_TK / 8), PER = (NP + SLOTS - 1) / SLOTS;
-					__builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-					for (int q = 0; q < PER; q++)
-					{
-						const int slot = g * 4 + c;
-						if (BF_INTERLEAVE == 2 && NP * 2 <= SLOTS) { if (slot % 2 == 1) fetch_pass(ks_next, buf_next, slot / 2); }   // spread over the whole step
-						else fetch_pass(ks_next, buf_next, slot * PER + q);
-					}
-					__builtin_amdgcn_sched_barrier(0);
-				}
-#endif
 			}
-#if BF_SETPRIO
-			__builtin_amdgcn_s_setprio(0);
-#endif
 		}
 	};
 
@@ -251,48 +207,24 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void bf_mfma_filter_kern
 	// Software pipeline over two LDS buffers: the loads of K step ks + 1 are issued before the MFMAs of step ks, into the other buffer;
 	// one barrier per step.  (Measured and NOT kept, profiles/r5e_mfma_tile_variants.txt: a 64-float K step with one buffer 129 TFLOP/s,
 	// 64 x 128 wave tiles 128-130, operand reads written out one k-group ahead with counted lgkmcnt waits and the barrier in front of
-	// the last k-group — no LDS or memory round trip exposed inside the loop — 129; this plain form 134-136.)
-#if BF_NBUF == 3
-	// Three buffers (measurement build): the loads of steps ks + 1 AND ks + 2 are in flight during the MFMAs of step ks — twice the time for
-	// a slow line to arrive.  hipcc's own wait in front of a barrier is vmcnt(0), so the wait is written out: all but the newest step's
-	// loads (BF_PASSES + BF_PASSES_R per thread) have landed, then a raw barrier (everybody's loads of step ks are in LDS, and everybody is
-	// done reading the buffer the next fetch overwrites).
-	{
-		const uint32_t last = a.ksteps - 1;
-		fetch(0, 0);
-		fetch(min(1u, last), 1);
-		uint32_t cur = 0, nxt2 = 2;
-		for (uint32_t ks = 0; ks < a.ksteps; ks++)
-		{
-			asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BF_PASSES + BF_PASSES_R) : "memory");
-			__builtin_amdgcn_s_barrier();
-			asm volatile("" ::: "memory");
-			fetch(min(ks + 2, last), nxt2);
-			__builtin_amdgcn_sched_barrier(0);
-			contract(cur, 0, 0);
-			cur = cur == 2 ? 0 : cur + 1;
-			nxt2 = nxt2 == 2 ? 0 : nxt2 + 1;
-		}
-		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // nothing may still be writing this block's LDS when the block ends
-		__syncthreads();
-	}
-#else
+	// the last k-group — no LDS or memory round trip exposed inside the loop — 129; three buffers with a counted vmcnt 132.5; the next
+	// step's loads issued between the MFMAs 130 / 124; s_setprio around the MFMAs 131.7; a pipeline across tiles in resident blocks +0.6 % /
+	// -1.5 % (profiles/r5y_*); this plain form 134-136 with 128 x 128 tiles, 138 with 256 x 256.)
 	fetch(0, 0);
 	__syncthreads();                                            // (hipcc drains the LDS-bound loads, vmcnt(0), in front of the barrier)
 	for (uint32_t ks = 0; ks < a.ksteps; ks++)
 	{
-#if BF_ABLATE != 3 && !BF_INTERLEAVE                            // (ablation builds — wrong answers, timing only: profiles/r5l_mfma_ablation.txt)
+#if BF_ABLATE != 3                                              // (ablation builds — wrong answers, timing only: profiles/r5l_mfma_ablation.txt)
 		fetch(min(ks + 1, a.ksteps - 1), (ks + 1) & 1);            // its readers passed the previous barrier (branch-free: the last step re-reads itself)
 #endif
 		__builtin_amdgcn_sched_barrier(0);
-		contract(ks & 1, min(ks + 1, a.ksteps - 1), (ks + 1) & 1);
+		contract(ks & 1);
 #if BF_ABLATE == 1
 		__builtin_amdgcn_s_waitcnt(0);                             // the loads are still waited for; only the rendezvous of the four waves is gone
 #else
 		__syncthreads();
 #endif
 	}
-#endif
 	if (a.clocks && blockIdx.x == gridDim.x / 2 && t == 0)             // a block from the middle of the launch
 	{
 		a.clocks[0] = __builtin_readcyclecounter() - c0;
