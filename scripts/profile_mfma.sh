@@ -10,6 +10,13 @@ cd /tmp; export TMPDIR=/tmp
 CMD="python $R/scripts/exp_bf_mfma.py ${*:-1000000 1536 1024 10}"
 rocprofv3 --list-avail 2>/dev/null | grep -i -o "SQ_[A-Z_0-9]*MFMA[A-Z_0-9]*\|SQ_VALU_MFMA[A-Z_0-9]*" | sort -u > $OUT/mfma_counters_available.txt
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT/trace.log 2>&1
+# PROFILE_MFMA_SHORT=1: the kernel trace and the three MFMA / LDS passes only
+if [ "${PROFILE_MFMA_SHORT:-0}" = 1 ]; then
+for PASS in "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES" "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" "SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" "FETCH_SIZE"; do
+  N=$(echo $PASS | tr ' ' '_' | cut -c1-40)
+  timeout 300 rocprofv3 --kernel-trace --pmc $PASS --output-format csv -d $OUT/pmc_$N -- $CMD > $OUT/pmc_$N.log 2>&1 || echo "pass $N failed" >> $OUT/failed_passes.txt
+done
+else
 for PASS in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
             "SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE" \
             "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_BUSY_CU_CYCLES" \
@@ -19,6 +26,7 @@ for PASS in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU 
   N=$(echo $PASS | tr ' ' '_' | cut -c1-40)
   timeout 300 rocprofv3 --kernel-trace --pmc $PASS --output-format csv -d $OUT/pmc_$N -- $CMD > $OUT/pmc_$N.log 2>&1 || echo "pass $N failed" >> $OUT/failed_passes.txt
 done
+fi
 {
   echo "# rocprofv3 summary ($TAG): $CMD"; echo; echo '```'; grep "mfma path\|canonical" $OUT/trace.log; echo '```'; echo
   echo "MFMA counters this rocprofv3 knows: $(tr '\n' ' ' < $OUT/mfma_counters_available.txt)"; echo
