@@ -166,6 +166,8 @@ def gpu_lib():
     L.hnsw_gpu_merge_topk_strided_dev.argtypes = [i32, vp, sz, vp, sz, sz, sz, sz, vp, vp, vp, vp]
     L.hnsw_gpu_last_search_kernel.argtypes = [vp, C.c_char_p, sz]
     L.hnsw_gpu_team_counters.argtypes = [vp, _u32p]
+    L.hnsw_gpu_last_search_clock_mhz.argtypes = [vp, C.POINTER(C.c_double)]
+    L.hnsw_gpu_index_placement.argtypes = [vp, C.POINTER(C.c_uint64)]
     L.hnsw_gpu_gather_roof.argtypes = [vp, i32, i32, C.c_uint, _f32p]
     L.hnsw_gpu_sharded_create.argtypes = [C.POINTER(vp), sz, C.POINTER(vp)]
     L.hnsw_gpu_sharded_destroy.restype = None

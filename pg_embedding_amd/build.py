@@ -77,11 +77,15 @@ def _run(cmd) -> None:
 
 
 
+# the host-side units of libhnsw_gpu.so (csrc/gpu_host.h says what each holds)
+HOST_UNITS = ("hnsw_gpu", "gpu_search", "gpu_stream", "gpu_scan", "gpu_build", "gpu_sharded", "gpu_diag")
+
+
 # libhnsw_gpu.so = these translation units, compiled in parallel and linked: the host code + its small kernels, the pair sort,
 # and the search kernels of one load shape each (csrc/search_inst.hip, -DSEARCH_INST_SHAPE=n) — as one unit the 220 search
 # kernel instantiations took hipcc five and a half minutes, like this the library builds in about two.
 def _gpu_units(defines):
-    units = [("hnsw_gpu", "hnsw_gpu.hip", []), ("sort_pairs", "sort_pairs.hip", [])]
+    units = [(u, u + ".hip", []) for u in HOST_UNITS] + [("sort_pairs", "sort_pairs.hip", [])]
     shapes = range(1, 7) if "HNSW_EXPERIMENT" in defines else range(1, 6)
     return units + [(f"search_inst_{k}", "search_inst.hip", [f"-DSEARCH_INST_SHAPE={k}"]) for k in shapes]
 
@@ -117,7 +121,7 @@ def _build_gpu_lib(target, sources, defines, force=False, verbose=False):
 def build(force: bool = False, verbose: bool = False) -> None:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(BINDIR, exist_ok=True)
-    hdrs = [os.path.join(INC, h) for h in ("hnsw_abi.h", "hnsw_gpu.h", "hnsw_gpu_shim.h", "hnsw_gpu_server.h")]
+    hdrs = [os.path.join(INC, h) for h in ("hnsw_abi.h", "hnsw_gpu.h", "hnsw_gpu_diag.h", "hnsw_gpu_shim.h", "hnsw_gpu_server.h")]
     host_only = ("hgs_io.h", "host_walk.h", "host_dist.h", "shim_cache.h")
     gpu_src = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) and f not in host_only] + hdrs
 
@@ -157,7 +161,7 @@ def build_variant(tag: str, defines) -> str:
     defines = list(defines)
     if any(d.split("=")[0] in ("HNSW_TEAM_COUNTERS", "HNSW_HOP_STAMPS") for d in defines) and "HNSW_EXPERIMENT" not in defines:
         defines.append("HNSW_EXPERIMENT")                   # diagnostic builds read every knob from the environment
-    hdrs = [os.path.join(INC, h) for h in ("hnsw_abi.h", "hnsw_gpu.h", "hnsw_gpu_shim.h", "hnsw_gpu_server.h")]
+    hdrs = [os.path.join(INC, h) for h in ("hnsw_abi.h", "hnsw_gpu.h", "hnsw_gpu_diag.h", "hnsw_gpu_shim.h", "hnsw_gpu_server.h")]
     host_only = ("hgs_io.h", "host_walk.h", "host_dist.h", "shim_cache.h")
     gpu_src = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) and f not in host_only] + hdrs
     _build_gpu_lib(out, gpu_src, defines)

@@ -126,9 +126,23 @@ struct SearchArgs
 //   [HEALTH_ABORTED_WAVES]    waves that left a launch because of the abort word
 //   [HEALTH_SLICES_DELIVERED] team form: slices helpers scored for walking waves (says the mechanism is in use; one
 //                             non-returning atomic per job)
+//   [HEALTH_CLOCK .. +7]      not a health word: four 64-bit clock readings of the LAST launch's first wave (beam kernels) — shader clock and
+//                             constant 100 MHz clock when it started, the same two when it left — from which the host computes the shader
+//                             clock the launch ran at (hnsw_gpu_last_search_clock_mhz, include/hnsw_gpu_diag.h).  The narrow-row kernel is
+//                             bound by instruction issue: its time scales with that clock, and a process that finds the device at a lower
+//                             clock sees every launch slower by the same factor.  Two scalar loads + one store pair per LAUNCH.
 constexpr uint32_t STREAM_COPIES = 64, STREAM_COPY_WORDS = 32;      // stream mode: copies of the control words, words between two copies
 constexpr uint32_t ABORTED_COUNT = 0xFFFFFFFFu;     // out_counts[i] of a query an aborted launch did not answer (include/hnsw_gpu.h)
-enum : uint32_t { HEALTH_SLICE_TIMEOUTS = 1, HEALTH_PACKAGE_TIMEOUTS = 2, HEALTH_ABORTED_WAVES = 3, HEALTH_SLICES_DELIVERED = 4, HEALTH_WORDS = 16 };
+enum : uint32_t { HEALTH_SLICE_TIMEOUTS = 1, HEALTH_PACKAGE_TIMEOUTS = 2, HEALTH_ABORTED_WAVES = 3, HEALTH_SLICES_DELIVERED = 4, HEALTH_CLOCK = 8, HEALTH_WORDS = 16 };
+
+// the launch's first wave stamps both clocks into the health words: `which` = 0 at its start, 1 when it leaves
+__device__ __forceinline__ void clock_stamp(const SearchArgs &a, uint32_t slot, int lane, int which)
+{
+	if (slot != 0 || lane != 0 || !a.health) return;
+	uint64_t *c = reinterpret_cast<uint64_t *>(a.health + HEALTH_CLOCK) + 2 * which;
+	c[0] = __builtin_amdgcn_s_memtime();
+	c[1] = __builtin_amdgcn_s_memrealtime();
+}
 
 __device__ __forceinline__ bool abort_requested(const SearchArgs &a)
 {
@@ -1634,6 +1648,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 	float        *newdist = reinterpret_cast<float *>(my + a.off_newdist);
 
 	const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wib;
+	clock_stamp(a, slot, lane, 0);
 	uint32_t *vis  = a.vis + (size_t) slot * a.vis_words;
 	uint32_t *vlog = a.vlog + (size_t) slot * a.logcap;
 	uint64_t *scratch = a.beam_scratch + (size_t) slot * UCAP;
@@ -2239,6 +2254,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		}
 	}
 	if (aborted && lane == 0) atomicAdd(a.health + HEALTH_ABORTED_WAVES, 1u);
+	clock_stamp(a, slot, lane, 1);
 	if (TEAM)
 	{
 		if (lane == 0) ctl[wib].state = 2u;

@@ -338,6 +338,22 @@ class GpuIndex:
         """Ask the search launches of this mirror that are in flight to end (callable from any thread)."""
         check(self.L.hnsw_gpu_index_abort(self._h), "hnsw_gpu_index_abort")
 
+    def last_search_clock_mhz(self) -> float:
+        """Shader clock (MHz) the last search launch ran at, measured by its first wave (include/hnsw_gpu_diag.h); 0.0 = not recorded."""
+        v = C.c_double(0.0)
+        check(self.L.hnsw_gpu_last_search_clock_mhz(self._h, C.byref(v)), "hnsw_gpu_last_search_clock_mhz")
+        return float(v.value)
+
+    def placement(self) -> dict:
+        """Device address and size of the mirror's arena, its three arrays and the default search workspace (include/hnsw_gpu_diag.h):
+        {"rows": (address, bytes), ...} plus "aligned_2MiB": do the three arrays start on 2 MiB boundaries."""
+        v = (C.c_uint64 * 16)()
+        check(self.L.hnsw_gpu_index_placement(self._h, v), "hnsw_gpu_index_placement")
+        names = ("arena", "rows", "links", "labels", "visited_bitmaps", "bitmap_logs", "prune_scratch", "ticket")
+        out = {k: (int(v[2 * i]), int(v[2 * i + 1])) for i, k in enumerate(names)}
+        out["aligned_2MiB"] = all(out[k][0] % (2 << 20) == 0 for k in ("rows", "links", "labels"))
+        return out
+
     def last_search_slots(self) -> int:
         v = C.c_uint32(0)
         check(self.L.hnsw_gpu_last_search_slots(self._h, C.byref(v)), "hnsw_gpu_last_search_slots")

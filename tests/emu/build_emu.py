@@ -1,4 +1,4 @@
-"""Build tests/_build/libhnsw_gpu_simt.so: the product's own sources (pg_embedding_amd/csrc/hnsw_gpu.hip + device headers),
+"""Build tests/_build/libhnsw_gpu_simt.so: the product's own sources (pg_embedding_amd/csrc/hnsw_gpu.hip, gpu_*.hip + device headers),
 unmodified, compiled for the host against the SIMT emulator in tests/emu/hip/hip_runtime.h.  Test infrastructure only.
 
 The one textual change: an inline-asm register pin of the kernel uses the AMDGPU constraint "+s" (scalar register), which no
@@ -16,6 +16,8 @@ CSRC = os.path.join(ROOT, "pg_embedding_amd", "csrc")
 EMU = os.path.join(ROOT, "tests", "emu")
 OUT = os.path.join(ROOT, "tests", "_build")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+# the host-side translation units of the product library (pg_embedding_amd/build.py, HOST_UNITS)
+HOST_HIP = ("hnsw_gpu.hip", "gpu_search.hip", "gpu_stream.hip", "gpu_scan.hip", "gpu_build.hip", "gpu_sharded.hip", "gpu_diag.hip")
 
 
 def _deps(csrc):
@@ -32,20 +34,21 @@ def build_tree(csrc=CSRC, tag="", edit=None, force=False, verbose=False):
     os.makedirs(src)
     pins = 0
     for f in sorted(os.listdir(csrc)):                      # copies, so that quoted includes resolve among them
-        if f.endswith(".h") or f in ("hnsw_gpu.hip", "search_inst.hip"):
+        if f.endswith(".h") or f in HOST_HIP or f == "search_inst.hip":
             txt = open(os.path.join(csrc, f)).read()
             pins += txt.count('"+s"')
             txt = txt.replace('"+s"', '"+r"')
             if edit:
                 txt = edit(f, txt)
-            open(os.path.join(src, {"hnsw_gpu.hip": "hnsw_gpu_emu.cpp", "search_inst.hip": "search_inst_emu.cpp"}.get(f, f)), "w").write(txt)
+            open(os.path.join(src, f[:-4] + "_emu.cpp" if f.endswith(".hip") else f), "w").write(txt)
     assert pins == 1, "the emulator build expects exactly one scalar-register asm pin"
     cxx = CLANG if os.path.exists(CLANG) else "clang++"
     flags = ["-x", "c++", "-O0", "-std=c++17", "-mavx2", "-mfma", "-ffp-contract=off", "-fPIC", "-pthread",
              "-Wno-unused-value", "-Wno-pass-failed", "-Wno-unknown-attributes",
              "-I", src, "-I", EMU, "-I", os.path.join(ROOT, "include")]
     # the product's translation units (build.py): the host code and one unit per load shape of the search kernels, in parallel
-    units = [("hnsw_gpu_emu", os.path.join(src, "hnsw_gpu_emu.cpp"), []), ("sort_pairs_emu", os.path.join(EMU, "sort_pairs_emu.cpp"), [])]
+    units = [(f[:-4] + "_emu", os.path.join(src, f[:-4] + "_emu.cpp"), []) for f in HOST_HIP if os.path.exists(os.path.join(src, f[:-4] + "_emu.cpp"))]
+    units += [("sort_pairs_emu", os.path.join(EMU, "sort_pairs_emu.cpp"), [])]
     if os.path.exists(os.path.join(src, "search_inst_emu.cpp")):
         units += [(f"search_inst_{k}", os.path.join(src, "search_inst_emu.cpp"), [f"-DSEARCH_INST_SHAPE={k}"]) for k in range(1, 6)]
     procs = []

@@ -382,6 +382,15 @@ def others():
     lab, dist, cnt = ix.search(Q, 40)
     exact = np.argsort(((Q[:, None, :] - X[None, :, :]) ** 2).sum(-1), axis=1)[:, :10]
     out["batched_insert_recall_at_10"] = float(np.mean([len(set(map(int, lab[i][:10])) & set(map(int, exact[i]))) / 10 for i in range(16)]))
+    # diagnostics of include/hnsw_gpu_diag.h: the launch's first wave stamped both clocks (the emulator's two clocks are 32 : 1), and the
+    # mirror's three arrays sit inside ONE allocation on 2 MiB boundaries, also after the mirror has grown
+    pl = ix.placement()
+    ix.reserve(3 * n)
+    pl2 = ix.placement()
+    lab2, dist2, cnt2 = ix.search(Q, 40)
+    inside = lambda p: all(p["arena"][0] <= p[k][0] and p[k][0] + p[k][1] <= p["arena"][0] + p["arena"][1] for k in ("rows", "links", "labels"))
+    out["diag_clock_and_placement"] = int(not (ix.last_search_clock_mhz() > 0.0 and pl["aligned_2MiB"] and pl2["aligned_2MiB"] and inside(pl) and inside(pl2)
+                                               and pl2["rows"][1] == 3 * pl["rows"][1] and (lab2 == lab).all() and (U.bits(dist2) == U.bits(dist)).all()))
     ix.close()
     return out
 

@@ -105,6 +105,11 @@ def test_libraries_export_every_declared_symbol():
     assert declared("hnsw_gpu.h") - {"hnsw_search", "hnsw_bind_point", "hnsw_dist_func", "hnsw_init_dist_func",
                                       "hnsw_begin_read", "hnsw_end_read", "hnsw_begin_write", "hnsw_end_write",
                                       "hnsw_prefetch", "hnsw_is_deleted"} <= gpu
+    # measurement / diagnostics live in a header of their own (same library): the product header declares none of them
+    diag = declared("hnsw_gpu_diag.h") - declared("hnsw_gpu.h")
+    assert {"hnsw_gpu_team_counters", "hnsw_gpu_search_traced_dev", "hnsw_gpu_replay_roof", "hnsw_gpu_replay_roof_parts", "hnsw_gpu_gather_roof",
+            "hnsw_gpu_last_search_clock_mhz", "hnsw_gpu_index_placement", "hnsw_gpu_last_bruteforce_clock_mhz"} <= diag <= gpu
+    assert not any(w in open(os.path.join(INC, "hnsw_gpu.h")).read() for w in ("_roof", "team_counters", "traced_dev"))
     assert {"hnsw_search", "hnsw_bind_point", "hnsw_dist_func", "hnsw_init_dist_func"} <= shim   # embedding.h:46-47,55-56
     assert declared("hnsw_gpu_shim.h") <= shim
     # the shim imports the host's storage callbacks exactly like hnswalg.cpp does (embedding.h:44,48-53)
@@ -225,8 +230,8 @@ def test_the_shipped_library_knows_only_the_documented_knobs():
         assert gone not in in_lib
     # ... and no entry point of the search / insert paths imports getenv-by-name machinery beyond the once-only table: the symbol is
     # referenced (the table, the watchdog), but the call path reads plain words — checked by the source: launch_search has no getenv
-    src = open(os.path.join(ROOT, "pg_embedding_amd", "csrc", "hnsw_gpu.hip")).read()
-    body = src[src.index("static int launch_search("):src.index('extern "C" int hnsw_gpu_search_batch_dev(')]
+    src = open(os.path.join(ROOT, "pg_embedding_amd", "csrc", "gpu_search.hip")).read()
+    body = src[src.index("int launch_search("):src.index('extern "C" int hnsw_gpu_search_batch_dev(')]
     assert "getenv" not in body
 
 

@@ -1,4 +1,4 @@
-"""The kernels' OWN source on the CPU: pg_embedding_amd/csrc/hnsw_gpu.hip and its device headers, unmodified, compiled for the
+"""The kernels' OWN source on the CPU: pg_embedding_amd/csrc/hnsw_gpu.hip, gpu_*.hip and their device headers, unmodified, compiled for the
 host against a SIMT emulator (tests/emu/hip/hip_runtime.h: a wavefront = an OS thread, its 64 lanes = coroutines that meet at
 every cross-lane operation) and compared with the oracle bit for bit.
 
@@ -154,7 +154,7 @@ def test_the_emulator_notices_a_store_into_another_devices_memory():
     """teeth of the test above: the same source with the peer enabling removed (but the direct-store path kept) must die on the
     first cross-device store"""
     def no_enable(name, txt):
-        if name == "hnsw_gpu.hip":
+        if name == "gpu_sharded.hip":
             needle = "const hipError_t pe = hipDeviceEnablePeerAccess(s->home, 0);"
             assert txt.count(needle) == 1
             txt = txt.replace(needle, "const hipError_t pe = hipSuccess;")
