@@ -63,6 +63,12 @@ def parse():
     ap.add_argument("--recall-queries", type=int, default=1000)
     ap.add_argument("--alloc-probe", action="store_true",
                     help="diagnostic: do not empty torch's cache in front of the side configs and time the first one again with re-created tensors (profiles/r5af_*)")
+    ap.add_argument("--profile-config", default="", choices=["", "M", "C2", "C3", "C5", "hostile"],
+                    help="build and search ONE configuration as the bench does (its --steps timed launches and nothing else): the command "
+                         "scripts/profile_configs.sh runs under rocprofv3")
+    ap.add_argument("--device-build", action="store_true",
+                    help="headline on the batched device build of torch-generated rows even where the reference's own graph of the table "
+                         "(oracle/_ref/serial_graph_*.npy) is present")
     ap.add_argument("--no-side-configs", action="store_true",
                     help="skip the other BASELINE configs and the stress datasets (reported extras, N=1 only)")
     ap.add_argument("--hostile-rows", type=int, default=8_000_000,
@@ -293,6 +299,38 @@ def build_index(args, n, clusters, dev, local, func):
     return ix, t_gen, t_build
 
 
+def reference_graph_path(args, func):
+    """the reference's own serial graph of the headline table, if it travels with the tree (tests/experiments/make_ref_serial_graph.py)"""
+    path = REF_GRAPH.format(n=args.n, dim=args.dim, m=args.m, efc=args.efc)
+    ok = func == 0 and args.clusters == 1000 and not args.device_build and os.path.exists(path)
+    return path if ok else None
+
+
+def build_index_on_reference_graph(args, path, dev, local, func):
+    """The index the metric is about, as the REFERENCE builds it (hnswalg.cpp:279-291: serial hnsw_bind_point): link words made once by
+    oracle/_ref on a host core, rows from the seeded numpy generator (the bytes that graph was built over), uploaded as element images
+    chunk by chunk — the host never holds the 3 GB table.  Returns (index, upload seconds, figures of the graph)."""
+    import numpy as np
+    import pg_embedding_amd as pg
+    from pg_embedding_amd.datasets import gmm_chunks
+    links = np.load(path, mmap_mode="r")
+    n = links.shape[0]
+    assert n == args.n and links.shape[1] == 2 * args.m + 1
+    meta = pg.make_meta(args.dim, args.m, args.efc, args.ef, func)
+    es, od, ol = int(meta.size_data_per_element), int(meta.offset_data), int(meta.offset_label)
+    ix = pg.GpuIndex.empty(meta, n, device=local)
+    t0 = time.time()
+    for a, x in gmm_chunks(n, args.dim, k=args.clusters, sigma=0.3, seed=42, chunk=1 << 16):
+        b = a + x.shape[0]
+        raw = np.zeros((b - a, es), np.uint8)
+        raw[:, :od] = np.ascontiguousarray(links[a:b]).view(np.uint8)
+        raw[:, od:ol] = x.view(np.uint8)
+        raw[:, ol:] = np.arange(a, b, dtype=np.uint64)[:, None].view(np.uint8)
+        ix.update_from_flat(raw.reshape(-1), a, b - a)
+    deg = np.asarray(links[:, 0])
+    return ix, time.time() - t0, {"mean_degree": float(deg.mean()), "full_lists": float((deg == 2 * args.m).mean())}
+
+
 # ------------------------------------------------------------------------------------------ replicas
 def main():
     args = parse()
@@ -304,6 +342,8 @@ def main():
         return selftest_main(args)
     if args.mode == "sharded":
         return main_sharded(args)
+    if args.profile_config:
+        return profile_config_main(args)
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -322,11 +362,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- index: synthetic rows generated in HBM, graph built by the device insert path ----
-    ix, t_gen, t_build = build_index(args, args.n, args.clusters, dev, local, func)
-
-    # every rank searches its own query stream (weak scaling)
-    Q = gmm_torch(args.nq, args.dim, k=args.clusters, sigma=0.3, seed=42, stream=1 + rank, device=dev)
+    # ---- index.  Where the reference's OWN graph of the headline table travels with the tree (oracle/_ref/serial_graph_*: serial
+    # hnsw_bind_point by the unmodified reference, hnswalg.cpp:279-291) `value` is measured on it, uploaded byte for byte — the graph
+    # the metric is about; the batched device build of the same rows is then the side leg (serial_vs_batched_build).  Otherwise:
+    # synthetic rows generated in HBM, graph built by the device insert path.
+    ref_path = reference_graph_path(args, func)
+    ref_graph = None
+    if ref_path:
+        ix, t_gen, ref_graph = build_index_on_reference_graph(args, ref_path, dev, local, func)
+        t_build = None
+        from pg_embedding_amd.datasets import gmm
+        Q = torch.from_numpy(gmm(args.nq, args.dim, k=args.clusters, sigma=0.3, seed=42, stream=1 + rank)).to(dev)     # (the numpy generator's mixture)
+        built_by = ("graph built by the REFERENCE itself (oracle/_ref: unmodified hnswalg.cpp, serial hnsw_bind_point on a host core; "
+                    "link words uploaded byte for byte)")
+    else:
+        ix, t_gen, t_build = build_index(args, args.n, args.clusters, dev, local, func)
+        # every rank searches its own query stream (weak scaling)
+        Q = gmm_torch(args.nq, args.dim, k=args.clusters, sigma=0.3, seed=42, stream=1 + rank, device=dev)
+        built_by = "device build"
 
     # ---- recall@10 against exhaustive search with the same metric ---------------------
     nrec = min(args.recall_queries, args.nq)
@@ -426,7 +479,7 @@ def main():
     qps = total_queries / elapsed
 
     achieved = bytes_launch / (kms * 1e-3) / 1e9
-    traffic, traffic_src = pmc_traffic(args, kernel_name)
+    traffic, traffic_src = pmc_traffic(args, kernel_name, "reference" if ref_path else "device (batched)")
     result = {
         "metric": "queries/sec at recall@10>=0.95, 1Mx768 L2 efsearch=128",
         "value": qps,
@@ -442,8 +495,9 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"HNSW search: {args.n}x{args.dim} fp32 GMM({args.clusters}, sigma 0.3), "
-                        f"{args.metric}, m={args.m}, efconstruction={args.efc} (device build), "
+                        f"{args.metric}, m={args.m}, efconstruction={args.efc} ({built_by}), "
                         f"efsearch={args.ef}, {args.nq} queries/step/GPU resident in HBM",
+            "graph_built_by": "reference" if ref_path else "device (batched)",
             "rows": args.n, "dims": args.dim, "m": args.m, "efsearch": args.ef,
             "queries_per_step_per_gpu": args.nq,
             "parallelism": "replica per GPU, queries sharded" if world > 1 else "single GPU",
@@ -456,6 +510,7 @@ def main():
                   "roofline_frac_per_rank": [b / (k * 1e-3) / 1e9 / HBM_PEAK_GBS for b, k in zip(per_rank_bytes, per_rank_kms)]},
         "recall_at_10": float(rec_t.item()),
         "results_stable_across_steps": same,
+        "shader_clock_mhz": ix.last_search_clock_mhz(),
         "evals_per_query": float(E.mean()),
         "hops_per_query": float(H.mean()),
         "alg_bytes_per_query": float(bytes_q.mean()),
@@ -511,7 +566,11 @@ def main():
         result["roofline"]["hbm_only"] = leg(hostile, args, dev, local, func)
     # ---- the other BASELINE configs and the stress datasets of SURVEY.md §8(d), same kernels, N=1 only (extras, not `value`)
     if rank == 0 and world == 1 and args.serial_rows > 0:
-        result["serial_vs_batched_build"] = leg(serial_vs_batched, args, dev, local, func, min(args.serial_rows, args.n))
+        head_serial = None
+        if ref_path:                                            # the headline WAS the reference's graph: its figures are the leg's "serial" side
+            head_serial = dict(ref_graph, evals_per_query=float(E.mean()), hops_per_query=float(H.mean()), recall_at_10=recall,
+                               alg_bytes_per_query=float(bytes_q.mean()), queries_per_s=args.nq / kms * 1e3, kernel_ms_per_launch=kms)
+        result["serial_vs_batched_build"] = leg(serial_vs_batched, args, dev, local, func, min(args.serial_rows, args.n), 10_000, head_serial)
     if rank == 0 and world == 1 and not args.no_side_configs:
         result["other_configs"] = leg(side_configs, args, dev, local)
         result["serial_insert"] = leg(serial_insert, args, dev)
@@ -547,6 +606,7 @@ def emit(result):
     cfg["evals_per_query"] = result.get("evals_per_query")
     cfg["hops_per_query"] = result.get("hops_per_query")
     cfg["results_stable_across_steps"] = result.get("results_stable_across_steps")
+    cfg["shader_clock_mhz"] = result.get("shader_clock_mhz")
     svb = result.get("serial_vs_batched_build")
     if isinstance(svb, dict) and "serial" in svb:
         cfg["serial_vs_batched_rows"] = svb["rows"]
@@ -569,6 +629,15 @@ def emit(result):
     for key, name in (("C2_sift_like_1Mx128_l2_m16", "c2"), ("C3_1Mx768_cosine_m32", "c3"), ("C5_1Mx1536_cosine_m32_Q1024", "c5")):
         roof[name + "_frac"] = get(result, "other_configs", key, "frac_of_8TBps")
         roof[name + "_recall_at_10"] = get(result, "other_configs", key, "recall_at_10")
+        roof[name + "_traffic_over_algorithmic"] = get(result, "other_configs", key, "traffic_over_algorithmic")
+    # the narrow-row launch: one state or two?  (profiles/r5af_*) — spread of its 12 timed launches, the clock it ran at, where its mirror sits
+    mmm = get(result, "other_configs", "C2_sift_like_1Mx128_l2_m16", "kernel_ms_min_median_max")
+    if mmm:
+        roof["c2_kernel_ms_min"], roof["c2_kernel_ms_median"], roof["c2_kernel_ms_max"] = mmm
+    roof["c2_shader_clock_mhz"] = get(result, "other_configs", "C2_sift_like_1Mx128_l2_m16", "shader_clock_mhz")
+    roof["c2_mirror_arrays_on_2MiB_boundaries"] = get(result, "other_configs", "C2_sift_like_1Mx128_l2_m16", "mirror_arrays_on_2MiB_boundaries")
+    roof["c2_frac_two_streams"] = get(result, "other_configs", "C2_sift_like_1Mx128_l2_m16", "two_streams", "frac_of_8TBps")
+    roof["hbm_only_traffic_over_algorithmic"] = get(result, "roofline", "hbm_only", "traffic_over_algorithmic")
     roof["c5_kernel_ms"] = get(result, "other_configs", "C5_1Mx1536_cosine_m32_Q1024", "kernel_ms_per_launch")
     roof["mfma_gemm_frac"] = get(result, "other_configs", "C5_1Mx1536_cosine_m32_Q1024", "exhaustive_mfma_gemm", "frac")
     roof["mfma_gemm_tflops"] = get(result, "other_configs", "C5_1Mx1536_cosine_m32_Q1024", "exhaustive_mfma_gemm", "tflops")
@@ -741,20 +810,10 @@ def two_streams(ix, Qs, ef, labels_want, dev, reps=12):
             "queries_per_s_of_each_round": rounds, "results_identical": ok}
 
 
-def side_configs(args, dev, local):
-    """BASELINE.json configs 2, 3 and 5 at 1M rows, and two stress datasets for the headline shape: i.i.d. Gaussian rows
-    (no cluster structure: E_q several times larger, recall far below the gate — SURVEY.md §8d says report it, never gate
-    on it) and low-rank rows (16-d latent + noise).  One launch size each, kernel time from the library's HIP events."""
-    import numpy as np
+def side_cases(dev):
+    """(name, dims, m, metric, row generator, queries per launch) of BASELINE.json configs 2, 3 and 5 and the two stress datasets"""
     import torch
-    import pg_embedding_amd as pg
-    from pg_embedding_amd.datasets import gmm_torch, recall_at_k
-    n = min(args.n, 1_000_000)
-    # every leg in front of this one ends by handing torch's cached device blocks back; with those legs switched off (--serial-rows 0
-    # --hostile-rows 0) it did not happen, and the narrow-row launch was 40 % slower on every launch in two runs of four (profiles/r5af_*:
-    # cause open, this call not shown to be the remedy): start from the same allocator state whatever ran before
-    if not args.alloc_probe:
-        torch.cuda.empty_cache()
+    from pg_embedding_amd.datasets import gmm_torch
 
     def rows_gmm(cnt, dim, stream):
         return gmm_torch(cnt, dim, k=1000, sigma=0.3, seed=42, stream=stream, device=dev)
@@ -778,25 +837,52 @@ def side_configs(args, dev, local):
             out[i:i + m] = torch.randn((m, 16), generator=g, device=dev) @ basis + 0.05 * torch.randn((m, dim), generator=g, device=dev)
         return out
 
-    cases = [
+    return [
         ("C2_sift_like_1Mx128_l2_m16", 128, 16, "l2", rows_sift, 40000),
         ("C3_1Mx768_cosine_m32", 768, 32, "cosine", rows_gmm, 40000),
         ("C5_1Mx1536_cosine_m32_Q1024", 1536, 32, "cosine", rows_gmm, 1024),
         ("stress_iid_1Mx768_l2_m16", 768, 16, "l2", rows_iid, 10000),
         ("stress_lowrank16_1Mx768_l2_m16", 768, 16, "l2", rows_lowrank, 40000),
     ]
+
+
+def build_side_config(args, case, dev, local):
+    """index + queries of one side configuration, exactly as side_configs (and --profile-config) search them"""
+    import torch
+    import pg_embedding_amd as pg
+    name, dim, m, metric, gen, nq = case
+    n = min(args.n, 1_000_000)
+    func = {"l2": pg.DIST_L2, "cosine": pg.DIST_COSINE}[metric]
+    X = gen(n, dim, 0)
+    ix = pg.GpuIndex.empty(pg.make_meta(dim, m, args.efc, args.ef, func), n, device=local)
+    ix.append_torch(X)
+    del X
+    ix.link(0, n, args.max_batch, args.ratio, torch.cuda.current_stream(dev).cuda_stream)
+    torch.cuda.synchronize()
+    return ix, gen(nq, dim, 1)
+
+
+def side_configs(args, dev, local):
+    """BASELINE.json configs 2, 3 and 5 at 1M rows, and two stress datasets for the headline shape: i.i.d. Gaussian rows
+    (no cluster structure: E_q several times larger, recall far below the gate — SURVEY.md §8d says report it, never gate
+    on it) and low-rank rows (16-d latent + noise).  One launch size each, kernel time from the library's HIP events."""
+    import numpy as np
+    import torch
+    import pg_embedding_amd as pg
+    from pg_embedding_amd.datasets import gmm_torch, recall_at_k
+    n = min(args.n, 1_000_000)
+    # every leg in front of this one ends by handing torch's cached device blocks back; with those legs switched off (--serial-rows 0
+    # --hostile-rows 0) it did not happen, and the narrow-row launch was 40 % slower on every launch in two runs of four (profiles/r5af_*:
+    # cause open, this call not shown to be the remedy): start from the same allocator state whatever ran before
+    if not args.alloc_probe:
+        torch.cuda.empty_cache()
+
+    cases = side_cases(dev)
     res = {}
     for name, dim, m, metric, gen, nq in cases:
-        func = {"l2": pg.DIST_L2, "cosine": pg.DIST_COSINE}[metric]
         t0 = time.time()
-        X = gen(n, dim, 0)
-        ix = pg.GpuIndex.empty(pg.make_meta(dim, m, args.efc, args.ef, func), n, device=local)
-        ix.append_torch(X)
-        del X
-        ix.link(0, n, args.max_batch, args.ratio, torch.cuda.current_stream(dev).cuda_stream)
-        torch.cuda.synchronize()
+        ix, Q = build_side_config(args, (name, dim, m, metric, gen, nq), dev, local)
         t_build = time.time() - t0
-        Q = gen(nq, dim, 1)
         out = ix.search_torch(Q, args.ef, stats=True)
         torch.cuda.synchronize()
         st = out["stats"].cpu().numpy().astype(np.int64)
@@ -836,6 +922,8 @@ def side_configs(args, dev, local):
             ms.append(ix.last_search_ms())
         kms = float(np.median(ms[1:]))
         timed_kernel = ix.last_search_kernel()                 # (read BEFORE the traced launch below: that one runs another instantiation)
+        clock_mhz = ix.last_search_clock_mhz()                 # shader clock the last timed launch ran at (its first wave's stamps)
+        place = ix.placement()
         probe = None
         if args.alloc_probe and name.startswith("C2"):
             # diagnostic (profiles/r5af_*): the cache was NOT emptied in front of this index.  Which allocations carry the slow state —
@@ -864,7 +952,17 @@ def side_configs(args, dev, local):
                      "reads_beyond_infinity_cache_reach": tr["reads_beyond_infinity_cache_reach"],
                      "hbm_lower_bound_GBps": tr["hbm_lower_bound_GBps"], "evals_per_query": float(st[:, 0].mean()),
                      "hops_per_query": float(st[:, 1].mean()), "recall_at_10": rec, "kernel": timed_kernel,
-                     "datagen_plus_build_seconds": t_build}
+                     "datagen_plus_build_seconds": t_build,
+                     # which state of the device / of the process's allocations the launches ran in (profiles/r5af_*: a narrow-row launch
+                     # 40 % slower on every launch of some processes): the clock the kernel measured itself, where the mirror sits
+                     "shader_clock_mhz": clock_mhz, "mirror_arrays_on_2MiB_boundaries": place["aligned_2MiB"],
+                     "placement": {k: [hex(v[0]), v[1]] for k, v in place.items() if isinstance(v, tuple)}}
+        key = name.split("_")[0]
+        if key in ("C2", "C3", "C5"):
+            traffic, tsrc = pmc_traffic_for(key, timed_kernel, {"n": n, "dim": dim, "m": m, "efc": args.efc, "ef": args.ef, "nq": nq, "metric": metric})
+            res[name]["traffic"] = traffic
+            res[name]["traffic_source"] = tsrc
+            res[name]["traffic_over_algorithmic"] = (traffic / float(bq.sum())) if traffic else None
         if mfma:
             res[name]["exhaustive_mfma_gemm"] = mfma
         if probe:
@@ -960,50 +1058,50 @@ def graph_figures(ix, Q, ef, nrec, truth, dim, m):
 REF_GRAPH = os.path.join(ROOT, "oracle", "_ref", "serial_graph_{n}x{dim}_m{m}_efc{efc}_l2.npy")
 
 
-def reference_graph_vs_batched(args, dev, local, func, path, nq):
+def reference_graph_vs_batched(args, dev, local, func, path, nq, serial=None):
     """The headline table as the REFERENCE ITSELF builds it: oracle/_ref's serial hnsw_bind_point over the rows (hnswalg.cpp:279-291), made
     once on a host core by tests/experiments/make_ref_serial_graph.py (17 minutes for 1M x 768; the link words travel in oracle/_ref/ like
     the reference binaries), uploaded byte for byte and searched beside the BATCHED device build of the same rows with the same queries.
-    Rows and queries are the numpy generator's (the same bytes on every box); a checker leg, never part of `value`."""
+    Rows and queries are the numpy generator's (the same bytes on every box).  `serial`: the figures of the reference's graph when the
+    headline legs have already measured them (the headline IS that graph whenever it is present): only the batched build is made then."""
     import numpy as np
     import torch
     import pg_embedding_amd as pg
-    from pg_embedding_amd.datasets import gmm
-    links = np.load(path)
-    n = links.shape[0]
-    assert links.shape == (n, 2 * args.m + 1)
-    X = gmm(n, args.dim, k=args.clusters, sigma=0.3, seed=42)
+    from pg_embedding_amd.datasets import gmm, gmm_chunks
+    n = args.n
     Q = gmm(nq, args.dim, k=args.clusters, sigma=0.3, seed=42, stream=1)
     meta = pg.make_meta(args.dim, args.m, args.efc, args.ef, func)
-    raw = np.zeros((n, int(meta.size_data_per_element)), np.uint8)
-    raw[:, :int(meta.offset_data)] = links.view(np.uint8)
-    raw[:, int(meta.offset_data):int(meta.offset_label)] = X.view(np.uint8)
-    raw[:, int(meta.offset_label):] = np.arange(n, dtype=np.uint64)[:, None].view(np.uint8)
     Qd = torch.from_numpy(Q).to(dev)
     nrec = min(1000, nq)
     res = {"rows": n, "dims": args.dim, "m": args.m, "efconstruction": args.efc, "efsearch": args.ef, "queries_per_launch": nq,
            "serial_graph_built_by": "oracle/_ref = the unmodified reference (hnsw_bind_point row by row on one host core), " + os.path.relpath(path, ROOT)}
-    ix = pg.GpuIndex.from_flat(meta, raw.reshape(-1), n, device=local)
-    del raw
-    truth = ix.bruteforce_torch(Qd[:nrec].contiguous(), 10, mfma=True)[0].cpu().numpy()
-    res["serial"] = graph_figures(ix, Qd, args.ef, nrec, truth, args.dim, args.m)
-    ix.close()
+    truth = None
+    if serial is None:
+        ix, _, fig = build_index_on_reference_graph(args, path, dev, local, func)
+        truth = ix.bruteforce_torch(Qd[:nrec].contiguous(), 10, mfma=True)[0].cpu().numpy()
+        res["serial"] = graph_figures(ix, Qd, args.ef, nrec, truth, args.dim, args.m)
+        ix.close()
+    else:                                                       # (the headline legs searched exactly this graph with exactly these queries)
+        res["serial"] = dict(serial)
     ix = pg.GpuIndex.empty(meta, n, device=local)
-    ix.append_torch(torch.from_numpy(X).to(dev))
+    for _, x in gmm_chunks(n, args.dim, k=args.clusters, sigma=0.3, seed=42, chunk=1 << 16):
+        ix.append_torch(torch.from_numpy(x).to(dev))
     torch.cuda.synchronize()
     t0 = time.time()
     ix.link(0, n, args.max_batch, args.ratio, torch.cuda.current_stream(dev).cuda_stream)
     torch.cuda.synchronize()
     t_build = time.time() - t0
+    if truth is None:
+        truth = ix.bruteforce_torch(Qd[:nrec].contiguous(), 10, mfma=True)[0].cpu().numpy()
     res["batched"] = graph_figures(ix, Qd, args.ef, nrec, truth, args.dim, args.m)
     res["batched"]["build_seconds"] = t_build
     ix.close()
-    del ix, X, Qd
+    del ix, Qd
     torch.cuda.empty_cache()
     return res
 
 
-def serial_vs_batched(args, dev, local, func, n, nq=10_000):
+def serial_vs_batched(args, dev, local, func, n, nq=10_000, head_serial=None):
     """Is the headline index the reference's workload?  The reference builds its graph by serial hnsw_bind_point calls
     (hnswalg.cpp:279-291); the bench builds with the BATCHED device builder (hnsw_gpu_index_link, batches <= 4096: a different graph
     by construction).  Both graphs of the same rows are searched with the same queries: E_q, H_q, recall@10, mean degree and q/s side
@@ -1016,7 +1114,7 @@ def serial_vs_batched(args, dev, local, func, n, nq=10_000):
     from pg_embedding_amd.datasets import gmm_torch
     path = REF_GRAPH.format(n=args.n, dim=args.dim, m=args.m, efc=args.efc)
     if func == pg.DIST_L2 and os.path.exists(path):
-        res = reference_graph_vs_batched(args, dev, local, func, path, args.nq)
+        res = reference_graph_vs_batched(args, dev, local, func, path, args.nq, head_serial)
     else:
         clusters = max(10, args.clusters * n // max(args.n, 1)) if n < args.n else args.clusters
         X = gmm_torch(n, args.dim, k=clusters, sigma=0.3, seed=42, device=dev)
@@ -1123,14 +1221,9 @@ def serial_insert(args, dev):
     return res
 
 
-def hostile(args, dev, local, func):
-    """Same kernel, same row width, on a table built to defeat the caches: `--hostile-rows` rows (default 8 M = 24.6 GB, two
-    orders of magnitude above the 256 MB Infinity Cache) in clusters of 200, and every query of the launch from a cluster of its
-    OWN (a random permutation of the clusters).  Rows still repeat inside a launch — every walk starts at the same entry point,
-    and a walk of ~1 800 rows crosses its neighbours' clusters; a table in which 40 000 walks never meet would need > 70 M rows —
-    but almost never within cache reach: the launch's own trace says how many reads had their row read less than 256 MB of
-    traffic earlier (`reads_beyond_infinity_cache_reach` is the complement), and what HBM provably delivered."""
-    import numpy as np
+def hostile_setup(args, dev, local, func):
+    """index + queries of the cache-hostile table (see hostile()): returns (index, queries, args with the m / efsearch the recall gate
+    needed, what was tried, clusters, datagen seconds, build seconds)"""
     import torch
     from pg_embedding_amd.datasets import gmm_torch, recall_at_k
     import copy
@@ -1156,6 +1249,22 @@ def hostile(args, dev, local, func):
             break
     args = copy.copy(args)
     args.ef, args.m = ef_used, hargs.m
+    return ix, Q, args, tried, clusters, truth, t_gen, t_build
+
+
+def hostile(args, dev, local, func):
+    """Same kernel, same row width, on a table built to defeat the caches: `--hostile-rows` rows (default 8 M = 24.6 GB, two
+    orders of magnitude above the 256 MB Infinity Cache) in clusters of 200, and every query of the launch from a cluster of its
+    OWN (a random permutation of the clusters).  Rows still repeat inside a launch — every walk starts at the same entry point,
+    and a walk of ~1 800 rows crosses its neighbours' clusters; a table in which 40 000 walks never meet would need > 70 M rows —
+    but almost never within cache reach: the launch's own trace says how many reads had their row read less than 256 MB of
+    traffic earlier (`reads_beyond_infinity_cache_reach` is the complement), and what HBM provably delivered."""
+    import numpy as np
+    import torch
+    from pg_embedding_amd.datasets import recall_at_k
+    n = args.hostile_rows
+    ix, Q, args, tried, clusters, truth, t_gen, t_build = hostile_setup(args, dev, local, func)
+    nrec = min(500, args.nq)
     out = ix.search_torch(Q, args.ef, stats=True)
     torch.cuda.synchronize()
     stats = out["stats"].cpu().numpy().astype(np.int64)
@@ -1184,7 +1293,10 @@ def hostile(args, dev, local, func):
            "alg_bytes_per_launch": float(bq.sum()), "evals_per_query": float(stats[:, 0].mean()),
            "hops_per_query": float(stats[:, 1].mean()), "recall_at_10": rec, "recall_gate_0.95_holds": bool(rec >= 0.95),
            "m": args.m, "efsearch": args.ef, "recall_by_efsearch_tried": tried,
-           "build_seconds": t_build, "datagen_seconds": t_gen}
+           "build_seconds": t_build, "datagen_seconds": t_gen, "shader_clock_mhz": ix.last_search_clock_mhz()}
+    traffic, tsrc = pmc_traffic_for("hostile", res["kernel"], {"n": n, "dim": args.dim, "m": args.m, "efc": args.efc, "ef": args.ef, "nq": args.nq, "metric": args.metric})
+    res["traffic"], res["traffic_source"] = traffic, tsrc
+    res["traffic_over_algorithmic"] = (traffic / res["alg_bytes_per_launch"]) if traffic else None
     ix.close()
     return res
 
@@ -1369,31 +1481,97 @@ def kernel_source_digest():
     return h.hexdigest()[:16]
 
 
-def pmc_traffic(args, kernel_name):
-    """HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes of THIS command
-    ((2*FETCH_SIZE + WRITE_SIZE)*1024, gfx950 FETCH_SIZE correction of the micro-arch guide).  The
-    counters cannot be collected from inside the timed process, so the value measured by
-    scripts/profile_bench.sh is committed as profiles/traffic.json and reported here — with its source and the kernel
-    time of the profiled run named — only when it was taken for the same workload, the same kernel symbol as this run's
-    dominant kernel AND the same bytes of the kernel sources; otherwise null (a stale file is refused, not reported)."""
+def pmc_traffic_for(key, kernel_name, workload):
+    """HBM bytes per launch of configuration `key`'s search kernel from rocprofv3 PMC passes of `bench.py --profile-config key`
+    ((2*FETCH_SIZE + WRITE_SIZE)*1024: the gfx950 FETCH_SIZE correction of the micro-arch guide).  The counters cannot be
+    collected from inside the timed process, so what scripts/profile_configs.sh measured is committed as profiles/traffic.json —
+    one entry per configuration — and reported here, with its source and the kernel time of the profiled run, only when it was
+    taken for the same workload, the same kernel symbol AND the same bytes of the kernel sources; otherwise null (a stale entry
+    is refused, not reported)."""
     path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
         with open(path) as f:
-            t = json.load(f)
-        same = all(t["workload"].get(k) == getattr(args, k) for k in ("n", "dim", "m", "efc", "ef", "nq", "metric"))
-        if not same:
-            return None, "profiles/traffic.json is for another workload: not reported"
+            t = json.load(f).get(key)
+        if not t:
+            return None, f"profiles/traffic.json has no entry for {key}"
+        diff = [k for k, v in workload.items() if t["workload"].get(k) != v]
+        if diff:
+            return None, f"profiles/traffic.json[{key}] is for another workload ({', '.join(diff)} differ): not reported"
         if t.get("kernel") != kernel_name:
-            return None, f"profiles/traffic.json was taken for kernel {t.get('kernel')}, this run's is {kernel_name}: not reported"
+            return None, f"profiles/traffic.json[{key}] was taken for kernel {t.get('kernel')}, this run's is {kernel_name}: not reported"
         if t.get("kernel_source_digest") != kernel_source_digest():
-            return None, (f"profiles/traffic.json was taken for another version of the kernel sources ({t.get('kernel_source_digest')} vs "
-                          f"{kernel_source_digest()}): not reported; regenerate with scripts/profile_bench.sh")
-        src = f"profiles/traffic.json ({t.get('run', 'scripts/profile_bench.sh')}): " + t["source"]
+            return None, (f"profiles/traffic.json[{key}] was taken for another version of the kernel sources ({t.get('kernel_source_digest')} vs "
+                          f"{kernel_source_digest()}): not reported; regenerate with scripts/profile_configs.sh")
+        src = f"profiles/traffic.json[{key}] ({t.get('run', 'scripts/profile_configs.sh')}): " + t["source"]
         if t.get("kernel_ms_per_launch_of_that_run"):
             src += f"; kernel time of that run {t['kernel_ms_per_launch_of_that_run']:.3f} ms"
         return float(t["hbm_bytes_per_launch"]), src
     except Exception:
         return None, None
+
+
+def pmc_traffic(args, kernel_name, graph_built_by):
+    """the headline workload's entry ("M"): also tied to which graph was searched (the reference's own or the batched device build)"""
+    return pmc_traffic_for("M", kernel_name, {"n": args.n, "dim": args.dim, "m": args.m, "efc": args.efc, "ef": args.ef, "nq": args.nq,
+                                              "metric": args.metric, "graph_built_by": graph_built_by})
+
+
+PROFILE_CONFIGS = ("M", "C2", "C3", "C5", "hostile")
+
+
+def profile_config_main(args):
+    """`bench.py --profile-config M|C2|C3|C5|hostile`: ONE configuration exactly as the bench builds and searches it — its index, its
+    queries, `--steps` launches of the timed kernel and nothing else — for the rocprofv3 passes of scripts/profile_configs.sh (the LAST
+    `--steps` dispatches of the search kernel are the timed shape).  Prints one JSON line that scripts/make_traffic_json.py keys the
+    counters by."""
+    import numpy as np
+    import torch
+    import pg_embedding_amd as pg
+    name = args.profile_config
+    local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    func = {"l2": pg.DIST_L2, "cosine": pg.DIST_COSINE, "manhattan": pg.DIST_MANHATTAN}[args.metric]
+    extra = {}
+    if name == "M":
+        ref_path = reference_graph_path(args, func)
+        if ref_path:
+            from pg_embedding_amd.datasets import gmm
+            ix, _, _ = build_index_on_reference_graph(args, ref_path, dev, local, func)
+            Q = torch.from_numpy(gmm(args.nq, args.dim, k=args.clusters, sigma=0.3, seed=42, stream=1)).to(dev)
+        else:
+            from pg_embedding_amd.datasets import gmm_torch
+            ix, _, _ = build_index(args, args.n, args.clusters, dev, local, func)
+            Q = gmm_torch(args.nq, args.dim, k=args.clusters, sigma=0.3, seed=42, stream=1, device=dev)
+        wl = {"n": args.n, "dim": args.dim, "m": args.m, "efc": args.efc, "ef": args.ef, "nq": args.nq, "metric": args.metric,
+              "graph_built_by": "reference" if ref_path else "device (batched)"}
+        ef, m, dim = args.ef, args.m, args.dim
+    elif name == "hostile":
+        ix, Q, hargs, tried, clusters, truth, _, _ = hostile_setup(args, dev, local, func)
+        ef, m, dim = hargs.ef, hargs.m, args.dim
+        wl = {"n": args.hostile_rows, "dim": dim, "m": m, "efc": args.efc, "ef": ef, "nq": args.nq, "metric": args.metric}
+    else:
+        case = [c for c in side_cases(dev) if c[0].split("_")[0] == name][0]
+        _, dim, m, metric, _, nq = case
+        ix, Q = build_side_config(args, case, dev, local)
+        ef = args.ef
+        wl = {"n": min(args.n, 1_000_000), "dim": dim, "m": m, "efc": args.efc, "ef": ef, "nq": nq, "metric": metric}
+        extra["case"] = case[0]
+    out = ix.search_torch(Q, ef, stats=True)
+    torch.cuda.synchronize()
+    st = out["stats"].cpu().numpy().astype(np.int64)
+    cnt = out["counts"].cpu().numpy().astype(np.int64)
+    byt = float(alg_bytes(st, cnt, dim, m).sum())
+    ms = []
+    for _ in range(max(1, args.steps)):
+        ix.search_torch(Q, ef, out=out)
+        ms.append(ix.last_search_ms())
+    kms = float(np.mean(ms))
+    print(json.dumps(dict(extra, profile_config=name, kernel=ix.last_search_kernel(), kernel_source_digest=kernel_source_digest(),
+                          alg_bytes_per_launch=byt, kernel_ms_per_launch=kms, kernel_ms_all=ms, achieved_GBps=byt / kms / 1e6,
+                          frac_of_8TBps=byt / kms / 1e6 / HBM_PEAK_GBS, shader_clock_mhz=ix.last_search_clock_mhz(),
+                          evals_per_query=float(st[:, 0].mean()), hops_per_query=float(st[:, 1].mean()), launches=len(ms), workload=wl)), flush=True)
+    ix.close()
 
 
 def cpu_quota():
@@ -1435,16 +1613,20 @@ def cpu_baseline(args, ix, Q, gpu_labels, gpu_dists, func):
     n8 = int(max(64, min(args.nq, qps1 * 8 * args.cpu_seconds * 0.25)))
     r8 = cpu.search_many(Qh[:n8], args.ef, nthreads=min(8, ncores))
     qps8 = n8 / r8["seconds"]
+    quota = cpu_quota()
+    # cores = what the figure is worth: the threads that ran, capped by the CPU time the box grants the process tree (round 5: 64 threads
+    # on a 16-CPU quota were reported as 64 cores)
+    cores = threads if quota is None else max(1, min(threads, int(round(quota))))
     res = {
-        "value": qpst, "unit": "queries/s", "cores": threads, "kind": kind,
+        "value": qpst, "unit": "queries/s", "cores": cores, "threads": threads, "kind": kind,
         "sample": f"{nt} of the {args.nq} queries on {threads} host threads (one query per thread, "
-                  f"shared read-only index); single thread: {n1} queries",
+                  f"shared read-only index{'' if cores == threads else f'; the box grants {quota:g} CPUs of time'}); single thread: {n1} queries",
         "single_thread_qps": qps1,
         "eight_thread_qps": qps8,
         "host_cpus": ncores,
         # CPU time the box actually grants this process tree (cgroup v2 cpu.max = quota / period; null = unlimited or unknown): the MI355X
         # boxes of round 4 showed 256 CPUs and granted 16 — a 64-thread figure measured there is 16 CPUs' worth
-        "host_cpu_quota_cpus": cpu_quota(),
+        "host_cpu_quota_cpus": quota,
     }
     glab = gpu_labels[:nt].cpu().numpy().view(np.uint64)
     same = (rt["labels"] == glab).all(axis=1)
@@ -1505,6 +1687,19 @@ def cpu_baseline(args, ix, Q, gpu_labels, gpu_dists, func):
             "queries_with_a_diverging_decision": int((dk != 0).sum()),
             "queries_without_one_all_identical": bool(same[dk == 0].all()),
         }
+        # the same, as plain scalars of cpu_baseline itself: a record that keeps only scalars (the driver's) must still show that the
+        # id lists that differ from the compiled reference's are ALL classified near-ties and that the device equals the oracle
+        pv = res["parity_vs_reference"]
+        res["parity_queries"] = nt
+        res["device_equals_oracle_bit_exact"] = pv["device_equals_oracle_bit_exact"]
+        res["mismatch_count"] = pv["mismatch_count"]
+        res["mismatch_explained_by_near_tie"] = pv["mismatch_explained_by_near_tie"]
+        res["mismatch_unexplained"] = pv["mismatch_unexplained"]
+        res["largest_gap_at_a_mismatching_decision"] = pv["largest_gap_at_a_mismatching_decision"]
+        res["parity_tolerance"] = REL_TOL
+        res["reference_order_available"] = bool(ordered.get("available"))
+        res["reference_order_identical_queries"] = ordered.get("queries_with_the_references_id_list")
+        res["reference_order_queries"] = ordered.get("queries")
     return res
 
 

@@ -268,8 +268,9 @@ int  hnsw_gpu_ctx_idle(hnsw_gpu_ctx *ctx);
  *   hnsw_gpu_stream_close   stop: every wave leaves at its next look (a walking wave after its query); waits for the launch to end
  *                           (a launch that does not end within 2 s is asked through its abort word), frees the ring.  Queries
  *                           published but not yet started are dropped: close a stream when nothing is outstanding.
- *   hnsw_gpu_stream_abandon the same stop, but the ring is NOT freed (leaked on purpose): for a host that had to give a stream up while
- *                           it could not prove that none of its own threads was still inside the ring.
+ *   hnsw_gpu_stream_abandon the same stop, but neither the ring nor the handle is freed (leaked on purpose): for a host that had to give
+ *                           a stream up while it could not prove that none of its own threads was still inside the ring; such a late
+ *                           thread may still call _publish / _buffers on the handle (they touch the leaked memory only), nothing else.
  * Results do not depend on the mode: a query's walk is the same walk in a plain launch, a team launch or a stream. */
 typedef struct hnsw_gpu_stream hnsw_gpu_stream;
 int  hnsw_gpu_stream_open(hnsw_gpu_ctx *ctx, size_t ef, size_t ring, unsigned walkers, hnsw_gpu_stream **out);

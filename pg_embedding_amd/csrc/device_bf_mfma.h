@@ -211,7 +211,13 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void bf_mfma_filter_kern
 	// step's loads issued between the MFMAs 130 / 124; s_setprio around the MFMAs 131.7; a pipeline across tiles in resident blocks +0.6 % /
 	// -1.5 % (profiles/r5y_*); this plain form 134-136 with 128 x 128 tiles, 138 with 256 x 256.)
 	fetch(0, 0);
-	__syncthreads();                                            // (hipcc drains the LDS-bound loads, vmcnt(0), in front of the barrier)
+	// The tile loads are LDS-bound DMA (global_load_lds): what orders them before the other waves' LDS reads is vmcnt reaching 0 on the
+	// ISSUING wave before it arrives at the barrier.  hipcc emits that wait today, but nothing obliges it to (gfx950 has back-off
+	// barriers: no automatic waitcnt; a workgroup fence does not wait on vmcnt) — a compiler that dropped it would let a wave read tile
+	// rows another wave's DMA has not landed yet, and the filter would lose true neighbours silently.  Said explicitly (vmcnt(0) only:
+	// expcnt / lgkmcnt left alone); free where the compiler already waits.
+	__builtin_amdgcn_s_waitcnt(0x0F70);
+	__syncthreads();
 	for (uint32_t ks = 0; ks < a.ksteps; ks++)
 	{
 #if BF_ABLATE != 3                                              // (ablation builds — wrong answers, timing only: profiles/r5l_mfma_ablation.txt)
@@ -222,6 +228,7 @@ __global__ __launch_bounds__(128 * WM, WM == 2 ? 2 : 1) void bf_mfma_filter_kern
 #if BF_ABLATE == 1
 		__builtin_amdgcn_s_waitcnt(0);                             // the loads are still waited for; only the rendezvous of the four waves is gone
 #else
+		__builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): this wave's DMA of step ks + 1 has landed before anybody reads it
 		__syncthreads();
 #endif
 	}

@@ -120,6 +120,7 @@ struct hnsw_gpu_index
 	HnswMetadata meta;
 	int      device = 0;
 	int      num_cu = 0;
+	bool     gfx950 = false;        // the device's gcnArchName says so (the MFMA filter's direct-to-LDS loads and LDS sizes are gfx950's)
 	size_t   max_lds = 64 * 1024;   // dynamic LDS one block may ask for on this device (hipDeviceAttributeMaxSharedMemoryPerBlock)
 	bool     ins_dirty = false;     // an insert failed after its kernels were enqueued: block counters may be non-zero (insert_impl)
 	size_t   n = 0, cap = 0;

@@ -307,6 +307,12 @@ extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d
 	if (func == F_MANHATTAN || ix->n < 4096)          // not a contraction / too small to matter
 		return hnsw_gpu_bruteforce_dev(ix, d_queries, nq, k, d_idx, d_dists, stream_);
 	HIPCHK(hipSetDevice(ix->device));
+	{
+		// The filter kernel is written for gfx950: 16-byte direct-to-LDS loads and 69 / 134 KB of LDS per block.  Anything else gets the
+		// canonical scan — the same answer, bit for bit (the filter's survivors are re-scored by that code anyway).
+		if (!ix->gfx950 || ix->max_lds < (size_t) 72 * 1024)
+			return hnsw_gpu_bruteforce_dev(ix, d_queries, nq, k, d_idx, d_dists, stream_);
+	}
 	hipStream_t s = (hipStream_t) stream_;
 	const uint32_t n = (uint32_t) ix->n, stride = ix->stride, dim = (uint32_t) ix->meta.dim;
 	const uint32_t nchunks = stride / 4, kiters = (nchunks + 15) / 16;
@@ -371,6 +377,7 @@ extern "C" int hnsw_gpu_bruteforce_mfma_dev(hnsw_gpu_index *ix, const coord_t *d
 	a.queries = qpad; a.qnorm = qn; a.qbound = bound; a.vec = ix->vec; a.xnorm = ix->xnorm;
 	a.nq = (uint32_t) nq; a.n = n; a.stride = stride; a.qstride = qstride; a.ksteps = qstride / BF_TK; a.func = func;
 	a.cand = cand; a.cand_cnt = cnt; a.cap = cap; a.clocks = (unsigned long long *) (B + o_clk);
+	HIPCHK(hipMemsetAsync(a.clocks, 0, 16, s));                  // (written only by a block from the middle of the launch that does not exit early: a small table must not leave stale ticks behind)
 	if (!ix->bf_e0) { HIPCHK(hipEventCreate(&ix->bf_e0)); HIPCHK(hipEventCreate(&ix->bf_e1)); }
 	hipEvent_t e0 = ix->bf_e0, e1 = ix->bf_e1;
 	HIPCHK(hipEventRecord(e0, s));

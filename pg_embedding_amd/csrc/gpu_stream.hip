@@ -100,8 +100,10 @@ extern "C" int hnsw_gpu_stream_alive(hnsw_gpu_stream *s)
 
 static int stream_end(hnsw_gpu_stream *s, bool keep_buffers);
 extern "C" int hnsw_gpu_stream_close(hnsw_gpu_stream *s) { return stream_end(s, false); }
-/* the same stop, but the ring stays allocated (leaked on purpose): for a host that could not prove that none of its threads is
- * still reading or writing the ring it was given (hnsw_gpu_stream_buffers) when it had to give the stream up */
+/* the same stop, but the ring AND the handle stay allocated (leaked on purpose): for a host that could not prove that none of its
+ * threads is still reading or writing the ring it was given (hnsw_gpu_stream_buffers) — or still about to call
+ * hnsw_gpu_stream_publish on this handle, which reads s->host_ctl — when it had to give the stream up.  After this call the handle
+ * stays VALID for _publish and _buffers (they touch only the leaked memory; nothing listens any more) and for nothing else. */
 extern "C" int hnsw_gpu_stream_abandon(hnsw_gpu_stream *s) { return stream_end(s, true); }
 
 static int stream_end(hnsw_gpu_stream *s, bool keep_buffers)
@@ -132,7 +134,10 @@ static int stream_end(hnsw_gpu_stream *s, bool keep_buffers)
 		(void) hipHostFree(s->pin);
 		(void) hipFree(s->dev_ctl);
 	}                                                            // (a launch that never ended may still write them: leaked on purpose)
-	delete s;
+	// An abandoned stream keeps its handle too: the caller abandons exactly because one of its threads may still be inside the ring, and
+	// such a thread ends with hnsw_gpu_stream_publish(s, ...), which reads s->host_ctl and stores through it (freeing `s`
+	// here was a use-after-free and possibly a wild write).  ~100 bytes per abandoned stream, an event the server logs.
+	if (!keep_buffers) delete s;
 	return rc;
 }
 

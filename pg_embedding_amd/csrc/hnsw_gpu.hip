@@ -298,7 +298,11 @@ static int alloc_index(const HnswMetadata *meta, size_t capacity, int device, hn
 	ix->meta = *meta;
 	ix->device = device;
 	hipDeviceProp_t prop;
-	if (hipGetDeviceProperties(&prop, device) == hipSuccess) ix->num_cu = prop.multiProcessorCount;
+	if (hipGetDeviceProperties(&prop, device) == hipSuccess)
+	{
+		ix->num_cu = prop.multiProcessorCount;
+		ix->gfx950 = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+	}
 	if (ix->num_cu <= 0) ix->num_cu = 256;
 	{
 		int maxlds = 0;

@@ -694,6 +694,7 @@ struct Session
 	std::vector<uint64_t> t_pub;            // per slot: when it was published
 	std::unique_ptr<std::atomic<uint8_t>[]> busy;   // per slot: 1 = published, not answered yet
 	std::atomic<long> outstanding{0};
+	std::atomic<uint32_t> bailed{0};        // tickets a producer claimed and then gave up (submit, closing session): never ready, so `pub` stops in front of them
 	std::atomic<bool> accepting{false};
 	std::atomic<uint64_t> t_active{0};      // last publish or answer
 	std::atomic<uint64_t> t_crowded{0}, t_roomy{0};   // since when the launch has been too small / far too large for the load (0 = it is not)
@@ -719,7 +720,12 @@ struct Session
 		{
 			// ... or is a walk that hangs: then the session is closed over it (stream_manager_main), and this request queues instead of
 			// spinning inside a ring that is going away.  The ticket stays unpublished; the closer does not wait for it for ever.
-			if (spin > 1000 && !accepting.load(std::memory_order_acquire)) { outstanding.fetch_sub(1, std::memory_order_acq_rel); return false; }
+			if (spin > 1000 && !accepting.load(std::memory_order_acquire))
+			{
+				bailed.fetch_add(1);                                               // (the closer stops waiting for `pub` to reach `claim`: close_session)
+				outstanding.fetch_sub(1, std::memory_order_acq_rel);
+				return false;
+			}
 			if (spin > 1000) std::this_thread::yield(); else __builtin_ia32_pause();
 		}
 		memcpy(Q + (size_t) slot * dim, r.q.data(), dim * 4);
@@ -749,6 +755,16 @@ struct Session
 		while (ready[p & (ring - 1)].load() == p + 1)
 			if (pub.compare_exchange_weak(p, p + 1)) { p = p + 1; moved = true; }
 		if (moved) (void) hnsw_gpu_stream_publish(st, p);                  // (the library keeps the maximum: two advancers may arrive out of order)
+	}
+	// has the ticket that sits in `slot` been published (handed to the launch)?  (its ready word holds ticket + 1)
+	bool published(uint32_t slot) const { return (int32_t) (pub.load() - (ready[slot].load() - 1u)) > 0; }
+	// walks the launch still owes an answer: busy slots whose ticket was published
+	long walks_owed() const
+	{
+		long n = 0;
+		for (uint32_t slot = 0; slot < ring; slot++)
+			if (busy[slot].load(std::memory_order_acquire) && published(slot)) n++;
+		return n;
 	}
 };
 using SessionP = std::shared_ptr<Session>;
@@ -836,9 +852,13 @@ void close_session(SessionP &ss, const char *why, int unanswered_rc = HNSW_GPU_E
 	}
 	// producers that were past the check finish their slot; then every claimed ticket is published and, walked, answered
 	// (2 s of patience: on a host whose CPU time is capped the whole process may be frozen for tens of milliseconds at a time)
-	while ((ss->outstanding.load() > 0 || ss->pub.load() != ss->claim.load()) && now_ns() - t0 < 2000000000ull)
+	// A producer that gave its ticket up (Session::submit, bail-out) leaves a hole `pub` cannot cross: from then on the drain is over when
+	// every PUBLISHED walk is answered — what sits behind the hole was never handed to the launch and goes back to the queue below
+	// (such a close used to wait its whole 2 s and then answer those requests with an error).
+	while (now_ns() - t0 < 2000000000ull)
 	{
 		ss->advance();                      // (no producer will come by any more: a ready ticket that two of them left to each other is published here)
+		if (ss->bailed.load() == 0 ? (ss->outstanding.load() <= 0 && ss->pub.load() == ss->claim.load()) : ss->walks_owed() == 0) break;
 		std::this_thread::sleep_for(std::chrono::microseconds(20));
 	}
 	const uint64_t t_drained = now_ns();
@@ -865,7 +885,29 @@ void close_session(SessionP &ss, const char *why, int unanswered_rc = HNSW_GPU_E
 	if (now_ns() - t_drained > 200000000ull)
 		logf("slow close (%s): %.0f ms for the answer threads to let go, %.0f ms for the launch to end", why, (t_let_go - t_drained) / 1e6,
 			 (now_ns() - t_let_go) / 1e6);
-	long lost = 0;
+	long lost = 0, requeued = 0;
+	// requests that were written into the ring but never published (behind a bailed ticket): nobody has walked them and nobody will —
+	// back to the head of the queue, oldest ticket first, unless the server is going down
+	if (unanswered_rc != HGS_ERR_SHUTDOWN)
+	{
+		std::vector<std::pair<uint32_t, uint32_t>> back;     // (ticket, slot)
+		for (uint32_t slot = 0; slot < ss->ring; slot++)
+			if (ss->busy[slot].load() && !ss->published(slot) && !ss->F[slot]) back.emplace_back(ss->ready[slot].load() - 1u, slot);
+		std::sort(back.begin(), back.end(), [&](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) { return (int32_t) (a.first - b.first) > 0; });
+		if (!back.empty())
+		{
+			std::lock_guard<std::mutex> lk(g_q_mu);
+			for (auto &tb : back)                           // (newest first, each to the front: the oldest ends up first)
+			{
+				g_q.push_front(std::move(ss->req[tb.second]));
+				ss->busy[tb.second].store(0, std::memory_order_release);
+				ss->outstanding.fetch_sub(1, std::memory_order_relaxed);
+				requeued++;
+			}
+			g_q_waiting.store((long) g_q.size(), std::memory_order_release);
+		}
+		if (requeued) { logf("stream closed (%s): %ld requests behind a ticket its producer gave up go back to the queue", why, requeued); g_q_cv.notify_all(); }
+	}
 	for (uint32_t slot = 0; slot < ss->ring; slot++)
 		if (ss->busy[slot].load())
 		{
@@ -990,7 +1032,21 @@ void stream_manager_main()
 			continue;
 		}
 		// no session: wait for work, open one for the oldest request's (mirror, ef)
-		if (g_device_wanted.load() > 0) { std::this_thread::sleep_for(std::chrono::microseconds(50)); continue; }   // (control work first: it cannot run beside a resident launch)
+		if (g_device_wanted.load() > 0)
+		{
+			// control work first: it cannot run beside a resident launch — but the searches that are waiting need not wait for ALL of it
+			// (a long upload + link of one mirror used to stall the searches of every mirror): ordinary blocking launches run beside the
+			// control work's kernels, one batch at a time, until the count is down and a session can be opened again
+			batch.clear();
+			{
+				std::unique_lock<std::mutex> lk(g_q_mu);
+				if (!g_q.empty()) take_batch(batch);
+				g_q_waiting.store((long) g_q.size(), std::memory_order_release);
+			}
+			if (!batch.empty()) run_batch(0, batch, pin);
+			else std::this_thread::sleep_for(std::chrono::microseconds(50));
+			continue;
+		}
 		batch.clear();
 		EntryP e;
 		size_t ef = 0, backlog = 0;
@@ -1245,7 +1301,17 @@ void do_control(CReq &r)
 {
 	// (everything here may free or allocate device memory, launch kernels or wait for the device; a dropped mirror dies where its
 	// last reference goes, which is inside this function)
-	DeviceWanted wanted;
+	// ... but only the operations that do: SETGEN and a malformed request touch no device, and a trickle of them must not tear a
+	// resident session down again and again
+	std::unique_ptr<DeviceWanted> wanted;
+	switch (r.h.op)
+	{
+	case HGS_OP_UPLOAD: case HGS_OP_UPDATE: case HGS_OP_BIND: case HGS_OP_DROP: case HGS_OP_LINK: case HGS_OP_EXPORT: case HGS_OP_SET_DELETED:
+	case HGS_OP_DIST:
+		wanted.reset(new DeviceWanted());
+		break;
+	default: break;
+	}
 	switch (r.h.op)
 	{
 	case HGS_OP_UPLOAD: do_upload(r); break;

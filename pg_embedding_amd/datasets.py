@@ -20,6 +20,20 @@ def gmm(n: int, dim: int, k: int = 1000, sigma: float = 0.3, seed: int = 42, str
     return np.ascontiguousarray(x, dtype=np.float32)
 
 
+def gmm_chunks(n: int, dim: int, k: int = 1000, sigma: float = 0.3, seed: int = 42, stream: int = 0, chunk: int = 1 << 16):
+    """gmm() in pieces: yields (first_row, rows) with exactly the bytes gmm(n, ...) returns for those rows (the generator's normal stream
+    is sequential, so consecutive draws concatenate to the one big draw) without ever holding the table and its temporaries on the host:
+    1M x 768 is 3 GB, and gmm() peaks at three times that."""
+    crng = np.random.default_rng([seed, 0xC0])
+    centres = crng.standard_normal((k, dim), dtype=np.float32)
+    rng = np.random.default_rng([seed, 1 + stream])
+    which = rng.integers(0, k, n)
+    for a in range(0, n, chunk):
+        b = min(n, a + chunk)
+        x = centres[which[a:b]] + np.float32(sigma) * rng.standard_normal((b - a, dim), dtype=np.float32)
+        yield a, np.ascontiguousarray(x, dtype=np.float32)
+
+
 def sift_like(n: int, dim: int = 128, k: int = 256, seed: int = 42, stream: int = 0) -> np.ndarray:
     """SIFT-1M stand-in (the real files are not available offline): clustered non-negative
     integers in [0, 218] stored as fp32, which makes every L2^2 an exact integer."""

@@ -1,17 +1,11 @@
-"""Turn the FETCH_SIZE / WRITE_SIZE PMC passes of scripts/profile_bench.sh into profiles/traffic.json."""
-import csv, glob, hashlib, json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+"""Merge the FETCH_SIZE / WRITE_SIZE PMC passes of scripts/profile_configs.sh into profiles/traffic.json, one entry per configuration.
+
+usage: make_traffic_json.py <out-dir of one configuration> <traffic.json to update>
+  <out-dir> holds line.json (the JSON line `bench.py --profile-config <key>` printed) and pmc_FETCH_SIZE/, pmc_WRITE_SIZE/."""
+import csv, glob, json, os, sys
 
 
-def kernel_source_digest():
-    h = hashlib.sha256()
-    for f in ("device_dist.h", "device_search.h"):
-        with open(os.path.join(ROOT, "pg_embedding_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
-
-
-def last_mean(d, counter, last=3, pat="hnsw_search"):
+def last_mean(d, counter, last, pat="hnsw_search"):
     vals = []
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
         with open(f) as fh:
@@ -22,22 +16,30 @@ def last_mean(d, counter, last=3, pat="hnsw_search"):
     tail = [v for _, v in vals[-last:]]
     return sum(tail) / len(tail)
 
-out = sys.argv[1]
-fetch_kb = last_mean(os.path.join(out, "pmc_FETCH_SIZE"), "FETCH_SIZE")
-write_kb = last_mean(os.path.join(out, "pmc_WRITE_SIZE"), "WRITE_SIZE")
-line = json.loads(open(os.path.join(out, "bench_line.json")).read())
-cfg = line["config"]
-wl = {"n": cfg["rows"], "dim": cfg["dims"], "m": cfg["m"], "ef": cfg["efsearch"], "nq": cfg["queries_per_step_per_gpu"],
-      "efc": int(cfg["workload"].split("efconstruction=")[1].split()[0]), "metric": cfg["workload"].split(", ")[2] if False else None}
-wl["metric"] = "l2" if ", l2," in cfg["workload"] else ("cosine" if ", cosine," in cfg["workload"] else "manhattan")
-print(json.dumps({
-    "run": os.path.basename(os.path.normpath(out)),
-    "kernel": line["roofline"].get("kernel"),
-    "kernel_source_digest": kernel_source_digest(),
-    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), last 3 dispatches of hnsw_search_kernel of bench.py",
+
+out, path = sys.argv[1], sys.argv[2]
+line = json.loads(open(os.path.join(out, "line.json")).read())
+last = int(line.get("launches", 3))
+fetch_kb = last_mean(os.path.join(out, "pmc_FETCH_SIZE"), "FETCH_SIZE", last)
+write_kb = last_mean(os.path.join(out, "pmc_WRITE_SIZE"), "WRITE_SIZE", last)
+try:
+    allj = json.load(open(path))
+    if "workload" in allj:                      # (the single-object file of rounds 1-5)
+        allj = {}
+except (OSError, ValueError):
+    allj = {}
+key = line["profile_config"]
+allj[key] = {
+    "run": os.path.basename(os.path.dirname(os.path.normpath(out))) + "/" + os.path.basename(os.path.normpath(out)),
+    "kernel": line["kernel"],
+    "kernel_source_digest": line["kernel_source_digest"],
+    "source": f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), last {last} dispatches of hnsw_search_kernel of bench.py --profile-config {key}",
     "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
     "correction": "gfx950: FETCH_SIZE tallies 64 B per 128-B request for wide coalesced reads -> doubled (MI355X_MICROARCH.md, HBM section)",
     "hbm_bytes_per_launch": (2 * fetch_kb + write_kb) * 1024,
-    "alg_bytes_per_launch": line["roofline"]["alg_bytes_per_launch"],
-    "kernel_ms_per_launch_of_that_run": line["roofline"]["kernel_ms_per_launch"],
-    "workload": wl}, indent=1))
+    "alg_bytes_per_launch": line["alg_bytes_per_launch"],
+    "traffic_over_algorithmic": (2 * fetch_kb + write_kb) * 1024 / line["alg_bytes_per_launch"],
+    "kernel_ms_per_launch_of_that_run": line["kernel_ms_per_launch"],
+    "workload": line["workload"]}
+json.dump(allj, open(path, "w"), indent=1)
+print(json.dumps({key: allj[key]}, indent=1))

@@ -417,12 +417,12 @@ static int stream_end(hnsw_gpu_stream *s, int keep_buffers)
 	__atomic_store_n(&s->stop, 1, __ATOMIC_RELEASE);
 	for (int i = 0; i < s->nthreads; i++) pthread_join(s->th[i], NULL);
 	__atomic_store_n(&s->c->busy, 0, __ATOMIC_RELEASE);
-	if (!keep_buffers) { free(s->Q); free(s->L); free(s->D); free(s->C); free(s->F); }
-	free(s);
+	if (!keep_buffers) { free(s->Q); free(s->L); free(s->D); free(s->C); free(s->F); free(s); }      /* (abandoned: ring AND handle stay, as in the library —
+	                                                                                                     a late producer may still publish through it) */
 	return HNSW_GPU_OK;
 }
 int hnsw_gpu_stream_close(hnsw_gpu_stream *s) { return stream_end(s, 0); }
-int hnsw_gpu_stream_abandon(hnsw_gpu_stream *s) { return stream_end(s, 1); }      /* (the ring stays allocated, as in the library) */
+int hnsw_gpu_stream_abandon(hnsw_gpu_stream *s) { return stream_end(s, 1); }      /* (ring and handle stay allocated, as in the library) */
 int hnsw_gpu_device_blocks(int device) { (void) device; return 4; }   /* a tiny "device": the server's load policy is exercised with a handful of backends */
 
 static void *flags_worker(void *arg)
