@@ -74,8 +74,9 @@ int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries, size_
 	const bool use_beam = knob(K_BEAM, 1) != 0 && ix->cap < 0x80000000ull;
 	const bool beam16 = use_beam && ef > 256 && ef <= 512 && (knob_is_set(K_BEAM16) ? knob(K_BEAM16, 0) > 0 : shape_index(a.kiters) >= 2);
 	const size_t wide_min = (size_t) knob(K_WIDE_EF_MIN, (long long) WIDE_EF_MIN);
-	// Debug arithmetic (device_dist.h, F_L2_REF / F_MANHATTAN_REF / F_COSINE_REF): the summation order of oracle/_ref's own build, for a query-by-query
-	// comparison of id lists with the compiled reference.  One kernel set only: beam form, 4 set registers, one wave per query.
+	// Reference-order arithmetic (device_dist.h, F_L2_REF / F_MANHATTAN_REF / F_COSINE_REF; opt-in, HNSW_GPU_REF_ORDER=1): the summation order of
+	// oracle/_ref's own build, so that the id lists ARE the compiled reference's, query by query.  One kernel set only: beam form, 4 set
+	// registers, one wave per query; since round 6 with the canonical code's load shape (a timed mode of bench.py).
 	int func_code = (int) ix->meta.dist_func;
 	bool reforder = false;
 	if (knob(K_REF_ORDER, 0) > 0)
@@ -107,6 +108,8 @@ int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries, size_
 	const bool narrow5 = shape_index(a.kiters) == 0 && (rreg == -2 || rreg == -4) && (int) ix->meta.dist_func != F_COSINE &&
 						 !team_wanted && !reforder && knob(K_NARROW5, 1) != 0;
 	size_t off = (size_t) a.qpad_floats * 4;
+	// reference-order arithmetic: the per-wave stage of its transposed accumulation sits right behind the query image (device_dist.h, score_rows_ref)
+	if (reforder) off += (size_t) 8 * (func_code == F_COSINE_REF ? 2 : 1) * REF_STAGE_ROW * 4;
 	if (rreg == 3)
 	{
 		// wide-beam form: both sets in the slot's HBM area [res: P | cand: 2P], P = the power of two >= ef (the output sort is a

@@ -160,7 +160,10 @@ def reforder():
     if not oracle.have_ref():
         return {"skipped": "no oracle/_ref here"}
     out = []
-    for func, dim, n in ((pg.DIST_L2, 128, 2500), (pg.DIST_L2, 48, 1500), (pg.DIST_MANHATTAN, 36, 1500), (pg.DIST_COSINE, 44, 1500)):
+    # (round 6: the production load shape + transposed accumulation — partial slices (48, 36, 44 dims), whole slices (128), a whole load
+    # batch of the widest shape (768) and two of them (1536), every function in a narrow and in a wide shape)
+    for func, dim, n in ((pg.DIST_L2, 128, 2500), (pg.DIST_L2, 48, 1500), (pg.DIST_MANHATTAN, 36, 1500), (pg.DIST_COSINE, 44, 1500),
+                         (pg.DIST_COSINE, 768, 500), (pg.DIST_L2, 1536, 400), (pg.DIST_MANHATTAN, 300, 600), (pg.DIST_L2, 272, 600)):
         X = gmm(n, dim, k=20, seed=dim)
         Q = gmm(24, dim, k=20, seed=dim + 1)
         ref = oracle.RefIndex(dim, 8, 32, 64, func, capacity=n)

@@ -810,3 +810,29 @@ def test_reference_order_mode_returns_the_compiled_references_id_lists(func, dim
         for q in range(0, nq, 97):
             assert (bits(dst[q, :cnt[q]]) == bits(oracle.ref_dist_many(func, Q[q], X[lab[q, :cnt[q]].astype(np.int64)]))).all()
     ix.close()
+
+
+def test_a_launch_reports_the_clock_it_ran_at_and_the_mirror_sits_in_one_aligned_block():
+    """include/hnsw_gpu_diag.h (round 6, profiles/r5af_*: a launch state that depended on the process's history): the launch's first
+    wave stamps the shader clock and the constant clock when it starts and when it leaves — narrow rows (one wave per query, the
+    issue-bound kernel whose time scales with that clock) and wide rows (team form) — and rows | links | labels are three 2 MiB-aligned
+    pieces of ONE allocation, before and after the mirror grows; results are unchanged by a reserve."""
+    for dim, m, n, nq in ((128, 8, 6000, 4000), (768, 16, 3000, 600)):
+        port, X = build_port(n, dim, m, 48, pg.DIST_L2, seed=dim)
+        Q = gmm(nq, dim, k=50, seed=dim, stream=1)
+        ix = mirror(port, pg.DIST_L2)
+        labels, dists, counts = assert_same_as_oracle(ix, port, Q[:64], 64)
+        ix.search(Q, 64)
+        mhz = ix.last_search_clock_mhz()
+        assert 300.0 < mhz < 3500.0, (dim, mhz, ix.last_search_kernel())
+        p0 = ix.placement()
+        ix.reserve(3 * n)
+        p1 = ix.placement()
+        for p in (p0, p1):
+            assert p["aligned_2MiB"], p
+            lo, size = p["arena"]
+            assert all(lo <= p[k][0] and p[k][0] + p[k][1] <= lo + size for k in ("rows", "links", "labels")), p
+        assert p1["rows"][1] == 3 * p0["rows"][1]
+        l2, d2, c2 = ix.search(Q[:64], 64)
+        assert (l2 == labels).all() and (bits(d2) == bits(dists)).all() and (c2 == counts).all()
+        ix.close()
