@@ -152,16 +152,56 @@ def init_ranks(args):
 
 def selftest_main(args):
     """CPU check of the launch path (tests/test_bench_launch.py): ranks rendezvous over gloo, agree on the
-    world size through a collective, rank 0 prints one line.  No device work."""
+    world size through a collective, rank 0 prints one line.  No device work.  --mode sharded also runs the row-sharded
+    layout's exchange step for real — pg_embedding_amd.sharded.ShardedIndex with a synthetic per-rank search and a torch merge
+    injected: the packed block, the ONE all-gather per search, the persistent buffers, the per-rank step breakdown the device
+    run reports — so that the first N>1 run on hardware is not the first run of that code."""
     import torch
     import torch.distributed as dist
     world, rank, local, use_dist, backend = init_ranks(args)
     t = torch.ones(1)
     if use_dist:
         dist.all_reduce(t)
+    line = {"selftest": True, "n_gpus": world, "ranks_joined": int(t.item()), "backend": backend,
+            "mode": args.mode, "self_launched": os.environ.get("PGEMB_BENCH_SELF_LAUNCHED") == "1"}
+    if args.mode == "sharded":
+        from pg_embedding_amd.sharded import ShardedIndex, block_bytes
+        nq, ef, steps = 64, 16, max(1, args.steps)
+
+        def shard_lists(r, step):                               # rank r's result lists: ascending (dist, label), labels unique across ranks
+            g = torch.Generator().manual_seed(1000 * step + r)
+            d, _ = torch.sort(torch.rand((nq, ef), generator=g), dim=1)
+            lab = torch.arange(nq * ef, dtype=torch.int64).reshape(nq, ef) * world + r
+            return lab, d.to(torch.float32)
+
+        def merge(lab, dst, k):                                 # [world, nq, ef] -> the k best by (dist, label)
+            L = lab.permute(1, 0, 2).reshape(nq, -1)
+            D = dst.permute(1, 0, 2).reshape(nq, -1)
+            order = torch.argsort(D * 1.0, dim=1, stable=True)
+            return torch.gather(L, 1, order)[:, :k], torch.gather(D, 1, order)[:, :k], torch.full((nq,), k, dtype=torch.int32)
+
+        step_no = [0]
+        sh = ShardedIndex(local_search=lambda q, k: shard_lists(rank, step_no[0]), merge=merge)
+        sh.record_timing = True
+        ok = True
+        for s_ in range(steps):
+            step_no[0] = s_
+            lab, dst, cnt = sh.search(torch.zeros((nq, 4)), ef)
+            every = [shard_lists(r, s_) for r in range(world)]
+            wl, wd, _ = merge(torch.stack([e[0] for e in every]), torch.stack([e[1] for e in every]), ef)
+            ok = ok and bool((lab == wl).all()) and bool((dst == wd).all())
+        mine = torch.tensor([[float(sum(x[k] for x in sh.timings_ms()) / steps) for k in range(3)] + [1.0 if ok else 0.0]], dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        if use_dist:
+            dist.all_gather(every, mine)
+        else:
+            every = [mine]
+        line.update({"exchange": {"collectives_per_step": sh.exchanges / steps, "bytes_per_rank": block_bytes(nq, ef)},
+                     "buffers_allocated": len(sh._bufs),
+                     "merged_equals_the_global_order_on_every_rank": all(float(e[0][3]) == 1.0 for e in every),
+                     "step_breakdown_ms_per_rank": [{"local_search_ms": float(e[0][0]), "exchange_ms": float(e[0][1]), "merge_ms": float(e[0][2])} for e in every]})
     if rank == 0:
-        print(json.dumps({"selftest": True, "n_gpus": world, "ranks_joined": int(t.item()), "backend": backend,
-                          "mode": args.mode, "self_launched": os.environ.get("PGEMB_BENCH_SELF_LAUNCHED") == "1"}))
+        print(json.dumps(line))
     if use_dist:
         dist.destroy_process_group()
 
@@ -720,7 +760,7 @@ def multi_gpu_extras(args, result, world, rank, local, dev):
             "host": "pg_embedding_amd/sharded.py: one process per GPU, one packed all-gather over RCCL + merge kernel",
             "rows_per_shard": rows_per, "queries_per_step": 1024, "steps": 5, "queries_per_s": 1024 * 5 / float(el.item()),
             "ms_per_step": float(el.item()) / 5 * 1e3, "exchange_bytes_per_rank": block_bytes(1024, args.ef),
-            "step_breakdown_ms_per_rank": [{"local_search_ms": float(t[0][0]), "pack_and_exchange_ms": float(t[0][1]), "merge_ms": float(t[0][2])} for t in every],
+            "step_breakdown_ms_per_rank": [{"local_search_ms": float(t[0][0]), "exchange_ms": float(t[0][1]), "merge_ms": float(t[0][2])} for t in every],
             "merged_results_sorted_and_full": bool((counts == args.ef).all().item()) and bool((dists[:, 1:] >= dists[:, :-1]).all().item())}
         sh.index.close()
     except Exception as e:                                   # (a rank that fails here leaves the others in a collective: the timer ends them)
@@ -1352,20 +1392,30 @@ def main_sharded(args):
     truth, _, _ = tsh.search(Q[:nrec].contiguous(), 10)
     del rows
 
+    # this rank's share of the algorithmic bytes (its own E_q / H_q on its own shard) for its roofline fraction
+    st_out = sh.index.search_torch(Q, args.ef, stats=True)
+    torch.cuda.synchronize()
+    st = st_out["stats"].cpu().numpy().astype(np.int64)
+    my_bytes = float(alg_bytes(st, st_out["counts"].cpu().numpy().astype(np.int64), args.dim, args.m).sum())
+    del st_out
+    merged = (torch.empty((nq, args.ef), dtype=torch.int64, device=dev), torch.empty((nq, args.ef), dtype=torch.float32, device=dev),
+              torch.empty(nq, dtype=torch.int32, device=dev))            # the merge's outputs, allocated once
     for _ in range(args.warmup):
-        sh.search(Q, args.ef)
+        sh.search(Q, args.ef, out=merged)
     barrier()
     sh.record_timing = True
     ex0 = sh.exchanges
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        labels, dists, counts = sh.search(Q, args.ef)
+        labels, dists, counts = sh.search(Q, args.ef, out=merged)
     barrier()
     elapsed = time.perf_counter() - t0
     exchanges = sh.exchanges - ex0
     local_ms = sh.index.last_search_ms()
     steps_ms = sh.timings_ms()                       # per step on THIS rank: local search / pack + all-gather / merge
-    mine = torch.tensor([[float(np.mean([t[k] for t in steps_ms])) for k in range(3)]], dtype=torch.float64, device=dev)
+    kern_ms = float(np.mean([sh.index.last_search_ms(back) for back in range(min(args.steps, 64))]))     # the search kernel alone, its own HIP events
+    mine = torch.tensor([[float(np.mean([t[k] for t in steps_ms])) for k in range(3)] + [kern_ms, my_bytes, float(st[:, 0].mean()), float(st[:, 1].mean())]],
+                        dtype=torch.float64, device=dev)
     every = [torch.zeros_like(mine) for _ in range(world)]
     if use_dist:
         dist.all_gather(every, mine)
@@ -1393,8 +1443,15 @@ def main_sharded(args):
             "exchange": {"collectives_per_step": exchanges / max(args.steps, 1), "bytes_per_rank": block_bytes(nq, args.ef)},
             "local_search_kernel_ms": local_ms,
             # mean over the timed steps, device events on each rank's search stream: where a step's time goes, rank by rank
-            "step_breakdown_ms_per_rank": [{"local_search_ms": r[0], "pack_and_exchange_ms": r[1], "merge_ms": r[2]} for r in per_rank_steps],
-            "step_breakdown_ms_rank0_per_step": [{"local_search_ms": a, "pack_and_exchange_ms": b, "merge_ms": c} for a, b, c in steps_ms],
+            # (round 6: the local search writes straight into the rank's packed block — "exchange" is the all-gather alone, no pack kernels)
+            "step_breakdown_ms_per_rank": [{"local_search_ms": r[0], "exchange_ms": r[1], "merge_ms": r[2], "search_kernel_ms": r[3],
+                                            "alg_bytes_per_launch": r[4], "evals_per_query": r[5], "hops_per_query": r[6],
+                                            "roofline_frac": r[4] / (r[3] * 1e-3) / 1e9 / HBM_PEAK_GBS} for r in per_rank_steps],
+            "step_breakdown_ms_rank0_per_step": [{"local_search_ms": a, "exchange_ms": b, "merge_ms": c} for a, b, c in steps_ms],
+            "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS,
+                         "achieved_sum_over_ranks": sum(r[4] / (r[3] * 1e-3) / 1e9 for r in per_rank_steps),
+                         "frac_mean_over_ranks": float(np.mean([r[4] / (r[3] * 1e-3) / 1e9 / HBM_PEAK_GBS for r in per_rank_steps])),
+                         "note": "every rank's own algorithmic bytes (its E_q / H_q on its shard) over its own search kernel's HIP-event time"},
             "recall_at_10": rec,
             "build_seconds": t_build, "merged_results_sorted_and_full": ok}))
     if use_dist:

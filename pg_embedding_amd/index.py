@@ -631,19 +631,22 @@ class LocalShardedIndex:
                 "direct_peer_stores": [bool(x) for x in dr], "devices": [int(sh.device) for sh in self.shards]}
 
 
-def merge_packed_torch(blocks, nq: int, ef: int):
+def merge_packed_torch(blocks, nq: int, ef: int, out=None):
     """Merge the gathered per-rank blocks of ShardedIndex ([world, block_bytes] uint8, block =
     [labels nq*ef*8 | dists nq*ef*4 | pad]) in place: the strided merge entry reads every list where the
-    all-gather put it."""
+    all-gather put it.  out: (labels[nq, ef] int64, dists[nq, ef] float32, counts[nq] int32) to write into (allocated otherwise)."""
     torch = _torch()
     L = gpu_lib()
     assert blocks.is_cuda and blocks.dtype == torch.uint8 and blocks.is_contiguous()
     world, block = blocks.shape
     assert block % 8 == 0 and block >= nq * ef * 12
     dev = blocks.device
-    ol = torch.empty((nq, ef), dtype=torch.int64, device=dev)
-    od = torch.empty((nq, ef), dtype=torch.float32, device=dev)
-    oc = torch.empty(nq, dtype=torch.int32, device=dev)
+    if out is not None:
+        ol, od, oc = out
+    else:
+        ol = torch.empty((nq, ef), dtype=torch.int64, device=dev)
+        od = torch.empty((nq, ef), dtype=torch.float32, device=dev)
+        oc = torch.empty(nq, dtype=torch.int32, device=dev)
     s = torch.cuda.current_stream(dev).cuda_stream
     base = blocks.data_ptr()
     check(L.hnsw_gpu_merge_topk_strided_dev(dev.index or 0, base, block // 8, base + nq * ef * 8, block // 4, world, nq, ef,

@@ -8,8 +8,11 @@
   (dist, label) lists over RCCL (``torch.distributed`` backend "nccl") followed by the device
   merge kernel.  Labels carry the global row number, so they are unique across shards.  The exchange is
   latency-bound (nq*ef*12 bytes per rank), hence ONE all-gather of one packed block per rank
-  ([labels | dists], :func:`pack_block`) and no chunking; the device merge
-  (``hnsw_gpu_merge_topk_strided_dev``) reads the lists where the all-gather put them.
+  ([labels | dists]) and no chunking; the device merge (``hnsw_gpu_merge_topk_strided_dev``) reads the lists where the
+  all-gather put them.  Nothing in the step allocates or packs: the local search writes labels and distances STRAIGHT into
+  this rank's packed block; the block and the gather buffer are allocated once per (batch size, beam) and reused, the merge
+  writes into the caller's tensors when given (``search(..., out=)``).  (Rounds 1-5 packed through three extra kernels and two
+  allocations per search — :func:`pack_block`, kept for callers that bring their own result tensors.)
 
 The same layout inside one process (several devices, no torch.distributed) is native:
 ``hnsw_gpu_sharded_*`` in include/hnsw_gpu.h / :class:`pg_embedding_amd.LocalShardedIndex`.
@@ -78,15 +81,17 @@ class ShardedIndex:
             if index is None:
                 raise ValueError("need a GpuIndex or a local_search callable")
 
-            def local_search(q, ef):
-                out = index.search_torch(q, ef)
-                return out["labels"], out["dists"]
+            def local_search(q, ef, out=None):
+                res = index.search_torch(q, ef, out=out)
+                return res["labels"], res["dists"]
+            local_search.writes_in_place = True          # (takes `out`: labels / dists / counts tensors to write into)
         self.merge_packed = None
         if merge is None:
             from .index import merge_packed_torch
             self.merge_packed = merge_packed_torch
         self.local_search = local_search
         self.merge = merge
+        self._bufs = {}                        # (nq, ef, device) -> this rank's packed block (+ views into it) and the gather buffer
         self.exchanges = 0                     # collectives issued so far (one per search)
         self.record_timing = False             # bench.py --mode sharded: stamp the three steps of every search
         self._stamps = []                      # per search: 4 device events (or 4 host times for CPU tensors)
@@ -103,8 +108,9 @@ class ShardedIndex:
         ix.link(0, n, max_batch, ratio, torch.cuda.current_stream(rows.device).cuda_stream)
         return cls(index=ix)
 
-    def search(self, queries, ef: int):
-        """Every rank passes the SAME queries; every rank returns the merged result."""
+    def search(self, queries, ef: int, out=None):
+        """Every rank passes the SAME queries; every rank returns the merged result (labels[nq, ef], dists[nq, ef], counts[nq]).
+        out: those three tensors to write into (a caller that searches in a loop allocates them once); allocated per call otherwise."""
         import torch
 
         def stamp():
@@ -118,14 +124,21 @@ class ShardedIndex:
             return time.perf_counter()
 
         t0 = stamp()
-        labels, dists = self.local_search(queries, ef)
+        nq = queries.shape[0]
+        b = self._buffers(nq, ef, queries.device)
+        if getattr(self.local_search, "writes_in_place", False):
+            # labels | dists land in this rank's packed block as the search kernel writes them: no pack step at all
+            self.local_search(queries, ef, out={"labels": b["labels"], "dists": b["dists"], "counts": b["counts"]})
+        else:                                   # an injected search (the CPU tests) returns its own tensors: one copy each
+            labels, dists = self.local_search(queries, ef)
+            b["labels"].copy_(labels)
+            b["dists"].copy_(dists)
         t1 = stamp()
-        nq = labels.shape[0]
-        mine = pack_block(labels, dists)
+        mine = b["mine"]
         if self.world == 1:
             blocks = mine.unsqueeze(0)
         else:
-            flat = torch.empty(self.world * mine.numel(), dtype=torch.uint8, device=mine.device)
+            flat = b["flat"]
             blocks = flat.view(self.world, mine.numel())
             # THE exchange step: one all-gather.  (gloo with device tensors — the 2-process test on a
             # 1-GPU box — only has the list form; over RCCL and for CPU tensors the flat form is used.)
@@ -136,7 +149,7 @@ class ShardedIndex:
             self.exchanges += 1
         t2 = stamp()
         if self.merge_packed is not None:
-            res = self.merge_packed(blocks, nq, ef)
+            res = self.merge_packed(blocks, nq, ef, out=out)
         else:
             lab, dst = unpack_blocks(blocks, nq, ef)
             res = self.merge(lab, dst, ef)
@@ -144,8 +157,24 @@ class ShardedIndex:
             self._stamps.append((t0, t1, t2, stamp()))
         return res
 
+    def _buffers(self, nq: int, ef: int, device):
+        """the exchange step's memory for one (batch size, beam): allocated at the first search of that shape, reused ever after"""
+        import torch
+        key = (nq, ef, str(device))
+        b = self._bufs.get(key)
+        if b is None:
+            nb = block_bytes(nq, ef)
+            mine = torch.zeros(nb, dtype=torch.uint8, device=device)
+            b = {"mine": mine,
+                 "labels": mine[:nq * ef * 8].view(torch.int64).reshape(nq, ef),
+                 "dists": mine[nq * ef * 8:nq * ef * 12].view(torch.float32).reshape(nq, ef),
+                 "counts": torch.empty(nq, dtype=torch.int32, device=device),
+                 "flat": torch.empty(self.world * nb, dtype=torch.uint8, device=device) if self.world > 1 else None}
+            self._bufs[key] = b
+        return b
+
     def timings_ms(self):
-        """[(local_search_ms, pack_and_exchange_ms, merge_ms)] of the searches since record_timing was switched on (device
+        """[(local_search_ms, exchange_ms, merge_ms)] of the searches since record_timing was switched on (device
         events on the search stream; call after a synchronize)."""
         out = []
         for t0, t1, t2, t3 in self._stamps:

@@ -30,11 +30,18 @@ def _env():
 
 @pytest.mark.parametrize("mode", ["replicas", "sharded"])
 def test_plain_invocation_launches_the_ranks_itself(mode):
-    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "1", "--warmup", "0", "--mode", mode],
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "0", "--mode", mode],
                        env=_env(), capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     j = _line(r.stdout)
     assert j["n_gpus"] == 2 and j["ranks_joined"] == 2 and j["self_launched"] is True and j["mode"] == mode
+    if mode == "sharded":
+        # the row-sharded layout's exchange step ran for real over gloo (pg_embedding_amd.sharded.ShardedIndex): ONE collective per
+        # search, one set of buffers for all searches, the merged result is the global (dist, label) order on both ranks, and the
+        # line carries the per-rank step breakdown the device run reports
+        assert j["exchange"]["collectives_per_step"] == 1 and j["buffers_allocated"] == 1
+        assert j["merged_equals_the_global_order_on_every_rank"] is True
+        assert len(j["step_breakdown_ms_per_rank"]) == 2 and all(set(r) == {"local_search_ms", "exchange_ms", "merge_ms"} for r in j["step_breakdown_ms_per_rank"])
 
 
 def test_driver_style_launch_is_joined_not_relaunched():
