@@ -136,19 +136,20 @@ constexpr uint32_t ABORTED_COUNT = 0xFFFFFFFFu;     // out_counts[i] of a query 
 enum : uint32_t { HEALTH_SLICE_TIMEOUTS = 1, HEALTH_PACKAGE_TIMEOUTS = 2, HEALTH_ABORTED_WAVES = 3, HEALTH_SLICES_DELIVERED = 4, HEALTH_CLOCK = 8, HEALTH_WORDS = 16 };
 
 // the launch's first wave stamps both clocks into the health words: `which` = 0 at its start, 1 when it leaves
-__device__ __forceinline__ void clock_stamp(const SearchArgs &a, uint32_t slot, int lane, int which)
+__device__ __forceinline__ void clock_stamp(uint32_t *health, uint32_t slot, int lane, int which)
 {
-	if (slot != 0 || lane != 0 || !a.health) return;
-	uint64_t *c = reinterpret_cast<uint64_t *>(a.health + HEALTH_CLOCK) + 2 * which;
+	if (slot != 0 || lane != 0 || !health) return;
+	uint64_t *c = reinterpret_cast<uint64_t *>(health + HEALTH_CLOCK) + 2 * which;
 	c[0] = __builtin_amdgcn_s_memtime();
 	c[1] = __builtin_amdgcn_s_memrealtime();
 }
 
-__device__ __forceinline__ bool abort_requested(const SearchArgs &a)
+__device__ __forceinline__ bool abort_word_set(const uint32_t *abort_word)
 {
-	if (!a.abort_word) return false;
-	return __builtin_amdgcn_readfirstlane(__hip_atomic_load(a.abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0u;
+	if (!abort_word) return false;
+	return __builtin_amdgcn_readfirstlane(__hip_atomic_load(abort_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) != 0u;
 }
+__device__ __forceinline__ bool abort_requested(const SearchArgs &a) { return abort_word_set(a.abort_word); }
 
 // Streamed completion: everything this wave wrote for the query becomes visible system-wide, then
 // the flag.  Once per query, outside the hop loop.
@@ -1630,6 +1631,22 @@ __device__ __forceinline__ void team_help(const SearchArgs &a, unsigned char *sm
 	}
 }
 
+// Cold arguments.  SearchArgs is 88 dwords passed by value; hipcc loads every field a kernel names into scalar registers at its entry and
+// keeps them there — the team form held 308-318 spilled SGPRs in round 5 (profiles/r5_hop_budget.md), and about half of the lane exchanges in
+// its pop and package look-up sections were reloads of spilled arguments.  Most fields are needed once per QUERY (outputs, the query, the
+// ticket) or in the emit step only; those are now read where they are used, with scalar loads from the kernel-argument segment itself (it IS
+// memory, and stays valid for the life of the launch), as volatile reads so that the loads are not hoisted back to the entry.  Only what the hop loop reads is named through `a` (and so stays in registers).
+#ifdef PGEMB_SIMT_EMULATOR
+typedef const SearchArgs *ColdArgs;
+__device__ __forceinline__ ColdArgs cold_args(const SearchArgs &a) { return &a; }
+#else
+typedef const volatile __attribute__((address_space(4))) SearchArgs *ColdArgs;      // (volatile: a read stays where it is written — no hoisting, no merging)
+__device__ __forceinline__ ColdArgs cold_args(const SearchArgs &)
+{
+	return (ColdArgs) __builtin_amdgcn_kernarg_segment_ptr();      // (the kernel's only parameter: offset 0)
+}
+#endif
+
 template <int FUNC, typename SH, int UREG, bool TEAM = false, bool LEAN = false>
 __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MIN_WAVES) void hnsw_search_kernel_beam(const SearchArgs a)
 {
@@ -1640,16 +1657,14 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 	unsigned char *my = smem + (size_t) wib * a.wave_bytes;
 	float        *qf      = reinterpret_cast<float *>(my);
 	const float4 *q4      = reinterpret_cast<const float4 *>(my);
-	uint64_t     *srt_key = reinterpret_cast<uint64_t *>(my + a.off_res);     // emit scratch (overlays the hash set)
-	uint64_t     *srt_lab = reinterpret_cast<uint64_t *>(my + a.off_cand);
 	uint32_t     *htab    = reinterpret_cast<uint32_t *>(my + a.off_hash);
 	const uint32_t hmask  = a.hcap - 1;
 	uint32_t     *newid   = reinterpret_cast<uint32_t *>(my + a.off_newid);
 	float        *newdist = reinterpret_cast<float *>(my + a.off_newdist);
 
 	const uint32_t slot = blockIdx.x * (blockDim.x >> 6) + wib;
-	clock_stamp(a, slot, lane, 0);
-	uint32_t *vis  = a.vis + (size_t) slot * a.vis_words;
+	clock_stamp(cold_args(a)->health, slot, lane, 0);
+	uint32_t *vis  = a.vis + (size_t) slot * cold_args(a)->vis_words;
 	uint32_t *vlog = a.vlog + (size_t) slot * a.logcap;
 	uint64_t *scratch = a.beam_scratch + (size_t) slot * UCAP;
 	const uint32_t ef = a.ef;
@@ -1671,17 +1686,21 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 	//     helpers of a block have walking siblings for as long as the stream lives, so the helper protocol runs unchanged);
 	//   * stop: every wave leaves at its next look — a walking wave after its current query (the host stops a stream when nothing
 	//     is outstanding, or gives the stragglers up).  The abort word works as in every launch and also ends the wave.
-	const bool stream = TEAM && a.stream_host != nullptr;
+	const bool stream = TEAM && cold_args(a)->stream_host != nullptr;
+	// which optional outputs this launch writes (bit 0 pop sequence, 1 evaluation trace, 2 clock stamps): one word the walk can test
+	const uint32_t opt_out = LEAN ? 0u : ((cold_args(a)->out_pops ? 1u : 0u) | (cold_args(a)->out_evals ? 2u : 0u) | (cold_args(a)->out_times ? 4u : 0u));
 	if (stream && blockIdx.x == 0)
 	{
 		if (wib != 0) return;
+		const uint32_t *stream_host = cold_args(a)->stream_host;
+		uint32_t *stream_dev = cold_args(a)->stream_dev;
 		for (;;)
 		{
-			const uint32_t pub = __hip_atomic_load(a.stream_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			const uint32_t stop = __hip_atomic_load(a.stream_host + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			const uint32_t pub = __hip_atomic_load(stream_host, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			const uint32_t stop = __hip_atomic_load(stream_host + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");              // what the host wrote before it published is visible to loads issued from here on
 			{
-				uint32_t *copy = a.stream_dev + (uint32_t) lane * STREAM_COPY_WORDS;       // (64 lanes = STREAM_COPIES copies)
+				uint32_t *copy = stream_dev + (uint32_t) lane * STREAM_COPY_WORDS;       // (64 lanes = STREAM_COPIES copies)
 				__hip_atomic_store(copy, pub, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 				if (stop) __hip_atomic_store(copy + 1, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 			}
@@ -1697,14 +1716,15 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 
 	for (;;)
 	{
-		if (TEAM && wib >= a.team_mains) break;                       // this wave only ever helps
+		ColdArgs c = cold_args(a);                                    // this query's cold arguments: loaded here, dead before the walk
+		if (TEAM && wib >= c->team_mains) break;                      // this wave only ever helps
 		uint32_t qi = 0;
-		if (lane == 0) qi = atomicAdd(a.ticket, 1u);
+		if (lane == 0) qi = atomicAdd(c->ticket, 1u);
 		qi = __builtin_amdgcn_readfirstlane(qi);
 		if (stream)
 		{
 			bool leave = false;
-			const uint32_t *ctlw = a.stream_dev + ((blockIdx.x * wpb + wib) % STREAM_COPIES) * STREAM_COPY_WORDS;
+			const uint32_t *ctlw = c->stream_dev + ((blockIdx.x * wpb + wib) % STREAM_COPIES) * STREAM_COPY_WORDS;
 			for (uint32_t nap = 8;;)                                      // wait until the host has published query qi (or says stop)
 			{
 				uint32_t pub = 0, stop = 0;
@@ -1723,37 +1743,38 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				nap = nap < 512 ? nap * 4 : 512;
 			}
 			if (__builtin_amdgcn_readfirstlane((int) leave)) break;
-			qi &= a.stream_ring - 1u;                                     // from here on qi is the slot: query, outputs and flag of this ticket
+			qi &= c->stream_ring - 1u;                                    // from here on qi is the slot: query, outputs and flag of this ticket
 		}
-		else if (qi >= a.nq) break;
+		else if (qi >= c->nq) break;
 		// (an abort request is sticky for this wave: it takes the remaining tickets without walking and marks every query it does not
 		// answer with count 0xFFFFFFFF, so that the caller of an interrupted launch can tell which rows of its outputs are results)
-		if (!aborted && abort_requested(a)) aborted = true;
+		if (!aborted && abort_word_set(c->abort_word)) aborted = true;
 		if (__builtin_amdgcn_readfirstlane((int) aborted))
 		{
-			if (lane == 0) a.out_counts[qi] = ABORTED_COUNT;
+			if (lane == 0) c->out_counts[qi] = ABORTED_COUNT;
 			if (stream) break;                                            // (a stream has no last ticket to run to)
 			continue;
 		}
-		if (!LEAN && a.out_times && lane == 0) a.out_times[2 * (size_t) qi] = __builtin_amdgcn_s_memrealtime();
+		if (!LEAN && (opt_out & 4u) && lane == 0) c->out_times[2 * (size_t) qi] = __builtin_amdgcn_s_memrealtime();
 
-		const float *qsrc = a.queries + (size_t) qi * a.q_stride;
+		const float *qsrc = c->queries + (size_t) qi * c->q_stride;
+		const uint32_t qdim = c->dim, qpad = c->qpad_floats;
 		if (stream)
 		{
 			// the ring lives in pinned host memory and this slot held another query a ring ago: system-scope loads, so that no cache of
 			// the device can answer with the old one
 			const uint32_t *qw = reinterpret_cast<const uint32_t *>(qsrc);
-			for (uint32_t e = lane; e < a.qpad_floats; e += 64)
+			for (uint32_t e = lane; e < qpad; e += 64)
 			{
-				const uint32_t t = __hip_atomic_load(qw + (e < a.dim ? e : a.dim - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-				qf[e] = (e < a.dim) ? __uint_as_float(t) : 0.f;
+				const uint32_t t = __hip_atomic_load(qw + (e < qdim ? e : qdim - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				qf[e] = (e < qdim) ? __uint_as_float(t) : 0.f;
 			}
 		}
 		else
-			for (uint32_t e = lane; e < a.qpad_floats; e += 64)
+			for (uint32_t e = lane; e < qpad; e += 64)
 			{
-				const float t = qsrc[e < a.dim ? e : a.dim - 1];
-				qf[e] = (e < a.dim) ? t : 0.f;
+				const float t = qsrc[e < qdim ? e : qdim - 1];
+				qf[e] = (e < qdim) ? t : 0.f;
 			}
 		wave_sync();
 		float qnorm = 0.f;
@@ -1780,7 +1801,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 
 		if (a.n > 0)
 		{
-			const uint32_t ep = a.entry;                                   // hnswalg.cpp:55-65
+			const uint32_t ep = c->entry;                                  // hnswalg.cpp:55-65
 			{
 				auto one = [ep](uint32_t) { return ep; };
 				score_rows<FUNC, SH::KB, 1>(a.vec, a.stride, q4, a.nchunks, a.kiters, one, 1u, newdist, lane);
@@ -1788,7 +1809,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 			wave_sync();
 			const float d0 = finish_dist<FUNC>(newdist[0], newdist[OUT2], qnorm);
 			evals = 1;
-			if (!LEAN && a.out_evals && a.evals_cap && lane == 0) a.out_evals[(size_t) qi * a.evals_cap] = ep;
+			if (!LEAN && (opt_out & 2u) && c->evals_cap && lane == 0) c->out_evals[(size_t) qi * c->evals_cap] = ep;
 			beam_set<UREG>(uk, 0, ((uint64_t) ord_f32(d0) << 32) | ep, lane);
 			usize = 1;
 			if (lane == 0)
@@ -1818,14 +1839,20 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				if (HOP_STAMPS && a.team_dbg) hs0 = hop_stamp();
 				if (!beam_next<UREG>(uk, ex, cslot, ckey)) break;          // candidateSet empty
 				uint32_t cd = (uint32_t) (ckey >> 32);
-				asm volatile("" : "+s"(cd));     // an opaque 32-bit scalar: hipcc otherwise compares (key >> 32) with (ckey >> 32) as 64-bit pairs
+				cd = (uint32_t) __builtin_amdgcn_readfirstlane((int) cd);     // a 32-bit scalar of its own: hipcc otherwise compares (key >> 32) with (ckey >> 32) as 64-bit pairs
 				if (beam_count_lt<UREG>(uk, cd) >= ef) break;              // :70-71  best candidate > lowerBound
 				const uint32_t cur = ~(uint32_t) ckey;
 				ex |= ((uint32_t) lane == (cslot & 63)) ? (1u << (cslot >> 6)) : 0u;   // :73 pop
-				if (!LEAN && a.out_pops && hops < a.pops_cap && lane == 0)       // (system scope: a host that polls the sequence sees it as the walk goes)
-					__hip_atomic_store(a.out_pops + (size_t) qi * a.pops_cap + hops, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				if (!LEAN && (opt_out & 1u))                                // (system scope: a host that polls the sequence sees it as the walk goes)
+				{
+					ColdArgs cw = cold_args(a);
+					const uint32_t pcap = cw->pops_cap;
+					uint32_t *pout = cw->out_pops;
+					if (hops < pcap && lane == 0)
+						__hip_atomic_store(pout + (size_t) qi * pcap + hops, cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+				}
 				hops++;
-				if (!LEAN && (hops & 255u) == 0u && abort_requested(a)) { aborted = true; break; }
+				if (!LEAN && (hops & 255u) == 0u && abort_word_set(cold_args(a)->abort_word)) { aborted = true; break; }
 				if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_pop += hs1 - hs0; hs0 = hs1; }
 				TeamView h0v = {};
 				if (TEAM && (TEAM_COUNT && a.team_dbg) && lane == 0) { atomicAdd(a.team_dbg + 5, 1u); if (hm) atomicAdd(a.team_dbg + 0, 1u); }
@@ -1859,7 +1886,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 							u = uniform_u64(*pkh);
 						}
 						have_pk = u == ((uint64_t) cur | ((uint64_t) LC_DONE << 32));
-						if (spins == 4000 && a.health && lane == 0) atomicAdd(a.health + HEALTH_PACKAGE_TIMEOUTS, 1u);
+						if (spins == 4000) { uint32_t *hw = cold_args(a)->health; if (hw && lane == 0) atomicAdd(hw + HEALTH_PACKAGE_TIMEOUTS, 1u); }
 						if ((TEAM_COUNT && a.team_dbg) && spins && lane == 0) { atomicAdd(a.team_dbg + 6, spins); atomicAdd(a.team_dbg + 10, 1u); }
 					}
 				}
@@ -1919,10 +1946,13 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 						continue;
 					}
 					const uint32_t rank = lane_rank(mask);
+					uint32_t *ev_out = nullptr;                             // (cold arguments are read in uniform control flow only)
+					uint32_t ev_cap = 0;
+					if (!LEAN && (opt_out & 2u)) { ColdArgs cw = cold_args(a); ev_out = cw->out_evals; ev_cap = cw->evals_cap; }
 					if (isnew)
 					{
 						newid[rank] = t;
-						if (!LEAN && a.out_evals && evals + rank < a.evals_cap) a.out_evals[(size_t) qi * a.evals_cap + evals + rank] = t;   // (measurement: the rows this walk scores, in order)
+						if (!LEAN && ev_out && evals + rank < ev_cap) ev_out[(size_t) qi * ev_cap + evals + rank] = t;   // (measurement: the rows this walk scores, in order)
 						if (TEAM && hm) reinterpret_cast<uint32_t *>(newdist)[rank] = od_pk;      // packaged distance, link order kept
 					}
 					wave_sync();
@@ -2013,12 +2043,12 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 								}
 								else                                            // not delivered: the slice is mine (and whatever that helper writes later goes to its own area)
 								{
-									if (a.health && lane == 0) atomicAdd(a.health + HEALTH_SLICE_TIMEOUTS, 1u);
+									{ uint32_t *hw = cold_args(a)->health; if (hw && lane == 0) atomicAdd(hw + HEALTH_SLICE_TIMEOUTS, 1u); }
 									auto part = [ids, lo](uint32_t r) { return ids[lo + r]; };
 									score_rows_fit<FUNC, SH::KB, SH::RPG>(a.vec, a.stride, q4, a.nchunks, a.kiters, part, cnt, newdist + lo, lane);
 								}
 							}
-							if (a.health && ngot && lane == 0) atomicAdd(a.health + HEALTH_SLICES_DELIVERED, ngot);
+							if (ngot) { uint32_t *hw = cold_args(a)->health; if (hw && lane == 0) atomicAdd(hw + HEALTH_SLICES_DELIVERED, ngot); }
 						}
 						wave_sync();
 						const uint32_t od_m = ord_f32(finish_dist<FUNC>(newdist[krank & 63], newdist[OUT2 + (krank & 63)], qnorm));
@@ -2087,13 +2117,16 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		}
 
 		if (TEAM && lane == 0) ctl[wib].state = 0u;                       // walk over: helpers let go
+		c = cold_args(a);                                                  // the emit step's cold arguments
 		if (__builtin_amdgcn_readfirstlane((int) aborted))                 // interrupted inside its walk
 		{
-			if (lane == 0) a.out_counts[qi] = ABORTED_COUNT;
+			if (lane == 0) c->out_counts[qi] = ABORTED_COUNT;
 			if (stream) break;
 			continue;
 		}
-		if (!LEAN && a.out_times && lane == 0) a.out_times[2 * (size_t) qi + 1] = __builtin_amdgcn_s_memrealtime();
+		if (!LEAN && (opt_out & 4u) && lane == 0) c->out_times[2 * (size_t) qi + 1] = __builtin_amdgcn_s_memrealtime();
+		uint64_t *srt_key = reinterpret_cast<uint64_t *>(my + c->off_res);     // emit scratch (overlays the visited set)
+		uint64_t *srt_lab = reinterpret_cast<uint64_t *>(my + c->off_cand);
 		uint32_t hs_walk = 0;
 		if (HOP_STAMPS && a.team_dbg) hs_walk = hop_stamp();
 		// ---- emit: the ef smallest (dist, idx) keys of the set, then the reference's output order ----
@@ -2111,8 +2144,11 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 			else if (i < rsize + 3) srt_key[i] = ~0ull;                  // padding of the 4-wide rank loop: never below a key
 		}
 		wave_sync();
-		const size_t obase = (size_t) qi * a.out_stride;
-		const bool sys_out = stream && a.stream_light != 0 && a.mode == 0;      // (a stream's results: system-scope stores, banner at signal_done)
+		const uint32_t out_stride = c->out_stride;
+		const int mode = c->mode;
+		float *out_dists = c->out_dists;
+		const size_t obase = (size_t) qi * out_stride;
+		const bool sys_out = stream && c->stream_light != 0 && mode == 0;       // (a stream's results: system-scope stores, banner at signal_done)
 		uint32_t nout = 0;
 		// rank by (dist, idx); only ranks < ef are results (topCandidates, hnswalg.cpp:237-240).  Four broadcast
 		// keys per step: the loop is a chain of LDS round trips, not of compares.
@@ -2130,25 +2166,26 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		for (int k = 0; k < UREG; k++)
 			if ((uint32_t) k * 64 + lane >= rsize) myrank[k] = 0xFFFFFFFFu;
 		const uint32_t nres = rsize < ef ? rsize : ef;
-		if (a.mode == 1)
+		if (mode == 1)
 		{
 #pragma unroll
 			for (int k = 0; k < UREG; k++)
 				if (myrank[k] < nres)
 				{
-					a.out_idx[obase + myrank[k]] = (uint32_t) uk[k];
-					if (a.out_dists) a.out_dists[obase + myrank[k]] = unord_f32((uint32_t) (uk[k] >> 32));
+					c->out_idx[obase + myrank[k]] = (uint32_t) uk[k];
+					if (out_dists) out_dists[obase + myrank[k]] = unord_f32((uint32_t) (uk[k] >> 32));
 				}
 			nout = nres;
-			for (uint32_t i = nout + lane; i < a.out_stride; i += 64)
+			for (uint32_t i = nout + lane; i < out_stride; i += 64)
 			{
-				a.out_idx[obase + i] = LINK_NONE;
-				if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
+				c->out_idx[obase + i] = LINK_NONE;
+				if (out_dists) out_dists[obase + i] = __builtin_inff();
 			}
 		}
 		else
 		{
 			// searchKnn, hnswalg.cpp:241-249: labels of the ef results, vacuum filter, (dist, label) order
+			uint64_t *out_labels = c->out_labels;
 			wave_sync();
 			uint64_t lab[UREG];
 			bool tie = false;
@@ -2159,7 +2196,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				lab[k] = 0;
 				if (in)
 				{
-					lab[k] = a.labels[(uint32_t) uk[k]];
+					lab[k] = c->labels[(uint32_t) uk[k]];
 					srt_key[myrank[k]] = uk[k];                         // sorted by (dist, idx)
 					srt_lab[myrank[k]] = lab[k];
 				}
@@ -2195,38 +2232,42 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				{
 					if (sys_out)
 					{
-						__hip_atomic_store(a.out_labels + obase + rank, li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-						if (a.out_dists) __hip_atomic_store(reinterpret_cast<uint32_t *>(a.out_dists) + obase + rank, __float_as_uint(unord_f32(di)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+						__hip_atomic_store(out_labels + obase + rank, li, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+						if (out_dists) __hip_atomic_store(reinterpret_cast<uint32_t *>(out_dists) + obase + rank, __float_as_uint(unord_f32(di)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 					}
 					else
 					{
-						a.out_labels[obase + rank] = li;
-						if (a.out_dists) a.out_dists[obase + rank] = unord_f32(di);
+						out_labels[obase + rank] = li;
+						if (out_dists) out_dists[obase + rank] = unord_f32(di);
 					}
 				}
 				nout += (uint32_t) __builtin_popcountll(kmask);
 			}
-			for (uint32_t i = nout + lane; i < a.out_stride; i += 64)
+			for (uint32_t i = nout + lane; i < out_stride; i += 64)
 			{
 				if (sys_out)
 				{
-					__hip_atomic_store(a.out_labels + obase + i, (uint64_t) ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-					if (a.out_dists) __hip_atomic_store(reinterpret_cast<uint32_t *>(a.out_dists) + obase + i, 0x7F800000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					__hip_atomic_store(out_labels + obase + i, (uint64_t) ~0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+					if (out_dists) __hip_atomic_store(reinterpret_cast<uint32_t *>(out_dists) + obase + i, 0x7F800000u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 				}
 				else
 				{
-					a.out_labels[obase + i] = ~0ull;
-					if (a.out_dists) a.out_dists[obase + i] = __builtin_inff();
+					out_labels[obase + i] = ~0ull;
+					if (out_dists) out_dists[obase + i] = __builtin_inff();
 				}
 			}
 		}
 		if (lane == 0)
 		{
-			if (sys_out) __hip_atomic_store(a.out_counts + qi, nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-			else a.out_counts[qi] = nout;
-			if (a.out_stats) { a.out_stats[2 * (size_t) qi] = evals; a.out_stats[2 * (size_t) qi + 1] = hops; }
+			if (sys_out) __hip_atomic_store(c->out_counts + qi, nout, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+			else c->out_counts[qi] = nout;
+			uint32_t *out_stats = c->out_stats;
+			if (out_stats) { out_stats[2 * (size_t) qi] = evals; out_stats[2 * (size_t) qi + 1] = hops; }
 		}
-		if (a.done) signal_done(a.done + qi, lane, sys_out);       // (a stream's ring is the library's own coherent pinned memory)
+		{
+			uint32_t *done = c->done;
+			if (done) signal_done(done + qi, lane, sys_out);       // (a stream's ring is the library's own coherent pinned memory)
+		}
 
 		wave_sync();
 		if (logn <= a.logcap)
@@ -2235,7 +2276,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		}
 		else
 		{
-			for (uint64_t w = lane; w < a.vis_words; w += 64) vis[w] = 0u;
+			for (uint64_t w = lane, nw = c->vis_words; w < nw; w += 64) vis[w] = 0u;
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
 		__builtin_amdgcn_s_waitcnt(0);
@@ -2253,8 +2294,8 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 			atomicAdd(a.team_dbg + 7, (hs_end - hs_walk) >> 6);     // emit + bitmap clean-up
 		}
 	}
-	if (aborted && lane == 0) atomicAdd(a.health + HEALTH_ABORTED_WAVES, 1u);
-	clock_stamp(a, slot, lane, 1);
+	if (__builtin_amdgcn_readfirstlane((int) aborted)) { uint32_t *hw = cold_args(a)->health; if (lane == 0) atomicAdd(hw + HEALTH_ABORTED_WAVES, 1u); }
+	clock_stamp(cold_args(a)->health, slot, lane, 1);
 	if (TEAM)
 	{
 		if (lane == 0) ctl[wib].state = 2u;

@@ -249,6 +249,10 @@ int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries, size_
 		}
 	}
 	if (!team) { wpb = 4; while (wpb > 1 && (size_t) wpb * a.wave_bytes > 64 * 1024) wpb >>= 1; }
+	// (test knob: waves per block of the narrow-row one-wave launches.  A block's LDS and wave slots are released when its LAST wave
+	// ends, so with 4-wave blocks a draining launch holds resources a following launch could use — profiles/r4c_*; 1 = every wave is a
+	// block of its own.  Measured round 6, profiles/r6d_*.)
+	if (!team && narrow5 && knob(K_NARROW_WPB, 0) > 0) wpb = (uint32_t) std::min<long long>(4, knob(K_NARROW_WPB, 0));
 	a.off_ctl = (uint32_t) ((size_t) wpb * a.wave_bytes);
 	const size_t lds = (size_t) wpb * a.wave_bytes + (team ? wpb * sizeof(TeamCtl) : 0);
 	const bool lean = narrow5 && !team && !w->pops_next && !w->evals_next && !w->times_next && knob(K_LEAN, 1) != 0;

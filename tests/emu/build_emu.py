@@ -1,8 +1,8 @@
 """Build tests/_build/libhnsw_gpu_simt.so: the product's own sources (pg_embedding_amd/csrc/hnsw_gpu.hip, gpu_*.hip + device headers),
 unmodified, compiled for the host against the SIMT emulator in tests/emu/hip/hip_runtime.h.  Test infrastructure only.
 
-The one textual change: an inline-asm register pin of the kernel uses the AMDGPU constraint "+s" (scalar register), which no
-host compiler knows; it becomes "+r".  Everything else is the product's text.
+The one textual change: an inline-asm register pin with the AMDGPU constraint "+s" (scalar register), which no host compiler
+knows, becomes "+r" (rounds 2-5 had one; round 6's kernels have none).  Everything else is the product's text.
 
 build()                       the shipped sources
 build_tree(csrc, tag, edit)   another source tree (e.g. with scripts/pending applied), or the shipped one with a textual
@@ -41,7 +41,6 @@ def build_tree(csrc=CSRC, tag="", edit=None, force=False, verbose=False):
             if edit:
                 txt = edit(f, txt)
             open(os.path.join(src, f[:-4] + "_emu.cpp" if f.endswith(".hip") else f), "w").write(txt)
-    assert pins == 1, "the emulator build expects exactly one scalar-register asm pin"
     cxx = CLANG if os.path.exists(CLANG) else "clang++"
     flags = ["-x", "c++", "-O0", "-std=c++17", "-mavx2", "-mfma", "-ffp-contract=off", "-fPIC", "-pthread",
              "-Wno-unused-value", "-Wno-pass-failed", "-Wno-unknown-attributes",
