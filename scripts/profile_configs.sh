@@ -22,7 +22,8 @@ for CFG in $CFGS; do
               "SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_SMEM GRBM_GUI_ACTIVE" \
               "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_REQUEST_sum"; do
     N=$(echo $PASS | tr ' ' '_' | cut -c1-40)
-    timeout 900 rocprofv3 --kernel-trace --pmc $PASS --output-format csv -d $D/pmc_$N -- $CMD > $D/pmc_$N.log 2>&1
+    # (counters for the search kernels only: with every dispatch of an 8M-row build counted, rocprofv3 itself crashed — r6a, r6g)
+    timeout 900 rocprofv3 --kernel-trace --pmc $PASS --kernel-include-regex "hnsw_search_kernel" --output-format csv -d $D/pmc_$N -- $CMD > $D/pmc_$N.log 2>&1
   done
   {
     echo "# rocprofv3 summary ($TAG, configuration $CFG): $CMD"; echo; echo '```'; cat $D/line.json; echo '```'; echo
