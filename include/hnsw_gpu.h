@@ -352,6 +352,11 @@ int hnsw_gpu_merge_topk_strided_dev(int device, const label_t *d_in_labels, size
 									size_t nq, size_t ef, label_t *d_out_labels, dist_t *d_out_dists,
 									uint32_t *d_out_counts, void *stream);
 
+/* Wait until everything enqueued so far on `stream` (a hipStream_t; NULL = the device's default stream) of `device` has completed:
+ * the one synchronisation a C host without HIP needs around the asynchronous *_dev entry points (hnsw_gpu_server's row-sharded
+ * front waits for its merge with it). */
+int hnsw_gpu_device_wait(int device, void *stream);
+
 /* A device buffer shared between PROCESSES — the exchange buffer of a row-sharded search whose shards live in different
  * processes (one GPU-owning server per GPU; SURVEY.md §8e "direct P2P stores into rank-0 memory").  The merging process
  * allocates it and hands the 64-byte handle to the others over whatever channel they share; they map it

@@ -84,8 +84,21 @@ enum
 	HGS_OP_SET_DELETED = 12, /* key, aux = idx, a0 = 0/1 (embedding.c:920-926)                                */
 	HGS_OP_SETGEN      = 13, /* key, gen = NEW generation, payload = u64 expected current generation: the mirror
 	                            already holds the new state (it was changed through BIND), only its name moves   */
-	HGS_OP_SHM         = 14  /* fd = a memfd laid out as an hgs_shm (below): from now on this connection may POST its SEARCH
+	HGS_OP_SHM         = 14, /* fd = a memfd laid out as an hgs_shm (below): from now on this connection may POST its SEARCH
 	                            requests there instead of writing them to the socket, and finds the answers there          */
+	/* Row shards behind ONE front (SURVEY.md 8e mode 2 for process-per-connection hosts; round 6).  One server per GPU holds one row
+	 * shard of an index under the SAME key (labels globally unique: TIDs are); the server started with --shard-peers is the FRONT that
+	 * backends talk to.  Per batch of searches the front searches its own shard, asks every peer for the same queries on theirs — the
+	 * peers' kernels write their (dist, label) lists straight into the front's exchange buffer, a device allocation shared through an
+	 * IPC handle (hnsw_gpu_shared_alloc / _open, include/hnsw_gpu.h: peer stores over xGMI from another GPU) — and merges the lists
+	 * on its device (hnsw_gpu_merge_topk_strided_dev): per-shard hnsw_search + one top-k merge, nothing staged through a host.
+	 * The two operations below travel front -> peer only, on a connection of their own per dispatcher of the front. */
+	HGS_OP_SHARD_ATTACH = 15, /* a0 = bytes of the exchange buffer, payload = its hnsw_gpu_ipc_handle (64 bytes): the peer maps it for
+	                             this connection (a previous mapping of the connection is released)                         */
+	HGS_OP_SHARD_SEARCH = 16  /* key, aux = ef, a0 = nq, a1 = byte offset of this peer's [nq][ef] labels (u64) in the attached buffer,
+	                             gen = byte offset of its [nq][ef] distances (f32), payload = nq * dim floats: hnsw_search() of every
+	                             query on the peer's mirror of `key`, rows padded with ~0 / +inf as hnsw_gpu_search_batch_dev pads
+	                             them; answered (a0 = nq) once the peer's launch has left its device                        */
 };
 
 /* Searches through shared memory.  A backend's hnsw_search is one small request and one small answer, a thousand backends make a

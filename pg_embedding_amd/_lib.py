@@ -158,6 +158,7 @@ def gpu_lib():
     L.hnsw_gpu_last_bruteforce_gemm_ms.restype = C.c_float
     L.hnsw_gpu_last_bruteforce_clock_mhz.restype = C.c_double
     L.hnsw_gpu_last_bruteforce_tile.restype = C.c_int
+    L.hnsw_gpu_device_wait.argtypes = [C.c_int, vp]
     L.hnsw_gpu_shared_alloc.argtypes = [C.c_int, C.c_size_t, C.POINTER(vp), C.c_char_p]
     L.hnsw_gpu_shared_open.argtypes = [C.c_int, C.c_char_p, C.POINTER(vp)]
     L.hnsw_gpu_shared_close.argtypes = [C.c_int, vp]

@@ -101,6 +101,13 @@ extern "C" int hnsw_gpu_merge_topk_dev(int device, const label_t *d_in_labels, c
 // another GPU its stores cross xGMI as peer stores, exactly like the one-process form (hnsw_gpu_sharded_search_dev); no
 // staging copy, no collective library in a C host.
 // ------------------------------------------------------------------------------------
+extern "C" int hnsw_gpu_device_wait(int device, void *stream)
+{
+	HIPCHK(hipSetDevice(device));
+	HIPCHK(hipStreamSynchronize((hipStream_t) stream));
+	return HNSW_GPU_OK;
+}
+
 static_assert(sizeof(hipIpcMemHandle_t) <= sizeof(hnsw_gpu_ipc_handle), "the ABI's handle must hold a HIP IPC handle");
 
 extern "C" int hnsw_gpu_shared_alloc(int device, size_t bytes, void **d_ptr, hnsw_gpu_ipc_handle *handle)

@@ -79,6 +79,8 @@ struct Options
 	int walkers = -1;              // walking waves per block of a search launch: -1 = by load (below), 0 = the library's default, 1..8 fixed
 	int stream = 0;                // 1 = searches go through ONE resident launch per (mirror, ef) fed through a pinned ring (stream_manager)
 	size_t ring = 4096;            // slots of that ring
+	std::vector<std::string> shard_peers;   // sockets of the servers that hold the OTHER row shards of every mirror: this server is their front
+	                               // (include/hnsw_gpu_server.h, HGS_OP_SHARD_*); needs --lanes 0 --stream 0
 	int shm_pollers = 0;           // threads that poll the backends' mailboxes (HGS_OP_SHM); 0 (default) = mailboxes are refused: every
 	                               // request on the socket.  Opt-in: measured, the mailboxes gain nothing on a host whose CPU time is capped
 	                               // (the pollers spin), profiles/r4aj_mailboxes.txt
@@ -254,11 +256,15 @@ struct Conn
 	size_t shm_bytes = 0;
 	uint32_t shm_qcap = 0, shm_rcap = 0;
 	std::atomic<bool> shm_busy{false};   // a posted request has been taken and not answered yet (server-side word: the backend cannot touch it)
+	// a FRONT's exchange buffer mapped for this connection (HGS_OP_SHARD_ATTACH; the control thread is the only user)
+	void *shard_buf = nullptr;
+	size_t shard_bytes = 0;
 	~Conn()
 	{
 		for (int f : fds) close(f);
 		if (fd >= 0) close(fd);
 		if (shm) munmap(shm, shm_bytes);
+		if (shard_buf) (void) hnsw_gpu_shared_close(g_opt.device, shard_buf);
 	}
 	// the answer of a request that was posted through the mailbox
 	void respond_shm(const hgs_hdr &h, const void *p1, size_t l1, const void *p2, size_t l2)
@@ -349,14 +355,162 @@ struct Pinned
 	}
 };
 
+// ---- the front of a row-sharded index (--shard-peers; include/hnsw_gpu_server.h, HGS_OP_SHARD_*) ----------------------------------
+// Per dispatcher thread: a connection to every peer and ONE exchange buffer (device memory of this server, shared with the peers
+// through its IPC handle): [list][nq][ef] labels, then [list][nq][ef] distances, list 0 = this server's own shard.
+struct ShardFront
+{
+	std::vector<int> fds;                 // one per peer (-1 = not connected)
+	void *xbuf = nullptr; size_t xbytes = 0;
+	hnsw_gpu_ipc_handle handle;
+	std::vector<bool> attached;           // the peer has mapped the CURRENT buffer
+	~ShardFront()
+	{
+		for (int f : fds) if (f >= 0) close(f);
+		if (xbuf) (void) hnsw_gpu_shared_free(g_opt.device, xbuf);
+	}
+	// one request / response on a peer's connection; false = the connection is gone (closed here)
+	bool call(size_t k, hgs_hdr &h, const void *payload, size_t len, int timeout_ms)
+	{
+		h.magic = HGS_MAGIC; h.status = 0; h.len = (uint32_t) len;
+		hgs_hdr resp;
+		int got = -1;
+		if (hgs::send_msg(fds[k], &h, payload, len, nullptr, 0, -1, timeout_ms) != 0 ||
+			hgs::recv_exact(fds[k], &resp, sizeof(resp), &got, timeout_ms) != 0 || resp.magic != HGS_MAGIC || resp.op != h.op || resp.len > 64)
+		{
+			if (got >= 0) close(got);
+			close(fds[k]); fds[k] = -1; attached[k] = false;
+			return false;
+		}
+		char skip[64];
+		if (resp.len && hgs::recv_exact(fds[k], skip, resp.len, &got, timeout_ms) != 0) { close(fds[k]); fds[k] = -1; attached[k] = false; return false; }
+		if (got >= 0) close(got);
+		h = resp;
+		return true;
+	}
+	bool connect_peer(size_t k)
+	{
+		if (fds[k] >= 0) return true;
+		const std::string &path = g_opt.shard_peers[k];
+		struct sockaddr_un addr;
+		memset(&addr, 0, sizeof(addr));
+		addr.sun_family = AF_UNIX;
+		if (path.size() >= sizeof(addr.sun_path)) return false;
+		strncpy(addr.sun_path, path.c_str(), sizeof(addr.sun_path) - 1);
+		const int fd = socket(AF_UNIX, SOCK_STREAM | SOCK_CLOEXEC, 0);
+		if (fd < 0) return false;
+		if (connect(fd, (struct sockaddr *) &addr, sizeof(addr)) != 0) { close(fd); return false; }
+		fds[k] = fd;
+		hgs_hdr h;
+		memset(&h, 0, sizeof(h));
+		h.op = HGS_OP_HELLO; h.a0 = HGS_VERSION;
+		if (!call(k, h, nullptr, 0, 5000) || h.status != HGS_OK) { if (fds[k] >= 0) { close(fds[k]); fds[k] = -1; } return false; }
+		return true;
+	}
+	// room for `lists` lists of nq x ef: (re)allocates and re-attaches every peer when it grows
+	int ensure(size_t bytes)
+	{
+		if (fds.empty()) { fds.assign(g_opt.shard_peers.size(), -1); attached.assign(g_opt.shard_peers.size(), false); }
+		if (bytes > xbytes)
+		{
+			if (xbuf) (void) hnsw_gpu_shared_free(g_opt.device, xbuf);
+			xbuf = nullptr; xbytes = 0;
+			size_t nb = (size_t) 4 << 20;
+			while (nb < bytes) nb *= 2;
+			const int rc = hnsw_gpu_shared_alloc(g_opt.device, nb, &xbuf, &handle);
+			if (rc != HNSW_GPU_OK) { xbuf = nullptr; return rc; }
+			xbytes = nb;
+			attached.assign(attached.size(), false);
+		}
+		for (size_t k = 0; k < fds.size(); k++)
+		{
+			if (!connect_peer(k)) { fail_text = "cannot reach shard peer " + g_opt.shard_peers[k]; return HGS_ERR_IO; }
+			if (attached[k]) continue;
+			hgs_hdr h;
+			memset(&h, 0, sizeof(h));
+			h.op = HGS_OP_SHARD_ATTACH; h.a0 = xbytes;
+			if (!call(k, h, &handle, sizeof(handle), 10000) || h.status != HGS_OK)
+			{
+				fail_text = "shard peer " + g_opt.shard_peers[k] + " did not map the exchange buffer";
+				return HGS_ERR_IO;
+			}
+			attached[k] = true;
+		}
+		return HNSW_GPU_OK;
+	}
+	std::string fail_text;
+};
+
+// One batch on every shard + the merge.  Q (nq x dim), the merged labels / distances / counts live in `pin` (the kernels read and
+// write pinned host memory directly); returns an HGS / HNSW_GPU status.
+int run_batch_sharded(int d, Entry *e, size_t nq, size_t ef, const float *Q, label_t *L, dist_t *D, uint32_t *C, uint32_t *scratch_counts)
+{
+	static thread_local ShardFront sf;
+	const size_t lists = g_opt.shard_peers.size() + 1, dim = e->meta.dim;
+	const size_t lb = (lists * nq * ef * 8 + 255) & ~(size_t) 255, db = lists * nq * ef * 4;
+	int rc = sf.ensure(lb + db);
+	if (rc != HNSW_GPU_OK) { logf("sharded batch: %s", sf.fail_text.empty() ? hnsw_gpu_last_error() : sf.fail_text.c_str()); return rc; }
+	char *xb = (char *) sf.xbuf;
+	// the peers first (their searches run while ours does) ...
+	for (size_t k = 0; k < sf.fds.size(); k++)
+	{
+		hgs_hdr h;
+		memset(&h, 0, sizeof(h));
+		h.magic = HGS_MAGIC; h.op = HGS_OP_SHARD_SEARCH; h.key = e->key; h.aux = (uint32_t) ef; h.a0 = nq; h.len = (uint32_t) (nq * dim * 4);
+		h.a1 = (1 + k) * nq * ef * 8;                       // this peer's labels ...
+		h.gen = lb + (1 + k) * nq * ef * 4;                 // ... and distances
+		if (hgs::send_msg(sf.fds[k], &h, Q, nq * dim * 4, nullptr, 0, -1, 10000) != 0)
+		{
+			close(sf.fds[k]); sf.fds[k] = -1; sf.attached[k] = false;
+			logf("sharded batch: lost shard peer %s", g_opt.shard_peers[k].c_str());
+			// (the peers already asked answer into a buffer nobody merges; their connections are re-synchronised by the reads below)
+			rc = HGS_ERR_IO;
+		}
+	}
+	// ... then this server's own shard into list 0
+	hnsw_gpu_ctx *ctx = e->context(d);
+	if (rc == HNSW_GPU_OK && !ctx) rc = HNSW_GPU_ERR_HIP;
+	if (rc == HNSW_GPU_OK)
+		rc = hnsw_gpu_search_batch_ctx(ctx, Q, nq, ef, (label_t *) xb, (dist_t *) (xb + lb), scratch_counts, nullptr, nullptr);
+	float kms = 0.f;
+	if (rc == HNSW_GPU_OK && hnsw_gpu_ctx_search_ms(ctx, 0, &kms) == HNSW_GPU_OK) g_cnt.kernel_ns += (uint64_t) (kms * 1e6f);   // (waits for it)
+	// every peer's answer (also after a failure: a connection must not be left with a response in flight)
+	for (size_t k = 0; k < sf.fds.size(); k++)
+	{
+		if (sf.fds[k] < 0) continue;
+		hgs_hdr resp;
+		int got = -1;
+		if (hgs::recv_exact(sf.fds[k], &resp, sizeof(resp), &got, 60000) != 0 || resp.magic != HGS_MAGIC || resp.op != HGS_OP_SHARD_SEARCH || resp.len != 0)
+		{
+			if (got >= 0) close(got);
+			close(sf.fds[k]); sf.fds[k] = -1; sf.attached[k] = false;
+			logf("sharded batch: shard peer %s did not answer", g_opt.shard_peers[k].c_str());
+			if (rc == HNSW_GPU_OK) rc = HGS_ERR_IO;
+			continue;
+		}
+		if (got >= 0) close(got);
+		if (resp.status != HGS_OK && rc == HNSW_GPU_OK)
+		{
+			logf("sharded batch: shard peer %s answered %d", g_opt.shard_peers[k].c_str(), (int) resp.status);
+			rc = resp.status;
+		}
+	}
+	if (rc != HNSW_GPU_OK) return rc;
+	// the exchange is done: every list is in this device's memory.  Merge into the pinned outputs and wait for it.
+	rc = hnsw_gpu_merge_topk_strided_dev(g_opt.device, (const label_t *) xb, nq * ef, (const dist_t *) (xb + lb), nq * ef, lists, nq, ef, L, D, C, nullptr);
+	if (rc == HNSW_GPU_OK) rc = hnsw_gpu_device_wait(g_opt.device, nullptr);
+	return rc;
+}
+
 void run_batch(int d, std::vector<SReq> &batch, Pinned &pin)
 {
 	Entry *e = batch[0].e.get();
 	const size_t nq = batch.size(), ef = batch[0].h.aux, dim = e->meta.dim;
 	const size_t qb = (nq * dim * 4 + 255) & ~(size_t) 255, lb = (nq * ef * 8 + 255) & ~(size_t) 255,
-				 db = (nq * ef * 4 + 255) & ~(size_t) 255, cb = nq * 4;
+				 db = (nq * ef * 4 + 255) & ~(size_t) 255, cb = (nq * 4 + 255) & ~(size_t) 255;
+	const bool sharded = !g_opt.shard_peers.empty();
 	int rc = HNSW_GPU_OK;
-	if (!pin.reserve(qb + lb + db + cb)) rc = HNSW_GPU_ERR_NOMEM;
+	if (!pin.reserve(qb + lb + db + cb + (sharded ? cb : 0))) rc = HNSW_GPU_ERR_NOMEM;
 	char *base = (char *) pin.p;
 	float *Q = (float *) base;
 	label_t *L = (label_t *) (base + qb);
@@ -367,11 +521,16 @@ void run_batch(int d, std::vector<SReq> &batch, Pinned &pin)
 	{
 		for (size_t i = 0; i < nq; i++) memcpy(Q + i * dim, batch[i].q.data(), dim * 4);
 		e->begin_read();
-		hnsw_gpu_ctx *ctx = e->context(d);
-		if (!ctx) rc = HNSW_GPU_ERR_HIP;
-		else rc = hnsw_gpu_search_batch_ctx_host(ctx, Q, nq, ef, L, D, C);
-		float kms = 0.f;
-		if (rc == HNSW_GPU_OK && hnsw_gpu_ctx_search_ms(ctx, 0, &kms) == HNSW_GPU_OK) g_cnt.kernel_ns += (uint64_t) (kms * 1e6f);
+		if (sharded)                                             // this server is the front of a row-sharded index: every shard, then the merge
+			rc = run_batch_sharded(d, e, nq, ef, Q, L, D, C, (uint32_t *) (base + qb + lb + db + cb));
+		else
+		{
+			hnsw_gpu_ctx *ctx = e->context(d);
+			if (!ctx) rc = HNSW_GPU_ERR_HIP;
+			else rc = hnsw_gpu_search_batch_ctx_host(ctx, Q, nq, ef, L, D, C);
+			float kms = 0.f;
+			if (rc == HNSW_GPU_OK && hnsw_gpu_ctx_search_ms(ctx, 0, &kms) == HNSW_GPU_OK) g_cnt.kernel_ns += (uint64_t) (kms * 1e6f);
+		}
 		e->end_read();
 		if (rc != HNSW_GPU_OK) logf("search batch of %zu (ef %zu) failed: %s", nq, ef, hnsw_gpu_last_error());
 	}
@@ -1307,7 +1466,7 @@ void do_control(CReq &r)
 	switch (r.h.op)
 	{
 	case HGS_OP_UPLOAD: case HGS_OP_UPDATE: case HGS_OP_BIND: case HGS_OP_DROP: case HGS_OP_LINK: case HGS_OP_EXPORT: case HGS_OP_SET_DELETED:
-	case HGS_OP_DIST:
+	case HGS_OP_DIST: case HGS_OP_SHARD_ATTACH: case HGS_OP_SHARD_SEARCH:
 		wanted.reset(new DeviceWanted());
 		break;
 	default: break;
@@ -1390,6 +1549,52 @@ void do_control(CReq &r)
 			e->version.store(++g_vseq);
 		}
 		r.c->respond(r.h, rc);
+		break;
+	}
+	case HGS_OP_SHARD_ATTACH:
+	{
+		// a front hands over its exchange buffer: map it for this connection (csrc/gpu_sharded.hip, hnsw_gpu_shared_open)
+		if (r.payload.size() != sizeof(hnsw_gpu_ipc_handle) || r.h.a0 == 0) { r.c->respond(r.h, HGS_ERR_PROTOCOL); break; }
+		if (r.c->shard_buf) { (void) hnsw_gpu_shared_close(g_opt.device, r.c->shard_buf); r.c->shard_buf = nullptr; r.c->shard_bytes = 0; }
+		hnsw_gpu_ipc_handle hnd;
+		memcpy(&hnd, r.payload.data(), sizeof(hnd));
+		void *p = nullptr;
+		const int rc = hnsw_gpu_shared_open(g_opt.device, &hnd, &p);
+		if (rc != HNSW_GPU_OK) { logf("shard attach: %s", hnsw_gpu_last_error()); r.c->respond(r.h, rc); break; }
+		r.c->shard_buf = p; r.c->shard_bytes = (size_t) r.h.a0;
+		r.c->respond(r.h, HGS_OK);
+		break;
+	}
+	case HGS_OP_SHARD_SEARCH:
+	{
+		// this server's shard of a front's batch: hnsw_search for every query, the lists written where the front merges them
+		EntryP e = find_entry(r.h.key);
+		if (!e) { r.c->respond(r.h, HGS_ERR_NOKEY); break; }
+		const size_t nq = (size_t) r.h.a0, ef = r.h.aux, dim = e->meta.dim;
+		const size_t off_l = (size_t) r.h.a1, off_d = (size_t) r.h.gen;
+		if (!r.c->shard_buf || nq == 0 || ef == 0 || nq > g_opt.max_batch || r.payload.size() != nq * dim * 4 ||
+			off_l % 8 || off_d % 4 || off_l + nq * ef * 8 > r.c->shard_bytes || off_d + nq * ef * 4 > r.c->shard_bytes)
+		{
+			r.c->respond(r.h, HGS_ERR_PROTOCOL);
+			break;
+		}
+		static thread_local Pinned pin;                      // queries + counts where the kernel reads / writes them directly
+		const size_t qb = (nq * dim * 4 + 255) & ~(size_t) 255;
+		if (!pin.reserve(qb + nq * 4)) { r.c->respond(r.h, HNSW_GPU_ERR_NOMEM); break; }
+		memcpy(pin.p, r.payload.data(), nq * dim * 4);
+		int rc;
+		float ms = 0.f;
+		e->begin_read();
+		rc = hnsw_gpu_search_batch_dev(e->ix, (const coord_t *) pin.p, nq, ef, (label_t *) ((char *) r.c->shard_buf + off_l),
+									   (dist_t *) ((char *) r.c->shard_buf + off_d), (uint32_t *) ((char *) pin.p + qb), nullptr, nullptr);
+		if (rc == HNSW_GPU_OK) rc = hnsw_gpu_last_search_ms(e->ix, &ms);      // (waits for the launch: the lists are in the front's memory)
+		e->end_read();
+		e->last_used.store(now_ns());
+		g_cnt.batches++;
+		g_cnt.searches += nq;
+		g_cnt.kernel_ns += (uint64_t) (ms * 1e6f);
+		if (rc != HNSW_GPU_OK) { g_cnt.search_errors += nq; logf("shard search of %zu (ef %zu): %s", nq, ef, hnsw_gpu_last_error()); }
+		r.c->respond(r.h, rc, nq);
 		break;
 	}
 	case HGS_OP_DIST:
@@ -1618,6 +1823,7 @@ bool handle_message(const ConnP &c, const hgs_hdr &h, const char *payload)
 		return handle_shm(c, h);
 	case HGS_OP_UPLOAD: case HGS_OP_UPDATE: case HGS_OP_BIND: case HGS_OP_DROP: case HGS_OP_LINK:
 	case HGS_OP_EXPORT: case HGS_OP_SET_DELETED: case HGS_OP_DIST: case HGS_OP_SETGEN:
+	case HGS_OP_SHARD_ATTACH: case HGS_OP_SHARD_SEARCH:
 	{
 		CReq r;
 		r.c = c; r.h = h;
@@ -1735,7 +1941,9 @@ void usage()
 	fprintf(stderr,
 			"usage: hnsw_gpu_server --socket PATH [--device N] [--dispatchers N] [--readers N]\n"
 			"                       [--max-batch N] [--lanes N] [--linger-us N --min-batch N] [--walkers auto|0..8] [--stream 0|1 --ring N]\n"
-			"                       [--shm-pollers N] [--verbose] [--ready-fd N]\n"
+			"                       [--shm-pollers N] [--shard-peers SOCKET[,SOCKET...]] [--verbose] [--ready-fd N]\n"
+			"  --shard-peers  this server is the FRONT of a row-sharded index: the listed servers hold the other shards of every mirror (same\n"
+			"             key); a search runs on all shards and is merged here (needs --lanes 0 --stream 0)\n"
 			"  --shm-pollers  threads that poll the backends' mailboxes (searches through shared memory instead of the socket); 0 = off (default)\n"
 			"  --stream   1 = searches go through ONE resident launch per (mirror, efsearch), fed through a ring of N slots in pinned\n"
 			"             memory (no batches, no launch per query); the --dispatchers threads answer; 0 (default) = launches on lanes\n"
@@ -1765,12 +1973,27 @@ int main(int argc, char **argv)
 		else if (a == "--stream") g_opt.stream = atoi(val("--stream"));
 		else if (a == "--ring") g_opt.ring = (size_t) atol(val("--ring"));
 		else if (a == "--shm-pollers") g_opt.shm_pollers = atoi(val("--shm-pollers"));
+		else if (a == "--shard-peers")
+		{
+			std::string v = val("--shard-peers");
+			for (size_t at = 0; at <= v.size();)
+			{
+				const size_t comma = std::min(v.find(',', at), v.size());
+				if (comma > at) g_opt.shard_peers.push_back(v.substr(at, comma - at));
+				at = comma + 1;
+			}
+		}
 		else if (a == "--min-batch") g_opt.min_batch = (size_t) atol(val("--min-batch"));
 		else if (a == "--ready-fd") g_opt.ready_fd = atoi(val("--ready-fd"));
 		else if (a == "--verbose") g_opt.verbose = true;
 		else { usage(); return 2; }
 	}
 	if (g_opt.shm_pollers < 0 || g_opt.shm_pollers > MAX_SHM_POLLERS) { usage(); return 2; }
+	if (!g_opt.shard_peers.empty() && (g_opt.lanes != 0 || g_opt.stream != 0))
+	{
+		logf("--shard-peers (a front of row shards) takes blocking batches: --lanes 0 --stream 0");
+		return 2;
+	}
 	if (g_opt.path.empty() || g_opt.dispatchers < 1 || g_opt.readers < 1 || g_opt.max_batch < 1 || g_opt.lanes < 0 || g_opt.lanes > 16) { usage(); return 2; }
 	// (the ring keeps a margin of 64 slots, Session::submit: a 64-slot ring would take nothing at all and every request would queue for ever —
 	// what the CPU tier's first resident-launch run did; 256 is the smallest ring the server accepts)

@@ -142,7 +142,7 @@ class ServerProcess:
     def __init__(self, socket_path: Optional[str] = None, device: int = 0, dispatchers: int = 2,
                  max_batch: int = 16384, linger_us: int = 0, min_batch: int = 1, readers: int = 4, lanes: int = 3, binary: Optional[str] = None,
                  env: Optional[dict] = None, verbose: bool = False, start_timeout: float = 120.0, walkers: Optional[str] = None,
-                 stream: bool = False, ring: int = 4096, shm_pollers: Optional[int] = None):
+                 stream: bool = False, ring: int = 4096, shm_pollers: Optional[int] = None, shard_peers=None):
         self.binary = binary or _build.SERVER_BIN
         if not os.path.exists(self.binary):
             _build.build()
@@ -161,6 +161,8 @@ class ServerProcess:
             self.args += ["--stream", "1", "--ring", str(ring)]
         if shm_pollers is not None:
             self.args += ["--shm-pollers", str(shm_pollers)]
+        if shard_peers:                          # this server is the FRONT of a row-sharded index: the peers hold the other shards (needs lanes=0)
+            self.args += ["--shard-peers", ",".join(shard_peers)]
         if linger_us:
             self.args += ["--linger-us", str(linger_us), "--min-batch", str(min_batch)]
         if verbose:

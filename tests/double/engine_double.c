@@ -479,3 +479,143 @@ int hnsw_gpu_dist_batch(dist_func_t func, const coord_t *q, const coord_t *rows,
 	for (size_t i = 0; i < nrows; i++) out[i] = port_dist((int) func, q, rows + i * dim, dim);
 	return HNSW_GPU_OK;
 }
+
+/* ---- row shards behind a front (server_main.cpp, HGS_OP_SHARD_*): the device-pointer search forms, the merge, and the exchange buffer
+ * shared between PROCESSES.  "Device memory" of the double is host memory, so the shared buffer is a POSIX shared-memory object: its
+ * name and size travel in the 64-byte handle. ---- */
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+static int dev_search(hnsw_gpu_index *ix, const coord_t *q, size_t nq, size_t ef, label_t *labels, dist_t *dists, uint32_t *counts)
+{
+	const size_t dim = ix->meta.dim;
+	for (size_t i = 0; i < nq; i++)
+	{
+		size_t n = 0;
+		for (size_t k = 0; k < ef; k++) { labels[i * ef + k] = ~(label_t) 0; if (dists) dists[i * ef + k] = 1.0f / 0.0f; }
+		if (port_search(ix->p, q + i * dim, ef, labels + i * ef, dists ? dists + i * ef : NULL, &n, NULL, NULL) != 0) return HNSW_GPU_ERR_INTERNAL;
+		if (counts) counts[i] = (uint32_t) n;
+	}
+	return HNSW_GPU_OK;
+}
+
+int hnsw_gpu_search_batch_dev(hnsw_gpu_index *ix, const coord_t *d_queries, size_t nq, size_t ef, label_t *d_labels, dist_t *d_dists,
+							  uint32_t *d_counts, uint32_t *d_stats, void *stream)
+{
+	(void) d_stats; (void) stream;
+	return dev_search(ix, d_queries, nq, ef, d_labels, d_dists, d_counts);
+}
+
+int hnsw_gpu_search_batch_ctx(hnsw_gpu_ctx *c, const coord_t *d_queries, size_t nq, size_t ef, label_t *d_labels, dist_t *d_dists,
+							  uint32_t *d_counts, uint32_t *d_stats, void *stream)
+{
+	(void) d_stats; (void) stream;
+	return dev_search(c->ix, d_queries, nq, ef, d_labels, d_dists, d_counts);
+}
+
+int hnsw_gpu_last_search_ms(hnsw_gpu_index *ix, float *ms) { (void) ix; *ms = 0.f; return HNSW_GPU_OK; }
+int hnsw_gpu_device_wait(int device, void *stream) { (void) device; (void) stream; return HNSW_GPU_OK; }
+
+/* the ef best by (distance, label) of nlists ascending lists per query (include/hnsw_gpu.h; csrc/gpu_sharded.hip, topk_merge_kernel) */
+int hnsw_gpu_merge_topk_strided_dev(int device, const label_t *in_labels, size_t lstride, const dist_t *in_dists, size_t dstride, size_t nlists,
+									size_t nq, size_t ef, label_t *out_labels, dist_t *out_dists, uint32_t *out_counts, void *stream)
+{
+	(void) device; (void) stream;
+	size_t *at = (size_t *) malloc(nlists * sizeof(size_t));
+	if (!at) return HNSW_GPU_ERR_NOMEM;
+	for (size_t q = 0; q < nq; q++)
+	{
+		for (size_t l = 0; l < nlists; l++) at[l] = 0;
+		uint32_t n = 0;
+		for (size_t k = 0; k < ef; k++)
+		{
+			size_t best = nlists;
+			for (size_t l = 0; l < nlists; l++)
+			{
+				if (at[l] >= ef) continue;
+				const label_t la = in_labels[l * lstride + q * ef + at[l]];
+				if (la == ~(label_t) 0) continue;                  /* the list's padded tail */
+				const dist_t da = in_dists[l * dstride + q * ef + at[l]];
+				if (best == nlists) { best = l; continue; }
+				const dist_t db = in_dists[best * dstride + q * ef + at[best]];
+				const label_t lb = in_labels[best * lstride + q * ef + at[best]];
+				if (da < db || (da == db && la < lb)) best = l;
+			}
+			if (best == nlists) { out_labels[q * ef + k] = ~(label_t) 0; if (out_dists) out_dists[q * ef + k] = 1.0f / 0.0f; continue; }
+			out_labels[q * ef + k] = in_labels[best * lstride + q * ef + at[best]];
+			if (out_dists) out_dists[q * ef + k] = in_dists[best * dstride + q * ef + at[best]];
+			at[best]++;
+			n++;
+		}
+		out_counts[q] = n;
+	}
+	free(at);
+	return HNSW_GPU_OK;
+}
+
+typedef struct { char name[40]; unsigned long long bytes; } DoubleHandle;      /* what the 64 bytes of an hnsw_gpu_ipc_handle hold here */
+static int g_shared_seq = 0;
+typedef struct SharedMap { void *p; size_t bytes; char name[40]; int owner; struct SharedMap *next; } SharedMap;
+static SharedMap *g_shared = NULL;
+static pthread_mutex_t g_shared_mu = PTHREAD_MUTEX_INITIALIZER;
+
+static int shared_map(const char *name, size_t bytes, int create, void **out)
+{
+	const int fd = shm_open(name, create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
+	if (fd < 0) { snprintf(t_err, sizeof(t_err), "double: shm_open(%s) failed", name); return HNSW_GPU_ERR_HIP; }
+	if (create && ftruncate(fd, (off_t) bytes) != 0) { close(fd); shm_unlink(name); return HNSW_GPU_ERR_NOMEM; }
+	void *p = mmap(NULL, bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+	close(fd);
+	if (p == MAP_FAILED) { if (create) shm_unlink(name); snprintf(t_err, sizeof(t_err), "double: mmap of %s failed", name); return HNSW_GPU_ERR_NOMEM; }
+	SharedMap *m = (SharedMap *) calloc(1, sizeof(SharedMap));
+	m->p = p; m->bytes = bytes; m->owner = create; snprintf(m->name, sizeof(m->name), "%s", name);
+	pthread_mutex_lock(&g_shared_mu);
+	m->next = g_shared; g_shared = m;
+	pthread_mutex_unlock(&g_shared_mu);
+	*out = p;
+	return HNSW_GPU_OK;
+}
+
+static int shared_unmap(void *p, int owner)
+{
+	pthread_mutex_lock(&g_shared_mu);
+	SharedMap **at = &g_shared;
+	while (*at && (*at)->p != p) at = &(*at)->next;
+	SharedMap *m = *at;
+	if (m) *at = m->next;
+	pthread_mutex_unlock(&g_shared_mu);
+	if (!m) { snprintf(t_err, sizeof(t_err), "double: not a shared buffer"); return HNSW_GPU_ERR_ARG; }
+	munmap(m->p, m->bytes);
+	if (owner && m->owner) shm_unlink(m->name);
+	free(m);
+	return HNSW_GPU_OK;
+}
+
+int hnsw_gpu_shared_alloc(int device, size_t bytes, void **d_ptr, hnsw_gpu_ipc_handle *handle)
+{
+	(void) device;
+	DoubleHandle h;
+	memset(&h, 0, sizeof(h));
+	snprintf(h.name, sizeof(h.name), "/hgsd_%d_%d", (int) getpid(), __atomic_add_fetch(&g_shared_seq, 1, __ATOMIC_RELAXED));
+	h.bytes = bytes;
+	const int rc = shared_map(h.name, bytes, 1, d_ptr);
+	if (rc != HNSW_GPU_OK) return rc;
+	memset(handle, 0, sizeof(*handle));
+	memcpy(handle, &h, sizeof(h));
+	return HNSW_GPU_OK;
+}
+
+int hnsw_gpu_shared_open(int device, const hnsw_gpu_ipc_handle *handle, void **d_ptr)
+{
+	(void) device;
+	DoubleHandle h;
+	memcpy(&h, handle, sizeof(h));
+	h.name[sizeof(h.name) - 1] = 0;
+	if (h.name[0] != '/' || h.bytes == 0) { snprintf(t_err, sizeof(t_err), "double: not a handle"); return HNSW_GPU_ERR_ARG; }
+	return shared_map(h.name, (size_t) h.bytes, 0, d_ptr);
+}
+
+int hnsw_gpu_shared_close(int device, void *d_ptr) { (void) device; return shared_unmap(d_ptr, 0); }
+int hnsw_gpu_shared_free(int device, void *d_ptr) { (void) device; return shared_unmap(d_ptr, 1); }

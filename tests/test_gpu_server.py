@@ -122,3 +122,68 @@ def test_server_side_bulk_build_then_search(srv):
     assert hits / 500 > 0.9                               # the batched device build is a good graph
     c.drop(31)
     c.close()
+
+
+def test_row_shards_behind_one_front_on_the_device():
+    """Two product servers on this device, one row shard each under the same key; the one started with --shard-peers is the front
+    (include/hnsw_gpu_server.h, HGS_OP_SHARD_*): its own shard + the peer's lists — written by the PEER PROCESS's kernel into the front's
+    exchange buffer through the IPC mapping (hnsw_gpu_shared_alloc / _open; across two GPUs the same stores cross xGMI) — merged by
+    (distance, label) on the front's device.  Parity as the layout defines it: oracle per shard + CPU merge, ids and distance bits,
+    several backends at once; and what a sharded batch costs next to an unsharded one of the same size."""
+    import threading
+    import time
+    dim, m, efs, n0, n1 = 128, 8, 64, 6000, 5000
+    X = gmm(n0 + n1, dim, k=30, seed=91)
+    shards = []
+    for lo, hi in ((0, n0), (n0, n0 + n1)):
+        p = oracle.PortIndex(dim, m, 40, efs, pg.DIST_L2)
+        p.add(X[lo:hi], np.arange(lo, hi, dtype=np.uint64) + 10_000)
+        shards.append(p)
+    meta = pg.make_meta(dim, m, 40, efs, pg.DIST_L2)
+    key = 7
+
+    def want(q, ef):
+        both = [s.search(q, ef)[:2] for s in shards]
+        lab = np.concatenate([b[0] for b in both]); dst = np.concatenate([b[1] for b in both])
+        order = np.lexsort((lab, dst))[:ef]
+        return lab[order], dst[order]
+
+    with ServerProcess(lanes=0, dispatchers=1) as peer:
+        with ServerProcess(lanes=0, dispatchers=1, shard_peers=[peer.socket_path]) as front:
+            RemoteClient(front.socket_path).upload(meta, key, 1, shards[0].raw(), n0)
+            RemoteClient(peer.socket_path).upload(meta, key, 1, shards[1].raw(), n1)
+            Q = gmm(160, dim, k=30, seed=91, stream=1)
+            errors = []
+
+            def backend(t):
+                try:
+                    c = RemoteClient(front.socket_path)
+                    for i in range(t, len(Q), 8):
+                        for ef in (efs, 10):
+                            lab, dst = c.search(key, Q[i], ef)
+                            wl, wd = want(Q[i], ef)
+                            if not ((lab == wl).all() and (bits(dst) == bits(wd)).all()):
+                                errors.append((i, ef))
+                except Exception as e:                             # noqa: BLE001
+                    errors.append(repr(e))
+            th = [threading.Thread(target=backend, args=(t,)) for t in range(8)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            assert not errors, errors[:5]
+            sf, sp = RemoteClient(front.socket_path).stats(), RemoteClient(peer.socket_path).stats()
+            assert sf["searches"] == 320 and sp["searches"] == 320 and sf["search_errors"] == 0 and sp["search_errors"] == 0
+            # one backend alone: round trip of a sharded search (front + peer + merge) against the peer's own unsharded search
+            c = RemoteClient(front.socket_path)
+            t0 = time.perf_counter()
+            for q in Q[:100]:
+                c.search(key, q, efs)
+            sharded_ms = (time.perf_counter() - t0) * 10.0
+            c2 = RemoteClient(peer.socket_path)
+            t0 = time.perf_counter()
+            for q in Q[:100]:
+                c2.search(key, q, efs)
+            plain_ms = (time.perf_counter() - t0) * 10.0
+            print(f"\n[row shards behind a front, two server processes on one device] one backend: {sharded_ms:.3f} ms per sharded search "
+                  f"(front shard + peer shard through the shared buffer + merge) against {plain_ms:.3f} ms for an unsharded search of one shard")

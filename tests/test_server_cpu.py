@@ -781,3 +781,68 @@ def test_a_snapshot_cannot_replace_a_mirror_that_changed_since_its_lookup(srv):
         assert (c.search(key, q, efs)[0] == port.search(q, efs)[0]).all()
     assert 4242 in c.search(key, new, efs)[0].tolist()
     c.close()
+
+
+def test_row_shards_behind_one_front(double_bin):
+    """SURVEY.md 8e mode 2 for process-per-connection hosts (round 6; include/hnsw_gpu_server.h, HGS_OP_SHARD_*): two servers hold one row
+    shard each of an index under the SAME key; the one started with --shard-peers is the front backends talk to — it searches its own
+    shard, has the peer search the same queries into the exchange buffer it shares (hnsw_gpu_shared_alloc / _open: POSIX shared memory in
+    the engine double, an IPC-mapped device allocation in the product), merges by (distance, label) and answers.  Parity as the layout
+    defines it: the oracle per shard + a CPU merge, id lists and distance bits, from several backends at once (batches form)."""
+    dim, m, efs, n0, n1 = 24, 6, 32, 900, 700
+    X = gmm(n0 + n1, dim, k=20, seed=77)
+    shards = []
+    for lo, hi in ((0, n0), (n0, n0 + n1)):
+        p = oracle.PortIndex(dim, m, 32, efs, pg.DIST_L2)
+        p.add(X[lo:hi], np.arange(lo, hi, dtype=np.uint64) + 10_000)            # labels unique across the shards
+        shards.append(p)
+    meta = pg.make_meta(dim, m, 32, efs, pg.DIST_L2)
+    key = 99
+    with ServerProcess(binary=double_bin, lanes=0) as peer:
+        with ServerProcess(binary=double_bin, lanes=0, shard_peers=[peer.socket_path]) as front:
+            RemoteClient(front.socket_path).upload(meta, key, 1, shards[0].raw(), n0)
+            RemoteClient(peer.socket_path).upload(meta, key, 1, shards[1].raw(), n1)
+
+            def want(q, ef):
+                both = [s.search(q, ef)[:2] for s in shards]
+                lab = np.concatenate([b[0] for b in both]); dst = np.concatenate([b[1] for b in both])
+                order = np.lexsort((lab, dst))[:ef]
+                return lab[order], dst[order]
+
+            Q = gmm(120, dim, k=20, seed=77, stream=1)
+            errors = []
+
+            def backend(t):
+                try:
+                    c = RemoteClient(front.socket_path)
+                    for i in range(t, len(Q), 6):
+                        for ef in (efs, 5):
+                            lab, dst = c.search(key, Q[i], ef)
+                            wl, wd = want(Q[i], ef)
+                            if not ((lab == wl).all() and (bits(dst) == bits(wd)).all()):
+                                errors.append((i, ef))
+                except Exception as e:                             # noqa: BLE001
+                    errors.append(repr(e))
+            th = [threading.Thread(target=backend, args=(t,)) for t in range(6)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            assert not errors, errors[:5]
+            sf, sp = RemoteClient(front.socket_path).stats(), RemoteClient(peer.socket_path).stats()
+            assert sf["searches"] == 240 and sp["searches"] == 240 and sf["search_errors"] == 0 and sp["search_errors"] == 0
+            # a vacuum flag set on the PEER's shard is honoured in the merged answer (the peer filters its own list)
+            l0 = RemoteClient(front.socket_path).search(key, Q[0], efs)[0]
+            victim = next(int(x) for x in l0 if x >= 10_000 + n0)
+            RemoteClient(peer.socket_path).set_deleted(key, victim - 10_000 - n0, True)
+            shards[1].set_deleted(victim - 10_000 - n0, True)
+            lab, dst = RemoteClient(front.socket_path).search(key, Q[0], efs)
+            assert victim not in lab.tolist() and (lab == want(Q[0], efs)[0]).all()
+        # the peer outlives the front; a front whose peer is gone answers with an error, not with half an answer
+    with ServerProcess(binary=double_bin, lanes=0, shard_peers=["/nonexistent/hgs-peer"]) as lonely:
+        c = RemoteClient(lonely.socket_path)
+        c.upload(meta, key, 1, shards[0].raw(), n0)
+        with pytest.raises(RemoteError):
+            c.search(key, X[0], efs)
+    with pytest.raises(RuntimeError):                              # a front takes blocking batches only
+        ServerProcess(binary=double_bin, lanes=2, shard_peers=["/x"]).start()
