@@ -6,7 +6,8 @@
 A "step" is one pass of the hot path over one batch of `--nq` (default 40 000) synthetic queries
 (already resident in HBM): the fused searchBaseLayer/searchKnn kernel over an HBM-resident index.
 Workload at N=1 = the configuration the metric is quoted on: 1M x 768 fp32, L2,
-efsearch=128 (graph built in HBM by the device insert path before the timed region).
+efsearch=128 — on the graph the REFERENCE itself builds for the table (oracle/_ref's serial hnsw_bind_point, link words uploaded byte
+for byte) where that travels with the tree, otherwise on a graph built in HBM by the device insert path before the timed region.
 
 N>1: one process per GPU over RCCL (torch.distributed backend "nccl").  Started by the driver under
 `python -m torch.distributed.run ...` it reads RANK/LOCAL_RANK/WORLD_SIZE; started plainly as
@@ -37,6 +38,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 from pg_embedding_amd import watchdog                      # noqa: E402
 watchdog.arm(default_seconds=3000.0, env_sync=False)                    # --timeout SECONDS: a hung launch ends the run with status 124, not never
+
+# The two-stream legs keep launches in flight on two HIP streams.  HIP spreads streams over GPU_MAX_HW_QUEUES hardware queues (4 by
+# default) and launches that share a queue run one after the other — the narrow-row pair showed no overlap at all in the bench process
+# (0.60 of nominal) and full overlap in a fresh process (0.70, profiles/r6d_*): which queues two streams get depends on how many the
+# process has created before.  More queues than the bench ever creates streams; read by the runtime at its first HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 REL_TOL = 1e-5            # north-star tolerance (BASELINE.json)

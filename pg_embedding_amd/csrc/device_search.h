@@ -101,6 +101,7 @@ struct SearchArgs
 	uint32_t tm_off_ex, tm_off_miss, tm_off_lctag, tm_off_lcstate, tm_off_lclinks, tm_lcslots, tm_off_dc, tm_dccap;
 	uint32_t tm_spec;           // helpers of rank < tm_spec speculate (packages); the others score slices of the walking wave's rows
 	const uint32_t *abort_word; // null, or the workspace's abort word in pinned host memory (banner at abort_requested)
+	uint32_t abort_mask;        // a wave looks at the abort word at the top of query number qi when (qi & abort_mask) == 0: every 16th by default
 	uint32_t *health;           // HEALTH_WORDS device words: time-out and abort counters of the workspace
 	uint32_t *team_dbg;         // null, or 16 counters for the whole launch (hnsw_gpu_team_counters): hops with helpers,
 	                            // link-list hits, ids looked up, distance hits, hops that still scored rows, all hops
@@ -120,6 +121,12 @@ struct SearchArgs
 //     link, ~2 us, a fraction of a percent of a walk — and leaves.  Outputs of that launch are undefined and the workspace
 //     is re-zeroed before the next one.  Nothing in the kernels waits without a bound, so this is for the unknown: a hung
 //     launch costs its caller's timeout, not the device.
+//     Round 6: NOT at the top of every query any more, but of every 16th (abort_mask, by query number: no state in the wave).  Each look
+//     is an uncached read across the host link, and 40 000 narrow-row queries per 5.8 ms launch are 7 million such reads a second from
+//     5 120 waves: how fast the host serves them depends on where that pinned page sits, and with the wrong page EVERY launch of a
+//     workspace was 40 % slower — the "slow state" of rounds 5-6 (profiles/r6k_*: same process, same index, same kernel, same stream; one
+//     workspace 5.8 ms, another 8.6 ms).  The wide-row launches ask a quarter as often per second and never showed it.  An abort now takes
+//     effect within 16 queries of every wave (~10-20 ms) instead of one.
 //   health (device memory, totals of the workspace's life, all zero in a healthy one):
 //   [HEALTH_SLICE_TIMEOUTS]   team form: slices a helper did not deliver within SLICE_WAIT_POLLS (scored by the walking wave)
 //   [HEALTH_PACKAGE_TIMEOUTS] team form: packages still "claimed" after 4000 polls (fetched by the walking wave)
@@ -510,7 +517,7 @@ __global__ __launch_bounds__(256, SH::MIN_WAVES) void hnsw_search_kernel_reg(con
 		if (qi >= a.nq) break;
 		// (an abort request is sticky for this wave: it takes the remaining tickets without walking and marks every query it does not
 		// answer with count 0xFFFFFFFF, so that the caller of an interrupted launch can tell which rows of its outputs are results)
-		if (!aborted && abort_requested(a)) aborted = true;
+		if (!aborted && (qi & a.abort_mask) == 0u && abort_requested(a)) aborted = true;
 		if (__builtin_amdgcn_readfirstlane((int) aborted)) { if (lane == 0) a.out_counts[qi] = ABORTED_COUNT; continue; }   // (wave-uniform by construction; said explicitly)
 		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi] = __builtin_amdgcn_s_memrealtime();
 
@@ -902,7 +909,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 		if (qi >= a.nq) break;
 		// (an abort request is sticky for this wave: it takes the remaining tickets without walking and marks every query it does not
 		// answer with count 0xFFFFFFFF, so that the caller of an interrupted launch can tell which rows of its outputs are results)
-		if (!aborted && abort_requested(a)) aborted = true;
+		if (!aborted && (qi & a.abort_mask) == 0u && abort_requested(a)) aborted = true;
 		if (__builtin_amdgcn_readfirstlane((int) aborted)) { if (lane == 0) a.out_counts[qi] = ABORTED_COUNT; continue; }   // (wave-uniform by construction; said explicitly)
 		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi] = __builtin_amdgcn_s_memrealtime();
 
@@ -1748,7 +1755,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		else if (qi >= c->nq) break;
 		// (an abort request is sticky for this wave: it takes the remaining tickets without walking and marks every query it does not
 		// answer with count 0xFFFFFFFF, so that the caller of an interrupted launch can tell which rows of its outputs are results)
-		if (!aborted && abort_word_set(c->abort_word)) aborted = true;
+		if (!aborted && (qi & c->abort_mask) == 0u && abort_word_set(c->abort_word)) aborted = true;
 		if (__builtin_amdgcn_readfirstlane((int) aborted))
 		{
 			if (lane == 0) c->out_counts[qi] = ABORTED_COUNT;

@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_wide(const SearchArgs 
 		if (qi >= a.nq) break;
 		// (an abort request is sticky for this wave: it takes the remaining tickets without walking and marks every query it does not
 		// answer with count 0xFFFFFFFF, so that the caller of an interrupted launch can tell which rows of its outputs are results)
-		if (!aborted && abort_requested(a)) aborted = true;
+		if (!aborted && (qi & a.abort_mask) == 0u && abort_requested(a)) aborted = true;
 		if (__builtin_amdgcn_readfirstlane((int) aborted)) { if (lane == 0) a.out_counts[qi] = ABORTED_COUNT; continue; }   // (wave-uniform by construction; said explicitly)
 		if (a.out_times && lane == 0) a.out_times[2 * (size_t) qi] = __builtin_amdgcn_s_memrealtime();
 

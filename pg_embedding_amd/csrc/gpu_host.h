@@ -55,7 +55,7 @@ enum Knob : int
 	K_BEAM, K_FORCE_LDS_HEAPS, K_TEAM, K_TEAM_MAX_NQ, K_WIDE_EF_MIN, K_REF_ORDER, K_NO_POLL, K_POLL_LIMIT_S, K_INSERT_FUSED,
 	K_BLOCKS_PER_CU, K_STREAM_LIGHT,
 	// test knobs (hnsw_gpu_config_set only)
-	K_BEAM16, K_NARROW5, K_LEAN, K_HASH_ENTRIES, K_LDS_SET_MIN_WAVES, K_TEAM_SPEC, K_TEAM_WPB, K_NARROW_WPB, K_MAX_BLOCKS, K_SHARDED_NO_PEER, K_BF_BIG_MIN_BLOCKS,
+	K_BEAM16, K_NARROW5, K_LEAN, K_HASH_ENTRIES, K_LDS_SET_MIN_WAVES, K_TEAM_SPEC, K_TEAM_WPB, K_NARROW_WPB, K_ABORT_POLL_LOG2, K_MAX_BLOCKS, K_SHARDED_NO_PEER, K_BF_BIG_MIN_BLOCKS,
 #ifdef HNSW_EXPERIMENT
 	K_WIDE_WAVES, K_SHAPE_12X1, K_TEAM_MAINS, K_TEAM_COUNTERS,
 #endif

@@ -342,6 +342,10 @@ int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries, size_
 		__atomic_store_n(&w->abort_sent, 0, __ATOMIC_SEQ_CST);
 	}
 	a.health = w->health; a.abort_word = w->abort_host;
+	// a wave reads the abort word (pinned host memory: a read across the host link) at the top of every 2^k-th query, k = 4 (test knob:
+	// 0 = every query, rounds 1-5 — the read rate of a narrow-row launch then depends on where the host serves that page from, banner at
+	// abort_requested in device_search.h)
+	a.abort_mask = (1u << (uint32_t) std::min<long long>(16, std::max<long long>(0, knob(K_ABORT_POLL_LOG2, 4)))) - 1u;
 	a.vis = w->vis; a.vis_words = words; a.vlog = w->vlog; a.logcap = w->logcap;
 	if (ucap && slots * ucap > w->beam_keys)
 	{

@@ -44,7 +44,7 @@ static const KnobDef g_knob_def[K_COUNT] = {
 	{ "HNSW_GPU_WIDE_EF_MIN", true }, { "HNSW_GPU_REF_ORDER", true }, { "HNSW_GPU_NO_POLL", true }, { "HNSW_GPU_POLL_LIMIT_S", true },
 	{ "HNSW_GPU_INSERT_FUSED", true }, { "HNSW_GPU_BLOCKS_PER_CU", true }, { "HNSW_GPU_STREAM_LIGHT", true },
 	{ "HNSW_GPU_BEAM16", false }, { "HNSW_GPU_NARROW5", false }, { "HNSW_GPU_LEAN", false }, { "HNSW_GPU_HASH_ENTRIES", false }, { "HNSW_GPU_LDS_SET_MIN_WAVES", false },
-	{ "HNSW_GPU_TEAM_SPEC", false }, { "HNSW_GPU_TEAM_WPB", false }, { "HNSW_GPU_NARROW_WPB", false }, { "HNSW_GPU_MAX_BLOCKS", false }, { "HNSW_GPU_SHARDED_NO_PEER", false },
+	{ "HNSW_GPU_TEAM_SPEC", false }, { "HNSW_GPU_TEAM_WPB", false }, { "HNSW_GPU_NARROW_WPB", false }, { "HNSW_GPU_ABORT_POLL_LOG2", false }, { "HNSW_GPU_MAX_BLOCKS", false }, { "HNSW_GPU_SHARDED_NO_PEER", false },
 	{ "HNSW_GPU_BF_BIG_MIN_BLOCKS", false },
 #ifdef HNSW_EXPERIMENT
 	{ "HNSW_GPU_WIDE_WAVES", false }, { "HNSW_GPU_SHAPE_12X1", false }, { "HNSW_GPU_TEAM_MAINS", false }, { "HNSW_GPU_TEAM_COUNTERS", false },

@@ -413,6 +413,12 @@ class SearchContext:
               "hnsw_gpu_search_batch_ctx")
         return out
 
+    def last_search_ms(self, back: int = 0) -> float:
+        """Device milliseconds of this context's search launch `back` launches ago (HIP events on its stream; waits for it)."""
+        v = C.c_float(0)
+        check(self.L.hnsw_gpu_ctx_search_ms(self._h, back, C.byref(v)), "hnsw_gpu_ctx_search_ms")
+        return float(v.value)
+
     def search_host(self, Q: np.ndarray, ef: int):
         """Host arrays in and out on the context's own stream (hnsw_gpu_search_batch_ctx_host)."""
         Q = np.ascontiguousarray(Q, dtype=np.float32).reshape(-1, int(self.index.meta.dim))

@@ -40,3 +40,18 @@ def test_artefacts_are_current_by_content_not_by_mtime(tmp_path):
     assert not b._current(str(target), b._digest([str(src)], ["cc", "-O3"]))      # another command line
     os.remove(target)
     assert not b._current(str(target), d)                  # stamp without artefact
+
+
+def test_the_chunked_generator_yields_the_bytes_of_the_whole_table_generator():
+    """pg_embedding_amd.datasets.gmm_chunks (bench.py: the rows of the reference-built headline graph are uploaded chunk by chunk, so that the
+    host never holds the 3 GB table): the same bytes as gmm() for every row, whatever the chunk size — the graph in oracle/_ref/serial_graph_*
+    was built over exactly gmm()'s rows."""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    from pg_embedding_amd.datasets import gmm, gmm_chunks
+    X = gmm(3001, 37, k=50, sigma=0.3, seed=42, stream=0)
+    for chunk in (1, 777, 3001, 1 << 16):
+        parts = list(gmm_chunks(3001, 37, k=50, sigma=0.3, seed=42, stream=0, chunk=chunk))
+        assert [a for a, _ in parts] == list(range(0, 3001, chunk))
+        Y = np.concatenate([x for _, x in parts])
+        assert Y.shape == X.shape and (Y.view(np.uint32) == X.view(np.uint32)).all()
