@@ -240,7 +240,10 @@ def test_the_server_over_the_emulated_library(emu_lib, stream, mailboxes, monkey
     assert not bad, bad
     assert st["searches"] == 4 * len(Q) and st["search_errors"] == 0, st
     if stream:
-        assert st["max_batch"] == 0 and st["batches"] >= 1, st          # sessions, not batches
+        # sessions, not batches — except while the interleaved writer's control work holds the device: since round 6 the searches that are
+        # waiting then are served by ordinary blocking launches instead of waiting for all of it (server_main.cpp, "control work first"),
+        # so a batch of at most the four backends may have formed
+        assert st["max_batch"] <= len(th) and st["batches"] >= 1, st
     assert st["shm_searches"] == (st["searches"] if mailboxes else 0), st
 
 
