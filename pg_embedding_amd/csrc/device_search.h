@@ -1796,6 +1796,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		uint32_t bstale = 0xFFFFFFFFu;       // ord() of a valid upper bound of the reference's lowerBound
 		bool spill = a.hcap == 0;
 		uint32_t hs_pop = 0, hs_link = 0, hs_vis = 0, hs_score = 0, hs_acc = 0, hs_q0 = 0;
+		uint32_t hc_new = 0, hc_todo = 0, hc_iter = 0, hc_acc = 0, hc_fast = 0, hc_prune = 0, hc_pass2 = 0, hc_acc_loop = 0;   // (diagnostic build: what the accept section does per hop)
 		uint32_t jobseq = TEAM ? (uint32_t) __builtin_amdgcn_readfirstlane(lds_load_u32(&ctl[wib].jobseq)) : 0u;   // scoring jobs posted by this wave so far
 		if (HOP_STAMPS && a.team_dbg) hs_q0 = hop_stamp();
 		const uint32_t hnb = a.hcap / 4u;                                  // buckets of the visited set
@@ -2067,6 +2068,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 					if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_score += hs1 - hs0; hs0 = hs1; }
 					// rows at or above a valid upper bound of lowerBound cannot be accepted (:99)
 					uint64_t todo = __ballot((uint32_t) lane < nnew && od_mine < bstale);
+					if (HOP_STAMPS && a.team_dbg) { hc_new += nnew; hc_todo += (uint32_t) __builtin_popcountll(todo); if (nscore > 4u * SH::RPG) hc_pass2++; }
 					// While the accepted set is below ef every row is accepted whatever its distance (hnswalg.cpp:99: size < ef), one by
 					// one in the reference; the set is unordered here, so a hop whose rows ALL fit below ef is appended in one step:
 					// row r goes to slot usize + r, fetched by the lane that owns that slot (ds_bpermute), no count, no per-row loop.
@@ -2088,11 +2090,62 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 						}
 						usize += nnew;
 						todo = 0;
+						if (HOP_STAMPS && a.team_dbg) { hc_fast++; hc_acc += nnew; }
 					}
-					while (todo)                                            // :99-108, in link order
+#ifndef HNSW_SERIAL_ACCEPT
+					// Batch form of the accept loop (round 6).  A hop leaves ~4 rows below the stale bound and nearly all of them are accepted
+					// (profiles/r6u_*: 3.5 loop iterations, 3.3 accepts per hop), and an accept used to cost a slot write over all UREG
+					// registers — 12 of the ~19 VALU instructions of an iteration.  The decisions are still taken one by one in link order,
+					// but against the set AS IT STOOD AT THE START OF THE HOP plus the rows accepted so far in this hop:
+					//   count_le(set + accepted before r, od_r) = count_le(set, od_r) + |{accepted r' before r : od_r' <= od_r}|
+					// — the second term is one ballot over the lanes that hold the new rows — so the set is not touched inside the loop,
+					// and the accepted rows are appended in ONE step afterwards: lane r pushes its row to the lane that owns slot
+					// usize + (accepted rows before r) (ds_permute; the other lanes push to the lanes behind, so that every lane receives
+					// exactly one value).  Same decisions, same set (slot order is not observable).  A hop that could overflow the set
+					// (the prune belongs between two accepts) takes the one-by-one loop below.
+					if (todo && usize + (uint32_t) __builtin_popcountll(todo) <= UCAP)
+					{
+						uint64_t acc = 0;                                   // rows of this hop accepted so far (lane mask)
+						while (todo)                                        // :99-108, in link order
+						{
+							const uint32_t r = (uint32_t) __builtin_ctzll(todo);
+							todo &= todo - 1;
+							if (HOP_STAMPS && a.team_dbg) hc_iter++;
+							const uint32_t od = (uint32_t) __builtin_amdgcn_readlane((int) od_mine, (int) r);
+							const uint32_t c = beam_count_le<UREG>(uk, od) + (uint32_t) __builtin_popcountll(acc & __ballot(od_mine <= od));
+							if (c >= ef)                                    // rejected, and od is a fresh upper bound of lowerBound
+							{
+								bstale = od < bstale ? od : bstale;
+								todo &= __ballot(od_mine < bstale);
+								continue;
+							}
+							acc |= 1ull << r;
+						}
+						if (acc)
+						{
+							const uint32_t na = (uint32_t) __builtin_popcountll(acc);
+							const uint32_t ra = lane_rank(acc);             // accepted rows in the lanes below mine
+							const bool mine_acc = (acc >> lane) & 1ull;
+							const uint32_t dst = usize + (mine_acc ? ra : na + ((uint32_t) lane - ra));   // a permutation of the lanes (mod 64)
+							const uint32_t od_p = (uint32_t) __builtin_amdgcn_ds_permute((int) ((dst & 63u) << 2), (int) od_mine);
+							const uint32_t id_p = (uint32_t) __builtin_amdgcn_ds_permute((int) ((dst & 63u) << 2), (int) t_mine);
+							const uint32_t pos = ((uint32_t) lane - usize) & 63u;         // what I received is accepted row number `pos` (if pos < na) ...
+							const uint32_t slot = usize + pos;                            // ... and belongs in this slot
+							const bool take = pos < na;
+							const uint32_t kreg = take ? (slot >> 6) : 0xFFFFFFFFu;       // the register my slot is in (none: I received a row that was not accepted)
+#pragma unroll
+							for (int k = 0; k < UREG; k++)
+								uk[k] = kreg == (uint32_t) k ? (((uint64_t) od_p << 32) | id_p) : uk[k];
+							usize += na;
+							if (HOP_STAMPS && a.team_dbg) { hc_acc += na; hc_acc_loop += na; }
+						}
+					}
+#endif
+					while (todo)                                            // :99-108, in link order, one by one (a hop that may need the prune)
 					{
 						const uint32_t r = (uint32_t) __builtin_ctzll(todo);
 						todo &= todo - 1;
+						if (HOP_STAMPS && a.team_dbg) hc_iter++;
 						const uint32_t od = (uint32_t) __builtin_amdgcn_readlane((int) od_mine, (int) r);
 						if (beam_count_le<UREG>(uk, od) >= ef)              // top().first <= dist and full: rejected,
 						{                                                   // and od is a fresh upper bound of lowerBound
@@ -2106,9 +2159,11 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 							const uint32_t v = beam_select<UREG>(uk, ef);
 							usize = beam_compact<UREG>(uk, ex, v, scratch, lane);
 							bstale = v;                                     // lowerBound right now
+							if (HOP_STAMPS && a.team_dbg) hc_prune++;
 						}
 						beam_set<UREG>(uk, usize, ((uint64_t) od << 32) | t2, lane);   // :100,:102
 						usize++;
+						if (HOP_STAMPS && a.team_dbg) { hc_acc++; hc_acc_loop++; }
 					}
 					wave_sync();
 					if (HOP_STAMPS && a.team_dbg) { hs1 = hop_stamp(); hs_acc += hs1 - hs0; hs0 = hs1; }
@@ -2299,6 +2354,8 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 			atomicAdd(a.team_dbg + 5, hs_acc >> 6);
 			atomicAdd(a.team_dbg + 6, (hs_walk - hs_q0) >> 6);      // query start .. walk over (incl. set-up and entry point)
 			atomicAdd(a.team_dbg + 7, (hs_end - hs_walk) >> 6);     // emit + bitmap clean-up
+			atomicAdd(a.team_dbg + 8, hc_new); atomicAdd(a.team_dbg + 9, hc_todo); atomicAdd(a.team_dbg + 10, hc_iter); atomicAdd(a.team_dbg + 11, hc_acc);
+			atomicAdd(a.team_dbg + 12, hc_fast); atomicAdd(a.team_dbg + 13, hc_prune); atomicAdd(a.team_dbg + 14, hc_pass2); atomicAdd(a.team_dbg + 15, hc_acc_loop);
 		}
 	}
 	if (__builtin_amdgcn_readfirstlane((int) aborted)) { uint32_t *hw = cold_args(a)->health; if (lane == 0) atomicAdd(hw + HEALTH_ABORTED_WAVES, 1u); }

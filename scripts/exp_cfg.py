@@ -58,6 +58,9 @@ for bpc in bpcs:
                 names = ("pop", "link", "visited", "score", "accept")
                 stamps = " | cycles/hop " + " ".join(f"{nm} {c[1 + i] * 64 / c[0]:.0f}" for i, nm in enumerate(names)) + \
                          f" | per query: walk {c[6] * 64 / nq:.0f} emit+cleanup {c[7] * 64 / nq:.0f} hops {c[0] / nq:.1f}"
+                if len(c) >= 16 and c[8]:
+                    stamps += (f" | per hop: new rows {c[8] / c[0]:.2f}, below the stale bound {c[9] / c[0]:.2f}, accept-loop iterations {c[10] / c[0]:.2f}, accepted {c[11] / c[0]:.2f} "
+                               f"(in the loop {c[15] / c[0]:.2f}), hops appended whole {c[12] / c[0]:.3f}, prunes {c[13] / c[0]:.4f}, hops with a second scoring pass {c[14] / c[0]:.3f}")
         print(f"dim {dim} m {m} {metric} sift={sift} nq={nq:6d} blocks/CU={bpc or 'max'} slots={ix.last_search_slots():5d} "
               f"E_q {st[:, 0].mean():.0f} H_q {st[:, 1].mean():.0f} kernel {best:8.3f} ms {nq / best * 1e3:10.0f} q/s "
               f"{byt / best / 1e6:7.0f} GB/s alg = {byt / best / 1e6 / 8000:.3f} of 8 TB/s  [{ix.last_search_kernel()}] crc {sig:08x}{stamps}{spread}", flush=True)

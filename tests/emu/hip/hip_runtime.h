@@ -200,6 +200,25 @@ inline int ds_bpermute(int addr, int v)
 	const int s = (addr >> 2) & 63;
 	return ((w->gmask >> s) & 1) ? (int) (uint32_t) w->gather[s] : 0;
 }
+// ds_permute_b32: every lane WRITES its operand to lane (addr / 4) mod 64; a lane nobody writes to receives 0, and of several
+// writers the highest lane wins (the kernels only ever use it with a permutation of the lanes)
+inline int ds_permute(int addr, int v)
+{
+	exchange(K_SHFL, (uint32_t) ((addr >> 2) & 63));
+	int dst[64];
+	uint64_t act;
+	{
+		const Wave *w = tw;
+		act = w->gmask;
+		for (int l = 0; l < 64; l++) dst[l] = (int) (uint32_t) w->gather[l];
+	}
+	exchange(K_SHFL, (uint32_t) v);
+	const Wave *w = tw;
+	int r = 0;
+	for (int l = 0; l < 64; l++)
+		if (((act >> l) & 1) && dst[l] == w->cur) r = (int) (uint32_t) w->gather[l];
+	return r;
+}
 inline void wave_barrier() { exchange(K_WAVE_BARRIER, 0); }
 inline void syncthreads() { exchange(K_BLOCK_BARRIER, 0); }
 
@@ -315,6 +334,7 @@ namespace pgemb { alignas(16) static unsigned char smem[SIMT_LDS_BYTES]; }
 #define __builtin_amdgcn_update_dpp(o, s, c, rm, bm, bc) simt::update_dpp((o), (s), (c), (rm), (bm), (bc))
 #define __builtin_amdgcn_wave_barrier() simt::wave_barrier()
 #define __builtin_amdgcn_ds_bpermute(a, v) simt::ds_bpermute((a), (v))
+#define __builtin_amdgcn_ds_permute(a, v) simt::ds_permute((a), (v))
 #define __builtin_amdgcn_mbcnt_lo(m, b) simt::mbcnt_lo((m), (b))
 #define __builtin_amdgcn_mbcnt_hi(m, b) simt::mbcnt_hi((m), (b))
 // A fence is ONE instruction of the wave: what any lane stored before it is before it for every lane.  Lanes are not in lockstep

@@ -19,6 +19,7 @@ os.environ["PGEMB_GPU_LIB"] = sys.argv[2] if len(sys.argv) > 2 else build_emu.bu
 import numpy as np                                         # noqa: E402
 import pg_embedding_amd as pg                              # noqa: E402
 import util as U                                           # noqa: E402
+import oracle                                              # noqa: E402
 from pg_embedding_amd.datasets import gmm                  # noqa: E402
 
 KEYS = ("HNSW_GPU_TEAM", "HNSW_GPU_TEAM_WPB", "HNSW_GPU_MAX_BLOCKS", "HNSW_GPU_NARROW5", "HNSW_GPU_HASH_ENTRIES", "HNSW_GPU_BEAM",      # (HNSW_GPU_TEAM_SPEC: as the caller of this script set it)
@@ -62,6 +63,38 @@ def forms():
                 got = ix.search(Q, ef)
                 out.append({"dim": dim, "func": int(func), "ef": ef, "env": env, "kernel": ix.last_search_kernel(), "wrong": wrong(got, want, nq),
                             "seconds": round(time.time() - t0, 2)})
+            ix.close()
+    return out
+
+
+def accept():
+    """the accept decisions of a hop depend on each other when the beam is small or distances tie: beams of 1-9 over 32-link lists (every hop
+    brings rows that push each other out), once on quantised rows (exact ties: the `<=` of the count), every beam-kernel form; ids, distance
+    bits, counts == oracle, and the walk's pop sequence + evaluation count for the first queries (hnsw_gpu_search_trace)"""
+    out = []
+    variants = [{}, {"HNSW_GPU_TEAM": "0"}, {"HNSW_GPU_TEAM": "1", "HNSW_GPU_TEAM_WPB": "4"}, {"HNSW_GPU_TEAM": "0", "HNSW_GPU_NARROW5": "0"}]
+    for dim, m, func, quant in ((24, 16, pg.DIST_L2, False), (24, 16, pg.DIST_L2, True), (40, 16, pg.DIST_COSINE, False), (200, 12, pg.DIST_MANHATTAN, True)):
+        n, nq = 1500, 24
+        X = gmm(n, dim, k=6, seed=900 + dim)
+        Q = gmm(nq, dim, k=6, seed=901 + dim)
+        if quant:
+            X, Q = np.round(2.0 * X).astype(np.float32), np.round(2.0 * Q).astype(np.float32)
+        port = oracle.PortIndex(dim, m, 60, 16, func)
+        port.add(X, np.arange(n, dtype=np.uint64) + 7)
+        for ef in (1, 2, 3, 5, 9, 130):
+            ix = U.mirror(port, func, efs=ef)
+            want = port.search_many(Q, ef, nthreads=4)
+            for env in variants:
+                setenv(env)
+                t0 = time.time()
+                got = ix.search(Q, ef)
+                bad = wrong(got, want, nq)
+                tbad = 0
+                for q in range(4):
+                    lab, dst, pops, nev = ix.search_trace(Q[q], ef)
+                    tbad += 0 if (len(pops) == want["hops"][q] and nev == want["evals"][q]) else 1
+                out.append({"dim": dim, "func": int(func), "quantised": quant, "ef": ef, "env": env, "kernel": ix.last_search_kernel(), "wrong": bad,
+                            "trace_wrong": tbad, "seconds": round(time.time() - t0, 2)})
             ix.close()
     return out
 
@@ -511,4 +544,4 @@ def stream():
 
 
 if __name__ == "__main__":
-    print(json.dumps({"forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced, "sharded": sharded, "moving_helpers": moving_helpers, "wide": wide, "reforder": reforder, "insert": insert, "stream": stream}[sys.argv[1]]()))
+    print(json.dumps({"accept": accept, "forms": forms, "second_walk": second_walk, "others": others, "abort": abort, "traced": traced, "sharded": sharded, "moving_helpers": moving_helpers, "wide": wide, "reforder": reforder, "insert": insert, "stream": stream}[sys.argv[1]]()))

@@ -43,6 +43,26 @@ def test_every_kernel_form_walks_and_emits_like_the_oracle(emu_lib):
         assert any(needle in k for k in kernels), (needle, sorted(kernels))
 
 
+def test_accept_decisions_that_depend_on_each_other(emu_lib):
+    """Round 6's accept step decides the rows of a hop against the set as it stood at the hop's start plus the rows accepted so far in the
+    hop, and appends the accepted rows in one step: beams of 1-9 over 32-link lists and quantised rows (exact ties) make those decisions
+    depend on each other in every hop — ids, distance bits, counts, pop sequence length and evaluation count == oracle — and the same
+    source without the in-hop term answers wrongly (the scenario has teeth)."""
+    res = run_case("accept", emu_lib, timeout=1500)
+    bad = [r for r in res if r["wrong"] or r["trace_wrong"]]
+    assert not bad and len(res) >= 90, bad
+
+    def edit(f, txt):
+        if f == "device_search.h":
+            term = " + (uint32_t) __builtin_popcountll(acc & __ballot(od_mine <= od));"
+            assert txt.count(term) == 1
+            txt = txt.replace(term, ";")
+        return txt
+    broken = build_emu.build_tree(tag="noterm", edit=edit)
+    res = run_case("accept", broken, timeout=1500)
+    assert sum(r["wrong"] for r in res) > 0, "the scenario does not notice a missing in-hop term"
+
+
 def test_the_other_kernels_behind_the_c_abi(emu_lib):
     """serial device insert == the oracle's graph bytes, the walk's pop sequence, vacuum flags, a batched build that the
     search finds its way in; and the distance entry points: the device tier's own test file, unchanged, on the emulated library"""
