@@ -1658,6 +1658,11 @@ template <int FUNC, typename SH, int UREG, bool TEAM = false, bool LEAN = false>
 __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2) ? 2 : SH::MIN_WAVES) void hnsw_search_kernel_beam(const SearchArgs a)
 {
 	constexpr uint32_t UCAP = 64u * UREG;
+#ifdef HNSW_NO_EARLY_POP
+	constexpr bool EARLY_POP = false;
+#else
+	constexpr bool EARLY_POP = !TEAM;              // banner "Early pop" at the hop loop
+#endif
 	extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 	const int lane = threadIdx.x & 63;
 	const uint32_t wib = threadIdx.x >> 6;
@@ -1836,6 +1841,15 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 			wave_sync();
 			if (TEAM && lane == 0) ctl[wib].state = 1u;                     // helpers may attach from here on
 
+			// Early pop (round 6, one-wave kernels).  The next hop's pop is the best open element of the set as it stands NOW (after this hop's pop)
+			// unless a row accepted in this hop beats it — and that scan (per-lane minimum, a 6-step wave minimum, the slot from equality ballots:
+			// ~800 cycles of a wave's time) depends on nothing the link-list fetch returns.  So it is taken while that fetch is in flight (nx_*),
+			// and the hop's accept step only checks whether an accepted row lies below it (one ballot): if none does, the next hop starts from
+			// nx_* at once (~84 % of the hops: what the team form's helpers call the predicted next pop); if one does, or the set was pruned
+			// (slots move), the next hop scans as before.  Same pops, same order.
+			bool nx_valid = false, nx_has = false;       // nx_*: best open element after this hop's pop, taken during the link-list fetch
+			uint32_t nx_slot = 0;
+			uint64_t nx_key = 0;
 			for (;;)                                                        // hnswalg.cpp:67-112
 			{
 				// helpers attached to this walk (wave-uniform; read early, used after the pop)
@@ -1845,7 +1859,14 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				uint64_t ckey;
 				uint32_t hs0 = 0, hs1 = 0;
 				if (HOP_STAMPS && a.team_dbg) hs0 = hop_stamp();
-				if (!beam_next<UREG>(uk, ex, cslot, ckey)) break;          // candidateSet empty
+				if (EARLY_POP && nx_valid)
+				{
+					if (!nx_has) break;                                     // candidateSet empty
+					cslot = nx_slot; ckey = nx_key;
+				}
+				else if (!beam_next<UREG>(uk, ex, cslot, ckey)) break;     // candidateSet empty
+				nx_valid = false;
+				bool nx_taken = false, nx_beaten = false;                   // this hop: the scan was made / an accepted row lies below its result
 				uint32_t cd = (uint32_t) (ckey >> 32);
 				cd = (uint32_t) __builtin_amdgcn_readfirstlane((int) cd);     // a 32-bit scalar of its own: hipcc otherwise compares (key >> 32) with (ckey >> 32) as 64-bit pairs
 				if (beam_count_lt<UREG>(uk, cd) >= ef) break;              // :70-71  best candidate > lowerBound
@@ -1916,6 +1937,11 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 					if (pk_seen) t = LINK_NONE;
 					if (!lhit)
 						t = a.links[(size_t) cur * a.lstride + (j < a.lstride ? j : a.lstride - 1)];
+					if (EARLY_POP && j0 == 0)                               // while the link list is on its way
+					{
+						nx_has = beam_next<UREG>(uk, ex, nx_slot, nx_key);
+						nx_taken = true;
+					}
 					if (TEAM && (TEAM_COUNT && a.team_dbg) && lhit && lane == 0) atomicAdd(a.team_dbg + 1, 1u);
 					if (TEAM && (TEAM_COUNT && a.team_dbg)) { __builtin_amdgcn_s_waitcnt(0); tc1 = __builtin_amdgcn_s_memtime(); }
 					if (HOP_STAMPS && a.team_dbg) { __builtin_amdgcn_s_waitcnt(0); hs1 = hop_stamp(); hs_link += hs1 - hs0; hs0 = hs1; }
@@ -2090,6 +2116,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 						}
 						usize += nnew;
 						todo = 0;
+						if (EARLY_POP) nx_beaten = nx_beaten || !nx_has || __ballot((uint32_t) lane < nnew && (((uint64_t) od_mine << 32) | (uint32_t) ~t_mine) < nx_key) != 0;
 						if (HOP_STAMPS && a.team_dbg) { hc_fast++; hc_acc += nnew; }
 					}
 #ifndef HNSW_SERIAL_ACCEPT
@@ -2137,10 +2164,12 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 							for (int k = 0; k < UREG; k++)
 								uk[k] = kreg == (uint32_t) k ? (((uint64_t) od_p << 32) | id_p) : uk[k];
 							usize += na;
+							if (EARLY_POP) nx_beaten = nx_beaten || !nx_has || __ballot(mine_acc && (((uint64_t) od_mine << 32) | (uint32_t) ~t_mine) < nx_key) != 0;
 							if (HOP_STAMPS && a.team_dbg) { hc_acc += na; hc_acc_loop += na; }
 						}
 					}
 #endif
+					if (EARLY_POP && todo) nx_beaten = true;                // (rare: the one-by-one loop may prune, and then slots move)
 					while (todo)                                            // :99-108, in link order, one by one (a hop that may need the prune)
 					{
 						const uint32_t r = (uint32_t) __builtin_ctzll(todo);
@@ -2175,6 +2204,7 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 						atomicAdd(a.team_dbg + 9, (uint32_t) (tc3 - tc2));      // accept loop
 					}
 				}
+				nx_valid = EARLY_POP && nx_taken && !nx_beaten;             // the next hop may start from the early scan
 			}
 		}
 

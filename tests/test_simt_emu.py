@@ -62,6 +62,18 @@ def test_accept_decisions_that_depend_on_each_other(emu_lib):
     res = run_case("accept", broken, timeout=1500)
     assert sum(r["wrong"] for r in res) > 0, "the scenario does not notice a missing in-hop term"
 
+    # the one-wave kernels take the next hop's pop from a scan made during the link-list fetch unless a row accepted in the hop beats it
+    # ("Early pop"): the same source that never looks at the accepted rows pops the wrong element
+    def edit2(f, txt):
+        if f == "device_search.h":
+            line = "nx_valid = EARLY_POP && nx_taken && !nx_beaten;"
+            assert txt.count(line) == 1
+            txt = txt.replace(line, "nx_valid = EARLY_POP && nx_taken;")
+        return txt
+    broken = build_emu.build_tree(tag="earlypop", edit=edit2)
+    res = run_case("accept", broken, timeout=1500)
+    assert sum(r["wrong"] + r["trace_wrong"] for r in res) > 0, "the scenario does not notice an early pop that ignores the hop's accepted rows"
+
 
 def test_the_other_kernels_behind_the_c_abi(emu_lib):
     """serial device insert == the oracle's graph bytes, the walk's pop sequence, vacuum flags, a batched build that the
