@@ -59,7 +59,7 @@ def test_accept_decisions_that_depend_on_each_other(emu_lib):
             txt = txt.replace(term, ";")
         return txt
     broken = build_emu.build_tree(tag="noterm", edit=edit)
-    res = run_case("accept", broken, timeout=1500)
+    res = run_case("accept", broken, env={"EMU_ACCEPT_QUICK": "1"}, timeout=1500)
     assert sum(r["wrong"] for r in res) > 0, "the scenario does not notice a missing in-hop term"
 
     # the one-wave kernels take the next hop's pop from a scan made during the link-list fetch unless a row accepted in the hop beats it
@@ -71,7 +71,7 @@ def test_accept_decisions_that_depend_on_each_other(emu_lib):
             txt = txt.replace(line, "nx_valid = EARLY_POP && nx_taken;")
         return txt
     broken = build_emu.build_tree(tag="earlypop", edit=edit2)
-    res = run_case("accept", broken, timeout=1500)
+    res = run_case("accept", broken, env={"EMU_ACCEPT_QUICK": "1"}, timeout=1500)
     assert sum(r["wrong"] + r["trace_wrong"] for r in res) > 0, "the scenario does not notice an early pop that ignores the hop's accepted rows"
 
 
