@@ -1172,8 +1172,11 @@ __device__ __forceinline__ uint32_t beam_count_lt(const uint64_t (&uk)[U], uint3
 // The distance word decides alone unless two open elements share the smallest one (then the larger idx goes first,
 // as std::pair<-dist, idx> orders them): per-lane minimum of the open distance words, one wave minimum, and the slot
 // from UREG equality ballots — no 64-bit compares, no carried (key, register) pairs.
-template <int U>
-__device__ __forceinline__ bool beam_next(const uint64_t (&uk)[U], uint32_t ex, uint32_t &slot, uint64_t &ckey)
+// (WITH_LT: also the stop test's count — how many elements of the set, open or not, lie below the popped distance (hnswalg.cpp:70) — taken here,
+// where its compares issue together with the equality ballots instead of behind the slot selection.  Only for a pop that is used at once: the
+// early scan of the one-wave kernels looks at a set that the hop's accepts still change.)
+template <int U, bool WITH_LT = false>
+__device__ __forceinline__ bool beam_next(const uint64_t (&uk)[U], uint32_t ex, uint32_t &slot, uint64_t &ckey, uint32_t *n_lt = nullptr)
 {
 	uint32_t h[U];
 	uint32_t m = 0xFFFFFFFFu;
@@ -1192,6 +1195,13 @@ __device__ __forceinline__ bool beam_next(const uint64_t (&uk)[U], uint32_t ex, 
 	{
 		eq[k] = __ballot(h[k] == hmin);
 		cnt += (uint32_t) __builtin_popcountll(eq[k]);
+	}
+	if (WITH_LT)
+	{
+		uint32_t c = 0;
+#pragma unroll
+		for (int k = 0; k < U; k++) c += (uint32_t) __builtin_popcountll(__ballot((uint32_t) (uk[k] >> 32) < hmin));
+		*n_lt = c;
 	}
 	if (cnt > 1)                                            // equal distances: larger idx first
 	{
@@ -1241,6 +1251,52 @@ __device__ __forceinline__ uint32_t beam_select(const uint64_t (&uk)[U], uint32_
 
 // Drop every element whose distance word exceeds `v`; survivors keep their expanded bits and are
 // compacted to slots 0..n-1 (through this wave's HBM scratch line).  Returns n.
+#ifndef HNSW_OLD_COMPACT
+// (round 6: in registers.  Register k's survivors go to slots base .. base + n - 1: every lane pushes its key with ds_permute — a survivor to the
+// lane that owns its slot, the others to the lanes behind, a permutation — and a lane keeps what it received if that is one of the n survivors, in
+// the register its slot belongs to (two candidates per source register).  Rounds 1-5 went through a per-slot HBM scratch line: two memory round
+// trips per prune, ~5 prunes per walk.  `scratch` is unused.)
+template <int U>
+__device__ __forceinline__ uint32_t beam_compact(uint64_t (&uk)[U], uint32_t &ex, uint32_t v, uint64_t *scratch, int lane)
+{
+	(void) scratch;
+	uint64_t nk[U];
+#pragma unroll
+	for (int k = 0; k < U; k++) nk[k] = ~0ull;
+	uint32_t base = 0;
+#pragma unroll
+	for (int k = 0; k < U; k++)
+	{
+		const uint32_t hi = (uint32_t) (uk[k] >> 32);
+		const bool keep = hi <= v && hi != 0xFFFFFFFFu;
+		const uint64_t mask = __ballot(keep);
+		const uint32_t n = (uint32_t) __builtin_popcountll(mask);
+		if (n)                                                      // (wave-uniform)
+		{
+			const uint32_t rank = lane_rank(mask);
+			const uint32_t dst = base + (keep ? rank : n + ((uint32_t) lane - rank));
+			// expanded bit travels in bit 31 of the idx word (element numbers stay below 2^31 in this form)
+			const uint32_t lo = (uint32_t) uk[k] | (((ex >> k) & 1u) << 31);
+			const uint32_t r_hi = (uint32_t) __builtin_amdgcn_ds_permute((int) ((dst & 63u) << 2), (int) hi);
+			const uint32_t r_lo = (uint32_t) __builtin_amdgcn_ds_permute((int) ((dst & 63u) << 2), (int) lo);
+			const uint32_t pos = ((uint32_t) lane - base) & 63u;
+			const uint32_t dreg = pos < n ? (base + pos) >> 6 : 0xFFFFFFFFu;
+#pragma unroll
+			for (int d = 0; d < U; d++) nk[d] = dreg == (uint32_t) d ? (((uint64_t) r_hi << 32) | r_lo) : nk[d];
+		}
+		base += n;
+	}
+	ex = 0;
+#pragma unroll
+	for (int k = 0; k < U; k++)
+	{
+		const bool used = (uint32_t) k * 64 + (uint32_t) lane < base;
+		ex |= (used && ((nk[k] >> 31) & 1u)) ? (1u << k) : 0u;
+		uk[k] = used ? (nk[k] & ~(1ull << 31)) : ~0ull;
+	}
+	return base;
+}
+#else
 template <int U>
 __device__ __forceinline__ uint32_t beam_compact(uint64_t (&uk)[U], uint32_t &ex, uint32_t v, uint64_t *scratch, int lane)
 {
@@ -1271,6 +1327,7 @@ __device__ __forceinline__ uint32_t beam_compact(uint64_t (&uk)[U], uint32_t &ex
 	}
 	return base;
 }
+#endif
 
 template <int U>
 __device__ __forceinline__ void beam_set(uint64_t (&uk)[U], uint32_t slot, uint64_t key, int lane)
@@ -1859,17 +1916,29 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 				uint64_t ckey;
 				uint32_t hs0 = 0, hs1 = 0;
 				if (HOP_STAMPS && a.team_dbg) hs0 = hop_stamp();
+				uint32_t n_lt = 0;                                          // elements of the set below the popped distance (the stop test's count)
 				if (EARLY_POP && nx_valid)
 				{
 					if (!nx_has) break;                                     // candidateSet empty
 					cslot = nx_slot; ckey = nx_key;
+					uint32_t cd = (uint32_t) (ckey >> 32);
+					cd = (uint32_t) __builtin_amdgcn_readfirstlane((int) cd); // a 32-bit scalar of its own: hipcc otherwise compares (key >> 32) with (ckey >> 32) as 64-bit pairs
+					n_lt = beam_count_lt<UREG>(uk, cd);
 				}
-				else if (!beam_next<UREG>(uk, ex, cslot, ckey)) break;     // candidateSet empty
+#ifdef HNSW_OLD_POP_COUNT
+				else
+				{
+					if (!beam_next<UREG>(uk, ex, cslot, ckey)) break;
+					uint32_t cd = (uint32_t) (ckey >> 32);
+					cd = (uint32_t) __builtin_amdgcn_readfirstlane((int) cd);
+					n_lt = beam_count_lt<UREG>(uk, cd);
+				}
+#else
+				else if (!beam_next<UREG, true>(uk, ex, cslot, ckey, &n_lt)) break;     // candidateSet empty
+#endif
 				nx_valid = false;
 				bool nx_taken = false, nx_beaten = false;                   // this hop: the scan was made / an accepted row lies below its result
-				uint32_t cd = (uint32_t) (ckey >> 32);
-				cd = (uint32_t) __builtin_amdgcn_readfirstlane((int) cd);     // a 32-bit scalar of its own: hipcc otherwise compares (key >> 32) with (ckey >> 32) as 64-bit pairs
-				if (beam_count_lt<UREG>(uk, cd) >= ef) break;              // :70-71  best candidate > lowerBound
+				if (n_lt >= ef) break;                                      // :70-71  best candidate > lowerBound
 				const uint32_t cur = ~(uint32_t) ckey;
 				ex |= ((uint32_t) lane == (cslot & 63)) ? (1u << (cslot >> 6)) : 0u;   // :73 pop
 				if (!LEAN && (opt_out & 1u))                                // (system scope: a host that polls the sequence sees it as the walk goes)
