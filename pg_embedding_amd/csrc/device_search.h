@@ -2439,8 +2439,15 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		{
 			for (uint64_t w = lane, nw = c->vis_words; w < nw; w += 64) vis[w] = 0u;
 		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_s_waitcnt(0);
+#ifdef HNSW_ALWAYS_END_WAIT
+		if (true)
+#else
+		if (logn)                                                          // (nothing in the bitmap to wait for: the result stores need no wait, the next query touches none of them)
+#endif
+		{
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+			__builtin_amdgcn_s_waitcnt(0);
+		}
 		wave_sync();
 		if (HOP_STAMPS && a.team_dbg && lane == 0)
 		{
