@@ -1233,12 +1233,43 @@ __device__ __forceinline__ bool beam_next(const uint64_t (&uk)[U], uint32_t ex, 
 	return true;
 }
 
+// bitwise OR over the wavefront, returned uniformly (the DPP steps of wave_min_u32 with `|`; identity 0)
+__device__ __forceinline__ uint32_t wave_or_u32(uint32_t v)
+{
+	v |= dpp_u32<0xB1>(0u, v);
+	v |= dpp_u32<0x4E>(0u, v);
+	v |= dpp_u32<0x141>(0u, v);
+	v |= dpp_u32<0x140>(0u, v);
+	v |= dpp_u32<0x142, 0xA>(0u, v);
+	v |= dpp_u32<0x143, 0xC>(0u, v);
+	return (uint32_t) __builtin_amdgcn_readlane((int) v, 63);
+}
+
 // ef-th smallest distance word of the set (set holds >= ef used slots).
+// (The set holds the best ~ef .. 2 ef elements of a walk: their distance words share the sign, the exponent or all but its lowest bits, often
+// some of the mantissa.  The bits ALL used slots share decide nothing, so the radix descent starts below them — one OR-reduction of the
+// differences against slot 0 buys ~8-10 of the 32 steps.)
 template <int U>
 __device__ __forceinline__ uint32_t beam_select(const uint64_t (&uk)[U], uint32_t ef)
 {
+#ifdef HNSW_OLD_SELECT
+	int top = 31;
 	uint32_t prefix = 0, need = ef;
-	for (int bit = 31; bit >= 0; bit--)
+#else
+	const uint32_t ref = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (uk[0] >> 32), 0);     // slot 0 is always in use
+	uint32_t diff = 0;
+#pragma unroll
+	for (int k = 0; k < U; k++)
+	{
+		const uint32_t h = (uint32_t) (uk[k] >> 32);
+		diff |= h != 0xFFFFFFFFu ? h ^ ref : 0u;
+	}
+	diff = wave_or_u32(diff);
+	if (diff == 0u) return ref;                                     // every used slot holds the same distance word
+	const int top = 31 - __builtin_clz(diff);
+	uint32_t prefix = top == 31 ? 0u : ref & ~((2u << top) - 1u), need = ef;
+#endif
+	for (int bit = top; bit >= 0; bit--)
 	{
 		uint32_t c = 0;
 #pragma unroll
@@ -2316,6 +2347,30 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 		uint32_t myrank[UREG];
 #pragma unroll
 		for (int k = 0; k < UREG; k++) myrank[k] = 0;
+		// (round 6) the labels of the survivors are requested before the ranking instead of behind it (a random 8-byte gather: one memory round
+		// trip that the rank loop now covers; at most the ties beyond ef are fetched in vain) ...
+		uint64_t lab[UREG];
+#pragma unroll
+		for (int k = 0; k < UREG; k++)
+		{
+			lab[k] = 0;
+			if (mode != 1 && (uint32_t) k * 64 + lane < rsize) lab[k] = c->labels[(uint32_t) uk[k]];
+		}
+		// ... and the survivors sit in slots 0 .. rsize - 1, so with rsize <= 32 * UREG (the usual case: rsize = ef, the set's capacity 2 ef) the
+		// upper half of the registers is empty and stays out of the loop
+#ifndef HNSW_OLD_EMIT
+		if (UREG >= 2 && rsize <= 32u * UREG)
+		{
+			for (uint32_t jx = 0; jx < rsize; jx += 4)
+			{
+				const uint64_t k0 = srt_key[jx], k1 = srt_key[jx + 1], k2 = srt_key[jx + 2], k3 = srt_key[jx + 3];
+#pragma unroll
+				for (int k = 0; k < (UREG >= 2 ? UREG / 2 : 1); k++)
+					myrank[k] += ((k0 < uk[k]) ? 1u : 0u) + ((k1 < uk[k]) ? 1u : 0u) + ((k2 < uk[k]) ? 1u : 0u) + ((k3 < uk[k]) ? 1u : 0u);
+			}
+		}
+		else
+#endif
 		for (uint32_t jx = 0; jx < rsize; jx += 4)
 		{
 			const uint64_t k0 = srt_key[jx], k1 = srt_key[jx + 1], k2 = srt_key[jx + 2], k3 = srt_key[jx + 3];
@@ -2348,16 +2403,13 @@ __global__ __launch_bounds__(TEAM ? 512 : 256, (UREG >= 16 && SH::MIN_WAVES > 2)
 			// searchKnn, hnswalg.cpp:241-249: labels of the ef results, vacuum filter, (dist, label) order
 			uint64_t *out_labels = c->out_labels;
 			wave_sync();
-			uint64_t lab[UREG];
 			bool tie = false;
 #pragma unroll
 			for (int k = 0; k < UREG; k++)
 			{
 				const bool in = myrank[k] < nres;
-				lab[k] = 0;
 				if (in)
 				{
-					lab[k] = c->labels[(uint32_t) uk[k]];
 					srt_key[myrank[k]] = uk[k];                         // sorted by (dist, idx)
 					srt_lab[myrank[k]] = lab[k];
 				}
