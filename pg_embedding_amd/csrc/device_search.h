@@ -88,7 +88,7 @@ struct SearchArgs
 	// arrive after it is hmax full go to the HBM bitmap instead
 	uint32_t off_hash, hcap, hmax;
 	uint32_t hmagic;            // beam form: ceil(2^38 / buckets) of the bucketed set (hcap / 4 buckets of eight 16-bit tags)
-	uint64_t *beam_scratch;     // beam form: per-slot HBM scratch for the (rare) prune compaction, 64*UREG keys
+	uint64_t *beam_scratch;     // (unused since round 6: the beam form's prune compacts in registers; rounds 1-5: a per-slot HBM scratch line)
 	uint64_t *set_scratch;      // generic form with its sets in HBM: per-slot area, set_stride keys apart
 	uint32_t out_stride;        // result slots per query in the output arrays (the caller's ef; a.ef may be clamped to n)
 	size_t set_stride;
@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(256) void hnsw_search_kernel_lds(const SearchArgs a
 // slot, and NO sorted insert and NO second set:
 //   accept test = UREG compares + ballots; append = one slot write; pop = masked min-scan;
 //   prune (when the 64*UREG slots are full): 32-step radix select of the ef-th smallest distance word,
-//   compaction through a per-slot HBM scratch line (once per ~ef accepts).
+//   compaction in registers (ds_permute; rounds 1-5: through a per-slot HBM scratch line), once per ~ef accepts.
 // Output order is produced at the end by a rank sort over the <= ef survivors.
 // =====================================================================================
 
@@ -1281,7 +1281,7 @@ __device__ __forceinline__ uint32_t beam_select(const uint64_t (&uk)[U], uint32_
 }
 
 // Drop every element whose distance word exceeds `v`; survivors keep their expanded bits and are
-// compacted to slots 0..n-1 (through this wave's HBM scratch line).  Returns n.
+// compacted to slots 0..n-1.  Returns n.
 #ifndef HNSW_OLD_COMPACT
 // (round 6: in registers.  Register k's survivors go to slots base .. base + n - 1: every lane pushes its key with ds_permute — a survivor to the
 // lane that owns its slot, the others to the lanes behind, a permutation — and a lane keeps what it received if that is one of the n survivors, in

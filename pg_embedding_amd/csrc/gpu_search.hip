@@ -347,6 +347,7 @@ int launch_search(hnsw_gpu_index *ix, SearchWs *w, const float *d_queries, size_
 	// abort_requested in device_search.h)
 	a.abort_mask = (1u << (uint32_t) std::min<long long>(16, std::max<long long>(0, knob(K_ABORT_POLL_LOG2, 4)))) - 1u;
 	a.vis = w->vis; a.vis_words = words; a.vlog = w->vlog; a.logcap = w->logcap;
+	// (the beam form's prune scratch: read only by -DHNSW_OLD_COMPACT builds since round 6 — the shipped kernels compact in registers; 2 KB per slot)
 	if (ucap && slots * ucap > w->beam_keys)
 	{
 		if (w->beam) (void) hipFree(w->beam);
